@@ -1,0 +1,351 @@
+"""ctypes binding of include/deme_hip.h (libdeme_hip.so).
+
+Fails loudly when the HIP library has not been built: there is no CPU path in
+the product.  Structure layouts mirror the header field for field.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+NULL_MAPPING_PARTNER = 0xFFFFFFFF
+FAMILY_MASK_ENTRIES = 32896
+NUM_FAMILIES = 256
+FAMILY_FIXED = 1
+INTEGRATOR_FORWARD_EULER, INTEGRATOR_CENTERED_DIFFERENCE, INTEGRATOR_EXTENDED_TAYLOR = 0, 1, 2
+FORCE_HERTZIAN, FORCE_HERTZIAN_FRICTIONLESS, FORCE_CUSTOM = 0, 1, 2
+GHOST_BYTES = 56
+
+
+class DemeParams(C.Structure):
+    _fields_ = [
+        ("nvXp2", C.c_uint32), ("nvYp2", C.c_uint32), ("nvZp2", C.c_uint32),
+        ("nbX", C.c_uint32), ("nbY", C.c_uint32), ("nbZ", C.c_uint32),
+        ("l", C.c_double), ("voxelSize", C.c_double), ("binSize", C.c_double),
+        ("LBFX", C.c_float), ("LBFY", C.c_float), ("LBFZ", C.c_float),
+        ("Gx", C.c_float), ("Gy", C.c_float), ("Gz", C.c_float),
+        ("h", C.c_float), ("beta", C.c_float), ("approxMaxVel", C.c_float),
+        ("expSafetyMulti", C.c_float), ("expSafetyAdder", C.c_float),
+        ("integrator", C.c_uint32), ("forceModel", C.c_uint32), ("nContactWildcards", C.c_uint32),
+        ("cdUpdateFreq", C.c_uint32), ("errOutBinSphNum", C.c_uint32), ("errOutVel", C.c_float),
+        ("timeElapsed", C.c_double),
+    ]
+
+
+_P = C.c_void_p
+
+
+class DemeScene(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ("nOwners", "nOwnerClumps", "nSpheres", "nAnal", "nTri", "nMat", "nComp", "nMassProps")] + \
+               [(n, _P) for n in (
+                   "voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz",
+                   "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ", "familyID", "inertiaPropOffsets",
+                   "ownerClumpBody", "clumpComponentOffset", "sphereMaterialOffset",
+                   "Radii", "CDRelPosX", "CDRelPosY", "CDRelPosZ", "MassProperties", "moiX", "moiY", "moiZ",
+                   "objType", "objOwner", "objNormal", "objMaterial", "objRelPosX", "objRelPosY", "objRelPosZ",
+                   "objRotX", "objRotY", "objRotZ", "objSize1", "objSize2", "objSize3", "objMass",
+                   "E", "nu", "CoR", "mu", "Crr",
+                   "familyMasks", "familyExtraMarginSize", "familyFlags",
+                   "ownerMesh", "triNode1", "triNode2", "triNode3", "triMaterialOffset")]
+
+
+# field name -> numpy dtype, for building DemeScene / DemeOwnerState from arrays
+SCENE_DTYPES = {
+    "voxelID": np.uint64, "locX": np.uint16, "locY": np.uint16, "locZ": np.uint16,
+    "oriQw": np.float32, "oriQx": np.float32, "oriQy": np.float32, "oriQz": np.float32,
+    "vX": np.float32, "vY": np.float32, "vZ": np.float32,
+    "omgBarX": np.float32, "omgBarY": np.float32, "omgBarZ": np.float32,
+    "familyID": np.uint8, "inertiaPropOffsets": np.uint16,
+    "ownerClumpBody": np.uint32, "clumpComponentOffset": np.uint16, "sphereMaterialOffset": np.uint16,
+    "Radii": np.float32, "CDRelPosX": np.float32, "CDRelPosY": np.float32, "CDRelPosZ": np.float32,
+    "MassProperties": np.float32, "moiX": np.float32, "moiY": np.float32, "moiZ": np.float32,
+    "objType": np.uint8, "objOwner": np.uint32, "objNormal": np.float32, "objMaterial": np.uint16,
+    "objRelPosX": np.float32, "objRelPosY": np.float32, "objRelPosZ": np.float32,
+    "objRotX": np.float32, "objRotY": np.float32, "objRotZ": np.float32,
+    "objSize1": np.float32, "objSize2": np.float32, "objSize3": np.float32, "objMass": np.float32,
+    "E": np.float32, "nu": np.float32, "CoR": np.float32, "mu": np.float32, "Crr": np.float32,
+    "familyMasks": np.uint8, "familyExtraMarginSize": np.float32, "familyFlags": np.uint8,
+    "ownerMesh": np.uint32, "triNode1": np.float32, "triNode2": np.float32, "triNode3": np.float32,
+    "triMaterialOffset": np.uint16,
+}
+
+STATE_DTYPES = {
+    "voxelID": np.uint64, "locX": np.uint16, "locY": np.uint16, "locZ": np.uint16,
+    "oriQw": np.float32, "oriQx": np.float32, "oriQy": np.float32, "oriQz": np.float32,
+    "vX": np.float32, "vY": np.float32, "vZ": np.float32,
+    "omgBarX": np.float32, "omgBarY": np.float32, "omgBarZ": np.float32,
+    "aX": np.float32, "aY": np.float32, "aZ": np.float32,
+    "alphaX": np.float32, "alphaY": np.float32, "alphaZ": np.float32,
+    "familyID": np.uint8,
+}
+
+
+class DemeOwnerState(C.Structure):
+    _fields_ = [(n, _P) for n in STATE_DTYPES]
+
+
+class DemeCounts(C.Structure):
+    _fields_ = [("nContacts", C.c_uint64), ("nPrevContacts", C.c_uint64), ("nBinSphereTouches", C.c_uint64),
+                ("nActiveBins", C.c_uint64), ("nSteps", C.c_uint64), ("nDetections", C.c_uint64),
+                ("maxSpheresInBin", C.c_uint32), ("lastStatus", C.c_uint32)]
+
+
+def make_scene_struct(arrays, counts):
+    """arrays: dict name -> numpy array (kept alive by the caller); counts: dict of n* fields."""
+    sc = DemeScene()
+    keep = {}
+    for k, v in counts.items():
+        setattr(sc, k, int(v))
+    for name, dt in SCENE_DTYPES.items():
+        a = arrays.get(name)
+        if a is None:
+            setattr(sc, name, None)
+            continue
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep[name] = a
+        setattr(sc, name, a.ctypes.data if a.size else None)
+    sc._keep = keep
+    return sc
+
+
+def make_state_struct(n_owners, arrays=None):
+    """Allocate (or wrap) per-owner arrays for a state round trip."""
+    st = DemeOwnerState()
+    out = {}
+    for name, dt in STATE_DTYPES.items():
+        if arrays is not None and name in arrays and arrays[name] is not None:
+            a = np.ascontiguousarray(arrays[name], dtype=dt)
+        elif arrays is not None:
+            setattr(st, name, None)
+            continue
+        else:
+            a = np.zeros(n_owners, dtype=dt)
+        out[name] = a
+        setattr(st, name, a.ctypes.data)
+    st._keep = out
+    return st, out
+
+
+def library_path():
+    return os.path.join(_HERE, "csrc", "libdeme_hip.so")
+
+
+_lib = None
+
+
+class DemeError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libdeme_hip.so.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise DemeError(
+            f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback in this package.")
+    lib = C.CDLL(path)
+    lib.deme_last_error.restype = C.c_char_p
+    lib.deme_last_error.argtypes = [_P]
+    lib.deme_version.restype = C.c_char_p
+    lib.deme_ctx_create.argtypes = [C.c_int, C.POINTER(_P)]
+    lib.deme_ctx_destroy.argtypes = [_P]
+    lib.deme_ctx_destroy.restype = None
+    for name, args in {
+        "deme_ctx_set_stream": [_P, _P], "deme_sync": [_P],
+        "deme_set_params": [_P, C.POINTER(DemeParams)], "deme_upload_scene": [_P, C.POINTER(DemeScene)],
+        "deme_upload_owner_state": [_P, C.POINTER(DemeOwnerState)],
+        "deme_download_owner_state": [_P, C.POINTER(DemeOwnerState)],
+        "deme_update_tri_nodes": [_P, _P, _P, _P],
+        "deme_compute_margins": [_P, C.c_uint32], "deme_set_margins": [_P, _P],
+        "deme_detect_contacts": [_P], "deme_migrate_history": [_P], "deme_calc_forces": [_P],
+        "deme_integrate": [_P], "deme_step": [_P, C.c_uint32],
+        "deme_get_counts": [_P, C.POINTER(DemeCounts)],
+        "deme_download_bin_incidence": [_P, _P, _P, C.c_size_t],
+        "deme_download_contacts": [_P, _P, _P, _P, _P, C.c_size_t],
+        "deme_download_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
+        "deme_upload_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
+        "deme_set_record_contacts": [_P, C.c_int],
+        "deme_download_contact_records": [_P, _P, _P, _P, _P, C.c_size_t],
+        "deme_download_sphere_geometry": [_P, _P, _P, _P, _P, C.c_size_t],
+        "deme_compile_force_model": [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p],
+        "deme_kernel_time_ms": [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
+        "deme_kernel_time_reset": [_P], "deme_set_timing": [_P, C.c_int],
+        "deme_halo_pack": [_P, _P, C.c_uint32, _P], "deme_halo_unpack": [_P, _P, C.c_uint32, _P],
+    }.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names include/deme_hip.h declares (parsed from the header)."""
+    import re
+    hdr = os.path.join(_HERE, "..", "include", "deme_hip.h")
+    txt = open(hdr).read()
+    return sorted(set(re.findall(r"\b(deme_[a-z_0-9]+)\s*\(", txt)))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Context:
+    """One GPU context (mirrors what kT+dT own in the reference)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _P()
+        rc = self.lib.deme_ctx_create(int(device), C.byref(h))
+        if rc != 0 or not h:
+            raise DemeError(f"deme_ctx_create failed (status {rc}): is a HIP device visible?")
+        self.h = h
+        self.n_owners = 0
+        self.n_spheres = 0
+        self.n_wildcards = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.deme_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            msg = self.lib.deme_last_error(self.h)
+            raise DemeError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.deme_ctx_set_stream(self.h, stream_ptr), "deme_ctx_set_stream")
+
+    def sync(self):
+        self._ck(self.lib.deme_sync(self.h), "deme_sync")
+
+    def set_params(self, p):
+        self.n_wildcards = int(p.nContactWildcards)
+        self._ck(self.lib.deme_set_params(self.h, C.byref(p)), "deme_set_params")
+
+    def upload_scene(self, sc):
+        self.n_owners, self.n_spheres = int(sc.nOwners), int(sc.nSpheres)
+        self._ck(self.lib.deme_upload_scene(self.h, C.byref(sc)), "deme_upload_scene")
+
+    def upload_state(self, arrays):
+        st, _ = make_state_struct(self.n_owners, arrays)
+        self._ck(self.lib.deme_upload_owner_state(self.h, C.byref(st)), "deme_upload_owner_state")
+
+    def download_state(self):
+        st, out = make_state_struct(self.n_owners)
+        self._ck(self.lib.deme_download_owner_state(self.h, C.byref(st)), "deme_download_owner_state")
+        return out
+
+    def compute_margins(self, drift):
+        self._ck(self.lib.deme_compute_margins(self.h, int(drift)), "deme_compute_margins")
+
+    def set_margins(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        assert m.size == self.n_owners
+        self._ck(self.lib.deme_set_margins(self.h, m.ctypes.data), "deme_set_margins")
+
+    def detect(self):
+        self._ck(self.lib.deme_detect_contacts(self.h), "deme_detect_contacts")
+
+    def migrate(self):
+        self._ck(self.lib.deme_migrate_history(self.h), "deme_migrate_history")
+
+    def calc_forces(self):
+        self._ck(self.lib.deme_calc_forces(self.h), "deme_calc_forces")
+
+    def integrate(self):
+        self._ck(self.lib.deme_integrate(self.h), "deme_integrate")
+
+    def step(self, n):
+        self._ck(self.lib.deme_step(self.h, int(n)), "deme_step")
+
+    def counts(self):
+        c = DemeCounts()
+        self._ck(self.lib.deme_get_counts(self.h, C.byref(c)), "deme_get_counts")
+        return c
+
+    def bin_incidence(self):
+        n = int(self.counts().nBinSphereTouches)
+        b = np.zeros(n, np.uint32)
+        s = np.zeros(n, np.uint32)
+        self._ck(self.lib.deme_download_bin_incidence(self.h, _ptr(b), _ptr(s), n), "deme_download_bin_incidence")
+        return b, s
+
+    def contacts(self):
+        n = int(self.counts().nContacts)
+        a = np.zeros(n, np.uint32)
+        b = np.zeros(n, np.uint32)
+        t = np.zeros(n, np.uint8)
+        m = np.zeros(n, np.uint32)
+        self._ck(self.lib.deme_download_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), _ptr(m), n),
+                 "deme_download_contacts")
+        return a, b, t, m
+
+    def wildcard(self, w):
+        n = int(self.counts().nContacts)
+        out = np.zeros(n, np.float32)
+        self._ck(self.lib.deme_download_contact_wildcard(self.h, int(w), _ptr(out), n),
+                 "deme_download_contact_wildcard")
+        return out
+
+    def set_wildcard(self, w, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        self._ck(self.lib.deme_upload_contact_wildcard(self.h, int(w), _ptr(arr), arr.size),
+                 "deme_upload_contact_wildcard")
+
+    def set_record_contacts(self, enable=True):
+        self._ck(self.lib.deme_set_record_contacts(self.h, int(bool(enable))), "deme_set_record_contacts")
+
+    def contact_records(self):
+        n = int(self.counts().nContacts)
+        arrs = [np.zeros((n, 3), np.float32) for _ in range(4)]
+        self._ck(self.lib.deme_download_contact_records(self.h, *[_ptr(a) for a in arrs], n),
+                 "deme_download_contact_records")
+        return arrs
+
+    def sphere_geometry(self):
+        n = self.n_spheres
+        X, Y, Z = (np.zeros(n, np.float64) for _ in range(3))
+        R = np.zeros(n, np.float32)
+        self._ck(self.lib.deme_download_sphere_geometry(self.h, _ptr(X), _ptr(Y), _ptr(Z), _ptr(R), n),
+                 "deme_download_sphere_geometry")
+        return X, Y, Z, R
+
+    def compile_force_model(self, src, wildcard_names=(), prerequisites=""):
+        names = (C.c_char_p * max(1, len(wildcard_names)))(*[s.encode() for s in wildcard_names])
+        b = src.encode()
+        self._ck(self.lib.deme_compile_force_model(self.h, b, len(b), names, len(wildcard_names),
+                                                   prerequisites.encode()), "deme_compile_force_model")
+
+    def set_timing(self, enable=True):
+        self._ck(self.lib.deme_set_timing(self.h, int(bool(enable))), "deme_set_timing")
+
+    def kernel_time_reset(self):
+        self._ck(self.lib.deme_kernel_time_reset(self.h), "deme_kernel_time_reset")
+
+    def kernel_time_ms(self, name):
+        ms = C.c_double()
+        n = C.c_uint64()
+        self._ck(self.lib.deme_kernel_time_ms(self.h, name.encode(), C.byref(ms), C.byref(n)), "deme_kernel_time_ms")
+        return ms.value, n.value
+
+    def halo_pack(self, d_ids_ptr, n, d_buf_ptr):
+        self._ck(self.lib.deme_halo_pack(self.h, d_ids_ptr, int(n), d_buf_ptr), "deme_halo_pack")
+
+    def halo_unpack(self, d_ids_ptr, n, d_buf_ptr):
+        self._ck(self.lib.deme_halo_unpack(self.h, d_ids_ptr, int(n), d_buf_ptr), "deme_halo_unpack")

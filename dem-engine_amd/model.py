@@ -1,0 +1,587 @@
+"""Host-side model builder: the set-up half of ``deme::DEMSolver`` restated in numpy.
+
+Only the calls that define kernel inputs are mirrored (names and argument
+meaning follow DEM/API.h); everything else in the reference's API (writers,
+trackers, inspectors ...) is out of scope for the hot path.
+
+Reference behaviour followed here (paths relative to the reference's src/):
+  * voxel bit split and length unit `l`   DEM/APIPrivate.cpp:373-487 (figureOutNV)
+  * bin size / bin counts                 DEM/APIPrivate.cpp:489-566, DEM/HostSideHelpers.hpp:195-207
+  * world bounding planes                 DEM/APIPrivate.cpp:955-1014
+  * owner / sphere flattening order       DEM/dT.cpp:700-800, DEM/kT.cpp:766-832
+  * mass-property table order             DEM/APIPrivate.cpp:1802-1819 (clump templates, analytical, meshes)
+  * pairwise material matrices            DEM/APIPrivate.cpp:1877-2026 (off-diagonal default = mean)
+  * family mask indexing                  kernel/DEMHelperKernels.cuh:57-62
+"""
+import math
+
+import numpy as np
+
+from . import abi
+
+VOXEL_RES_POWER2 = 16
+VOXEL_COUNT_POWER2 = 64
+DEFAULT_BOX_DOMAIN_ENLARGE_RATIO = 0.2
+RESERVED_FAMILY_NUM = 255
+
+# data/clumps/3_clump.csv of the reference (three spheres; x,y,z,r) -- a data fixture
+THREE_SPHERE_CLUMP = np.array([[0.5, 0.341729, 0.0, 0.8],
+                               [0.0, -0.658271, 0.0, 0.8],
+                               [-0.5, 0.341729, 0.0, 0.8]], dtype=np.float32)
+THREE_SPHERE_CLUMP_VOLUME = 5.5886717
+THREE_SPHERE_CLUMP_MOI_MIXER = (2.928, 2.6029, 3.9908)  # DEMdemo_Mixer.cpp:62-67
+
+
+def mask_pair(i, j):
+    if i > j:
+        i, j = j, i
+    return (1 + j) * j // 2 + i
+
+
+def encode_positions(xyz_shifted, nvXp2, nvYp2, voxel_size, l):
+    """positionToVoxelID (kernel/DEMHelperKernels.cuh:138-159) on an (n,3) float64 array."""
+    X = np.asarray(xyz_shifted, dtype=np.float64)
+    n = np.floor(X / voxel_size).astype(np.uint64)  # positions are >= 0: truncation == floor
+    sub = ((X - n.astype(np.float64) * voxel_size) / l).astype(np.uint16)
+    vid = n[:, 0] + (n[:, 1] << np.uint64(nvXp2)) + (n[:, 2] << np.uint64(nvXp2 + nvYp2))
+    return vid.astype(np.uint64), sub[:, 0].copy(), sub[:, 1].copy(), sub[:, 2].copy()
+
+
+def decode_positions(vid, lx, ly, lz, nvXp2, nvYp2, voxel_size, l):
+    vid = np.asarray(vid, dtype=np.uint64)
+    vx = vid & np.uint64((1 << nvXp2) - 1)
+    vy = (vid >> np.uint64(nvXp2)) & np.uint64((1 << nvYp2) - 1)
+    vz = vid >> np.uint64(nvXp2 + nvYp2)
+    X = vx.astype(np.float64) * voxel_size + np.asarray(lx, np.float64) * l
+    Y = vy.astype(np.float64) * voxel_size + np.asarray(ly, np.float64) * l
+    Z = vz.astype(np.float64) * voxel_size + np.asarray(lz, np.float64) * l
+    return np.stack([X, Y, Z], axis=1)
+
+
+class ClumpTemplate:
+    def __init__(self, mass, moi, radii, relpos, materials):
+        self.mass = float(mass)
+        self.moi = tuple(float(x) for x in moi)
+        self.radii = np.asarray(radii, np.float32).reshape(-1)
+        self.relpos = np.asarray(relpos, np.float32).reshape(-1, 3)
+        self.materials = list(materials)
+        self.mark = None
+
+    def Scale(self, s):
+        """DEMClumpTemplate::Scale (DEM/Structs.h): lengths*s, mass*s^3, MOI*s^5."""
+        s = float(s)
+        self.mass *= s ** 3
+        self.moi = tuple(m * s ** 5 for m in self.moi)
+        self.radii = (self.radii * np.float32(s)).astype(np.float32)
+        self.relpos = (self.relpos * np.float32(s)).astype(np.float32)
+        return self
+
+
+class ClumpBatch:
+    def __init__(self, templates, xyz):
+        self.templates = templates
+        self.xyz = np.asarray(xyz, np.float32).reshape(-1, 3)
+        n = len(self.xyz)
+        self.vel = np.zeros((n, 3), np.float32)
+        self.angvel = np.zeros((n, 3), np.float32)
+        self.oriq = np.tile(np.array([0, 0, 0, 1], np.float32), (n, 1))  # x y z w (float4 order)
+        self.family = np.zeros(n, np.uint8)
+
+    def SetVel(self, v):
+        self.vel[:] = np.asarray(v, np.float32)
+
+    def SetAngVel(self, w):
+        self.angvel[:] = np.asarray(w, np.float32)
+
+    def SetOriQ(self, q_xyzw):
+        self.oriq[:] = np.asarray(q_xyzw, np.float32)
+
+    def SetFamily(self, f):
+        self.family[:] = np.asarray(f, np.uint8)
+
+
+class ExternObj:
+    def __init__(self):
+        self.comps = []  # (type, pos, rot/dir, size1, size2, size3, normal_sign, material)
+        self.family = RESERVED_FAMILY_NUM
+        self.init_pos = (0.0, 0.0, 0.0)
+        self.init_oriq = (0.0, 0.0, 0.0, 1.0)  # x y z w
+        self.mass = 1e6
+        self.moi = (1e6, 1e6, 1e6)
+
+    def AddPlane(self, pos, normal, material):
+        n = np.asarray(normal, np.float32)
+        inv = np.float32(1.0) / np.sqrt(np.float32(np.dot(n, n)))  # normalize(): rsqrtf * v
+        n = (n * inv).astype(np.float32)
+        self.comps.append((0, tuple(np.float32(pos)), tuple(n), 0.0, 0.0, 0.0, 1.0, material))
+
+    def AddCylinder(self, pos, axis, rad, material, normal_inward=True):
+        a = np.asarray(axis, np.float32)
+        inv = np.float32(1.0) / np.sqrt(np.float32(np.dot(a, a)))
+        a = (a * inv).astype(np.float32)
+        self.comps.append((2, tuple(np.float32(pos)), tuple(a), float(rad), 0.0, 0.0, 1.0 if normal_inward else -1.0,
+                           material))
+
+    def SetFamily(self, f):
+        self.family = int(f)
+
+    def SetInitPos(self, p):
+        self.init_pos = tuple(float(x) for x in p)
+
+    def SetMass(self, m):
+        self.mass = float(m)
+
+
+class SceneBuilder:
+    """Python mirror of the DEMSolver set-up surface needed by the hot path."""
+
+    def __init__(self):
+        self.materials = []
+        self.pair_overrides = {}
+        self.templates = []
+        self.batches = []
+        self.ext_objs = []
+        self.user_box_min = np.array([-10, -10, -10], np.float32)
+        self.user_box_max = np.array([10, 10, 10], np.float32)
+        self.target_box_min = self.user_box_min * np.float32(1.2)
+        self.target_box_max = self.user_box_max * np.float32(1.2)
+        self.bounding_bc = "none"
+        self.bounding_mat = None
+        self.h = 1e-5
+        self.G = (0.0, 0.0, -9.81)
+        self.cd_update_freq = 20
+        self.bin_size = None
+        self.bin_multiple = 8.0  # API.h:1410 m_binSize_as_multiple
+        self.target_bin_num = None
+        self.expand_factor = 0.0
+        self.safety_multi = 1.0
+        self.safety_adder = 0.0
+        self.approx_max_vel = 1e15
+        self.err_out_vel = 1e15
+        self.err_out_bin_sph = 32768
+        self.integrator = abi.INTEGRATOR_EXTENDED_TAYLOR  # API.h:1556 default
+        self.force_model = abi.FORCE_HERTZIAN
+        self.family_masks = np.zeros(abi.FAMILY_MASK_ENTRIES, np.uint8)
+        self.family_extra = np.zeros(abi.NUM_FAMILIES, np.float32)
+        self.family_flags = np.zeros(abi.NUM_FAMILIES, np.uint8)
+        self.family_flags[RESERVED_FAMILY_NUM] = abi.FAMILY_FIXED  # APIPrivate.cpp:1351
+        self.n_custom_wildcards = 0
+
+    # ---- materials ---------------------------------------------------------
+    def LoadMaterial(self, props):
+        self.materials.append(dict(props))
+        return len(self.materials) - 1
+
+    def SetMaterialPropertyPair(self, name, m1, m2, val):
+        self.pair_overrides[(name, m1, m2)] = float(val)
+        self.pair_overrides[(name, m2, m1)] = float(val)
+
+    # ---- templates ---------------------------------------------------------
+    def LoadClumpType(self, mass, moi, radii, relpos, material):
+        radii = np.asarray(radii, np.float32).reshape(-1)
+        mats = [material] * len(radii) if np.isscalar(material) else list(material)
+        t = ClumpTemplate(mass, moi, radii, relpos, mats)
+        self.templates.append(t)
+        return t
+
+    def LoadSphereType(self, mass, radius, material):
+        moi = 2.0 / 5.0 * mass * radius * radius
+        return self.LoadClumpType(mass, (moi, moi, moi), [radius], [[0, 0, 0]], material)
+
+    def LoadThreeSphereClump(self, scale, density, material, moi_unit=THREE_SPHERE_CLUMP_MOI_MIXER):
+        """data/clumps/3_clump.csv as the Mixer demo loads it (DEMdemo_Mixer.cpp:62-67)."""
+        t = self.LoadClumpType(density * THREE_SPHERE_CLUMP_VOLUME, tuple(m * density for m in moi_unit),
+                               THREE_SPHERE_CLUMP[:, 3], THREE_SPHERE_CLUMP[:, :3], material)
+        return t.Scale(scale)
+
+    # ---- domain --------------------------------------------------------------
+    def InstructBoxDomainDimension(self, x, y, z):
+        """x,y,z: sizes (centred box) or (lo, hi) pairs.  APIPublic.cpp:845-904."""
+        def rng(v):
+            if np.isscalar(v):
+                return (-float(v) / 2.0, float(v) / 2.0)
+            return (float(min(v)), float(max(v)))
+        r = [rng(x), rng(y), rng(z)]
+        self.user_box_min = np.array([a for a, _ in r], np.float32)
+        self.user_box_max = np.array([b for _, b in r], np.float32)
+        enlarge = np.array([(b - a) * DEFAULT_BOX_DOMAIN_ENLARGE_RATIO / 2.0 for a, b in r], np.float32)
+        self.target_box_min = (self.user_box_min - enlarge).astype(np.float32)
+        self.target_box_max = (self.user_box_max + enlarge).astype(np.float32)
+
+    def InstructBoxDomainBoundingBC(self, inst, material):
+        self.bounding_bc = inst
+        self.bounding_mat = material
+
+    # ---- entities --------------------------------------------------------------
+    def AddClumps(self, templates, xyz):
+        xyz = np.asarray(xyz, np.float32).reshape(-1, 3)
+        if isinstance(templates, ClumpTemplate):
+            templates = [templates] * len(xyz)
+        b = ClumpBatch(list(templates), xyz)
+        self.batches.append(b)
+        return b
+
+    def AddExternalObject(self):
+        o = ExternObj()
+        self.ext_objs.append(o)
+        return o
+
+    def AddBCPlane(self, pos, normal, material):
+        o = self.AddExternalObject()
+        o.AddPlane(pos, normal, material)
+        return o
+
+    # ---- solver knobs -----------------------------------------------------------
+    def SetInitTimeStep(self, h):
+        self.h = float(h)
+
+    def SetGravitationalAcceleration(self, g):
+        self.G = tuple(float(x) for x in g)
+
+    def SetCDUpdateFreq(self, k):
+        self.cd_update_freq = int(k)
+
+    def SetInitBinSize(self, s):
+        self.bin_size = float(s)
+
+    def SetInitBinSizeAsMultipleOfSmallestSphere(self, m):
+        self.bin_multiple = float(m)
+        self.bin_size = None
+
+    def SetInitBinNumTarget(self, n):
+        self.target_bin_num = int(n)
+
+    def SetExpandFactor(self, beta):
+        self.expand_factor = float(beta)
+
+    def SetExpandSafetyMultiplier(self, m):
+        self.safety_multi = float(m)
+
+    def SetExpandSafetyAdder(self, a):
+        self.safety_adder = float(a)
+
+    def SetMaxVelocity(self, v):
+        self.approx_max_vel = float(v)
+
+    def SetErrorOutVelocity(self, v):
+        self.err_out_vel = float(v)
+
+    def SetIntegrator(self, which):
+        self.integrator = {"FORWARD_EULER": 0, "CENTERED_DIFFERENCE": 1, "EXTENDED_TAYLOR": 2}.get(which, which)
+
+    def UseFrictionalHertzianModel(self):
+        self.force_model = abi.FORCE_HERTZIAN
+
+    def UseFrictionlessHertzianModel(self):
+        self.force_model = abi.FORCE_HERTZIAN_FRICTIONLESS
+
+    def UseCustomModel(self, n_wildcards):
+        self.force_model = abi.FORCE_CUSTOM
+        self.n_custom_wildcards = int(n_wildcards)
+
+    def SetFamilyFixed(self, fam):
+        self.family_flags[int(fam)] |= abi.FAMILY_FIXED
+
+    def DisableContactBetweenFamilies(self, a, b):
+        self.family_masks[mask_pair(int(a), int(b))] = 1
+
+    def SetFamilyExtraMargin(self, fam, m):
+        self.family_extra[int(fam)] = np.float32(m)
+
+    # ---- sizing ---------------------------------------------------------------
+    def _figure_out_nv(self):
+        size = (self.target_box_max - self.target_box_min).astype(np.float32)
+        xyz = [float(size[0]), float(size[1]), float(size[2])]
+        rank = [0, 1, 2]
+        for i in range(2):
+            for j in range(i + 1, 3):
+                if xyz[i] > xyz[j]:
+                    xyz[i], xyz[j] = xyz[j], xyz[i]
+                    rank[i], rank[j] = rank[j], rank[i]
+        user321 = list(xyz)
+        more = [0, 0]
+        # float arithmetic in the reference (float XYZ[3] *= 2.)
+        a0, a1, a2 = np.float32(xyz[0]), np.float32(xyz[1]), np.float32(xyz[2])
+        while a0 < a1:
+            if math.sqrt(2.0) * float(a0) > float(a1):
+                break
+            more[0] += 1
+            a0 = np.float32(float(a0) * 2.0)
+        while a1 < a2:
+            if math.sqrt(2.0) * float(a1) > float(a2):
+                break
+            more[1] += 1
+            a1 = np.float32(float(a1) * 2.0)
+        budget = VOXEL_COUNT_POWER2 - 2 * more[0] - more[1]
+        base, left = budget // 3, budget % 3
+        b3 = base
+        b2 = b3 + more[0]
+        b1 = b2 + more[1]
+        while left > 0:
+            if b3 < b2:
+                b3 += 1
+            elif b2 < b1:
+                b2 += 1
+            else:
+                b1 += 1
+            left -= 1
+        bits = [b3, b2, b1]
+        ls = [user321[k] / 2.0 ** VOXEL_RES_POWER2 / 2.0 ** bits[k] for k in range(3)]
+        l = max(ls)
+        nv = [0, 0, 0]
+        for k in range(3):
+            nv[rank[k]] = bits[k]
+        voxel = float(1 << VOXEL_RES_POWER2) * l
+        return nv, l, voxel
+
+    @staticmethod
+    def _calc_bin_num(voxel, bin_size, nv):
+        nb = [int(voxel * float(1 << nv[k]) / bin_size) + 1 for k in range(3)]
+        return nb, nb[0] * nb[1] * nb[2]
+
+    # ---- flatten ----------------------------------------------------------------
+    def Initialize(self):
+        nv, l, voxel = self._figure_out_nv()
+        lbf = self.target_box_min.astype(np.float32)
+
+        # templates sorted by component count (APIPrivate.cpp:696-742); stable here
+        order = sorted(range(len(self.templates)), key=lambda i: len(self.templates[i].radii))
+        comp_prefix = {}
+        radii, rel = [], []
+        for mark, ti in enumerate(order):
+            t = self.templates[ti]
+            t.mark = mark
+            comp_prefix[mark] = len(radii)
+            radii.extend(t.radii.tolist())
+            rel.extend(t.relpos.tolist())
+        radii = np.asarray(radii, np.float32)
+        rel = np.asarray(rel, np.float32).reshape(-1, 3)
+        tmpl_sorted = [self.templates[i] for i in order]
+
+        smallest = float(radii.min()) if len(radii) else 1.0
+        bin_size = self.bin_size if self.bin_size is not None else self.bin_multiple * smallest
+        nb, nbins = self._calc_bin_num(voxel, bin_size, nv)
+        if self.target_bin_num is not None and self.bin_size is None:
+            prev = nbins
+            tgt = self.target_bin_num
+            while nbins < 0.67 * tgt or nbins > 1.5 * tgt:
+                bin_size *= 0.8 if nbins < tgt else 1.2
+                nb, nbins = self._calc_bin_num(voxel, bin_size, nv)
+                if (prev < tgt <= nbins) or (prev >= tgt > nbins):
+                    break
+                prev = nbins
+        while nbins > 0xFFFFFFFE:
+            bin_size *= 1.5
+            nb, nbins = self._calc_bin_num(voxel, bin_size, nv)
+
+        # world bounding box as one analytical owner (APIPrivate.cpp:955-1014)
+        ext = list(self.ext_objs)
+        if self.bounding_bc != "none":
+            bottom = self.bounding_bc in ("only_bottom", "top_open", "all")
+            sides = self.bounding_bc in ("only_sides", "top_open", "all")
+            top = self.bounding_bc == "all"
+            box = ExternObj()
+            c = ((self.user_box_min + self.user_box_max) / np.float32(2.0)).astype(np.float32)
+            mat = self.bounding_mat
+            if bottom:
+                box.AddPlane((c[0], c[1], self.user_box_min[2]), (0, 0, 1), mat)
+            if sides:
+                box.AddPlane((self.user_box_min[0], c[1], c[2]), (1, 0, 0), mat)
+                box.AddPlane((self.user_box_max[0], c[1], c[2]), (-1, 0, 0), mat)
+                box.AddPlane((c[0], self.user_box_min[1], c[2]), (0, 1, 0), mat)
+                box.AddPlane((c[0], self.user_box_max[1], c[2]), (0, -1, 0), mat)
+            if top:
+                box.AddPlane((c[0], c[1], self.user_box_max[2]), (0, 0, -1), mat)
+            ext.append(box)
+
+        # owners: clumps (batch load order) then analytical objects
+        n_clumps = sum(len(b.xyz) for b in self.batches)
+        n_owners = n_clumps + len(ext)
+        xyz = np.zeros((n_owners, 3), np.float32)
+        oriq = np.tile(np.array([0, 0, 0, 1], np.float32), (n_owners, 1))
+        vel = np.zeros((n_owners, 3), np.float32)
+        ang = np.zeros((n_owners, 3), np.float32)
+        fam = np.zeros(n_owners, np.uint8)
+        inert = np.zeros(n_owners, np.uint16)
+        sph_owner, sph_comp, sph_mat = [], [], []
+        o = 0
+        for b in self.batches:
+            n = len(b.xyz)
+            xyz[o:o + n] = b.xyz
+            oriq[o:o + n] = b.oriq
+            vel[o:o + n] = b.vel
+            ang[o:o + n] = b.angvel
+            fam[o:o + n] = b.family
+            marks = np.array([t.mark for t in b.templates], np.int64)
+            inert[o:o + n] = marks
+            uniq = np.unique(marks)
+            if len(uniq) == 1:
+                t = tmpl_sorted[int(uniq[0])]
+                k = len(t.radii)
+                sph_owner.append(np.repeat(np.arange(o, o + n, dtype=np.uint32), k))
+                sph_comp.append(np.tile(np.arange(k, dtype=np.uint16) + np.uint16(comp_prefix[int(uniq[0])]), n))
+                sph_mat.append(np.tile(np.asarray(t.materials, np.uint16), n))
+            else:
+                for i in range(n):
+                    t = tmpl_sorted[int(marks[i])]
+                    k = len(t.radii)
+                    sph_owner.append(np.full(k, o + i, np.uint32))
+                    sph_comp.append(np.arange(k, dtype=np.uint16) + np.uint16(comp_prefix[int(marks[i])]))
+                    sph_mat.append(np.asarray(t.materials, np.uint16))
+            o += n
+        n_tmpl = len(tmpl_sorted)
+        mass = [t.mass for t in tmpl_sorted]
+        moi = [t.moi for t in tmpl_sorted]
+        obj = {k: [] for k in ("type", "owner", "normal", "mat", "px", "py", "pz", "rx", "ry", "rz", "s1", "s2", "s3",
+                               "mass")}
+        for ei, e in enumerate(ext):
+            owner = n_clumps + ei
+            xyz[owner] = np.asarray(e.init_pos, np.float32)
+            oriq[owner] = np.asarray(e.init_oriq, np.float32)
+            fam[owner] = e.family
+            inert[owner] = n_tmpl + ei
+            mass.append(e.mass)
+            moi.append(e.moi)
+            for (ty, pos, rot, s1, s2, s3, nsign, mat) in e.comps:
+                obj["type"].append(ty), obj["owner"].append(owner), obj["normal"].append(nsign), obj["mat"].append(mat)
+                obj["px"].append(pos[0]), obj["py"].append(pos[1]), obj["pz"].append(pos[2])
+                obj["rx"].append(rot[0]), obj["ry"].append(rot[1]), obj["rz"].append(rot[2])
+                obj["s1"].append(s1), obj["s2"].append(s2), obj["s3"].append(s3), obj["mass"].append(e.mass)
+
+        shifted = (xyz - lbf[None, :]).astype(np.float32).astype(np.float64)  # float3 subtraction, dT.cpp:745
+        vid, lx, ly, lz = encode_positions(shifted, nv[0], nv[1], voxel, l)
+
+        # materials (APIPrivate.cpp:1877-2026)
+        nm = max(1, len(self.materials))
+        def prop(name, default=0.0):
+            return np.array([m.get(name, default) for m in self.materials] or [default], np.float32)
+        E, nu = prop("E"), prop("nu")
+        def pair(name):
+            v = prop(name)
+            M = ((v[:, None] + v[None, :]) / np.float32(2.0)).astype(np.float32)
+            for i in range(nm):
+                M[i, i] = v[i]
+            for (n_, a, b), val in self.pair_overrides.items():
+                if n_ == name:
+                    M[a, b] = np.float32(val)
+            return M.reshape(-1)
+        CoR, mu, Crr = pair("CoR"), pair("mu"), pair("Crr")
+
+        nW = {abi.FORCE_HERTZIAN: 4, abi.FORCE_HERTZIAN_FRICTIONLESS: 0}.get(self.force_model, self.n_custom_wildcards)
+        p = abi.DemeParams()
+        p.nvXp2, p.nvYp2, p.nvZp2 = nv
+        p.nbX, p.nbY, p.nbZ = nb
+        p.l, p.voxelSize, p.binSize = l, voxel, bin_size
+        p.LBFX, p.LBFY, p.LBFZ = [float(x) for x in lbf]
+        p.Gx, p.Gy, p.Gz = self.G
+        p.h = self.h
+        p.beta = self.expand_factor
+        p.approxMaxVel = self.approx_max_vel
+        p.expSafetyMulti, p.expSafetyAdder = self.safety_multi, self.safety_adder
+        p.integrator, p.forceModel, p.nContactWildcards = self.integrator, self.force_model, nW
+        p.cdUpdateFreq = self.cd_update_freq
+        p.errOutBinSphNum = self.err_out_bin_sph
+        p.errOutVel = self.err_out_vel
+        p.timeElapsed = 0.0
+
+        cat = lambda lst, dt: (np.concatenate(lst).astype(dt) if lst else np.zeros(0, dt))
+        arrays = {
+            "voxelID": vid, "locX": lx, "locY": ly, "locZ": lz,
+            "oriQw": oriq[:, 3].copy(), "oriQx": oriq[:, 0].copy(), "oriQy": oriq[:, 1].copy(), "oriQz": oriq[:, 2].copy(),
+            "vX": vel[:, 0].copy(), "vY": vel[:, 1].copy(), "vZ": vel[:, 2].copy(),
+            "omgBarX": ang[:, 0].copy(), "omgBarY": ang[:, 1].copy(), "omgBarZ": ang[:, 2].copy(),
+            "familyID": fam, "inertiaPropOffsets": inert,
+            "ownerClumpBody": cat(sph_owner, np.uint32), "clumpComponentOffset": cat(sph_comp, np.uint16),
+            "sphereMaterialOffset": cat(sph_mat, np.uint16),
+            "Radii": radii, "CDRelPosX": rel[:, 0].copy() if len(rel) else np.zeros(0, np.float32),
+            "CDRelPosY": rel[:, 1].copy() if len(rel) else np.zeros(0, np.float32),
+            "CDRelPosZ": rel[:, 2].copy() if len(rel) else np.zeros(0, np.float32),
+            "MassProperties": np.asarray(mass, np.float32),
+            "moiX": np.asarray([m[0] for m in moi], np.float32), "moiY": np.asarray([m[1] for m in moi], np.float32),
+            "moiZ": np.asarray([m[2] for m in moi], np.float32),
+            "objType": np.asarray(obj["type"], np.uint8), "objOwner": np.asarray(obj["owner"], np.uint32),
+            "objNormal": np.asarray(obj["normal"], np.float32), "objMaterial": np.asarray(obj["mat"], np.uint16),
+            "objRelPosX": np.asarray(obj["px"], np.float32), "objRelPosY": np.asarray(obj["py"], np.float32),
+            "objRelPosZ": np.asarray(obj["pz"], np.float32),
+            "objRotX": np.asarray(obj["rx"], np.float32), "objRotY": np.asarray(obj["ry"], np.float32),
+            "objRotZ": np.asarray(obj["rz"], np.float32),
+            "objSize1": np.asarray(obj["s1"], np.float32), "objSize2": np.asarray(obj["s2"], np.float32),
+            "objSize3": np.asarray(obj["s3"], np.float32), "objMass": np.asarray(obj["mass"], np.float32),
+            "E": E, "nu": nu, "CoR": CoR, "mu": mu, "Crr": Crr,
+            "familyMasks": self.family_masks, "familyExtraMarginSize": self.family_extra,
+            "familyFlags": self.family_flags,
+        }
+        counts = {"nOwners": n_owners, "nOwnerClumps": n_clumps, "nSpheres": len(arrays["ownerClumpBody"]),
+                  "nAnal": len(obj["type"]), "nTri": 0, "nMat": nm, "nComp": len(radii), "nMassProps": len(mass)}
+        self.params, self.arrays, self.counts = p, arrays, counts
+        self.scene = abi.make_scene_struct(arrays, counts)
+        return p, self.scene
+
+
+def hcp_points(lo, hi, sep):
+    """HCPSampler box sampling (DEM/utils/Samplers.hpp:498-533), float arithmetic."""
+    lo = np.asarray(lo, np.float32)
+    hi = np.asarray(hi, np.float32)
+    dx = np.float32(sep)
+    dy = np.float32(sep) * np.float32(math.sqrt(3.0) / 2)
+    dz = np.float32(sep) * np.float32(math.sqrt(2.0 / 3.0))
+    size = hi - lo
+    nx, ny, nz = int(size[0] / dx) + 1, int(size[1] / dy) + 1, int(size[2] / dz) + 1
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    offy = np.where(k % 2 == 0, np.float32(0), dy / np.float32(3)).astype(np.float32)
+    offx = np.where((j + k) % 2 == 0, np.float32(0), dx / np.float32(2)).astype(np.float32)
+    x = lo[0] + (offx + i.astype(np.float32) * dx)
+    y = lo[1] + (offy + j.astype(np.float32) * dy)
+    z = lo[2] + (k.astype(np.float32) * dz)
+    pts = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1).astype(np.float32)
+    ok = np.all((pts >= lo) & (pts <= hi), axis=1)
+    return pts[ok]
+
+
+def random_unit_quaternions(n, rng):
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True).astype(np.float32)
+    return q.astype(np.float32)  # x y z w
+
+
+def packed_bed(n_target, seed=2024, scale=0.005, spacing_mult=3.0, jitter=0.05, aspect=(1.0, 1.0, 0.45),
+               three_sphere=True, cd_freq=0, E=1e8, nu=0.3, CoR=0.6, mu=0.2, Crr=0.0, h=5e-6, bin_multiple=4.0,
+               radii_poly=None, force_model=abi.FORCE_HERTZIAN, init_vz=0.0):
+    """BASELINE.md config-2 recipe: three-sphere clumps (3_clump.csv * scale) on an HCP lattice of
+    spacing 3*scale with seeded jitter and random orientations inside a box with 5 wall planes."""
+    rng = np.random.default_rng(seed)
+    sep = spacing_mult * scale
+    vol_per = sep ** 3 / math.sqrt(2.0)
+    vol = n_target * vol_per
+    a = np.asarray(aspect, float)
+    s = (vol / float(np.prod(a))) ** (1.0 / 3.0)
+    dims = a * s
+    b = SceneBuilder()
+    mat = b.LoadMaterial({"E": E, "nu": nu, "CoR": CoR, "mu": mu, "Crr": Crr})
+    pad = 2.0 * sep
+    box = dims + 2 * pad
+    b.InstructBoxDomainDimension((0.0, float(box[0])), (0.0, float(box[1])), (0.0, float(box[2] * 1.3)))
+    b.InstructBoxDomainBoundingBC("top_open", mat)
+    pts = hcp_points([pad, pad, pad], [pad + dims[0], pad + dims[1], pad + dims[2]], sep)
+    if len(pts) > n_target:
+        pts = pts[:n_target]  # keep the lowest layers (z-major ordering)
+    pts = pts + ((rng.random(pts.shape) * 2 - 1) * (jitter * sep)).astype(np.float32)
+    if three_sphere:
+        tmpl = b.LoadThreeSphereClump(scale, 2.6e3, mat)
+        batch = b.AddClumps(tmpl, pts)
+    else:
+        radii_poly = radii_poly or [scale]
+        tmpls = [b.LoadSphereType(2.6e3 * 4.0 / 3.0 * math.pi * r ** 3, r, mat) for r in radii_poly]
+        pick = rng.integers(0, len(tmpls), len(pts))
+        batch = b.AddClumps([tmpls[i] for i in pick], pts)
+    batch.SetOriQ(random_unit_quaternions(len(pts), rng))
+    if init_vz:
+        batch.SetVel(np.tile(np.array([0, 0, init_vz], np.float32), (len(pts), 1)))
+    b.SetInitTimeStep(h)
+    b.SetGravitationalAcceleration((0, 0, -9.81))
+    b.SetCDUpdateFreq(cd_freq)
+    b.SetInitBinSizeAsMultipleOfSmallestSphere(bin_multiple)
+    b.force_model = force_model
+    b.SetMaxVelocity(5.0)
+    b.SetErrorOutVelocity(1e3)
+    return b

@@ -1,0 +1,237 @@
+/*
+ * deme_hip.h -- C-ABI of the MI355X-native DEM hot path (libdeme_hip.so).
+ *
+ * The reference (projectchrono/DEM-Engine) has no C ABI: its host classes call
+ * C++ functions and runtime-compiled CUDA kernels directly.  Each entry point
+ * below names the reference interface it replaces (paths relative to the
+ * reference tree, src/...).  Plain pointers and sizes only; no C++ or torch
+ * types cross this boundary; no exception crosses it (every call returns an
+ * int status, 0 = OK, and deme_last_error() gives the message).
+ *
+ * One context per GPU.  Calls on one context must be serialised by the caller.
+ * All work is enqueued on the context's HIP stream (deme_ctx_set_stream lets a
+ * caller such as PyTorch hand in its own stream).
+ */
+#ifndef DEME_HIP_H
+#define DEME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants (reference: DEM/Defines.h:74-82, 99-112, 146) ------------- */
+#define DEME_NOT_A_CONTACT 0
+#define DEME_SPHERE_SPHERE_CONTACT 1
+#define DEME_SPHERE_MESH_CONTACT 2
+#define DEME_SPHERE_PLANE_CONTACT 11
+#define DEME_SPHERE_CYL_CONTACT 13
+
+#define DEME_ANAL_OBJ_TYPE_PLANE 0
+#define DEME_ANAL_OBJ_TYPE_PLATE 1
+#define DEME_ANAL_OBJ_TYPE_CYL_INF 2
+
+#define DEME_NULL_MAPPING_PARTNER 0xFFFFFFFFu
+#define DEME_NULL_BINID 0xFFFFFFFFu
+#define DEME_NUM_FAMILIES 256
+#define DEME_FAMILY_MASK_ENTRIES 32896 /* 256*257/2, DEM/kT.cpp:609 */
+#define DEME_MAX_WILDCARD_NUM 16
+
+#define DEME_INTEGRATOR_FORWARD_EULER 0
+#define DEME_INTEGRATOR_CENTERED_DIFFERENCE 1
+#define DEME_INTEGRATOR_EXTENDED_TAYLOR 2
+
+#define DEME_FORCE_HERTZIAN 0              /* FullHertzianForceModel.cu: 4 contact wildcards */
+#define DEME_FORCE_HERTZIAN_FRICTIONLESS 1 /* FrictionlessHertzianForceModel.cu: 0 wildcards */
+#define DEME_FORCE_CUSTOM 2                /* user fragment, see deme_compile_force_model */
+
+/* familyFlags bits: data-driven form of the prescription `switch` the
+ * reference JIT-compiles into integrateOwners (DEMIntegrationKernels.cu:26-33,
+ * APIPublic.cpp:980-1011 SetFamilyFixed). */
+#define DEME_FAMILY_FIXED 1
+
+/* status codes */
+#define DEME_OK 0
+#define DEME_ERR_INVALID 1
+#define DEME_ERR_HIP 2
+#define DEME_ERR_OVERFLOW 3 /* an arena (incidences / contacts) was too small even after growth */
+#define DEME_ERR_BIN_TOO_FULL 4 /* reference: errOutBinSphNum abort, DEMContactKernels_SphereSphere.cu:121 */
+#define DEME_ERR_VELOCITY 5     /* reference: errOutVel, kT.cpp:136-149 */
+#define DEME_ERR_COMPILE 6
+
+/* ---- parameter block: replaces deme::DEMSimParams (DEM/Defines.h:194-265) - */
+typedef struct DemeParams {
+    uint32_t nvXp2, nvYp2, nvZp2; /* voxel-count bit split, APIPrivate.cpp:373-487 */
+    uint32_t nbX, nbY, nbZ;       /* bins per axis, HostSideHelpers.hpp:195-207 */
+    double l;                     /* sub-voxel length unit */
+    double voxelSize;             /* 2^16 * l */
+    double binSize;
+    float LBFX, LBFY, LBFZ; /* left-bottom-front corner of the world */
+    float Gx, Gy, Gz;
+    float h;              /* time step */
+    float beta;           /* constant radius inflation (SetExpandFactor) */
+    float approxMaxVel;   /* cap used by the margin formula, DEMMiscKernels.cu:50 */
+    float expSafetyMulti; /* margin = (min(v,cap)*multi+adder)*h*drift + familyExtra */
+    float expSafetyAdder;
+    uint32_t integrator;        /* DEME_INTEGRATOR_* */
+    uint32_t forceModel;        /* DEME_FORCE_* */
+    uint32_t nContactWildcards; /* 4 for Hertzian, 0 frictionless, user value for custom */
+    uint32_t cdUpdateFreq;      /* contact detection every K steps; 0 = every step with zero margin
+                                   (the reference's SetCDUpdateFreq(0) parity mode) */
+    uint32_t errOutBinSphNum;   /* default 32768 */
+    float errOutVel;            /* default 1e15 (DEME_HUGE_FLOAT) */
+    double timeElapsed;
+} DemeParams;
+
+/* ---- model description: replaces the DEMDataKT/DEMDataDT struct-of-pointers
+ * (DEM/Defines.h:269-428) plus the JIT constant tables (_clumpTemplateDefs_,
+ * _massDefs_, _moiDefs_, _analyticalEntityDefs_, _materialDefs_).
+ * All pointers are HOST pointers, copied at upload time.  Owner order: clumps,
+ * then analytical objects, then meshes (kT.cpp:804-829).  Sphere order is
+ * clump-major. */
+typedef struct DemeScene {
+    uint32_t nOwners, nOwnerClumps, nSpheres, nAnal, nTri, nMat, nComp, nMassProps;
+    /* per owner */
+    const uint64_t* voxelID;
+    const uint16_t *locX, *locY, *locZ;
+    const float *oriQw, *oriQx, *oriQy, *oriQz;
+    const float *vX, *vY, *vZ;
+    const float *omgBarX, *omgBarY, *omgBarZ;
+    const uint8_t* familyID;
+    const uint16_t* inertiaPropOffsets;
+    /* per sphere */
+    const uint32_t* ownerClumpBody;
+    const uint16_t* clumpComponentOffset;
+    const uint16_t* sphereMaterialOffset;
+    /* clump component tables (nComp) and mass-property tables (nMassProps) */
+    const float *Radii, *CDRelPosX, *CDRelPosY, *CDRelPosZ;
+    const float *MassProperties, *moiX, *moiY, *moiZ;
+    /* analytical components (nAnal), AnalyticalCompDefJitify.cu:2-15 */
+    const uint8_t* objType;
+    const uint32_t* objOwner;
+    const float* objNormal; /* +1 inward, -1 outward */
+    const uint16_t* objMaterial;
+    const float *objRelPosX, *objRelPosY, *objRelPosZ;
+    const float *objRotX, *objRotY, *objRotZ;
+    const float *objSize1, *objSize2, *objSize3;
+    const float* objMass;
+    /* materials: E[nMat], nu[nMat]; CoR/mu/Crr are nMat*nMat row-major (APIPrivate.cpp:1877-2026) */
+    const float *E, *nu, *CoR, *mu, *Crr;
+    /* families */
+    const uint8_t* familyMasks;         /* DEME_FAMILY_MASK_ENTRIES, DEMHelperKernels.cuh:58-62 */
+    const float* familyExtraMarginSize; /* 256 */
+    const uint8_t* familyFlags;         /* 256, DEME_FAMILY_* bits */
+    /* triangles (nTri): mesh-major, owner-local node coordinates, APIPrivate.cpp:756-810 */
+    const uint32_t* ownerMesh;
+    const float *triNode1, *triNode2, *triNode3; /* nTri*3 floats each, xyz interleaved */
+    const uint16_t* triMaterialOffset;
+} DemeScene;
+
+/* mutable owner state for download/upload round trips */
+typedef struct DemeOwnerState {
+    uint64_t* voxelID;
+    uint16_t *locX, *locY, *locZ;
+    float *oriQw, *oriQx, *oriQy, *oriQz;
+    float *vX, *vY, *vZ;
+    float *omgBarX, *omgBarY, *omgBarZ;
+    float *aX, *aY, *aZ;
+    float *alphaX, *alphaY, *alphaZ;
+    uint8_t* familyID;
+} DemeOwnerState;
+
+typedef struct DemeCounts {
+    uint64_t nContacts;        /* current contact list length */
+    uint64_t nPrevContacts;    /* previous list length (history source) */
+    uint64_t nBinSphereTouches;/* (bin, sphere) incidences in the last detection */
+    uint64_t nActiveBins;
+    uint64_t nSteps;           /* steps taken since creation */
+    uint64_t nDetections;
+    uint32_t maxSpheresInBin;
+    uint32_t lastStatus;
+} DemeCounts;
+
+typedef struct deme_ctx deme_ctx;
+
+/* lifecycle.  Replaces DEMKinematicThread/DEMDynamicThread construction
+ * (DEM/APIPublic.cpp:22-72) -- one object, one stream, no worker threads. */
+int deme_ctx_create(int device, deme_ctx** out);
+void deme_ctx_destroy(deme_ctx* ctx);
+const char* deme_last_error(const deme_ctx* ctx);
+const char* deme_version(void);
+int deme_ctx_set_stream(deme_ctx* ctx, void* hip_stream); /* NULL = context-owned stream */
+int deme_sync(deme_ctx* ctx);
+
+/* setSimParams / UpdateSimParams (APIPrivate.cpp:1121, dT.cpp:2463-2466) */
+int deme_set_params(deme_ctx* ctx, const DemeParams* p);
+/* allocateGPUArrays + initGPUArrays + packDataPointers (APIPrivate.cpp:1169-1290) */
+int deme_upload_scene(deme_ctx* ctx, const DemeScene* s);
+/* DEMTracker setters / SetTriNodeRelPos analogue: overwrite owner state (n = nOwners) */
+int deme_upload_owner_state(deme_ctx* ctx, const DemeOwnerState* st);
+int deme_download_owner_state(deme_ctx* ctx, DemeOwnerState* st);
+/* SetTriNodeRelPos / DEMTracker::UpdateMesh (APIPublic.cpp:709-730): rewrite nTri*3 floats per node array */
+int deme_update_tri_nodes(deme_ctx* ctx, const float* n1, const float* n2, const float* n3);
+
+/* kT unpackMyBuffer margin step (kT.cpp:100-191, DEMMiscKernels.cu:37-61):
+ * per-owner margin from |v|; drift = number of steps the list must stay valid.
+ * drift 0 => margin = familyExtraMargin only. */
+int deme_compute_margins(deme_ctx* ctx, uint32_t drift);
+/* direct margin override, n = nOwners (tests) */
+int deme_set_margins(deme_ctx* ctx, const float* marginSize);
+
+/* contactDetection() (algorithms/DEMCubContactDetection.cu:38-1123): binning,
+ * bin-sorted sweep, sphere-analytical and sphere-triangle detection, history map. */
+int deme_detect_contacts(deme_ctx* ctx);
+/* dT unpack + migrateEnduringContacts (dT.cpp:1955-1987, 2040-2144): permute
+ * contact wildcards through the history map of the last detection. */
+int deme_migrate_history(deme_ctx* ctx);
+/* calculateForces() (dT.cpp:2146-2214): clear a/alpha, per-contact force, accumulate. */
+int deme_calc_forces(deme_ctx* ctx);
+/* integrateOwnerMotions() (dT.cpp:2216-2224) */
+int deme_integrate(deme_ctx* ctx);
+/* DoDynamics inner loop (dT.cpp:2401-2467): nsteps of {detect every K, forces, integrate}. */
+int deme_step(deme_ctx* ctx, uint32_t nsteps);
+
+int deme_get_counts(deme_ctx* ctx, DemeCounts* out);
+
+/* outputs for parity checks (capacity in elements; returns DEME_ERR_INVALID if too small) */
+/* (bin, sphere) incidence list in bin-sorted order: binIDsEachSphereTouches_sorted /
+ * sphereIDsEachBinTouches_sorted (DEMCubContactDetection.cu:169-186) */
+int deme_download_bin_incidence(deme_ctx* ctx, uint32_t* binIDs, uint32_t* sphereIDs, size_t cap);
+/* contact list: idGeometryA/B, contactType, contactMapping (Defines.h:306-322) */
+int deme_download_contacts(deme_ctx* ctx, uint32_t* idA, uint32_t* idB, uint8_t* type, uint32_t* mapping, size_t cap);
+/* contact wildcards, array w (0..nContactWildcards-1), length nContacts */
+int deme_download_contact_wildcard(deme_ctx* ctx, uint32_t w, float* out, size_t cap);
+int deme_upload_contact_wildcard(deme_ctx* ctx, uint32_t w, const float* in, size_t n);
+/* per-contact records (ContactInfoWriteBack.cu): force, torque-only force, local contact
+ * points; each nContacts*3 floats; any pointer may be NULL. Recording must have been enabled. */
+int deme_set_record_contacts(deme_ctx* ctx, int enable);
+int deme_download_contact_records(deme_ctx* ctx, float* force, float* torqueOnly, float* cpA, float* cpB, size_t cap);
+/* per-sphere world position (LBF-shifted frame, as kT sees it) and inflated radius */
+int deme_download_sphere_geometry(deme_ctx* ctx, double* X, double* Y, double* Z, float* R, size_t cap);
+
+/* Force-model hook (DEMForceModel::DefineCustomModel, AuxClasses.h:422-485;
+ * equipForceModel APIPrivate.cpp:1381-1574): splice a user statement block into
+ * the contact-force kernel and compile it for gfx950 at run time (hipRTC).
+ * wildcardNames: nWildcards names of per-contact float history variables. */
+int deme_compile_force_model(deme_ctx* ctx, const char* src, size_t len, const char* const* wildcardNames,
+                             uint32_t nWildcards, const char* prerequisites);
+
+/* timing of the kernels this library launched (HIP events on the context stream);
+ * names: "calc_forces", "integrate", "detect"; returns avg ms per launch since last reset */
+int deme_kernel_time_ms(deme_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches);
+int deme_kernel_time_reset(deme_ctx* ctx);
+int deme_set_timing(deme_ctx* ctx, int enable);
+
+/* multi-GPU slab decomposition helpers (no reference equivalent).
+ * pack/unpack ghost-owner state into a caller-provided DEVICE buffer that the
+ * host exchanges with RCCL send/recv. 56 bytes per ghost. */
+#define DEME_GHOST_BYTES 56
+int deme_halo_pack(deme_ctx* ctx, const uint32_t* d_ownerIDs, uint32_t n, void* d_buf);
+int deme_halo_unpack(deme_ctx* ctx, const uint32_t* d_ownerIDs, uint32_t n, const void* d_buf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEME_HIP_H */
