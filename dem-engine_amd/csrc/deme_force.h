@@ -1,0 +1,296 @@
+// deme_force.h -- the contact-force kernel and the built-in force models.
+//
+// Replaces kernel/DEMCalcForceKernels.cu:44-267 (calculateContactForces), the in-kernel
+// reduction of DEMCustomizablePolicies/ForceInKernelReductionStrat.cu and the two built-in
+// model fragments (FullHertzianForceModel.cu, FrictionlessHertzianForceModel.cu).
+//
+// Hook vocabulary kept from the reference: inside the model body the names
+// overlapDepth, B2A, contactPnt, AOwnerPos/BOwnerPos, bodyAPos/bodyBPos, AOwnerMass/BOwnerMass,
+// ARadius/BRadius, AOriQ/BOriQ, bodyAMatType/bodyBMatType, ContactType, locCPA/locCPB, force,
+// torque_only_force, AOwnerFamily/BOwnerFamily, ts, time, ALinVel/BLinVel, ARotVel/BRotVel,
+// AOwner/BOwner, AGeo/BGeo, AOwnerMOI/BOwnerMOI and myContactID are in scope with the
+// reference's meaning.  Self-contained so the same text compiles under hipRTC.
+#pragma once
+#include "deme_device.h"
+
+namespace deme_dev {
+
+struct ForceArgs {
+    const OwnerRec* owners;
+    const SphereRec* spheres;
+    const uint64_t* keys;  // sorted contact keys
+    float* wc;             // contact wildcards, AoS: wc[c*nW + w]
+    AccRec* acc;           // accumulation target
+    float* recForce;       // optional per-contact records (3 floats each), may be null
+    float* recTorque;
+    float* recCPA;
+    float* recCPB;
+    uint32_t nContacts;
+    float timeElapsed;
+};
+
+struct HertzIn {
+    double overlapDepth;
+    f3 B2A;
+    float AOwnerMass, BOwnerMass, ARadius, BRadius;
+    RotM RA, RB;  // rotation coefficients of AOriQ / BOriQ (forward)
+    f3 locCPA, locCPB;
+    f3 ALinVel, BLinVel, ARotVel, BRotVel;
+    float ts;
+};
+
+// FullHertzianForceModel.cu:5-135.  E_cnt/G_cnt/beta come from the per-material-pair table
+// (same formulas evaluated once on the host: matProxy2ContactParam, the log/sqrt of CoR).
+__device__ inline void hertz_full(const HertzIn& in, const MatPair& mp, float& dtx, float& dty, float& dtz, float& dtime,
+                                  f3& force, f3& torque_only) {
+    if (in.overlapDepth > 0) {
+        const f3 rotVelCPA = rot_apply(in.RA, cross3(in.ARotVel, in.locCPA));
+        const f3 rotVelCPB = rot_apply(in.RB, cross3(in.BRotVel, in.locCPB));
+        const f3 velB2A = (in.ALinVel + rotVelCPA) - (in.BLinVel + rotVelCPB);
+        const float projection = dot3(velB2A, in.B2A);
+        const f3 vrel_tan = velB2A - projection * in.B2A;
+        f3 delta_tan = mk3(dtx, dty, dtz);
+        delta_tan = delta_tan + in.ts * vrel_tan;
+        const float disp_proj = dot3(delta_tan, in.B2A);
+        delta_tan = delta_tan - disp_proj * in.B2A;
+        dtime += in.ts;
+
+        const float mass_eff = (in.AOwnerMass * in.BOwnerMass) / (in.AOwnerMass + in.BOwnerMass);
+        const float sqrt_Rd =
+            (float)sqrt(in.overlapDepth * (double)(in.ARadius * in.BRadius) / (double)(in.ARadius + in.BRadius));
+        const float Sn = (float)(2. * mp.E_cnt * sqrt_Rd);
+        const float beta = mp.beta;
+        const float k_n = (float)((2. / 3.) * Sn);
+        const float gamma_n = (float)(1.825741858350554 * beta * sqrt((double)(Sn * mass_eff)));
+        force = force + (float)(k_n * in.overlapDepth + gamma_n * projection) * in.B2A;
+
+        if (mp.Crr > 0.0f) {
+            bool roll = true;
+            const float R_eff = sqrtf((in.ARadius * in.BRadius) / (in.ARadius + in.BRadius));
+            const float kn_simple = (float)((4. / 3.) * mp.E_cnt * sqrtf(R_eff));
+            const float gn_simple = -2.f * sqrtf((float)((5. / 3.) * mass_eff * mp.E_cnt)) * beta * powf(R_eff, 0.25f);
+            const float d_coeff = gn_simple / (2.f * sqrtf(kn_simple * mass_eff));
+            if (d_coeff < 1.0) {
+                const float t_collision =
+                    (float)(3.1415926535897932385 * sqrtf(mass_eff / (kn_simple * (1.f - d_coeff * d_coeff))));
+                if (dtime <= t_collision)
+                    roll = false;
+            }
+            if (roll) {
+                const f3 v_rot = rotVelCPB - rotVelCPA;
+                const float v_rot_mag = len3(v_rot);
+                if (v_rot_mag > 1e-12)
+                    torque_only = (v_rot / v_rot_mag) * (mp.Crr * len3(force));
+            }
+        }
+        if (mp.mu > 0.0f) {
+            const float kt = (float)(8. * mp.G_cnt * sqrt_Rd);
+            const float gt = (float)(-1.825741858350554 * beta * sqrt((double)(mass_eff * kt)));
+            f3 tangent_force = (-kt) * delta_tan - gt * vrel_tan;
+            const float ft = len3(tangent_force);
+            if (ft > 1e-12) {
+                const float ft_max = len3(force) * mp.mu;
+                if (ft > ft_max) {
+                    tangent_force = (ft_max / ft) * tangent_force;
+                    delta_tan = (tangent_force + gt * vrel_tan) / (-kt);
+                }
+            } else {
+                tangent_force = mk3(0, 0, 0);
+            }
+            force = force + tangent_force;
+        }
+        dtx = delta_tan.x;
+        dty = delta_tan.y;
+        dtz = delta_tan.z;
+    } else {
+        dtime = 0;
+        dtx = 0;
+        dty = 0;
+        dtz = 0;
+    }
+}
+
+// FrictionlessHertzianForceModel.cu:3-42
+__device__ inline void hertz_frictionless(const HertzIn& in, const MatPair& mp, f3& force) {
+    if (in.overlapDepth > 0) {
+        const f3 rotVelCPA = rot_apply(in.RA, cross3(in.ARotVel, in.locCPA));
+        const f3 rotVelCPB = rot_apply(in.RB, cross3(in.BRotVel, in.locCPB));
+        const f3 velB2A = (in.ALinVel + rotVelCPA) - (in.BLinVel + rotVelCPB);
+        const float projection = dot3(velB2A, in.B2A);
+        const float mass_eff = (in.AOwnerMass * in.BOwnerMass) / (in.AOwnerMass + in.BOwnerMass);
+        const float sqrt_Rd =
+            (float)sqrt(in.overlapDepth * (double)(in.ARadius * in.BRadius) / (double)(in.ARadius + in.BRadius));
+        const float Sn = (float)(2. * mp.E_cnt * sqrt_Rd);
+        const float k_n = (float)((2. / 3.) * Sn);
+        const float gamma_n = (float)(1.825741858350554 * mp.beta * sqrt((double)(Sn * mass_eff)));
+        force = force + (float)(k_n * in.overlapDepth + gamma_n * projection) * in.B2A;
+    }
+}
+
+// Accumulate one side of a contact into its owner: ForceInKernelReductionStrat.cu:2-33
+// (same arithmetic as DEMCollectForceKernels_Compact.cu:13-101).  Hardware fp32 atomics.
+__device__ inline void accumulate_side(AccRec* acc, uint32_t owner, f3 F, f3 Ftot, float mass, f3 moi, const RotM& Rinv,
+                                       f3 locCP) {
+    float* a = reinterpret_cast<float*>(acc + owner);
+    unsafeAtomicAdd(a + 0, F.x / mass);
+    unsafeAtomicAdd(a + 1, F.y / mass);
+    unsafeAtomicAdd(a + 2, F.z / mass);
+    const f3 myF = rot_apply(Rinv, Ftot);
+    const f3 cr = cross3(locCP, myF);
+    unsafeAtomicAdd(a + 4, cr.x / moi.x);
+    unsafeAtomicAdd(a + 5, cr.y / moi.y);
+    unsafeAtomicAdd(a + 6, cr.z / moi.z);
+}
+
+// One thread per contact.  MODEL: 0 full Hertzian (4 wildcards), 1 frictionless (none).
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_calc_forces(const DevParams p, const ForceArgs a) {
+    const uint32_t myContactID = blockIdx.x * blockDim.x + threadIdx.x;
+    if (myContactID >= a.nContacts)
+        return;
+    const uint64_t key = a.keys[myContactID];
+    const uint32_t cls = key_class(key);
+    uint32_t ContactType = (cls == DEME_KEY_CLASS_SS) ? 1u : 0u;
+
+    HertzIn in;
+    in.ts = p.h;
+    d3 contactPnt{0, 0, 0}, AOwnerPos, BOwnerPos, bodyAPos, bodyBPos;
+    // ---- A: always a sphere (DEMCalcForceKernels.cu:63-94)
+    const uint32_t AGeo = key_a(key);
+    const SphereRec sA = load_sphere(a.spheres, AGeo);
+    const uint32_t AOwner = sA.owner;
+    const OwnerRec oA = load_owner(a.owners, AOwner);
+    const float4 mpA = p.massProps[oA.inertiaOff];
+    in.AOwnerMass = mpA.x;
+    in.ALinVel = mk3(oA.vx, oA.vy, oA.vz);
+    in.ARotVel = mk3(oA.wx, oA.wy, oA.wz);
+    AOwnerPos = decode_pos(oA.voxelID, oA.locX, oA.locY, oA.locZ, p);
+    AOwnerPos.x += p.LBFX;
+    AOwnerPos.y += p.LBFY;
+    AOwnerPos.z += p.LBFZ;
+    in.RA = rot_coeffs(oA.qw, oA.qx, oA.qy, oA.qz);
+    {
+        const float4 c = p.comp[sA.comp];
+        const f3 rel = rot_apply(in.RA, mk3(c.x, c.y, c.z));
+        bodyAPos = {AOwnerPos.x + (double)rel.x, AOwnerPos.y + (double)rel.y, AOwnerPos.z + (double)rel.z};
+        in.ARadius = c.w;
+    }
+    const uint32_t AOwnerFamily = oA.family;
+    float extraMarginSize = p.familyTrivial ? 0.f : p.familyExtra[AOwnerFamily];
+    const uint32_t bodyAMatType = sA.mat;
+    uint32_t bodyBMatType = 0, BOwner = 0;
+    const uint32_t BGeo = key_b(key);
+    float4 mpB;
+    OwnerRec oB;
+    if (cls == DEME_KEY_CLASS_SS) {  // DEMCalcForceKernels.cu:97-136
+        const SphereRec sB = load_sphere(a.spheres, BGeo);
+        BOwner = sB.owner;
+        oB = load_owner(a.owners, BOwner);
+        mpB = p.massProps[oB.inertiaOff];
+        in.BOwnerMass = mpB.x;
+        BOwnerPos = decode_pos(oB.voxelID, oB.locX, oB.locY, oB.locZ, p);
+        BOwnerPos.x += p.LBFX;
+        BOwnerPos.y += p.LBFY;
+        BOwnerPos.z += p.LBFZ;
+        in.RB = rot_coeffs(oB.qw, oB.qx, oB.qy, oB.qz);
+        const float4 c = p.comp[sB.comp];
+        const f3 rel = rot_apply(in.RB, mk3(c.x, c.y, c.z));
+        bodyBPos = {BOwnerPos.x + (double)rel.x, BOwnerPos.y + (double)rel.y, BOwnerPos.z + (double)rel.z};
+        in.BRadius = c.w;
+        bodyBMatType = sB.mat;
+        if (!p.familyTrivial) {
+            const float eB = p.familyExtra[oB.family];
+            extraMarginSize = (extraMarginSize > eB) ? extraMarginSize : eB;
+        }
+        spheres_overlap(bodyAPos.x, bodyAPos.y, bodyAPos.z, (double)in.ARadius, bodyBPos.x, bodyBPos.y, bodyBPos.z,
+                        (double)in.BRadius, contactPnt, in.B2A, in.overlapDepth);
+        if (in.overlapDepth < -extraMarginSize)
+            ContactType = 0u;
+    } else if (cls == DEME_KEY_CLASS_SA) {  // DEMCalcForceKernels.cu:184-232
+        const AnalObj ob = p.anal[BGeo];
+        BOwner = ob.owner;
+        oB = load_owner(a.owners, BOwner);
+        mpB = p.massProps[oB.inertiaOff];
+        bodyBMatType = ob.mat;
+        in.BOwnerMass = ob.mass;
+        in.BRadius = 1e15f;  // DEME_HUGE_FLOAT
+        BOwnerPos = decode_pos(oB.voxelID, oB.locX, oB.locY, oB.locZ, p);
+        BOwnerPos.x += p.LBFX;
+        BOwnerPos.y += p.LBFY;
+        BOwnerPos.z += p.LBFZ;
+        in.RB = rot_coeffs(oB.qw, oB.qx, oB.qy, oB.qz);
+        const f3 rel = rot_apply(in.RB, mk3(ob.relx, ob.rely, ob.relz));
+        bodyBPos = {BOwnerPos.x + (double)rel.x, BOwnerPos.y + (double)rel.y, BOwnerPos.z + (double)rel.z};
+        if (!p.familyTrivial) {
+            const float eB = p.familyExtra[oB.family];
+            extraMarginSize = (extraMarginSize > eB) ? extraMarginSize : eB;
+        }
+        const f3 rot = rot_apply(in.RB, mk3(ob.rotx, ob.roty, ob.rotz));
+        ContactType = sphere_entity(bodyAPos, in.ARadius, ob.type, bodyBPos, rot, ob.size1, ob.normal, 0.0f, contactPnt,
+                                    in.B2A, in.overlapDepth);
+        // the list entry keeps its type even when the exact test says "not touching"; only the
+        // grace-margin test below can retire it (DEMCalcForceKernels.cu:228-231)
+        ContactType = (ob.type == 0) ? 11u : 13u;
+        if (in.overlapDepth < -extraMarginSize)
+            ContactType = 0u;
+    } else {
+        ContactType = 0u;  // sphere-mesh contacts: see deme_mesh.h
+        oB = oA;
+        mpB = mpA;
+        in.RB = in.RA;
+        BOwnerPos = AOwnerPos;
+    }
+    in.BLinVel = mk3(oB.vx, oB.vy, oB.vz);
+    in.BRotVel = mk3(oB.wx, oB.wy, oB.wz);
+
+    // contact wildcards (contact history): _forceModelContactWildcardAcq_
+    float4 hist = make_float4(0, 0, 0, 0);
+    float4* wcp = nullptr;
+    if (MODEL == 0) {
+        wcp = reinterpret_cast<float4*>(a.wc) + myContactID;
+        hist = *wcp;  // delta_tan_x, delta_tan_y, delta_tan_z, delta_time (std::set order, Models.h:363-378)
+    }
+    if (ContactType != 0u) {
+        f3 force = mk3(0, 0, 0), torque_only_force = mk3(0, 0, 0);
+        const RotM RAinv = rot_coeffs(oA.qw, -oA.qx, -oA.qy, -oA.qz);
+        const RotM RBinv = rot_coeffs(oB.qw, -oB.qx, -oB.qy, -oB.qz);
+        in.locCPA = rot_apply(RAinv, mk3((float)(contactPnt.x - AOwnerPos.x), (float)(contactPnt.y - AOwnerPos.y),
+                                         (float)(contactPnt.z - AOwnerPos.z)));
+        in.locCPB = rot_apply(RBinv, mk3((float)(contactPnt.x - BOwnerPos.x), (float)(contactPnt.y - BOwnerPos.y),
+                                         (float)(contactPnt.z - BOwnerPos.z)));
+        const MatPair mp = p.matPair[bodyAMatType * p.nMat + bodyBMatType];
+        if (MODEL == 0)
+            hertz_full(in, mp, hist.x, hist.y, hist.z, hist.w, force, torque_only_force);
+        else
+            hertz_frictionless(in, mp, force);
+        if (a.recForce) {  // _contactInfoWrite_ (ContactInfoWriteBack.cu)
+            float* r = a.recForce + 3ull * myContactID;
+            r[0] = force.x, r[1] = force.y, r[2] = force.z;
+            r = a.recTorque + 3ull * myContactID;
+            r[0] = torque_only_force.x, r[1] = torque_only_force.y, r[2] = torque_only_force.z;
+            r = a.recCPA + 3ull * myContactID;
+            r[0] = in.locCPA.x, r[1] = in.locCPA.y, r[2] = in.locCPA.z;
+            r = a.recCPB + 3ull * myContactID;
+            r[0] = in.locCPB.x, r[1] = in.locCPB.y, r[2] = in.locCPB.z;
+        }
+        // _forceCollectInPlaceStrat_
+        const f3 tot = force + torque_only_force;
+        accumulate_side(a.acc, AOwner, force, tot, in.AOwnerMass, mk3(mpA.y, mpA.z, mpA.w), RAinv, in.locCPA);
+        const f3 nF = mk3(-force.x, -force.y, -force.z);
+        accumulate_side(a.acc, BOwner, nF, -1.f * tot, in.BOwnerMass, mk3(mpB.y, mpB.z, mpB.w), RBinv, in.locCPB);
+    } else {
+        hist = make_float4(0, 0, 0, 0);  // _forceModelContactWildcardDestroy_
+        if (a.recForce) {
+            for (int k = 0; k < 3; k++) {
+                a.recForce[3ull * myContactID + k] = 0.f;
+                a.recTorque[3ull * myContactID + k] = 0.f;
+                a.recCPA[3ull * myContactID + k] = 0.f;
+                a.recCPB[3ull * myContactID + k] = 0.f;
+            }
+        }
+    }
+    if (MODEL == 0)
+        *wcp = hist;  // _forceModelContactWildcardWrite_
+}
+
+}  // namespace deme_dev

@@ -1,0 +1,998 @@
+// deme_hip.hip -- host orchestration (C++) and the C-ABI of include/deme_hip.h.
+//
+// One context = one GPU = one HIP stream.  The reference splits this work between a kinematic
+// thread (DEM/kT.cpp) and a dynamic thread (DEM/dT.cpp) that exchange device buffers under mutexes;
+// here contact detection and stepping are phases on the same stream, sized through two small
+// device->host reads per detection (the reference makes >=10, DEMCubContactDetection.cu:121-905).
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/deme_hip.h"
+#include "deme_device.h"
+#include "deme_force.h"
+#include "deme_kernels.h"
+
+using namespace deme_dev;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    template <typename T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+struct TimerSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0;
+    uint64_t launches = 0;
+};
+
+}  // namespace
+
+struct deme_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = true;
+    std::string err;
+    DemeParams hp{};
+    bool haveParams = false, haveScene = false;
+    DevParams dp{};
+    uint32_t nOwners = 0, nOwnerClumps = 0, nSpheres = 0, nAnal = 0, nMat = 0, nComp = 0, nMassProps = 0;
+    // model
+    DevBuf owners, spheres, acc[2], comp, massProps, anal, matPair, E, nu, CoR, mu, Crr, famMasks, famExtra, famFlags;
+    int accCur = 0, accLast = 0;
+    std::vector<uint8_t> hObjType;  // host copy for contact-type decoding on download
+    // detection scratch
+    DevBuf geo, binLo, binN, counts, offsets, incKeys[2], incVals[2], keysRaw, keysSorted[2], mapping, wc[2], ctr,
+        scanTmp, sortTmp, rec[4], stage;
+    int keysCur = 0, wcCur = 0;
+    size_t incCap = 0, cntCap = 0;
+    uint64_t nInc = 0, nContacts = 0, nPrev = 0, nWcStored = 0;
+    uint64_t nActiveBins = 0;
+    uint32_t maxInBin = 0;
+    bool haveList = false, mapFresh = false;
+    bool record = false;
+    uint64_t nSteps = 0, nDetections = 0;
+    uint32_t stepsSinceCD = 0;
+    uint32_t lastStatus = 0;
+    double timeElapsed = 0;
+    bool timing = false;
+    std::map<std::string, TimerSlot> timers;
+    std::vector<hipEvent_t> eventPool;
+};
+
+namespace {
+
+int fail(deme_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) {
+        c->err = buf;
+        c->lastStatus = (uint32_t)code;
+    }
+    return code;
+}
+
+#define HIPCK(call)                                                                                   \
+    do {                                                                                              \
+        hipError_t _e = (call);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return fail(c, DEME_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+int ensure(deme_ctx* c, DevBuf& b, size_t bytes, bool keep = false) {
+    if (bytes <= b.bytes && b.p)
+        return DEME_OK;
+    const size_t want = std::max<size_t>(bytes, 256);
+    void* np = nullptr;
+    HIPCK(hipMalloc(&np, want));
+    if (keep && b.p && b.bytes)
+        HIPCK(hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (b.p) {
+        HIPCK(hipStreamSynchronize(c->stream));
+        HIPCK(hipFree(b.p));
+    }
+    b.p = np;
+    b.bytes = want;
+    return DEME_OK;
+}
+
+template <typename T>
+int upload(deme_ctx* c, DevBuf& b, const T* src, size_t n) {
+    int rc = ensure(c, b, std::max<size_t>(n, 1) * sizeof(T));
+    if (rc)
+        return rc;
+    if (n && src)
+        HIPCK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    else if (n)
+        HIPCK(hipMemsetAsync(b.p, 0, n * sizeof(T), c->stream));
+    return DEME_OK;
+}
+
+inline unsigned grid_for(size_t n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
+
+// ---- kernel timing (HIP events on the context stream) ------------------------------------------
+hipEvent_t get_event(deme_ctx* c) {
+    if (!c->eventPool.empty()) {
+        hipEvent_t e = c->eventPool.back();
+        c->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+struct ScopedTimer {
+    deme_ctx* c;
+    TimerSlot* slot = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(deme_ctx* ctx, const char* name) : c(ctx) {
+        if (!c->timing)
+            return;
+        slot = &c->timers[name];
+        if (slot->pending.size() >= 8192) {  // bounded bookkeeping
+            slot = nullptr;
+            return;
+        }
+        a = get_event(c);
+        b = get_event(c);
+        hipEventRecord(a, c->stream);
+    }
+    ~ScopedTimer() {
+        if (slot) {
+            hipEventRecord(b, c->stream);
+            slot->pending.emplace_back(a, b);
+        }
+    }
+};
+void drain_timers(deme_ctx* c) {
+    for (auto& kv : c->timers) {
+        for (auto& pr : kv.second.pending) {
+            hipEventSynchronize(pr.second);
+            float ms = 0;
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            kv.second.total_ms += ms;
+            kv.second.launches++;
+            c->eventPool.push_back(pr.first);
+            c->eventPool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+void refresh_dev_params(deme_ctx* c) {
+    DevParams& d = c->dp;
+    const DemeParams& h = c->hp;
+    d.nvXp2 = h.nvXp2, d.nvYp2 = h.nvYp2;
+    d.nbX = h.nbX, d.nbY = h.nbY, d.nbZ = h.nbZ;
+    d.l = h.l, d.voxelSize = h.voxelSize, d.binSize = h.binSize;
+    d.LBFX = h.LBFX, d.LBFY = h.LBFY, d.LBFZ = h.LBFZ;
+    d.Gx = h.Gx, d.Gy = h.Gy, d.Gz = h.Gz;
+    d.h = h.h;
+    d.approxMaxVel = h.approxMaxVel, d.expSafetyMulti = h.expSafetyMulti, d.expSafetyAdder = h.expSafetyAdder;
+    d.errOutVel = h.errOutVel;
+    d.integrator = h.integrator, d.forceModel = h.forceModel, d.nW = h.nContactWildcards;
+    d.nOwners = c->nOwners, d.nSpheres = c->nSpheres, d.nAnal = c->nAnal, d.nMat = c->nMat;
+    d.errOutBinSphNum = h.errOutBinSphNum ? h.errOutBinSphNum : 32768u;
+    d.comp = c->comp.as<float4>();
+    d.massProps = c->massProps.as<float4>();
+    d.anal = c->anal.as<AnalObj>();
+    d.matPair = c->matPair.as<MatPair>();
+    d.E = c->E.as<float>(), d.nu = c->nu.as<float>(), d.CoR = c->CoR.as<float>(), d.mu = c->mu.as<float>(),
+    d.Crr = c->Crr.as<float>();
+    d.familyMasks = c->famMasks.as<uint8_t>();
+    d.familyExtra = c->famExtra.as<float>();
+    d.familyFlags = c->famFlags.as<uint8_t>();
+}
+
+int check_ready(deme_ctx* c) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    if (!c->haveParams || !c->haveScene)
+        return fail(c, DEME_ERR_INVALID, "deme_set_params and deme_upload_scene must be called first");
+    return DEME_OK;
+}
+
+// per-material-pair constants of the Hertzian models, evaluated once on the host with the formulas
+// of kernel/DEMHelperKernels.cuh:433-445 (matProxy2ContactParam<float>) and
+// FullHertzianForceModel.cu:56-57 (loge, beta).  Host overload resolution (log/sqrt in double) as in
+// the pinned reference build.
+void build_mat_pairs(const DemeScene* s, std::vector<MatPair>& out) {
+    const uint32_t n = s->nMat;
+    out.resize((size_t)n * n);
+    for (uint32_t a = 0; a < n; a++)
+        for (uint32_t b = 0; b < n; b++) {
+            MatPair m{};
+            const float Y1 = s->E[a], nu1 = s->nu[a], Y2 = s->E[b], nu2 = s->nu[b];
+            const float invE = (1.0f - nu1 * nu1) / Y1 + (1.0f - nu2 * nu2) / Y2;
+            m.E_cnt = 1.0f / invE;
+            const float invG = 2.0f * (2.0f - nu1) * (1.0f + nu1) / Y1 + 2.0f * (2.0f - nu2) * (1.0f + nu2) / Y2;
+            m.G_cnt = 1.0f / invG;
+            m.CoR = s->CoR ? s->CoR[a * n + b] : 0.f;
+            m.mu = s->mu ? s->mu[a * n + b] : 0.f;
+            m.Crr = s->Crr ? s->Crr[a * n + b] : 0.f;
+            const float loge = (float)((m.CoR < 1e-12) ? log(1e-12) : log((double)m.CoR));
+            m.beta = (float)(loge / sqrt(loge * loge + 9.869604401089358));
+            out[(size_t)a * n + b] = m;
+        }
+}
+
+int grow_contact_arena(deme_ctx* c, size_t cap) {
+    const uint32_t nW = std::max<uint32_t>(c->hp.nContactWildcards, 1);
+    int rc = 0;
+    rc |= ensure(c, c->keysRaw, cap * 8);
+    // sorted lists and wildcards carry state between detections: keep their contents
+    rc |= ensure(c, c->keysSorted[0], cap * 8, true);
+    rc |= ensure(c, c->keysSorted[1], cap * 8, true);
+    rc |= ensure(c, c->mapping, cap * 4, true);
+    rc |= ensure(c, c->wc[0], cap * 4 * nW, true);
+    rc |= ensure(c, c->wc[1], cap * 4 * nW, true);
+    if (c->record)
+        for (int k = 0; k < 4; k++)
+            rc |= ensure(c, c->rec[k], cap * 12);
+    if (rc)
+        return rc;
+    c->cntCap = cap;
+    return DEME_OK;
+}
+
+int grow_incidence_arena(deme_ctx* c, size_t cap) {
+    int rc = 0;
+    for (int k = 0; k < 2; k++) {
+        rc |= ensure(c, c->incKeys[k], cap * 4);
+        rc |= ensure(c, c->incVals[k], cap * 4);
+    }
+    if (rc)
+        return rc;
+    c->incCap = cap;
+    return DEME_OK;
+}
+
+int status_to_error(deme_ctx* c, uint32_t st) {
+    if (st & DEME_ST_NONFINITE)
+        return fail(c, DEME_ERR_VELOCITY, "a non-finite owner velocity was found at time %.9g", c->timeElapsed);
+    if (st & DEME_ST_VELOCITY)
+        return fail(c, DEME_ERR_VELOCITY,
+                    "system max velocity exceeded the error-out velocity %.7g at time %.9g (SetErrorOutVelocity)",
+                    (double)c->hp.errOutVel, c->timeElapsed);
+    return DEME_OK;
+}
+
+int do_margins(deme_ctx* c, uint32_t drift) {
+    HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->stream));
+    hipLaunchKernelGGL(k_margins, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
+                       drift, c->ctr.as<DetectCounters>());
+    return DEME_OK;
+}
+
+// contactDetection() equivalent
+int do_detect(deme_ctx* c) {
+    ScopedTimer tm(c, "detect");
+    const uint32_t nS = c->nSpheres;
+    DetectCounters hc{};
+    // margins kernel may have left status bits in ctr: fetch them before zeroing
+    HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (int rc = status_to_error(c, hc.status))
+        return rc;
+
+    for (int attempt = 0; attempt < 4; attempt++) {
+        HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->stream));
+        if (nS) {
+            hipLaunchKernelGGL(k_sphere_prep, dim3(grid_for(nS)), dim3(256), 0, c->stream, c->dp,
+                               c->owners.as<OwnerRec>(), c->spheres.as<SphereRec>(), c->geo.as<GeoRec>(),
+                               c->binLo.as<uint4>(), c->binN.as<uint2>(), c->counts.as<uint32_t>(),
+                               c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap, c->ctr.as<DetectCounters>());
+            size_t tmp = c->scanTmp.bytes;
+            HIPCK(rocprim::exclusive_scan(c->scanTmp.p, tmp, c->counts.as<uint32_t>(), c->offsets.as<uint32_t>(), 0u,
+                                          (size_t)nS + 1, rocprim::plus<uint32_t>(), c->stream));
+        }
+        uint32_t P = 0;
+        if (nS) {
+            HIPCK(hipMemcpyAsync(&P, c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipStreamSynchronize(c->stream));
+        }
+        if (P > c->incCap) {
+            if (int rc = grow_incidence_arena(c, (size_t)P + P / 4 + 1024))
+                return rc;
+        }
+        c->nInc = P;
+        int sortedIdx = 0;
+        if (P) {
+            hipLaunchKernelGGL(k_fill_incidence, dim3(grid_for(nS)), dim3(256), 0, c->stream, c->dp,
+                               c->binLo.as<uint4>(), c->binN.as<uint2>(), c->offsets.as<uint32_t>(),
+                               c->incKeys[0].as<uint32_t>(), c->incVals[0].as<uint32_t>(), (uint64_t)c->incCap);
+            const uint64_t nBins = (uint64_t)c->hp.nbX * c->hp.nbY * c->hp.nbZ;
+            unsigned bits = 1;
+            while (bits < 32 && (1ull << bits) < nBins)
+                bits++;
+            size_t need = 0;
+            HIPCK(rocprim::radix_sort_pairs(nullptr, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
+                                            c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
+                                            c->stream));
+            if (int rc = ensure(c, c->sortTmp, need))
+                return rc;
+            need = c->sortTmp.bytes;
+            HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
+                                            c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
+                                            c->stream));
+            sortedIdx = 1;
+            hipLaunchKernelGGL(k_sweep, dim3(grid_for(P, SW_T)), dim3(SW_T), 0, c->stream, c->dp,
+                               c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
+                               c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
+                               c->ctr.as<DetectCounters>());
+        }
+        (void)sortedIdx;
+        HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        if (hc.nContactsRaw > c->cntCap) {  // arena too small: grow and redo the emitting kernels
+            if (int rc = grow_contact_arena(c, (size_t)hc.nContactsRaw + hc.nContactsRaw / 4 + 1024))
+                return rc;
+            continue;
+        }
+        c->nActiveBins = hc.nActiveBins;
+        c->maxInBin = hc.maxInBin ? hc.maxInBin : (P ? 1u : 0u);
+        if (c->maxInBin > c->dp.errOutBinSphNum)
+            return fail(c, DEME_ERR_BIN_TOO_FULL,
+                        "a bin contains %u sphere components, exceeding the allowance %u (SetMaxSphereInBin)", c->maxInBin,
+                        c->dp.errOutBinSphNum);
+        const uint64_t nC = hc.nContactsRaw;
+        const int next = c->keysCur ^ 1;
+        if (nC) {
+            size_t need = 0;
+            HIPCK(rocprim::radix_sort_keys(nullptr, need, c->keysRaw.as<uint64_t>(), c->keysSorted[next].as<uint64_t>(),
+                                           (size_t)nC, 0, 64, c->stream));
+            if (int rc = ensure(c, c->sortTmp, need))
+                return rc;
+            need = c->sortTmp.bytes;
+            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, need, c->keysRaw.as<uint64_t>(),
+                                           c->keysSorted[next].as<uint64_t>(), (size_t)nC, 0, 64, c->stream));
+            const uint64_t nPrev = c->haveList ? c->nContacts : 0;
+            hipLaunchKernelGGL(k_history, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC,
+                               c->keysSorted[next].as<uint64_t>(), (uint32_t)nPrev,
+                               c->keysSorted[c->keysCur].as<uint64_t>(), c->mapping.as<uint32_t>());
+        }
+        c->nPrev = c->haveList ? c->nContacts : 0;
+        c->nContacts = nC;
+        c->keysCur = next;
+        c->haveList = true;
+        c->mapFresh = true;
+        c->nDetections++;
+        return DEME_OK;
+    }
+    return fail(c, DEME_ERR_OVERFLOW, "contact arena kept overflowing");
+}
+
+int do_migrate(deme_ctx* c) {
+    const uint32_t nW = c->hp.nContactWildcards;
+    if (!c->mapFresh)
+        return DEME_OK;
+    c->mapFresh = false;
+    if (nW == 0) {
+        c->nWcStored = c->nContacts;
+        return DEME_OK;
+    }
+    const int next = c->wcCur ^ 1;
+    if (c->nContacts)
+        hipLaunchKernelGGL(k_migrate, dim3(grid_for(c->nContacts)), dim3(256), 0, c->stream, (uint32_t)c->nContacts, nW,
+                           c->mapping.as<uint32_t>(), (uint32_t)c->nWcStored, c->wc[c->wcCur].as<float>(),
+                           c->wc[next].as<float>());
+    c->wcCur = next;
+    c->nWcStored = c->nContacts;
+    return DEME_OK;
+}
+
+int launch_forces(deme_ctx* c) {
+    c->accLast = c->accCur;
+    if (c->nContacts == 0)
+        return DEME_OK;
+    if (c->hp.forceModel == DEME_FORCE_CUSTOM)
+        return fail(c, DEME_ERR_INVALID, "custom force model selected but none compiled (deme_compile_force_model)");
+    ForceArgs a{};
+    a.owners = c->owners.as<OwnerRec>();
+    a.spheres = c->spheres.as<SphereRec>();
+    a.keys = c->keysSorted[c->keysCur].as<uint64_t>();
+    a.wc = c->wc[c->wcCur].as<float>();
+    a.acc = c->acc[c->accCur].as<AccRec>();
+    a.nContacts = (uint32_t)c->nContacts;
+    a.timeElapsed = (float)c->timeElapsed;
+    if (c->record) {
+        a.recForce = c->rec[0].as<float>(), a.recTorque = c->rec[1].as<float>(), a.recCPA = c->rec[2].as<float>(),
+        a.recCPB = c->rec[3].as<float>();
+    }
+    c->accLast = c->accCur;
+    ScopedTimer tm(c, "calc_forces");
+    if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
+        hipLaunchKernelGGL(k_calc_forces<0>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
+    else
+        hipLaunchKernelGGL(k_calc_forces<1>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
+    return DEME_OK;
+}
+
+int launch_integrate(deme_ctx* c) {
+    ScopedTimer tm(c, "integrate");
+    hipLaunchKernelGGL(k_integrate, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
+                       c->acc[c->accCur].as<AccRec>(), c->acc[c->accCur ^ 1].as<AccRec>());
+    c->accCur ^= 1;
+    return DEME_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* deme_version(void) { return "deme_hip 0.1 (gfx950)"; }
+
+int deme_ctx_create(int device, deme_ctx** out) {
+    if (!out)
+        return DEME_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device >= n)
+        return DEME_ERR_HIP;  // reference: DEMSolver construction throws when no device (GpuManager.cpp:64-68)
+    if (hipSetDevice(device) != hipSuccess)
+        return DEME_ERR_HIP;
+    deme_ctx* c = new deme_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return DEME_ERR_HIP;
+    }
+    if (ensure(c, c->ctr, sizeof(DetectCounters)) || ensure(c, c->scanTmp, 1 << 20)) {
+        delete c;
+        return DEME_ERR_HIP;
+    }
+    hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->stream);
+    *out = c;
+    return DEME_OK;
+}
+
+void deme_ctx_destroy(deme_ctx* c) {
+    if (!c)
+        return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    for (auto e : c->eventPool)
+        hipEventDestroy(e);
+    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc[0], &c->acc[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+                     &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
+                     &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
+                     &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
+                     &c->wc[1], &c->ctr, &c->scanTmp, &c->sortTmp, &c->rec[0], &c->rec[1], &c->rec[2], &c->rec[3],
+                     &c->stage};
+    for (DevBuf* b : all)
+        if (b->p)
+            hipFree(b->p);
+    if (c->ownStream && c->stream)
+        hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* deme_last_error(const deme_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int deme_ctx_set_stream(deme_ctx* c, void* s) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (s) {
+        if (c->ownStream)
+            hipStreamDestroy(c->stream);
+        c->stream = (hipStream_t)s;
+        c->ownStream = false;
+    } else if (!c->ownStream) {
+        HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->ownStream = true;
+    }
+    return DEME_OK;
+}
+
+int deme_sync(deme_ctx* c) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_set_params(deme_ctx* c, const DemeParams* p) {
+    if (!c || !p)
+        return DEME_ERR_INVALID;
+    if (p->nContactWildcards > DEME_MAX_WILDCARD_NUM)
+        return fail(c, DEME_ERR_INVALID, "at most %d contact wildcards", DEME_MAX_WILDCARD_NUM);
+    if (p->forceModel == DEME_FORCE_HERTZIAN && p->nContactWildcards != 4)
+        return fail(c, DEME_ERR_INVALID, "the Hertzian model carries 4 contact wildcards");
+    if (c->haveParams && c->hp.nContactWildcards != p->nContactWildcards && c->haveList)
+        return fail(c, DEME_ERR_INVALID, "the wildcard count cannot change once a contact list exists");
+    if (p->nbX == 0 || p->nbY == 0 || p->nbZ == 0 || !(p->binSize > 0) || !(p->voxelSize > 0) || !(p->l > 0))
+        return fail(c, DEME_ERR_INVALID, "bin / voxel sizing is incomplete");
+    c->hp = *p;
+    c->timeElapsed = p->timeElapsed;
+    c->haveParams = true;
+    refresh_dev_params(c);
+    return DEME_OK;
+}
+
+int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
+    if (!c || !s)
+        return DEME_ERR_INVALID;
+    if (!c->haveParams)
+        return fail(c, DEME_ERR_INVALID, "call deme_set_params before deme_upload_scene");
+    if (s->nSpheres >= (1u << 31))
+        return fail(c, DEME_ERR_INVALID, "sphere ids must fit 31 bits");
+    hipSetDevice(c->device);
+    c->nOwners = s->nOwners, c->nOwnerClumps = s->nOwnerClumps, c->nSpheres = s->nSpheres, c->nAnal = s->nAnal;
+    c->nMat = s->nMat, c->nComp = s->nComp, c->nMassProps = s->nMassProps;
+    const size_t nO = s->nOwners, nS = s->nSpheres;
+    // owners
+    std::vector<OwnerRec> ho(nO);
+    for (size_t i = 0; i < nO; i++) {
+        OwnerRec& r = ho[i];
+        r.voxelID = s->voxelID[i];
+        r.locX = s->locX[i], r.locY = s->locY[i], r.locZ = s->locZ[i];
+        r.inertiaOff = s->inertiaPropOffsets ? s->inertiaPropOffsets[i] : 0;
+        r.qw = s->oriQw ? s->oriQw[i] : 1.f, r.qx = s->oriQx ? s->oriQx[i] : 0.f, r.qy = s->oriQy ? s->oriQy[i] : 0.f,
+        r.qz = s->oriQz ? s->oriQz[i] : 0.f;
+        r.vx = s->vX ? s->vX[i] : 0.f, r.vy = s->vY ? s->vY[i] : 0.f, r.vz = s->vZ ? s->vZ[i] : 0.f;
+        r.wx = s->omgBarX ? s->omgBarX[i] : 0.f, r.wy = s->omgBarY ? s->omgBarY[i] : 0.f,
+        r.wz = s->omgBarZ ? s->omgBarZ[i] : 0.f;
+        r.family = s->familyID ? s->familyID[i] : 0;
+        r.margin = 0.f;
+    }
+    if (int rc = upload(c, c->owners, ho.data(), nO))
+        return rc;
+    for (int k = 0; k < 2; k++) {
+        if (int rc = ensure(c, c->acc[k], std::max<size_t>(nO, 1) * sizeof(AccRec)))
+            return rc;
+        HIPCK(hipMemsetAsync(c->acc[k].p, 0, c->acc[k].bytes, c->stream));
+    }
+    c->accCur = 0;
+    // spheres
+    std::vector<SphereRec> hs(nS);
+    for (size_t i = 0; i < nS; i++) {
+        hs[i].owner = s->ownerClumpBody[i];
+        hs[i].comp = s->clumpComponentOffset[i];
+        hs[i].mat = s->sphereMaterialOffset ? s->sphereMaterialOffset[i] : 0;
+    }
+    if (int rc = upload(c, c->spheres, hs.data(), nS))
+        return rc;
+    // tables
+    std::vector<float4> hc(s->nComp), hm(s->nMassProps);
+    for (uint32_t i = 0; i < s->nComp; i++)
+        hc[i] = make_float4(s->CDRelPosX[i], s->CDRelPosY[i], s->CDRelPosZ[i], s->Radii[i]);
+    for (uint32_t i = 0; i < s->nMassProps; i++)
+        hm[i] = make_float4(s->MassProperties[i], s->moiX[i], s->moiY[i], s->moiZ[i]);
+    if (int rc = upload(c, c->comp, hc.data(), hc.size()))
+        return rc;
+    if (int rc = upload(c, c->massProps, hm.data(), hm.size()))
+        return rc;
+    std::vector<AnalObj> ha(s->nAnal);
+    c->hObjType.assign(s->nAnal, 0);
+    for (uint32_t i = 0; i < s->nAnal; i++) {
+        AnalObj& a = ha[i];
+        memset(&a, 0, sizeof(a));
+        a.relx = s->objRelPosX[i], a.rely = s->objRelPosY[i], a.relz = s->objRelPosZ[i];
+        a.rotx = s->objRotX[i], a.roty = s->objRotY[i], a.rotz = s->objRotZ[i];
+        a.size1 = s->objSize1 ? s->objSize1[i] : 0.f, a.size2 = s->objSize2 ? s->objSize2[i] : 0.f,
+        a.size3 = s->objSize3 ? s->objSize3[i] : 0.f;
+        a.normal = s->objNormal ? s->objNormal[i] : 1.f;
+        a.mass = s->objMass ? s->objMass[i] : 1e6f;
+        a.owner = s->objOwner[i];
+        a.type = s->objType[i];
+        a.mat = s->objMaterial ? s->objMaterial[i] : 0;
+        c->hObjType[i] = s->objType[i];
+    }
+    if (int rc = upload(c, c->anal, ha.data(), ha.size()))
+        return rc;
+    std::vector<MatPair> hp;
+    build_mat_pairs(s, hp);
+    if (int rc = upload(c, c->matPair, hp.data(), hp.size()))
+        return rc;
+    const size_t nM = s->nMat;
+    if (upload(c, c->E, s->E, nM) || upload(c, c->nu, s->nu, nM) || upload(c, c->CoR, s->CoR, nM * nM) ||
+        upload(c, c->mu, s->mu, nM * nM) || upload(c, c->Crr, s->Crr, nM * nM))
+        return c->lastStatus;
+    if (upload(c, c->famMasks, s->familyMasks, (size_t)DEME_FAMILY_MASK_ENTRIES) ||
+        upload(c, c->famExtra, s->familyExtraMarginSize, (size_t)DEME_NUM_FAMILIES) ||
+        upload(c, c->famFlags, s->familyFlags, (size_t)DEME_NUM_FAMILIES))
+        return c->lastStatus;
+    bool trivial = true;
+    if (s->familyMasks)
+        for (size_t i = 0; i < DEME_FAMILY_MASK_ENTRIES && trivial; i++)
+            trivial = s->familyMasks[i] == 0;
+    if (s->familyExtraMarginSize)
+        for (size_t i = 0; i < DEME_NUM_FAMILIES && trivial; i++)
+            trivial = s->familyExtraMarginSize[i] == 0.f;
+    c->dp.familyTrivial = trivial ? 1u : 0u;
+    // detection scratch
+    if (ensure(c, c->geo, std::max<size_t>(nS, 1) * sizeof(GeoRec)) || ensure(c, c->binLo, std::max<size_t>(nS, 1) * 16) ||
+        ensure(c, c->binN, std::max<size_t>(nS, 1) * 8) || ensure(c, c->counts, (nS + 1) * 4) ||
+        ensure(c, c->offsets, (nS + 1) * 4))
+        return c->lastStatus;
+    {
+        size_t need = 0;
+        HIPCK(rocprim::exclusive_scan(nullptr, need, c->counts.as<uint32_t>(), c->offsets.as<uint32_t>(), 0u, nS + 1,
+                                      rocprim::plus<uint32_t>(), c->stream));
+        if (int rc = ensure(c, c->scanTmp, need))
+            return rc;
+    }
+    if (int rc = grow_incidence_arena(c, std::max<size_t>(8 * nS, 4096)))
+        return rc;
+    if (int rc = grow_contact_arena(c, std::max<size_t>(6 * nS, 4096)))
+        return rc;
+    c->haveScene = true;
+    c->haveList = false;
+    c->mapFresh = false;
+    c->nContacts = c->nPrev = c->nWcStored = 0;
+    c->stepsSinceCD = 0;
+    refresh_dev_params(c);
+    HIPCK(hipStreamSynchronize(c->stream));  // host staging vectors die here
+    return DEME_OK;
+}
+
+static int owner_state_io(deme_ctx* c, const DemeOwnerState* st, int dir) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (!st)
+        return DEME_ERR_INVALID;
+    const size_t n = c->nOwners;
+    // stage: one device buffer holding every SoA column back to back
+    struct Col {
+        void* host;
+        size_t elem;
+        void** dev;
+    };
+    OwnerSoA soa{};
+    Col cols[] = {{st->voxelID, 8, (void**)&soa.voxelID},   {st->locX, 2, (void**)&soa.locX},
+                  {st->locY, 2, (void**)&soa.locY},         {st->locZ, 2, (void**)&soa.locZ},
+                  {st->oriQw, 4, (void**)&soa.oriQw},       {st->oriQx, 4, (void**)&soa.oriQx},
+                  {st->oriQy, 4, (void**)&soa.oriQy},       {st->oriQz, 4, (void**)&soa.oriQz},
+                  {st->vX, 4, (void**)&soa.vX},             {st->vY, 4, (void**)&soa.vY},
+                  {st->vZ, 4, (void**)&soa.vZ},             {st->omgBarX, 4, (void**)&soa.omgBarX},
+                  {st->omgBarY, 4, (void**)&soa.omgBarY},   {st->omgBarZ, 4, (void**)&soa.omgBarZ},
+                  {st->aX, 4, (void**)&soa.aX},             {st->aY, 4, (void**)&soa.aY},
+                  {st->aZ, 4, (void**)&soa.aZ},             {st->alphaX, 4, (void**)&soa.alphaX},
+                  {st->alphaY, 4, (void**)&soa.alphaY},     {st->alphaZ, 4, (void**)&soa.alphaZ},
+                  {st->familyID, 1, (void**)&soa.familyID}};
+    size_t total = 0;
+    for (auto& cl : cols)
+        if (cl.host)
+            total += ((n * cl.elem + 15) / 16) * 16;
+    if (int rc = ensure(c, c->stage, std::max<size_t>(total, 16)))
+        return rc;
+    size_t off = 0;
+    for (auto& cl : cols) {
+        if (!cl.host)
+            continue;
+        *cl.dev = (char*)c->stage.p + off;
+        if (dir == 0)
+            HIPCK(hipMemcpyAsync(*cl.dev, cl.host, n * cl.elem, hipMemcpyHostToDevice, c->stream));
+        off += ((n * cl.elem + 15) / 16) * 16;
+    }
+    // acceleration of "this step" lives in the buffer the last integrate consumed (accCur^1 after the
+    // swap is the zeroed one); expose the most recently accumulated buffer
+    AccRec* accView = c->acc[dir == 1 ? c->accLast : c->accCur].as<AccRec>();
+    if (dir == 0)
+        c->accLast = c->accCur;
+    if (n)
+        hipLaunchKernelGGL(k_pack_owners, dim3(grid_for(n)), dim3(256), 0, c->stream, (uint32_t)n,
+                           c->owners.as<OwnerRec>(), accView, soa, dir);
+    if (dir == 1) {
+        off = 0;
+        for (auto& cl : cols) {
+            if (!cl.host)
+                continue;
+            HIPCK(hipMemcpyAsync(cl.host, (char*)c->stage.p + off, n * cl.elem, hipMemcpyDeviceToHost, c->stream));
+            off += ((n * cl.elem + 15) / 16) * 16;
+        }
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_upload_owner_state(deme_ctx* c, const DemeOwnerState* st) { return owner_state_io(c, st, 0); }
+int deme_download_owner_state(deme_ctx* c, DemeOwnerState* st) { return owner_state_io(c, st, 1); }
+
+int deme_update_tri_nodes(deme_ctx* c, const float*, const float*, const float*) {
+    return fail(c, DEME_ERR_INVALID, "mesh path not built yet");
+}
+
+int deme_compute_margins(deme_ctx* c, uint32_t drift) {
+    if (int rc = check_ready(c))
+        return rc;
+    return do_margins(c, drift);
+}
+
+int deme_set_margins(deme_ctx* c, const float* m) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (!m)
+        return DEME_ERR_INVALID;
+    if (int rc = ensure(c, c->stage, std::max<size_t>(c->nOwners, 4) * 4))
+        return rc;
+    HIPCK(hipMemcpyAsync(c->stage.p, m, (size_t)c->nOwners * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_set_margins, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->nOwners,
+                       c->owners.as<OwnerRec>(), c->stage.as<float>());
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_detect_contacts(deme_ctx* c) {
+    if (int rc = check_ready(c))
+        return rc;
+    return do_detect(c);
+}
+
+int deme_migrate_history(deme_ctx* c) {
+    if (int rc = check_ready(c))
+        return rc;
+    return do_migrate(c);
+}
+
+int deme_calc_forces(deme_ctx* c) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (c->mapFresh)
+        if (int rc = do_migrate(c))
+            return rc;
+    // stand-alone call: clear the accumulators first (prepareAccArrays, DEMPrepForceKernels.cu:32-37)
+    HIPCK(hipMemsetAsync(c->acc[c->accCur].p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
+    return launch_forces(c);
+}
+
+int deme_integrate(deme_ctx* c) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (int rc = launch_integrate(c))
+        return rc;
+    c->nSteps++;
+    c->timeElapsed += (double)c->hp.h;
+    return DEME_OK;
+}
+
+int deme_step(deme_ctx* c, uint32_t nsteps) {
+    if (int rc = check_ready(c))
+        return rc;
+    const uint32_t K = c->hp.cdUpdateFreq;
+    for (uint32_t i = 0; i < nsteps; i++) {
+        if (!c->haveList || K == 0 || c->stepsSinceCD >= K) {
+            if (int rc = do_margins(c, K))
+                return rc;
+            if (int rc = do_detect(c))
+                return rc;
+            if (int rc = do_migrate(c))
+                return rc;
+            c->stepsSinceCD = 0;
+        }
+        if (int rc = launch_forces(c))
+            return rc;
+        if (int rc = launch_integrate(c))
+            return rc;
+        c->stepsSinceCD++;
+        c->nSteps++;
+        c->timeElapsed += (double)c->hp.h;
+    }
+    return DEME_OK;
+}
+
+int deme_get_counts(deme_ctx* c, DemeCounts* out) {
+    if (!c || !out)
+        return DEME_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    out->nContacts = c->nContacts;
+    out->nPrevContacts = c->nPrev;
+    out->nBinSphereTouches = c->nInc;
+    out->nActiveBins = c->nActiveBins;
+    out->nSteps = c->nSteps;
+    out->nDetections = c->nDetections;
+    out->maxSpheresInBin = c->maxInBin;
+    out->lastStatus = c->lastStatus;
+    return DEME_OK;
+}
+
+int deme_download_bin_incidence(deme_ctx* c, uint32_t* bins, uint32_t* sph, size_t cap) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (cap < c->nInc)
+        return fail(c, DEME_ERR_INVALID, "buffer too small: need %llu", (unsigned long long)c->nInc);
+    if (c->nInc) {
+        if (bins)
+            HIPCK(hipMemcpyAsync(bins, c->incKeys[1].p, c->nInc * 4, hipMemcpyDeviceToHost, c->stream));
+        if (sph)
+            HIPCK(hipMemcpyAsync(sph, c->incVals[1].p, c->nInc * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_download_contacts(deme_ctx* c, uint32_t* idA, uint32_t* idB, uint8_t* type, uint32_t* mapping, size_t cap) {
+    if (int rc = check_ready(c))
+        return rc;
+    const size_t n = c->nContacts;
+    if (cap < n)
+        return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    std::vector<uint64_t> k(n);
+    if (n) {
+        HIPCK(hipMemcpyAsync(k.data(), c->keysSorted[c->keysCur].p, n * 8, hipMemcpyDeviceToHost, c->stream));
+        if (mapping)
+            HIPCK(hipMemcpyAsync(mapping, c->mapping.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t cls = key_class(k[i]);
+        if (idA)
+            idA[i] = key_a(k[i]);
+        if (idB)
+            idB[i] = key_b(k[i]);
+        if (type) {
+            if (cls == DEME_KEY_CLASS_SS)
+                type[i] = DEME_SPHERE_SPHERE_CONTACT;
+            else if (cls == DEME_KEY_CLASS_SM)
+                type[i] = DEME_SPHERE_MESH_CONTACT;
+            else
+                type[i] = (c->hObjType[key_b(k[i])] == DEME_ANAL_OBJ_TYPE_PLANE) ? DEME_SPHERE_PLANE_CONTACT
+                                                                                   : DEME_SPHERE_CYL_CONTACT;
+        }
+    }
+    return DEME_OK;
+}
+
+int deme_download_contact_wildcard(deme_ctx* c, uint32_t w, float* out, size_t cap) {
+    if (int rc = check_ready(c))
+        return rc;
+    const uint32_t nW = c->hp.nContactWildcards;
+    if (w >= nW)
+        return fail(c, DEME_ERR_INVALID, "wildcard %u out of range (%u)", w, nW);
+    if (c->mapFresh)
+        if (int rc = do_migrate(c))
+            return rc;
+    const size_t n = c->nContacts;
+    if (cap < n)
+        return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    std::vector<float> h(n * nW);
+    if (n)
+        HIPCK(hipMemcpyAsync(h.data(), c->wc[c->wcCur].p, n * nW * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++)
+        out[i] = h[i * nW + w];
+    return DEME_OK;
+}
+
+int deme_upload_contact_wildcard(deme_ctx* c, uint32_t w, const float* in, size_t n) {
+    if (int rc = check_ready(c))
+        return rc;
+    const uint32_t nW = c->hp.nContactWildcards;
+    if (w >= nW || n != c->nContacts)
+        return fail(c, DEME_ERR_INVALID, "wildcard upload: index %u of %u, %zu values for %llu contacts", w, nW, n,
+                    (unsigned long long)c->nContacts);
+    if (c->mapFresh)
+        if (int rc = do_migrate(c))
+            return rc;
+    std::vector<float> h(n * nW);
+    if (n)
+        HIPCK(hipMemcpyAsync(h.data(), c->wc[c->wcCur].p, n * nW * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++)
+        h[i * nW + w] = in[i];
+    if (n)
+        HIPCK(hipMemcpyAsync(c->wc[c->wcCur].p, h.data(), n * nW * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_set_record_contacts(deme_ctx* c, int enable) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    c->record = enable != 0;
+    if (c->record && c->cntCap)
+        for (int k = 0; k < 4; k++)
+            if (int rc = ensure(c, c->rec[k], c->cntCap * 12))
+                return rc;
+    return DEME_OK;
+}
+
+int deme_download_contact_records(deme_ctx* c, float* force, float* torqueOnly, float* cpA, float* cpB, size_t cap) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (!c->record)
+        return fail(c, DEME_ERR_INVALID, "contact recording is off (deme_set_record_contacts)");
+    const size_t n = c->nContacts;
+    if (cap < n)
+        return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    float* dst[4] = {force, torqueOnly, cpA, cpB};
+    for (int k = 0; k < 4; k++)
+        if (dst[k] && n)
+            HIPCK(hipMemcpyAsync(dst[k], c->rec[k].p, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_download_sphere_geometry(deme_ctx* c, double* X, double* Y, double* Z, float* R, size_t cap) {
+    if (int rc = check_ready(c))
+        return rc;
+    const size_t n = c->nSpheres;
+    if (cap < n)
+        return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    std::vector<GeoRec> h(n);
+    if (n)
+        HIPCK(hipMemcpyAsync(h.data(), c->geo.p, n * sizeof(GeoRec), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        if (X) X[i] = h[i].x;
+        if (Y) Y[i] = h[i].y;
+        if (Z) Z[i] = h[i].z;
+        if (R) R[i] = h[i].r;
+    }
+    return DEME_OK;
+}
+
+int deme_compile_force_model(deme_ctx* c, const char*, size_t, const char* const*, uint32_t, const char*) {
+    return fail(c, DEME_ERR_COMPILE, "run-time force-model compilation is not built yet");
+}
+
+int deme_set_timing(deme_ctx* c, int enable) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    c->timing = enable != 0;
+    return DEME_OK;
+}
+int deme_kernel_time_reset(deme_ctx* c) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    for (auto& kv : c->timers) {
+        kv.second.total_ms = 0;
+        kv.second.launches = 0;
+    }
+    return DEME_OK;
+}
+int deme_kernel_time_ms(deme_ctx* c, const char* name, double* avg_ms, uint64_t* launches) {
+    if (!c || !name)
+        return DEME_ERR_INVALID;
+    hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    auto it = c->timers.find(name);
+    const double tot = it == c->timers.end() ? 0.0 : it->second.total_ms;
+    const uint64_t n = it == c->timers.end() ? 0 : it->second.launches;
+    if (avg_ms)
+        *avg_ms = n ? tot / (double)n : 0.0;
+    if (launches)
+        *launches = n;
+    return DEME_OK;
+}
+
+int deme_halo_pack(deme_ctx* c, const uint32_t* d_ids, uint32_t n, void* d_buf) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (n)
+        hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(n)), dim3(256), 0, c->stream, n, d_ids, c->owners.as<OwnerRec>(),
+                           (GhostRec*)d_buf);
+    return DEME_OK;
+}
+int deme_halo_unpack(deme_ctx* c, const uint32_t* d_ids, uint32_t n, const void* d_buf) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (n)
+        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->stream, n, d_ids, c->owners.as<OwnerRec>(),
+                           (const GhostRec*)d_buf);
+    return DEME_OK;
+}
+
+}  // extern "C"

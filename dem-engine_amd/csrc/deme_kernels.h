@@ -1,0 +1,580 @@
+// deme_kernels.h -- contact-detection, margin and integration kernels (gfx950).
+//
+// Pipeline of one contact-detection update (replaces algorithms/DEMCubContactDetection.cu:38-1123,
+// which runs ~7 radix sorts, 6 scans, 3 run-length encodes and >=10 host syncs):
+//   k_sphere_prep   sphere world geometry + bin span + sphere-analytical contacts   (1 pass)
+//   exclusive scan  of per-sphere bin counts                                         (rocPRIM)
+//   k_fill_incidence (bin, sphere) pairs in sphere order
+//   radix sort      pairs by bin (only ceil(log2(nBins)) key bits)                   (rocPRIM)
+//   k_sweep         LDS-staged chunks of the bin-sorted list, all pairs inside a bin,
+//                   contact-point-in-this-bin de-duplication, wavefront ballot/prefix
+//                   compaction into 64-bit contact keys (single sweep, no count pass)
+//   radix sort      contact keys -> canonical order (type class, A, B)               (rocPRIM)
+//   k_history       new->previous index by binary search over the previous sorted keys
+#pragma once
+#include "deme_device.h"
+
+namespace deme_dev {
+
+#define DEME_NULL_BINID_DEV 0xFFFFFFFFu
+// device status bits (host reads them at sync points)
+#define DEME_ST_VELOCITY 1u
+#define DEME_ST_NONFINITE 2u
+
+struct DetectCounters {  // one 64-byte block of device counters, zeroed per detection
+    unsigned long long nContactsRaw;  // keys appended (may exceed capacity: then nothing was written past it)
+    unsigned int nActiveBins;
+    unsigned int maxInBin;
+    unsigned int status;
+    unsigned int pad[11];
+};
+
+// ---------------------------------------------------------------------------
+// kernel/DEMMiscKernels.cu:37-61 (computeMarginFromAbsv) with the "absv" inspector
+// (DEM/AuxClasses.cpp:54-61) and the max-velocity check of DEM/kT.cpp:136-149.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_margins(const DevParams p, OwnerRec* owners, uint32_t drift,
+                                                 DetectCounters* ctr) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= p.nOwners)
+        return;
+    OwnerRec* r = owners + o;
+    const double vx = r->vx, vy = r->vy, vz = r->vz;
+    float absv = (float)sqrt(vx * vx + vy * vy + vz * vz);
+    if (!isfinite(absv))
+        atomicOr(&ctr->status, DEME_ST_NONFINITE);
+    else if (absv > p.errOutVel)
+        atomicOr(&ctr->status, DEME_ST_VELOCITY);
+    if (absv > p.approxMaxVel)
+        absv = p.approxMaxVel;
+    const float extra = p.familyTrivial ? 0.f : p.familyExtra[r->family];
+    r->margin = (float)((double)(absv * p.expSafetyMulti + p.expSafetyAdder) * (double)p.h * (double)drift + (double)extra);
+}
+
+__global__ __launch_bounds__(256) void k_set_margins(uint32_t n, OwnerRec* owners, const float* m) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < n)
+        owners[o].margin = m[o];
+}
+
+// ---------------------------------------------------------------------------
+// Per sphere: world position (fp64) and inflated radii, bin span, sphere-analytical contacts.
+// kernel/DEMBinSphereKernels.cu:11-131 (getNumberOfBinsEachSphereTouches) + the analytical half of
+// :133-278 (populateBinSphereTouchingPairs), fused: one pass, contacts appended as keys.
+// ---------------------------------------------------------------------------
+struct ObjWorld {
+    double x, y, z;
+    float dx, dy, dz;
+    float size1, nsign, margin;
+    uint32_t type, family;
+};
+
+__global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const OwnerRec* __restrict__ owners,
+                                                     const SphereRec* __restrict__ spheres, GeoRec* __restrict__ geo,
+                                                     uint4* __restrict__ binLo, uint2* __restrict__ binN,
+                                                     uint32_t* __restrict__ counts, uint64_t* __restrict__ outKeys,
+                                                     uint64_t cap, DetectCounters* ctr) {
+    __shared__ ObjWorld sObj[64];
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = s < p.nSpheres;
+    d3 pos{0, 0, 0};
+    double rBin = 0;
+    uint32_t fam = 0;
+    if (valid) {
+        const SphereRec sr = load_sphere(spheres, s);
+        const OwnerRec o = load_owner(owners, sr.owner);
+        const float4 c = p.comp[sr.comp];
+        const d3 op = decode_pos(o.voxelID, o.locX, o.locY, o.locZ, p);
+        const f3 rel = rot_apply(rot_coeffs(o.qw, o.qx, o.qy, o.qz), mk3(c.x, c.y, c.z));
+        pos = {op.x + (double)rel.x, op.y + (double)rel.y, op.z + (double)rel.z};
+        rBin = (double)c.w;
+        rBin += o.margin;  // fp64 sum, DEMBinSphereKernels.cu:36
+        float rSweep = c.w;
+        rSweep += o.margin;  // fp32 sum, DEMContactKernels_SphereSphere.cu:40
+        fam = o.family;
+        GeoRec g;
+        g.x = pos.x, g.y = pos.y, g.z = pos.z, g.r = rSweep, g.owner = sr.owner;
+        geo[s] = g;
+        uint32_t lx, hx, ly, hy, lz, hz;
+        bin_range(pos.x, rBin, p.binSize, p.nbX, lx, hx);
+        bin_range(pos.y, rBin, p.binSize, p.nbY, ly, hy);
+        bin_range(pos.z, rBin, p.binSize, p.nbZ, lz, hz);
+        const uint32_t nx = hx - lx + 1, ny = hy - ly + 1, nz = hz - lz + 1;
+        binLo[s] = make_uint4(lx, ly, lz, nx);
+        binN[s] = make_uint2(ny, nz);
+        counts[s] = nx * ny * nz;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        counts[p.nSpheres] = 0;  // scan sentinel: offsets[nSpheres] = total
+
+    for (uint32_t ob0 = 0; ob0 < p.nAnal; ob0 += 64) {
+        __syncthreads();
+        if (threadIdx.x < 64 && ob0 + threadIdx.x < p.nAnal) {
+            const AnalObj ob = p.anal[ob0 + threadIdx.x];
+            const OwnerRec o = load_owner(owners, ob.owner);
+            const d3 op = decode_pos(o.voxelID, o.locX, o.locY, o.locZ, p);
+            const RotM m = rot_coeffs(o.qw, o.qx, o.qy, o.qz);
+            const f3 rp = rot_apply(m, mk3(ob.relx, ob.rely, ob.relz));
+            const f3 rd = rot_apply(m, mk3(ob.rotx, ob.roty, ob.rotz));
+            ObjWorld w;
+            w.x = op.x + (double)rp.x, w.y = op.y + (double)rp.y, w.z = op.z + (double)rp.z;
+            w.dx = rd.x, w.dy = rd.y, w.dz = rd.z;
+            w.size1 = ob.size1, w.nsign = ob.normal, w.margin = o.margin;
+            w.type = ob.type, w.family = o.family;
+            sObj[threadIdx.x] = w;
+        }
+        __syncthreads();
+        if (valid) {
+            const uint32_t nHere = min(64u, p.nAnal - ob0);
+            for (uint32_t k = 0; k < nHere; k++) {
+                const ObjWorld w = sObj[k];
+                float thres = 0.f;
+                if (!p.familyTrivial) {
+                    if (p.familyMasks[mask_pair(fam, w.family)] != 0)
+                        continue;
+                    const float ea = p.familyExtra[fam], eb = p.familyExtra[w.family];
+                    thres = (ea < eb) ? ea : eb;
+                }
+                d3 cp;
+                f3 nr;
+                double depth;
+                const uint32_t t = sphere_entity(pos, (float)rBin, w.type, {w.x, w.y, w.z}, mk3(w.dx, w.dy, w.dz),
+                                                 w.size1, w.nsign, w.margin, cp, nr, depth);
+                if (t && depth > (double)thres) {
+                    const unsigned long long slot = atomicAdd(&ctr->nContactsRaw, 1ull);
+                    if (slot < cap)
+                        outKeys[slot] = make_key(DEME_KEY_CLASS_SA, s, ob0 + k);
+                }
+            }
+        }
+    }
+}
+
+// kernel/DEMBinSphereKernels.cu:181-211: z-y-x loop nest, sphere-major output
+__global__ __launch_bounds__(256) void k_fill_incidence(const DevParams p, const uint4* __restrict__ binLo,
+                                                        const uint2* __restrict__ binN,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        uint64_t cap) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.nSpheres)
+        return;
+    const uint4 lo = binLo[s];
+    const uint2 n = binN[s];
+    uint64_t off = offsets[s];
+    for (uint32_t k = lo.z; k < lo.z + n.y; k++)
+        for (uint32_t j = lo.y; j < lo.y + n.x; j++)
+            for (uint32_t i = lo.x; i < lo.x + lo.w; i++) {
+                if (off < cap) {
+                    keys[off] = i + j * p.nbX + k * p.nbX * p.nbY;  // binIDFrom3Indices, DEMHelperKernels.cuh:339-347
+                    vals[off] = s;
+                }
+                off++;
+            }
+}
+
+// ---------------------------------------------------------------------------
+// Bin sweep.  One workgroup owns SW_T consecutive entries of the bin-sorted incidence list and
+// stages their sphere geometry in LDS.  Entry t is paired with every EARLIER entry of the same bin
+// (walking backwards through LDS, then -- only for a bin that began in an earlier chunk -- through
+// global memory), so each unordered pair of a bin is tested exactly once, by the thread of its
+// later member.  Decision arithmetic: DEMContactKernels_SphereSphere.cu:57-89 (calcContactPoint)
+// and :177-216; the pair counts iff the contact point's bin is this bin.
+// Output: wavefront ballot + prefix compaction into an LDS buffer, one global reservation per
+// workgroup, coalesced copy-out.
+// ---------------------------------------------------------------------------
+#define SW_T 256
+#define SW_OUT 1536
+
+struct SweepLDS {
+    double x[SW_T], y[SW_T], z[SW_T];
+    float r[SW_T];
+    uint32_t owner[SW_T], sph[SW_T], bin[SW_T], fam[SW_T];
+    uint64_t out[SW_OUT];
+    unsigned long long gBase;
+    uint32_t nOut;
+};
+
+__device__ inline bool pair_test(const DevParams& p, double ax, double ay, double az, float ar, uint32_t ao,
+                                 uint32_t af, double bx, double by, double bz, float br, uint32_t bo, uint32_t bf,
+                                 uint32_t bin) {
+    if (ao == bo)
+        return false;
+    float am = 0.f;
+    if (!p.familyTrivial) {
+        if (p.familyMasks[mask_pair(af, bf)] != 0)
+            return false;
+        const float ea = p.familyExtra[af], eb = p.familyExtra[bf];
+        am = (ea < eb) ? ea : eb;
+    }
+    d3 cp;
+    f3 n;
+    double depth;
+    bool in = spheres_overlap(ax, ay, az, (double)ar, bx, by, bz, (double)br, cp, n, depth);
+    in = in && (depth > (double)am);
+    return in && (point_bin(cp.x, cp.y, cp.z, p) == bin);
+}
+
+__global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_t* __restrict__ keys,
+                                                const uint32_t* __restrict__ sphIds, uint32_t P,
+                                                const GeoRec* __restrict__ geo, const OwnerRec* __restrict__ owners,
+                                                uint64_t* __restrict__ outKeys, uint64_t cap, DetectCounters* ctr) {
+    __shared__ SweepLDS L;
+    const uint32_t t = threadIdx.x;
+    const uint32_t base = blockIdx.x * SW_T;
+    const uint32_t j = base + t;
+    const bool valid = j < P;
+    const uint32_t lane = t & 63u;
+    if (t == 0)
+        L.nOut = 0;
+    uint32_t myBin = DEME_NULL_BINID_DEV, mySph = 0, myOwner = 0, myFam = 0;
+    double mx = 0, my = 0, mz = 0;
+    float mr = 0;
+    if (valid) {
+        myBin = keys[j];
+        mySph = sphIds[j];
+        const GeoRec g = geo[mySph];
+        mx = g.x, my = g.y, mz = g.z, mr = g.r, myOwner = g.owner;
+        if (!p.familyTrivial)
+            myFam = owners[myOwner].family;
+    }
+    L.x[t] = mx, L.y[t] = my, L.z[t] = mz, L.r[t] = mr;
+    L.owner[t] = myOwner, L.sph[t] = mySph, L.bin[t] = myBin, L.fam[t] = myFam;
+    __syncthreads();
+
+    // statistics: active bins (segment heads) and the largest bin (rank of its last entry + 1)
+    const uint32_t prevBin = (j == 0) ? DEME_NULL_BINID_DEV : ((t == 0) ? keys[j - 1] : L.bin[t - 1]);
+    const bool head = valid && (myBin != prevBin);
+    {
+        const unsigned long long hm = __ballot(head);
+        if (lane == 0 && hm)
+            atomicAdd(&ctr->nActiveBins, (unsigned int)__popcll(hm));
+    }
+
+    uint32_t rank = 0;  // number of earlier entries in my bin
+    // ---- phase 1: partners inside this chunk (LDS)
+    int i = (int)t - 1;
+    while (true) {
+        const bool act = valid && (i >= 0) && (L.bin[i >= 0 ? i : 0] == myBin);
+        if (!__any(act))
+            break;
+        bool hit = false;
+        uint64_t key = 0;
+        if (act) {
+            rank++;
+            hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], mx, my, mz, mr, myOwner, myFam, myBin);
+            if (hit) {
+                const uint32_t a = L.sph[i];
+                key = (a < mySph) ? make_key(DEME_KEY_CLASS_SS, a, mySph) : make_key(DEME_KEY_CLASS_SS, mySph, a);
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t pos0 = 0;
+            if ((int)lane == leader)
+                pos0 = atomicAdd(&L.nOut, (uint32_t)__popcll(m));
+            pos0 = __shfl(pos0, leader);
+            if (hit) {
+                const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < SW_OUT) {
+                    L.out[pos] = key;
+                } else {  // LDS buffer full: spill straight to global
+                    const unsigned long long slot = atomicAdd(&ctr->nContactsRaw, 1ull);
+                    if (slot < cap)
+                        outKeys[slot] = key;
+                }
+            }
+        }
+        i--;
+    }
+    // ---- phase 2: my bin began in an earlier chunk (only lanes that ran off the front of LDS)
+    {
+        long long g = (long long)base - 1;
+        bool more = valid && (i < 0) && (base > 0) && (L.bin[0] == myBin);
+        while (true) {
+            bool act = more && (g >= 0);
+            uint32_t oSph = 0;
+            if (act) {
+                act = (keys[g] == myBin);
+                more = act;
+            }
+            if (!__any(act))
+                break;
+            bool hit = false;
+            uint64_t key = 0;
+            if (act) {
+                rank++;
+                oSph = sphIds[g];
+                const GeoRec og = geo[oSph];
+                const uint32_t of = p.familyTrivial ? 0u : owners[og.owner].family;
+                hit = pair_test(p, og.x, og.y, og.z, og.r, og.owner, of, mx, my, mz, mr, myOwner, myFam, myBin);
+                if (hit)
+                    key = (oSph < mySph) ? make_key(DEME_KEY_CLASS_SS, oSph, mySph) : make_key(DEME_KEY_CLASS_SS, mySph, oSph);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t pos0 = 0;
+                if ((int)lane == leader)
+                    pos0 = atomicAdd(&L.nOut, (uint32_t)__popcll(m));
+                pos0 = __shfl(pos0, leader);
+                if (hit) {
+                    const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < SW_OUT) {
+                        L.out[pos] = key;
+                    } else {
+                        const unsigned long long slot = atomicAdd(&ctr->nContactsRaw, 1ull);
+                        if (slot < cap)
+                            outKeys[slot] = key;
+                    }
+                }
+            }
+            g--;
+        }
+    }
+    // last entry of a bin knows the bin's population
+    {
+        const uint32_t nextBin = (j + 1 < P) ? ((t + 1 < SW_T) ? L.bin[t + 1] : keys[j + 1]) : DEME_NULL_BINID_DEV;
+        uint32_t pop = (valid && nextBin != myBin) ? rank + 1 : 0;
+        for (int off = 32; off > 0; off >>= 1)
+            pop = max(pop, (uint32_t)__shfl_xor((int)pop, off));
+        if (lane == 0 && pop > 1)
+            atomicMax(&ctr->maxInBin, pop);
+    }
+    __syncthreads();
+    const uint32_t nOut = min(L.nOut, (uint32_t)SW_OUT);
+    if (t == 0)
+        L.gBase = nOut ? atomicAdd(&ctr->nContactsRaw, (unsigned long long)nOut) : 0ull;
+    __syncthreads();
+    for (uint32_t k = t; k < nOut; k += SW_T) {
+        const unsigned long long slot = L.gBase + k;
+        if (slot < cap)
+            outKeys[slot] = L.out[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// History map + wildcard migration.  Semantics of kernel/DEMHistoryMappingKernels.cu:17-61
+// ("same (A, B, type) as in the previous list") and kernel/DEMPrepForceKernels.cu:46-68
+// (rearrangeContactWildcards); the per-sphere linear search becomes a binary search because both
+// lists are key-sorted.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_history(uint32_t nNew, const uint64_t* __restrict__ newKeys, uint32_t nPrev,
+                                                 const uint64_t* __restrict__ prevKeys, uint32_t* __restrict__ mapping) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nNew)
+        return;
+    const uint64_t k = newKeys[c];
+    uint32_t lo = 0, hi = nPrev;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (prevKeys[mid] < k)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    mapping[c] = (lo < nPrev && prevKeys[lo] == k) ? lo : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void k_migrate(uint32_t nNew, uint32_t nW, const uint32_t* __restrict__ mapping,
+                                                 uint32_t nPrevStored, const float* __restrict__ oldW,
+                                                 float* __restrict__ newW) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nNew)
+        return;
+    const uint32_t m = mapping[c];
+    const bool have = (m != 0xFFFFFFFFu) && (m < nPrevStored);
+    if (nW == 4) {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (have)
+            v = reinterpret_cast<const float4*>(oldW)[m];
+        reinterpret_cast<float4*>(newW)[c] = v;
+    } else {
+        for (uint32_t w = 0; w < nW; w++)
+            newW[(size_t)c * nW + w] = have ? oldW[(size_t)m * nW + w] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Integration.  kernel/DEMIntegrationKernels.cu:100-264 (integrateVelPos / integrateOwners) with the
+// pass-on of IntegrationVelPassOn*.cu; fixed families follow SetFamilyFixed (APIPublic.cpp:980-1011).
+// Fused with the clearing of the NEXT step's accumulators (DEMPrepForceKernels.cu:15-37): the
+// accumulators are double-buffered so this step's a/alpha stay readable.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* __restrict__ owners,
+                                                   const AccRec* __restrict__ acc, AccRec* __restrict__ accNext) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= p.nOwners)
+        return;
+    OwnerRec r = load_owner(owners, o);
+    const float4* ap = reinterpret_cast<const float4*>(acc + o);
+    const float4 a = ap[0], al = ap[1];
+    float4* zp = reinterpret_cast<float4*>(accNext + o);
+    zp[0] = make_float4(0, 0, 0, 0);
+    zp[1] = make_float4(0, 0, 0, 0);
+
+    const bool fixed = (p.familyFlags[r.family] & 1u) != 0;
+    const float h = p.h;
+    f3 old_v = mk3(r.vx, r.vy, r.vz), old_w = mk3(r.wx, r.wy, r.wz);
+    d3 X = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);
+    X.x += (double)p.LBFX;
+    X.y += (double)p.LBFY;
+    X.z += (double)p.LBFZ;
+    f3 v_upd = mk3(0, 0, 0), w_upd = mk3(0, 0, 0);
+    if (fixed) {
+        r.vx = r.vy = r.vz = 0.f;
+        r.wx = r.wy = r.wz = 0.f;
+        old_v = mk3(0, 0, 0);
+        old_w = mk3(0, 0, 0);
+    } else {
+        v_upd.x = (a.x + 0.f + p.Gx) * h;
+        r.vx += v_upd.x;
+        v_upd.y = (a.y + 0.f + p.Gy) * h;
+        r.vy += v_upd.y;
+        v_upd.z = (a.z + 0.f + p.Gz) * h;
+        r.vz += v_upd.z;
+        w_upd.x = (al.x + 0.f) * h;
+        r.wx += w_upd.x;
+        w_upd.y = (al.y + 0.f) * h;
+        r.wy += w_upd.y;
+        w_upd.z = (al.z + 0.f) * h;
+        r.wz += w_upd.z;
+    }
+    f3 v, w;
+    if (p.integrator == 0) {
+        v = old_v;
+        w = old_w;
+    } else if (p.integrator == 1) {
+        v = old_v + v_upd;
+        w = old_w + w_upd;
+    } else {
+        v = old_v + v_upd * 0.5f;
+        w = old_w + w_upd * 0.5f;
+    }
+    if (!fixed) {
+        X.x += (double)v.x * h;
+        X.y += (double)v.y * h;
+        X.z += (double)v.z * h;
+    }
+    X.x -= (double)p.LBFX;
+    X.y -= (double)p.LBFY;
+    X.z -= (double)p.LBFZ;
+    encode_pos(X, p, r.voxelID, r.locX, r.locY, r.locZ);
+    if (!fixed) {
+        const float hh = (float)(0.5 * h);
+        const f3 ha = hh * w;
+        // HamiltonProduct(q, (1, ha)) : DEMHelperKernels.cuh:228-245
+        const float a1 = r.qw, b1 = r.qx, c1 = r.qy, d1 = r.qz;
+        const float a2 = 1.0f, b2 = ha.x, c2 = ha.y, d2 = ha.z;
+        const float qw = a1 * a2 - b1 * b2 - c1 * c2 - d1 * d2;
+        const float qx = a1 * b2 + b1 * a2 + c1 * d2 - d1 * c2;
+        const float qy = a1 * c2 - b1 * d2 + c1 * a2 + d1 * b2;
+        const float qz = a1 * d2 + b1 * c2 - c1 * b2 + d1 * a2;
+        const float len = sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
+        r.qw = qw / len;
+        r.qx = qx / len;
+        r.qy = qy / len;
+        r.qz = qz / len;
+    }
+    store_owner(owners, o, r);
+}
+
+// ---- packing between the C-ABI's SoA view and the device records -------------------------------
+struct OwnerSoA {
+    uint64_t* voxelID;
+    uint16_t *locX, *locY, *locZ;
+    float *oriQw, *oriQx, *oriQy, *oriQz, *vX, *vY, *vZ, *omgBarX, *omgBarY, *omgBarZ;
+    float *aX, *aY, *aZ, *alphaX, *alphaY, *alphaZ;
+    uint8_t* familyID;
+    uint16_t* inertiaPropOffsets;
+};
+
+// dir 0: SoA -> records (null members keep the record's value); dir 1: records -> SoA
+__global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owners, AccRec* acc, OwnerSoA s, int dir) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n)
+        return;
+    OwnerRec r = owners[o];
+    AccRec a = acc[o];
+    if (dir == 0) {
+        if (s.voxelID) r.voxelID = s.voxelID[o];
+        if (s.locX) r.locX = s.locX[o];
+        if (s.locY) r.locY = s.locY[o];
+        if (s.locZ) r.locZ = s.locZ[o];
+        if (s.oriQw) r.qw = s.oriQw[o];
+        if (s.oriQx) r.qx = s.oriQx[o];
+        if (s.oriQy) r.qy = s.oriQy[o];
+        if (s.oriQz) r.qz = s.oriQz[o];
+        if (s.vX) r.vx = s.vX[o];
+        if (s.vY) r.vy = s.vY[o];
+        if (s.vZ) r.vz = s.vZ[o];
+        if (s.omgBarX) r.wx = s.omgBarX[o];
+        if (s.omgBarY) r.wy = s.omgBarY[o];
+        if (s.omgBarZ) r.wz = s.omgBarZ[o];
+        if (s.familyID) r.family = s.familyID[o];
+        if (s.inertiaPropOffsets) r.inertiaOff = s.inertiaPropOffsets[o];
+        if (s.aX) a.ax = s.aX[o];
+        if (s.aY) a.ay = s.aY[o];
+        if (s.aZ) a.az = s.aZ[o];
+        if (s.alphaX) a.lx = s.alphaX[o];
+        if (s.alphaY) a.ly = s.alphaY[o];
+        if (s.alphaZ) a.lz = s.alphaZ[o];
+        owners[o] = r;
+        acc[o] = a;
+    } else {
+        if (s.voxelID) s.voxelID[o] = r.voxelID;
+        if (s.locX) s.locX[o] = r.locX;
+        if (s.locY) s.locY[o] = r.locY;
+        if (s.locZ) s.locZ[o] = r.locZ;
+        if (s.oriQw) s.oriQw[o] = r.qw;
+        if (s.oriQx) s.oriQx[o] = r.qx;
+        if (s.oriQy) s.oriQy[o] = r.qy;
+        if (s.oriQz) s.oriQz[o] = r.qz;
+        if (s.vX) s.vX[o] = r.vx;
+        if (s.vY) s.vY[o] = r.vy;
+        if (s.vZ) s.vZ[o] = r.vz;
+        if (s.omgBarX) s.omgBarX[o] = r.wx;
+        if (s.omgBarY) s.omgBarY[o] = r.wy;
+        if (s.omgBarZ) s.omgBarZ[o] = r.wz;
+        if (s.familyID) s.familyID[o] = (uint8_t)r.family;
+        if (s.aX) s.aX[o] = a.ax;
+        if (s.aY) s.aY[o] = a.ay;
+        if (s.aZ) s.aZ[o] = a.az;
+        if (s.alphaX) s.alphaX[o] = a.lx;
+        if (s.alphaY) s.alphaY[o] = a.ly;
+        if (s.alphaZ) s.alphaZ[o] = a.lz;
+    }
+}
+
+// ghost-owner exchange records for the slab decomposition: pose + velocities + family
+struct __attribute__((aligned(8))) GhostRec {
+    uint64_t voxelID;
+    uint16_t locX, locY, locZ, family;
+    float qw, qx, qy, qz, vx, vy, vz, wx, wy, wz;
+};
+static_assert(sizeof(GhostRec) == 56, "ghost record is 56 bytes");
+
+__global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const uint32_t* ids, const OwnerRec* owners, GhostRec* buf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const OwnerRec r = load_owner(owners, ids[i]);
+    GhostRec g;
+    g.voxelID = r.voxelID, g.locX = r.locX, g.locY = r.locY, g.locZ = r.locZ, g.family = (uint16_t)r.family;
+    g.qw = r.qw, g.qx = r.qx, g.qy = r.qy, g.qz = r.qz;
+    g.vx = r.vx, g.vy = r.vy, g.vz = r.vz, g.wx = r.wx, g.wy = r.wy, g.wz = r.wz;
+    buf[i] = g;
+}
+__global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n, const uint32_t* ids, OwnerRec* owners, const GhostRec* buf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const GhostRec g = buf[i];
+    OwnerRec* r = owners + ids[i];
+    r->voxelID = g.voxelID, r->locX = g.locX, r->locY = g.locY, r->locZ = g.locZ, r->family = g.family;
+    r->qw = g.qw, r->qx = g.qx, r->qy = g.qy, r->qz = g.qz;
+    r->vx = g.vx, r->vy = g.vy, r->vz = g.vz, r->wx = g.wx, r->wy = g.wy, r->wz = g.wz;
+}
+
+}  // namespace deme_dev

@@ -302,6 +302,11 @@ class OracleSim:
         return X, Y, Z, R
 
 
+def make_sim(pkg, p, sc):
+    """Oracle twin of a dem_engine_amd.Context built from the same params/scene structs."""
+    return OracleSim(p, sc, pkg.abi.STATE_DTYPES, pkg.DemeCounts, pkg.abi.make_state_struct)
+
+
 def num_threads():
     return lib().orc_num_threads()
 

@@ -32,5 +32,3 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "elementwise.npz"))
 
 
-def make_oracle_sim(pkg, orc, p, sc):
-    return orc.OracleSim(p, sc, pkg.abi.STATE_DTYPES, pkg.DemeCounts, pkg.abi.make_state_struct)

@@ -1,0 +1,115 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/deme_hip.h declares (no compute
+calls without a GPU), ctypes layouts match the header, and the host-side model builder reproduces the
+reference's sizing rules."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.abi.load_library()
+    names = pkg.abi.exported_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/deme_hip.h but not exported"
+    assert b"gfx950" in lib.deme_version()
+
+
+def test_no_device_is_a_loud_error(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.abi.DemeError):
+        pkg.Context(0)
+
+
+def test_struct_layouts_match_header(pkg):
+    # sizes computed by a C compiler from the real header
+    import subprocess
+    import tempfile
+    src = ('#include <stdio.h>\n#include "deme_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(DemeParams),'
+           'sizeof(DemeScene),sizeof(DemeOwnerState),sizeof(DemeCounts));}')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o",
+                               os.path.join(d, "s")])
+        out = subprocess.check_output([os.path.join(d, "s")]).split()
+    got = [C.sizeof(pkg.DemeParams), C.sizeof(pkg.DemeScene), C.sizeof(pkg.DemeOwnerState), C.sizeof(pkg.DemeCounts)]
+    assert [int(x) for x in out] == got
+
+
+def test_product_never_touches_the_oracle(pkg):
+    for dp, _, files in os.walk(os.path.join(ROOT, "dem-engine_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "libdeme_oracle" not in txt and "/root/reference" not in txt, f
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
+                assert not re.search(r"#include\s*[\"<][^\">]*oracle", txt), f
+
+
+def test_voxel_bit_split_and_bins(pkg):
+    b = pkg.SceneBuilder()
+    m = b.LoadMaterial({"E": 1e8, "nu": 0.3, "CoR": 0.5})
+    b.InstructBoxDomainDimension(0.2, 0.2, 2.0)  # BallDrop box (DEMdemo_BallDrop.cpp)
+    b.InstructBoxDomainBoundingBC("top_open", m)
+    t = b.LoadSphereType(1e-3, 0.00125, m)
+    b.AddClumps(t, [[0, 0, 0]])
+    p, sc = b.Initialize()
+    assert p.nvXp2 + p.nvYp2 + p.nvZp2 == 64
+    assert (p.nvXp2, p.nvYp2, p.nvZp2) == (20, 21, 23)  # z is 10x longer: 3 more bits; the left-over bit goes to y
+    assert p.voxelSize == 65536 * p.l
+    # the voxel grid covers the (20% enlarged) target box in every direction
+    for n, size in ((p.nvXp2, 0.24), (p.nvYp2, 0.24), (p.nvZp2, 2.4)):
+        assert p.voxelSize * 2 ** n >= size * 0.999999
+    assert p.binSize == pytest.approx(8 * 0.00125)
+    assert p.nbX == int(p.voxelSize * 2 ** p.nvXp2 / p.binSize) + 1
+    assert sc.nAnal == 5 and sc.nOwners == 2
+    # wall planes sit on the USER box faces, normals inward
+    a = b.arrays
+    assert a["objRelPosZ"][0] == np.float32(-1.0) and a["objRotZ"][0] == 1.0
+    assert a["familyID"][1] == 255 and a["familyFlags"][255] == 1
+
+
+def test_position_encoding_matches_oracle(pkg, orc):
+    b = pkg.model.packed_bed(500, seed=3)
+    p, sc = b.Initialize()
+    xyz = np.concatenate([bb.xyz for bb in b.batches]).astype(np.float32)
+    lbf = np.array([p.LBFX, p.LBFY, p.LBFZ], np.float32)
+    sh = (xyz - lbf).astype(np.float32).astype(np.float64)
+    vid, sx, sy, sz = orc.encode("orc", np.ascontiguousarray(sh[:, 0]), np.ascontiguousarray(sh[:, 1]),
+                                 np.ascontiguousarray(sh[:, 2]), p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    n = len(xyz)
+    assert (b.arrays["voxelID"][:n] == vid).all() and (b.arrays["locX"][:n] == sx).all()
+    assert (b.arrays["locY"][:n] == sy).all() and (b.arrays["locZ"][:n] == sz).all()
+
+
+def test_three_sphere_template_and_pair_matrix(pkg):
+    b = pkg.SceneBuilder()
+    m0 = b.LoadMaterial({"E": 1e8, "nu": 0.3, "CoR": 0.6, "mu": 0.2, "Crr": 0.0})
+    m1 = b.LoadMaterial({"E": 1e9, "nu": 0.3, "CoR": 0.8, "mu": 0.4, "Crr": 0.1})
+    b.SetMaterialPropertyPair("mu", m0, m1, 0.5)
+    t = b.LoadThreeSphereClump(0.005, 2.6e3, m0)
+    b.AddClumps(t, [[0, 0, 0]])
+    p, sc = b.Initialize()
+    a = b.arrays
+    assert np.allclose(a["Radii"], 0.004) and sc.nSpheres == 3 and sc.nComp == 3
+    assert a["MassProperties"][0] == pytest.approx(2.6e3 * 5.5886717 * 0.005 ** 3, rel=1e-6)
+    assert a["moiX"][0] == pytest.approx(2.928 * 2.6e3 * 0.005 ** 5, rel=1e-6)
+    CoR = a["CoR"].reshape(2, 2)
+    mu = a["mu"].reshape(2, 2)
+    assert CoR[0, 1] == pytest.approx(0.7) and CoR[0, 0] == np.float32(0.6)  # off-diagonal default = mean
+    assert mu[0, 1] == mu[1, 0] == np.float32(0.5)  # explicit pair override
+    assert p.nContactWildcards == 4
+
+
+def test_hcp_sampler_spacing(pkg):
+    pts = pkg.model.hcp_points([0, 0, 0], [0.1, 0.1, 0.1], 0.015)
+    d = np.linalg.norm(pts[None, :60] - pts[:60, None], axis=2)
+    d[d == 0] = 1
+    assert d.min() == pytest.approx(0.015, rel=1e-4)

@@ -1,0 +1,261 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every stage of the HIP hot path, called through
+the C-ABI, against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): contact sets, bin assignments, history maps and the position codec
+are integer work -> bit-exact.  Forces / accelerations / velocities are fp32 with float atomics in
+the accumulation (order differs from the oracle's list order) -> tolerances stated per test.
+"""
+import numpy as np
+import pytest
+
+
+pytestmark = pytest.mark.gpu
+
+NULL = 0xFFFFFFFF
+
+
+def pair(pkg, orc, builder):
+    p, sc = builder.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p)
+    ctx.upload_scene(sc)
+    sim = orc.make_sim(pkg, p, sc)
+    return ctx, sim, p, sc
+
+
+def positions(pkg, st, p):
+    return pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+
+
+def assert_same_contacts(ctx, sim):
+    a, b, t, m = ctx.contacts()
+    oa, ob, ot, om = sim.contacts()
+    assert len(a) == len(oa), f"contact count {len(a)} vs oracle {len(oa)}"
+    assert (a == oa).all() and (b == ob).all() and (t == ot).all()
+    return a, b, t, m, om
+
+
+def test_geometry_and_bin_assignment_bit_exact(pkg, orc):
+    b = pkg.model.packed_bed(3000, seed=11, cd_freq=0, spacing_mult=2.6)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    for drift in (0, 25):  # zero margin and a velocity-based margin
+        ctx.compute_margins(drift)
+        sim.compute_margins(drift)
+        ctx.detect()
+        sim.detect()
+        for g, o in zip(ctx.sphere_geometry(), sim.sphere_geometry()):
+            assert (g == o).all()
+        gb, gs = ctx.bin_incidence()
+        ob, os_ = sim.bin_incidence()
+        assert len(gb) == len(ob) and (gb == ob).all() and (gs == os_).all()
+        cg, co = ctx.counts(), sim.counts()
+        assert cg.nActiveBins == co.nActiveBins and cg.maxSpheresInBin == co.maxSpheresInBin
+        assert_same_contacts(ctx, sim)
+    # sortedness + uniqueness of the canonical list
+    a, bb, t, _ = ctx.contacts()
+    ss = t == 1
+    key = a[ss].astype(np.uint64) << np.uint64(32) | bb[ss].astype(np.uint64)
+    assert (np.diff(key.astype(np.int64)) > 0).all() and (a[ss] < bb[ss]).all()
+
+
+def test_margin_inflated_detection_with_velocities(pkg, orc):
+    b = pkg.model.packed_bed(2500, seed=5, cd_freq=10, spacing_mult=3.0, init_vz=-0.8)
+    b.SetExpandSafetyAdder(0.5)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.compute_margins(10)
+    sim.compute_margins(10)
+    ctx.detect(), sim.detect()
+    a, *_ = assert_same_contacts(ctx, sim)
+    assert len(a) > 0
+
+
+def test_history_map_and_wildcard_migration(pkg, orc):
+    b = pkg.model.packed_bed(2000, seed=3, cd_freq=0, spacing_mult=2.5, init_vz=-0.3)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.step(3), sim.step(3)
+    a, bb, t, m, om = assert_same_contacts(ctx, sim)
+    assert (m == om).all()
+    assert (m != NULL).sum() > 0.5 * len(m)  # most contacts persist between consecutive detections
+    # mapped contacts point at the same (A, B, type) in the previous list: check through a 2nd detection
+    prev = set(zip(a.tolist(), bb.tolist(), t.tolist()))
+    ctx.step(1), sim.step(1)
+    a2, b2, t2, m2, om2 = assert_same_contacts(ctx, sim)
+    assert (m2 == om2).all()
+    for i in np.nonzero(m2 != NULL)[0][:2000]:
+        assert (int(a2[i]), int(b2[i]), int(t2[i])) == (int(a[m2[i]]), int(bb[m2[i]]), int(t[m2[i]]))
+    for i in np.nonzero(m2 == NULL)[0][:2000]:
+        assert (int(a2[i]), int(b2[i]), int(t2[i])) not in prev
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_forces_against_oracle(pkg, orc, model):
+    b = pkg.model.packed_bed(3000, seed=21, cd_freq=0, spacing_mult=2.5, init_vz=-0.4, force_model=model, Crr=0.0)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.set_record_contacts(True)
+    # a few steps so contact history and angular velocities are non-trivial, then one staged force pass
+    ctx.step(5), sim.step(5)
+    st = sim.download_state()
+    ctx.upload_state({k: st[k] for k in st if k not in ("aX", "aY", "aZ", "alphaX", "alphaY", "alphaZ")})
+    ctx.compute_margins(0), sim.compute_margins(0)
+    ctx.detect(), sim.detect()
+    ctx.migrate(), sim.migrate()
+    nC = assert_same_contacts(ctx, sim)[0].size
+    if model == 0:
+        for w in range(4):  # identical history going in
+            ctx.set_wildcard(w, sim.wildcard(w))
+    ctx.calc_forces()
+    sim.calc_forces(record=True)
+    F, T, PA, PB = ctx.contact_records()
+    oF, oT, oPA, oPB = sim.contact_records()
+    scale = np.abs(oF).max()
+    assert scale > 0
+    # per-contact quantities involve no atomics: same arithmetic, so agreement is at rounding level
+    assert np.abs(F - oF).max() <= 2e-6 * scale
+    assert np.abs(PA - oPA).max() <= 1e-9 and np.abs(PB - oPB).max() <= 1e-6 * max(1.0, np.abs(oPB).max())
+    if model == 0:
+        for w in range(4):
+            gw, ow = ctx.wildcard(w), sim.wildcard(w)
+            assert np.abs(gw - ow).max() <= 1e-6 * max(np.abs(ow).max(), 1e-12)
+    gs, os_ = ctx.download_state(), sim.download_state()
+    for k in ("aX", "aY", "aZ", "alphaX", "alphaY", "alphaZ"):
+        ref = np.abs(os_[k][:-1]).max()
+        # clumps: fp32 atomics in a different order -> 1e-5 relative to the largest entry
+        assert np.abs(gs[k][:-1] - os_[k][:-1]).max() <= 1e-5 * ref, k
+        # the wall owner sums thousands of terms: looser
+        assert abs(gs[k][-1] - os_[k][-1]) <= 1e-3 * max(abs(os_[k][-1]), 1e-6), k
+    assert nC > 1000
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 2])
+def test_integrator_bit_exact_given_same_accelerations(pkg, orc, integrator):
+    b = pkg.model.packed_bed(1500, seed=8, cd_freq=0, spacing_mult=2.6, init_vz=-0.2)
+    b.SetIntegrator(integrator)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    rng = np.random.default_rng(4)
+    n = sc.nOwners
+    st = sim.download_state()
+    for k in ("aX", "aY", "aZ"):
+        st[k] = rng.uniform(-50, 50, n).astype(np.float32)
+    for k in ("alphaX", "alphaY", "alphaZ"):
+        st[k] = rng.uniform(-500, 500, n).astype(np.float32)
+    for k in ("omgBarX", "omgBarY", "omgBarZ"):
+        st[k] = rng.uniform(-20, 20, n).astype(np.float32)
+    sim.upload_state(st), ctx.upload_state(st)
+    for _ in range(3):
+        ctx.integrate(), sim.integrate()
+        sim.upload_state({k: st[k] for k in ("aX", "aY", "aZ", "alphaX", "alphaY", "alphaZ")})
+        ctx.upload_state({k: st[k] for k in ("aX", "aY", "aZ", "alphaX", "alphaY", "alphaZ")})
+    gs, os_ = ctx.download_state(), sim.download_state()
+    for k in ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX",
+              "omgBarY", "omgBarZ"):
+        assert (gs[k] == os_[k]).all(), k
+    # the fixed wall owner did not move
+    assert gs["vZ"][-1] == 0 and gs["voxelID"][-1] == st["voxelID"][-1]
+
+
+def test_trajectory_parity_mode(pkg, orc):
+    """End-to-end (SURVEY G10 analogue): 1000 clumps, detection every step, 200 steps.
+    Contact counts bit-exact at every checkpoint; positions within 1e-7 m, velocities 1e-4 m/s."""
+    b = pkg.model.packed_bed(1000, seed=2, cd_freq=0, spacing_mult=2.7, init_vz=-0.5)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    for chunk in range(4):
+        ctx.step(50), sim.step(50)
+        assert ctx.counts().nContacts == sim.counts().nContacts
+        gs, os_ = ctx.download_state(), sim.download_state()
+        dx = np.abs(positions(pkg, gs, p) - positions(pkg, os_, p)).max()
+        dv = max(np.abs(gs[k] - os_[k]).max() for k in ("vX", "vY", "vZ"))
+        assert dx < 1e-7 and dv < 1e-4, (chunk, dx, dv)
+    assert ctx.counts().nContacts > 100
+
+
+def test_trajectory_throughput_mode(pkg, orc):
+    """Detection every 10 steps with the velocity margin: list built at step n serves n..n+9."""
+    b = pkg.model.packed_bed(1000, seed=9, cd_freq=10, spacing_mult=2.8, init_vz=-0.6)
+    b.SetExpandSafetyAdder(0.2)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.step(100), sim.step(100)
+    assert ctx.counts().nDetections == sim.counts().nDetections == 10
+    assert ctx.counts().nContacts == sim.counts().nContacts
+    gs, os_ = ctx.download_state(), sim.download_state()
+    assert np.abs(positions(pkg, gs, p) - positions(pkg, os_, p)).max() < 1e-7
+
+
+def test_family_masks_and_fixed_family(pkg, orc):
+    b = pkg.model.packed_bed(1500, seed=13, cd_freq=0, spacing_mult=2.5, init_vz=-0.3)
+    fam = (np.arange(len(b.batches[0].xyz)) % 3).astype(np.uint8)
+    b.batches[0].SetFamily(fam)
+    b.DisableContactBetweenFamilies(1, 2)
+    b.SetFamilyFixed(2)
+    b.SetFamilyExtraMargin(0, 2e-4)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.step(20), sim.step(20)
+    a, bb, t, *_ = assert_same_contacts(ctx, sim)
+    own = b.arrays["ownerClumpBody"]
+    ss = t == 1
+    fa, fb = fam[own[a[ss]]], fam[own[bb[ss]]]
+    assert not (((fa == 1) & (fb == 2)) | ((fa == 2) & (fb == 1))).any()
+    gs = ctx.download_state()
+    fixed = np.nonzero(fam == 2)[0]
+    assert (gs["vZ"][fixed] == 0).all()
+
+
+def test_crowded_bins_span_chunks(pkg, orc):
+    """Bins holding more spheres than one 256-entry sweep chunk exercise the global look-back path."""
+    b = pkg.model.packed_bed(1200, seed=17, cd_freq=0, spacing_mult=2.6)
+    b.SetInitBinSize(0.12)  # ~8 clump spacings per bin edge => hundreds of spheres per bin
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.detect(), sim.detect()
+    assert ctx.counts().maxSpheresInBin == sim.counts().maxSpheresInBin > 256
+    assert_same_contacts(ctx, sim)
+
+
+def test_empty_and_single(pkg, orc):
+    # no clumps at all: only the wall owner
+    b = pkg.SceneBuilder()
+    m = b.LoadMaterial({"E": 1e8, "nu": 0.3, "CoR": 0.5, "mu": 0.3, "Crr": 0.0})
+    b.InstructBoxDomainDimension(1, 1, 1)
+    b.InstructBoxDomainBoundingBC("all", m)
+    b.LoadSphereType(1e-3, 0.01, m)
+    b.SetCDUpdateFreq(0)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.step(3), sim.step(3)
+    assert ctx.counts().nContacts == 0 and ctx.counts().nBinSphereTouches == 0
+    # one sphere resting into the floor
+    b = pkg.SceneBuilder()
+    m = b.LoadMaterial({"E": 1e8, "nu": 0.3, "CoR": 0.5, "mu": 0.3, "Crr": 0.0})
+    b.InstructBoxDomainDimension(1, 1, 1)
+    b.InstructBoxDomainBoundingBC("all", m)
+    t = b.LoadSphereType(1e-3, 0.01, m)
+    b.AddClumps(t, [[0.0, 0.0, -0.4905]])
+    b.SetCDUpdateFreq(0)
+    b.SetInitTimeStep(1e-5)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.step(10), sim.step(10)
+    a, bb, tt, _ = ctx.contacts()
+    assert len(a) == 1 and tt[0] == 11 and a[0] == 0 and bb[0] == 0  # sphere 0 on the bottom plane (component 0)
+    gs, os_ = ctx.download_state(), sim.download_state()
+    assert abs(gs["vZ"][0] - os_["vZ"][0]) < 1e-5 and gs["vZ"][0] > 1.0  # pushed out of the floor
+    ctx.step(40), sim.step(40)  # it has bounced off by now: the list empties on both sides
+    assert ctx.counts().nContacts == sim.counts().nContacts == 0
+
+
+def test_contact_arena_growth(pkg, orc):
+    """Dense start (many more contacts than the initial arena guess per sphere) still yields the full set."""
+    b = pkg.model.packed_bed(800, seed=23, cd_freq=0, spacing_mult=1.5)  # heavy overlaps: >6 contacts per sphere
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.detect(), sim.detect()
+    a = assert_same_contacts(ctx, sim)[0]
+    assert len(a) > 6 * sc.nSpheres
+
+
+def test_error_paths(pkg):
+    ctx = pkg.Context(0)
+    with pytest.raises(pkg.abi.DemeError):
+        ctx.detect()  # nothing uploaded
+    b = pkg.model.packed_bed(500, seed=1, cd_freq=0, spacing_mult=2.6, init_vz=-0.3)
+    b.SetErrorOutVelocity(0.1)  # below the initial speed: detection must refuse (kT.cpp:136-149)
+    p, sc = b.Initialize()
+    ctx.set_params(p)
+    ctx.upload_scene(sc)
+    with pytest.raises(pkg.abi.DemeError, match="velocity"):
+        ctx.step(1)
