@@ -89,17 +89,17 @@ struct DevParams {
     const uint8_t* familyFlags;
 };
 
-// contact key: type class in the top 2 bits, then A (31 bits), then B (31 bits).
-// Sorting keys ascending yields the canonical list order: sphere-sphere, sphere-mesh,
-// sphere-analytical, each by (A, B).
+// contact key: sphere A (31 bits) | type class (2 bits) | B (31 bits).  Sorting keys ascending yields the
+// canonical list order: by A, then sphere-sphere / sphere-mesh / sphere-analytical, then B.  Spheres are
+// clump-major, so the list is also sorted by A's owner: every owner's A-side contacts are one contiguous run.
 #define DEME_KEY_CLASS_SS 0ull
 #define DEME_KEY_CLASS_SM 1ull
 #define DEME_KEY_CLASS_SA 2ull
 __host__ __device__ inline uint64_t make_key(uint64_t cls, uint32_t a, uint32_t b) {
-    return (cls << 62) | ((uint64_t)a << 31) | (uint64_t)b;
+    return ((uint64_t)a << 33) | (cls << 31) | (uint64_t)b;
 }
-__host__ __device__ inline uint32_t key_class(uint64_t k) { return (uint32_t)(k >> 62); }
-__host__ __device__ inline uint32_t key_a(uint64_t k) { return (uint32_t)((k >> 31) & 0x7FFFFFFFu); }
+__host__ __device__ inline uint32_t key_class(uint64_t k) { return (uint32_t)((k >> 31) & 3u); }
+__host__ __device__ inline uint32_t key_a(uint64_t k) { return (uint32_t)(k >> 33); }
 __host__ __device__ inline uint32_t key_b(uint64_t k) { return (uint32_t)(k & 0x7FFFFFFFu); }
 
 // ---------------------------------------------------------------------------

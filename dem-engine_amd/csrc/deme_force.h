@@ -20,7 +20,12 @@ struct ForceArgs {
     const SphereRec* spheres;
     const uint64_t* keys;  // sorted contact keys
     float* wc;             // contact wildcards, AoS: wc[c*nW + w]
-    AccRec* acc;           // accumulation target
+    // per-contact, per-side contributions to the owners' a and alpha (no atomics: the integrator
+    // gathers them per owner in contact order).  side A: conA4 = (ax, ay, az, alx), conA2 = (aly, alz)
+    float4* conA4;
+    float2* conA2;
+    float4* conB4;
+    float2* conB2;
     float* recForce;       // optional per-contact records (3 floats each), may be null
     float* recTorque;
     float* recCPA;
@@ -127,19 +132,14 @@ __device__ inline void hertz_frictionless(const HertzIn& in, const MatPair& mp, 
     }
 }
 
-// Accumulate one side of a contact into its owner: ForceInKernelReductionStrat.cu:2-33
-// (same arithmetic as DEMCollectForceKernels_Compact.cu:13-101).  Hardware fp32 atomics.
-__device__ inline void accumulate_side(AccRec* acc, uint32_t owner, f3 F, f3 Ftot, float mass, f3 moi, const RotM& Rinv,
-                                       f3 locCP) {
-    float* a = reinterpret_cast<float*>(acc + owner);
-    unsafeAtomicAdd(a + 0, F.x / mass);
-    unsafeAtomicAdd(a + 1, F.y / mass);
-    unsafeAtomicAdd(a + 2, F.z / mass);
+// One side's contribution to its owner's a and alpha: ForceInKernelReductionStrat.cu:2-33 (same arithmetic
+// as DEMCollectForceKernels_Compact.cu:13-101), evaluated per contact and stored instead of atomically added.
+__device__ inline void side_contribution(f3 F, f3 Ftot, float mass, f3 moi, const RotM& Rinv, f3 locCP, float4& c4,
+                                         float2& c2) {
     const f3 myF = rot_apply(Rinv, Ftot);
     const f3 cr = cross3(locCP, myF);
-    unsafeAtomicAdd(a + 4, cr.x / moi.x);
-    unsafeAtomicAdd(a + 5, cr.y / moi.y);
-    unsafeAtomicAdd(a + 6, cr.z / moi.z);
+    c4 = make_float4(F.x / mass, F.y / mass, F.z / mass, cr.x / moi.x);
+    c2 = make_float2(cr.y / moi.y, cr.z / moi.z);
 }
 
 // One thread per contact.  MODEL: 0 full Hertzian (4 wildcards), 1 frictionless (none).
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void k_calc_forces(const DevParams p, const Fo
     float extraMarginSize = p.familyTrivial ? 0.f : p.familyExtra[AOwnerFamily];
     const uint32_t bodyAMatType = sA.mat;
     uint32_t bodyBMatType = 0, BOwner = 0;
+    (void)AOwner;
     const uint32_t BGeo = key_b(key);
     float4 mpB;
     OwnerRec oB;
@@ -273,12 +274,22 @@ __global__ __launch_bounds__(256) void k_calc_forces(const DevParams p, const Fo
             r = a.recCPB + 3ull * myContactID;
             r[0] = in.locCPB.x, r[1] = in.locCPB.y, r[2] = in.locCPB.z;
         }
-        // _forceCollectInPlaceStrat_
+        // _forceCollectInPlaceStrat_ -> per-side contributions
         const f3 tot = force + torque_only_force;
-        accumulate_side(a.acc, AOwner, force, tot, in.AOwnerMass, mk3(mpA.y, mpA.z, mpA.w), RAinv, in.locCPA);
+        float4 c4;
+        float2 c2;
+        side_contribution(force, tot, in.AOwnerMass, mk3(mpA.y, mpA.z, mpA.w), RAinv, in.locCPA, c4, c2);
+        a.conA4[myContactID] = c4;
+        a.conA2[myContactID] = c2;
         const f3 nF = mk3(-force.x, -force.y, -force.z);
-        accumulate_side(a.acc, BOwner, nF, -1.f * tot, in.BOwnerMass, mk3(mpB.y, mpB.z, mpB.w), RBinv, in.locCPB);
+        side_contribution(nF, -1.f * tot, in.BOwnerMass, mk3(mpB.y, mpB.z, mpB.w), RBinv, in.locCPB, c4, c2);
+        a.conB4[myContactID] = c4;
+        a.conB2[myContactID] = c2;
     } else {
+        a.conA4[myContactID] = make_float4(0, 0, 0, 0);
+        a.conA2[myContactID] = make_float2(0, 0);
+        a.conB4[myContactID] = make_float4(0, 0, 0, 0);
+        a.conB2[myContactID] = make_float2(0, 0);
         hist = make_float4(0, 0, 0, 0);  // _forceModelContactWildcardDestroy_
         if (a.recForce) {
             for (int k = 0; k < 3; k++) {

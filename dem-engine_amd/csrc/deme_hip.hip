@@ -52,12 +52,15 @@ struct deme_ctx {
     DevParams dp{};
     uint32_t nOwners = 0, nOwnerClumps = 0, nSpheres = 0, nAnal = 0, nMat = 0, nComp = 0, nMassProps = 0;
     // model
-    DevBuf owners, spheres, acc[2], comp, massProps, anal, matPair, E, nu, CoR, mu, Crr, famMasks, famExtra, famFlags;
-    int accCur = 0, accLast = 0;
+    DevBuf owners, spheres, acc, comp, massProps, anal, matPair, E, nu, CoR, mu, Crr, famMasks, famExtra, famFlags;
     std::vector<uint8_t> hObjType;  // host copy for contact-type decoding on download
     // detection scratch
     DevBuf geo, binLo, binN, counts, offsets, incKeys[2], incVals[2], keysRaw, keysSorted[2], mapping, wc[2], ctr,
         scanTmp, sortTmp, rec[4], stage;
+    // per-contact contributions and the per-owner gather lists (built once per detection)
+    DevBuf conA4, conA2, conB4, conB2, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
+    uint32_t nHeavy = 0, nHeavyFree = 0;
+    bool conValid = false;
     int keysCur = 0, wcCur = 0;
     size_t incCap = 0, cntCap = 0;
     uint64_t nInc = 0, nContacts = 0, nPrev = 0, nWcStored = 0;
@@ -246,6 +249,15 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
     if (c->record)
         for (int k = 0; k < 4; k++)
             rc |= ensure(c, c->rec[k], cap * 12);
+    rc |= ensure(c, c->conA4, cap * 16);
+    rc |= ensure(c, c->conA2, cap * 8);
+    rc |= ensure(c, c->conB4, cap * 16);
+    rc |= ensure(c, c->conB2, cap * 8);
+    rc |= ensure(c, c->ownerA, cap * 4);
+    for (int k = 0; k < 2; k++) {
+        rc |= ensure(c, c->ownerB[k], cap * 4);
+        rc |= ensure(c, c->bIdx[k], cap * 4);
+    }
     if (rc)
         return rc;
     c->cntCap = cap;
@@ -368,6 +380,39 @@ int do_detect(deme_ctx* c) {
                                c->keysSorted[next].as<uint64_t>(), (uint32_t)nPrev,
                                c->keysSorted[c->keysCur].as<uint64_t>(), c->mapping.as<uint32_t>());
         }
+        // per-owner gather lists for the atomics-free accumulation
+        HIPCK(hipMemsetAsync(c->rangeCtr.p, 0, sizeof(RangeCounters), c->stream));
+        if (nC) {
+            hipLaunchKernelGGL(k_contact_owners, dim3(grid_for(nC)), dim3(256), 0, c->stream, c->dp, (uint32_t)nC,
+                               c->keysSorted[next].as<uint64_t>(), c->spheres.as<SphereRec>(), c->ownerA.as<uint32_t>(),
+                               c->ownerB[0].as<uint32_t>(), c->bIdx[0].as<uint32_t>());
+            unsigned obits = 1;
+            while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
+                obits++;
+            size_t need = 0;
+            HIPCK(rocprim::radix_sort_pairs(nullptr, need, c->ownerB[0].as<uint32_t>(), c->ownerB[1].as<uint32_t>(),
+                                            c->bIdx[0].as<uint32_t>(), c->bIdx[1].as<uint32_t>(), (size_t)nC, 0, obits,
+                                            c->stream));
+            if (int rc = ensure(c, c->sortTmp, need))
+                return rc;
+            need = c->sortTmp.bytes;
+            HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, need, c->ownerB[0].as<uint32_t>(), c->ownerB[1].as<uint32_t>(),
+                                            c->bIdx[0].as<uint32_t>(), c->bIdx[1].as<uint32_t>(), (size_t)nC, 0, obits,
+                                            c->stream));
+        }
+        hipLaunchKernelGGL(k_owner_ranges, dim3(grid_for((size_t)c->nOwners + 1)), dim3(256), 0, c->stream, c->dp,
+                           (uint32_t)nC, c->ownerA.as<uint32_t>(), c->ownerB[1].as<uint32_t>(), c->owners.as<OwnerRec>(),
+                           c->aStart.as<uint32_t>(), c->bStart.as<uint32_t>(), c->heavy.as<uint8_t>(),
+                           c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(), (uint32_t)(c->heavyList.bytes / 4),
+                           c->rangeCtr.as<RangeCounters>());
+        RangeCounters hr{};
+        HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        if (hr.nHeavy > c->heavyList.bytes / 4)
+            return fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", hr.nHeavy);
+        c->nHeavy = hr.nHeavy;
+        c->nHeavyFree = hr.nHeavyFree;
+        c->conValid = false;
         c->nPrev = c->haveList ? c->nContacts : 0;
         c->nContacts = nC;
         c->keysCur = next;
@@ -398,10 +443,29 @@ int do_migrate(deme_ctx* c) {
     return DEME_OK;
 }
 
+GatherArgs gather_args(deme_ctx* c) {
+    GatherArgs g{};
+    g.aStart = c->aStart.as<uint32_t>(), g.bStart = c->bStart.as<uint32_t>(), g.bIdx = c->bIdx[1].as<uint32_t>();
+    g.heavy = c->heavy.as<uint8_t>();
+    g.conA4 = c->conA4.as<float4>(), g.conA2 = c->conA2.as<float2>();
+    g.conB4 = c->conB4.as<float4>(), g.conB2 = c->conB2.as<float2>();
+    return g;
+}
+
+// heavy owners: skipFixed=true in the stepping loop (a fixed owner's a/alpha are only needed by queries)
+void launch_reduce_heavy(deme_ctx* c, bool skipFixed) {
+    if (c->nHeavy == 0 || (skipFixed && c->nHeavyFree == 0))
+        return;
+    hipLaunchKernelGGL(k_reduce_heavy, dim3(std::min<uint32_t>(c->nHeavy, 1024)), dim3(256), 0, c->stream, gather_args(c),
+                       c->heavyList.as<uint32_t>(), &c->rangeCtr.as<RangeCounters>()->nHeavy,
+                       skipFixed ? c->fixedFlag.as<uint8_t>() : (const uint8_t*)nullptr, c->acc.as<AccRec>());
+}
+
 int launch_forces(deme_ctx* c) {
-    c->accLast = c->accCur;
-    if (c->nContacts == 0)
+    if (c->nContacts == 0) {
+        c->conValid = true;
         return DEME_OK;
+    }
     if (c->hp.forceModel == DEME_FORCE_CUSTOM)
         return fail(c, DEME_ERR_INVALID, "custom force model selected but none compiled (deme_compile_force_model)");
     ForceArgs a{};
@@ -409,28 +473,43 @@ int launch_forces(deme_ctx* c) {
     a.spheres = c->spheres.as<SphereRec>();
     a.keys = c->keysSorted[c->keysCur].as<uint64_t>();
     a.wc = c->wc[c->wcCur].as<float>();
-    a.acc = c->acc[c->accCur].as<AccRec>();
+    a.conA4 = c->conA4.as<float4>(), a.conA2 = c->conA2.as<float2>();
+    a.conB4 = c->conB4.as<float4>(), a.conB2 = c->conB2.as<float2>();
     a.nContacts = (uint32_t)c->nContacts;
     a.timeElapsed = (float)c->timeElapsed;
     if (c->record) {
         a.recForce = c->rec[0].as<float>(), a.recTorque = c->rec[1].as<float>(), a.recCPA = c->rec[2].as<float>(),
         a.recCPB = c->rec[3].as<float>();
     }
-    c->accLast = c->accCur;
-    ScopedTimer tm(c, "calc_forces");
-    if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
-        hipLaunchKernelGGL(k_calc_forces<0>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
-    else
-        hipLaunchKernelGGL(k_calc_forces<1>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
+    {
+        ScopedTimer tm(c, "calc_forces");
+        if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
+            hipLaunchKernelGGL(k_calc_forces<0>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
+        else
+            hipLaunchKernelGGL(k_calc_forces<1>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
+    }
+    c->conValid = true;
     return DEME_OK;
 }
 
-int launch_integrate(deme_ctx* c) {
+int launch_integrate(deme_ctx* c, bool fused) {
     ScopedTimer tm(c, "integrate");
-    hipLaunchKernelGGL(k_integrate, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
-                       c->acc[c->accCur].as<AccRec>(), c->acc[c->accCur ^ 1].as<AccRec>());
-    c->accCur ^= 1;
+    if (fused) {
+        launch_reduce_heavy(c, true);
+        hipLaunchKernelGGL(k_integrate<true>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
+                           c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c));
+    } else {
+        hipLaunchKernelGGL(k_integrate<false>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
+                           c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c));
+    }
     return DEME_OK;
+}
+
+// a/alpha of every owner from the current contributions (stand-alone force pass and state downloads)
+void launch_full_reduction(deme_ctx* c) {
+    hipLaunchKernelGGL(k_gather_acc, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, gather_args(c),
+                       c->acc.as<AccRec>());
+    launch_reduce_heavy(c, false);
 }
 
 }  // namespace
@@ -472,7 +551,7 @@ void deme_ctx_destroy(deme_ctx* c) {
     drain_timers(c);
     for (auto e : c->eventPool)
         hipEventDestroy(e);
-    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc[0], &c->acc[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -557,12 +636,19 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     }
     if (int rc = upload(c, c->owners, ho.data(), nO))
         return rc;
-    for (int k = 0; k < 2; k++) {
-        if (int rc = ensure(c, c->acc[k], std::max<size_t>(nO, 1) * sizeof(AccRec)))
-            return rc;
-        HIPCK(hipMemsetAsync(c->acc[k].p, 0, c->acc[k].bytes, c->stream));
-    }
-    c->accCur = 0;
+    if (int rc = ensure(c, c->acc, std::max<size_t>(nO, 1) * sizeof(AccRec)))
+        return rc;
+    HIPCK(hipMemsetAsync(c->acc.p, 0, c->acc.bytes, c->stream));
+    if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
+        ensure(c, c->fixedFlag, nO + 1) || ensure(c, c->heavyList, 4096 * 4) || ensure(c, c->rangeCtr, sizeof(RangeCounters)))
+        return c->lastStatus;
+    HIPCK(hipMemsetAsync(c->aStart.p, 0, c->aStart.bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->bStart.p, 0, c->bStart.bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->heavy.p, 0, c->heavy.bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->fixedFlag.p, 0, c->fixedFlag.bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->rangeCtr.p, 0, sizeof(RangeCounters), c->stream));
+    c->nHeavy = c->nHeavyFree = 0;
+    c->conValid = false;
     // spheres
     std::vector<SphereRec> hs(nS);
     for (size_t i = 0; i < nS; i++) {
@@ -685,11 +771,12 @@ static int owner_state_io(deme_ctx* c, const DemeOwnerState* st, int dir) {
             HIPCK(hipMemcpyAsync(*cl.dev, cl.host, n * cl.elem, hipMemcpyHostToDevice, c->stream));
         off += ((n * cl.elem + 15) / 16) * 16;
     }
-    // acceleration of "this step" lives in the buffer the last integrate consumed (accCur^1 after the
-    // swap is the zeroed one); expose the most recently accumulated buffer
-    AccRec* accView = c->acc[dir == 1 ? c->accLast : c->accCur].as<AccRec>();
-    if (dir == 0)
-        c->accLast = c->accCur;
+    // downloads see a/alpha of EVERY owner (fixed and heavy ones are only reduced on demand)
+    if (dir == 1 && c->conValid && c->haveList)
+        launch_full_reduction(c);
+    if (dir == 0 && (st->aX || st->aY || st->aZ || st->alphaX || st->alphaY || st->alphaZ))
+        c->conValid = false;  // the caller now owns a/alpha
+    AccRec* accView = c->acc.as<AccRec>();
     if (n)
         hipLaunchKernelGGL(k_pack_owners, dim3(grid_for(n)), dim3(256), 0, c->stream, (uint32_t)n,
                            c->owners.as<OwnerRec>(), accView, soa, dir);
@@ -751,15 +838,18 @@ int deme_calc_forces(deme_ctx* c) {
     if (c->mapFresh)
         if (int rc = do_migrate(c))
             return rc;
-    // stand-alone call: clear the accumulators first (prepareAccArrays, DEMPrepForceKernels.cu:32-37)
-    HIPCK(hipMemsetAsync(c->acc[c->accCur].p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
-    return launch_forces(c);
+    if (!c->haveList)
+        return fail(c, DEME_ERR_INVALID, "no contact list yet: call deme_detect_contacts first");
+    if (int rc = launch_forces(c))
+        return rc;
+    launch_full_reduction(c);  // stand-alone call: a/alpha of every owner (prepareAccArrays + forceToAcc)
+    return DEME_OK;
 }
 
 int deme_integrate(deme_ctx* c) {
     if (int rc = check_ready(c))
         return rc;
-    if (int rc = launch_integrate(c))
+    if (int rc = launch_integrate(c, false))  // from the stored a/alpha
         return rc;
     c->nSteps++;
     c->timeElapsed += (double)c->hp.h;
@@ -782,7 +872,7 @@ int deme_step(deme_ctx* c, uint32_t nsteps) {
         }
         if (int rc = launch_forces(c))
             return rc;
-        if (int rc = launch_integrate(c))
+        if (int rc = launch_integrate(c, true))
             return rc;
         c->stepsSinceCD++;
         c->nSteps++;

@@ -399,22 +399,200 @@ __global__ __launch_bounds__(256) void k_migrate(uint32_t nNew, uint32_t nW, con
 // ---------------------------------------------------------------------------
 // Integration.  kernel/DEMIntegrationKernels.cu:100-264 (integrateVelPos / integrateOwners) with the
 // pass-on of IntegrationVelPassOn*.cu; fixed families follow SetFamilyFixed (APIPublic.cpp:980-1011).
-// Fused with the clearing of the NEXT step's accumulators (DEMPrepForceKernels.cu:15-37): the
-// accumulators are double-buffered so this step's a/alpha stay readable.
+// FUSED variant: the owner's a/alpha are gathered from the per-contact contributions inside the same
+// kernel (no clear pass, no atomics, no accumulator round trip: replaces prepareAccArrays +
+// forceToAcc + integrateOwners, DEMPrepForceKernels.cu:32, DEMCollectForceKernels_Compact.cu:13).
 // ---------------------------------------------------------------------------
+// Per-owner gather of the per-contact contributions written by k_calc_forces (atomics-free, and in
+// contact-list order so the fp32 sum is reproducible run to run and equals the oracle's list-order sum).
+// An owner's A-side contacts are the contiguous run [aStart[o], aStart[o+1]); its B-side contacts are
+// bIdx[bStart[o] .. bStart[o+1]) (ascending).  The two ascending sequences are merged by contact index.
+struct GatherArgs {
+    const uint32_t* aStart;  // nOwners+1
+    const uint32_t* bStart;  // nOwners+1
+    const uint32_t* bIdx;    // contact indices sorted by B's owner (stable)
+    const uint8_t* heavy;    // 1: too many contacts for one thread; summed by k_reduce_heavy into acc
+    const float4* conA4;
+    const float2* conA2;
+    const float4* conB4;
+    const float2* conB2;
+};
+
+__device__ inline void gather_owner(const GatherArgs& g, uint32_t o, float4& a, float4& al) {
+    float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
+    uint32_t ia = g.aStart[o];
+    const uint32_t ea = g.aStart[o + 1];
+    uint32_t ib = g.bStart[o];
+    const uint32_t eb = g.bStart[o + 1];
+    uint32_t cb = (ib < eb) ? g.bIdx[ib] : 0xFFFFFFFFu;
+    while (ia < ea || ib < eb) {
+        float4 c4;
+        float2 c2;
+        if (ia < ea && ia < cb) {
+            c4 = g.conA4[ia];
+            c2 = g.conA2[ia];
+            ia++;
+        } else {
+            c4 = g.conB4[cb];
+            c2 = g.conB2[cb];
+            ib++;
+            cb = (ib < eb) ? g.bIdx[ib] : 0xFFFFFFFFu;
+        }
+        ax += c4.x, ay += c4.y, az += c4.z;
+        lx += c4.w, ly += c2.x, lz += c2.y;
+    }
+    a = make_float4(ax, ay, az, 0.f);
+    al = make_float4(lx, ly, lz, 0.f);
+}
+
+// stand-alone reduction (deme_calc_forces): a/alpha of every non-heavy owner
+__global__ __launch_bounds__(256) void k_gather_acc(const DevParams p, const GatherArgs g, AccRec* __restrict__ acc) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= p.nOwners || g.heavy[o])
+        return;
+    float4 a, al;
+    gather_owner(g, o, a, al);
+    float4* ap = reinterpret_cast<float4*>(acc + o);
+    ap[0] = a;
+    ap[1] = al;
+}
+
+// Owners with very many contacts (walls, large meshes): one workgroup each, fixed-shape tree
+// reduction (deterministic; summation order differs from list order).
+__global__ __launch_bounds__(256) void k_reduce_heavy(const GatherArgs g, const uint32_t* __restrict__ heavyList,
+                                                      const uint32_t* __restrict__ nHeavy,
+                                                      const uint8_t* __restrict__ skip, AccRec* __restrict__ acc) {
+    __shared__ float red[6][256];
+    const uint32_t n = *nHeavy;
+    for (uint32_t h = blockIdx.x; h < n; h += gridDim.x) {
+        const uint32_t o = heavyList[h];
+        if (skip && skip[o])
+            continue;
+        float s[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t c = g.aStart[o] + threadIdx.x; c < g.aStart[o + 1]; c += 256) {
+            const float4 c4 = g.conA4[c];
+            const float2 c2 = g.conA2[c];
+            s[0] += c4.x, s[1] += c4.y, s[2] += c4.z, s[3] += c4.w, s[4] += c2.x, s[5] += c2.y;
+        }
+        for (uint32_t i = g.bStart[o] + threadIdx.x; i < g.bStart[o + 1]; i += 256) {
+            const uint32_t c = g.bIdx[i];
+            const float4 c4 = g.conB4[c];
+            const float2 c2 = g.conB2[c];
+            s[0] += c4.x, s[1] += c4.y, s[2] += c4.z, s[3] += c4.w, s[4] += c2.x, s[5] += c2.y;
+        }
+        for (int k = 0; k < 6; k++)
+            red[k][threadIdx.x] = s[k];
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off)
+                for (int k = 0; k < 6; k++)
+                    red[k][threadIdx.x] += red[k][threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float4* ap = reinterpret_cast<float4*>(acc + o);
+            ap[0] = make_float4(red[0][0], red[1][0], red[2][0], 0.f);
+            ap[1] = make_float4(red[3][0], red[4][0], red[5][0], 0.f);
+        }
+        __syncthreads();
+    }
+}
+
+// Owner of each contact's B side (sort key for the B-side lists) and of its A side.
+__global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint32_t nC, const uint64_t* __restrict__ keys,
+                                                        const SphereRec* __restrict__ spheres,
+                                                        uint32_t* __restrict__ ownerA, uint32_t* __restrict__ ownerB,
+                                                        uint32_t* __restrict__ idx) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nC)
+        return;
+    const uint64_t k = keys[c];
+    ownerA[c] = spheres[key_a(k)].owner;
+    const uint32_t cls = key_class(k);
+    uint32_t ob = 0;
+    if (cls == DEME_KEY_CLASS_SS)
+        ob = spheres[key_b(k)].owner;
+    else if (cls == DEME_KEY_CLASS_SA)
+        ob = p.anal[key_b(k)].owner;
+    ownerB[c] = ob;
+    idx[c] = c;
+}
+
+__device__ inline uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+#define DEME_HEAVY_THRESHOLD 256u
+struct RangeCounters {
+    unsigned int nHeavy;
+    unsigned int nHeavyFree;  // heavy owners that are not fixed (they must be reduced every step)
+    unsigned int pad[14];
+};
+
+// aStart / bStart by binary search (once per detection), plus the heavy-owner list.
+__global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_t nC, const uint32_t* __restrict__ ownerA,
+                                                      const uint32_t* __restrict__ ownerBSorted,
+                                                      const OwnerRec* __restrict__ owners, uint32_t* __restrict__ aStart,
+                                                      uint32_t* __restrict__ bStart, uint8_t* __restrict__ heavy,
+                                                      uint8_t* __restrict__ fixedFlag, uint32_t* __restrict__ heavyList,
+                                                      uint32_t heavyCap, RangeCounters* rc) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o > p.nOwners)
+        return;
+    if (o == p.nOwners) {
+        aStart[o] = nC;
+        bStart[o] = nC;
+        return;
+    }
+    const uint32_t a0 = lower_bound_u32(ownerA, nC, o), a1 = lower_bound_u32(ownerA, nC, o + 1);
+    const uint32_t b0 = lower_bound_u32(ownerBSorted, nC, o), b1 = lower_bound_u32(ownerBSorted, nC, o + 1);
+    aStart[o] = a0;
+    bStart[o] = b0;
+    const bool isFixed = (p.familyFlags[owners[o].family] & 1u) != 0;
+    fixedFlag[o] = isFixed ? 1 : 0;
+    const bool hv = (a1 - a0) + (b1 - b0) > DEME_HEAVY_THRESHOLD;
+    heavy[o] = hv ? 1 : 0;
+    if (hv) {
+        const unsigned int slot = atomicAdd(&rc->nHeavy, 1u);
+        if (slot < heavyCap)
+            heavyList[slot] = o;
+        if (!isFixed)
+            atomicAdd(&rc->nHeavyFree, 1u);
+    }
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* __restrict__ owners,
-                                                   const AccRec* __restrict__ acc, AccRec* __restrict__ accNext) {
+                                                   AccRec* __restrict__ acc, const GatherArgs g) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= p.nOwners)
         return;
     OwnerRec r = load_owner(owners, o);
-    const float4* ap = reinterpret_cast<const float4*>(acc + o);
-    const float4 a = ap[0], al = ap[1];
-    float4* zp = reinterpret_cast<float4*>(accNext + o);
-    zp[0] = make_float4(0, 0, 0, 0);
-    zp[1] = make_float4(0, 0, 0, 0);
-
+    float4* ap = reinterpret_cast<float4*>(acc + o);
+    float4 a, al;
     const bool fixed = (p.familyFlags[r.family] & 1u) != 0;
+    if (FUSED && !g.heavy[o]) {
+        if (fixed) {  // a fixed owner's a/alpha never feed the integrator; they are reduced on demand
+            a = make_float4(0, 0, 0, 0);
+            al = a;
+        } else {
+            gather_owner(g, o, a, al);
+        }
+        ap[0] = a;  // kept for queries (GetOwnerAcc-style reads)
+        ap[1] = al;
+    } else {
+        a = ap[0];
+        al = ap[1];
+    }
+
     const float h = p.h;
     f3 old_v = mk3(r.vx, r.vy, r.vz), old_w = mk3(r.wx, r.wy, r.wz);
     d3 X = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);

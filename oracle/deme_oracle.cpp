@@ -459,15 +459,17 @@ struct Key {
     uint32_t a, b;
     uint8_t t;
 };
-inline int type_class(uint8_t t) {  // canonical list order: sphere-sphere, sphere-mesh, sphere-analytical
+inline int type_class(uint8_t t) {  // within one sphere A: sphere-sphere, sphere-mesh, sphere-analytical
     return t == DEME_SPHERE_SPHERE_CONTACT ? 0 : (t == DEME_SPHERE_MESH_CONTACT ? 1 : 2);
 }
+// canonical list order of this build: by sphere A, then type class, then B.  (The reference's final
+// order is type-major then A, DEMCubContactDetection.cu:1045-1051; only the SET is comparable with it.)
 inline bool key_less(const Key& x, const Key& y) {
+    if (x.a != y.a)
+        return x.a < y.a;
     const int cx = type_class(x.t), cy = type_class(y.t);
     if (cx != cy)
         return cx < cy;
-    if (x.a != y.a)
-        return x.a < y.a;
     return x.b < y.b;
 }
 
