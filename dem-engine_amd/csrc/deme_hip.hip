@@ -345,7 +345,9 @@ int do_detect(deme_ctx* c) {
                                             c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
                                             c->stream));
             sortedIdx = 1;
-            hipLaunchKernelGGL(k_sweep, dim3(grid_for(P, SW_T)), dim3(SW_T), 0, c->stream, c->dp,
+            hipLaunchKernelGGL(k_bin_stats, dim3(std::min<unsigned>(grid_for(P), 1024u)), dim3(256), 0, c->stream, c->incKeys[1].as<uint32_t>(), P,
+                               c->ctr.as<DetectCounters>());
+            hipLaunchKernelGGL(k_sweep, dim3(std::min<unsigned>(grid_for(P, SW_T), 4096u)), dim3(SW_T), 0, c->stream, c->dp,
                                c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
                                c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
                                c->ctr.as<DetectCounters>());

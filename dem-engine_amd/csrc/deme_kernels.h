@@ -174,31 +174,43 @@ __global__ __launch_bounds__(256) void k_fill_incidence(const DevParams p, const
 }
 
 // ---------------------------------------------------------------------------
-// Bin sweep.  One workgroup owns SW_T consecutive entries of the bin-sorted incidence list and
-// stages their sphere geometry in LDS.  Entry t is paired with every EARLIER entry of the same bin
-// (walking backwards through LDS, then -- only for a bin that began in an earlier chunk -- through
-// global memory), so each unordered pair of a bin is tested exactly once, by the thread of its
-// later member.  Decision arithmetic: DEMContactKernels_SphereSphere.cu:57-89 (calcContactPoint)
-// and :177-216; the pair counts iff the contact point's bin is this bin.
-// Output: wavefront ballot + prefix compaction into an LDS buffer, one global reservation per
-// workgroup, coalesced copy-out.
+// Bin sweep.  The bin-sorted incidence list is cut into windows of SW_T entries; the workgroup of window
+// w owns every bin whose FIRST entry lies in the window (so a bin is never split between workgroups and
+// no look-back through global memory is needed).  The owned range [start, end) holds at most 2*SW_T
+// entries and is staged in LDS (two entries per thread).  Inside LDS a bin is the segment [s, e) found
+// by binary search over the sorted keys; its n(n-1)/2 pairs are spread evenly over its n entries by
+// cyclic pairing: entry k tests partners k+1 .. k+floor((n-1)/2) (mod n), plus k+n/2 for k < n/2 when n
+// is even -- every unordered pair exactly once, equal work for all lanes of a bin.  A bin with more than
+// SW_T entries (only possible with very coarse bins) is handled by its owner in SW_T x SW_T tiles.
+// Decision arithmetic: DEMContactKernels_SphereSphere.cu:57-89 (calcContactPoint) and :177-216 -- the pair
+// counts iff the contact point's bin is this bin -- with the cheap fp64 distance test first.
+// Output: wavefront ballot + prefix compaction into an LDS buffer, one global reservation per flush,
+// coalesced copy-out (replaces the count -> scan -> fill double sweep of the reference).
 // ---------------------------------------------------------------------------
 #define SW_T 256
-#define SW_OUT 1536
+#define SW_W (2 * SW_T)
+#define SW_OUT 1024
+#define SW_FLUSH 512
 
 struct SweepLDS {
-    double x[SW_T], y[SW_T], z[SW_T];
-    float r[SW_T];
-    uint32_t owner[SW_T], sph[SW_T], bin[SW_T], fam[SW_T];
+    double x[SW_W], y[SW_W], z[SW_W];
+    float r[SW_W];
+    uint32_t owner[SW_W], sph[SW_W], bin[SW_W], fam[SW_W];
     uint64_t out[SW_OUT];
     unsigned long long gBase;
     uint32_t nOut;
+    uint32_t start, endIdx, giant;
 };
 
 __device__ inline bool pair_test(const DevParams& p, double ax, double ay, double az, float ar, uint32_t ao,
                                  uint32_t af, double bx, double by, double bz, float br, uint32_t bo, uint32_t bf,
                                  uint32_t bin) {
     if (ao == bo)
+        return false;
+    // distance test first (the reference evaluates everything and ANDs the flags: same outcome)
+    const double rA = (double)ar, rB = (double)br;
+    const double d2 = (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
+    if (d2 > (rA + rB) * (rA + rB))
         return false;
     float am = 0.f;
     if (!p.familyTrivial) {
@@ -210,9 +222,53 @@ __device__ inline bool pair_test(const DevParams& p, double ax, double ay, doubl
     d3 cp;
     f3 n;
     double depth;
-    bool in = spheres_overlap(ax, ay, az, (double)ar, bx, by, bz, (double)br, cp, n, depth);
+    bool in = spheres_overlap(ax, ay, az, rA, bx, by, bz, rB, cp, n, depth);
     in = in && (depth > (double)am);
     return in && (point_bin(cp.x, cp.y, cp.z, p) == bin);
+}
+
+// wave-wide append of `key` for lanes with `hit` (all lanes of the wave must call this together)
+__device__ inline void sweep_emit(SweepLDS& L, bool hit, uint64_t key, uint32_t lane, uint64_t* outKeys, uint64_t cap,
+                                  DetectCounters* ctr) {
+    const unsigned long long m = __ballot(hit);
+    if (!m)
+        return;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t pos0 = 0;
+    if ((int)lane == leader)
+        pos0 = atomicAdd(&L.nOut, (uint32_t)__popcll(m));
+    pos0 = __shfl(pos0, leader);
+    if (hit) {
+        const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < SW_OUT) {
+            L.out[pos] = key;
+        } else {  // LDS buffer full: spill straight to global
+            const unsigned long long slot = atomicAdd(&ctr->nContactsRaw, 1ull);
+            if (slot < cap)
+                outKeys[slot] = key;
+        }
+    }
+}
+
+__device__ inline uint64_t ss_key(uint32_t a, uint32_t b) {
+    return (a < b) ? make_key(DEME_KEY_CLASS_SS, a, b) : make_key(DEME_KEY_CLASS_SS, b, a);
+}
+
+// block-wide flush of the LDS output buffer (call from uniform control flow)
+__device__ inline void sweep_flush(SweepLDS& L, uint32_t t, uint64_t* outKeys, uint64_t cap, DetectCounters* ctr) {
+    const uint32_t nOut = min(L.nOut, (uint32_t)SW_OUT);
+    if (t == 0)
+        L.gBase = nOut ? atomicAdd(&ctr->nContactsRaw, (unsigned long long)nOut) : 0ull;
+    __syncthreads();
+    for (uint32_t q = t; q < nOut; q += SW_T) {
+        const unsigned long long slot = L.gBase + q;
+        if (slot < cap)
+            outKeys[slot] = L.out[q];
+    }
+    __syncthreads();
+    if (t == 0)
+        L.nOut = 0;
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_t* __restrict__ keys,
@@ -221,136 +277,227 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                                                 uint64_t* __restrict__ outKeys, uint64_t cap, DetectCounters* ctr) {
     __shared__ SweepLDS L;
     const uint32_t t = threadIdx.x;
-    const uint32_t base = blockIdx.x * SW_T;
-    const uint32_t j = base + t;
-    const bool valid = j < P;
     const uint32_t lane = t & 63u;
+    const uint32_t nWin = (P + SW_T - 1) / SW_T;
     if (t == 0)
         L.nOut = 0;
-    uint32_t myBin = DEME_NULL_BINID_DEV, mySph = 0, myOwner = 0, myFam = 0;
-    double mx = 0, my = 0, mz = 0;
-    float mr = 0;
-    if (valid) {
-        myBin = keys[j];
-        mySph = sphIds[j];
-        const GeoRec g = geo[mySph];
-        mx = g.x, my = g.y, mz = g.z, mr = g.r, myOwner = g.owner;
-        if (!p.familyTrivial)
-            myFam = owners[myOwner].family;
-    }
-    L.x[t] = mx, L.y[t] = my, L.z[t] = mz, L.r[t] = mr;
-    L.owner[t] = myOwner, L.sph[t] = mySph, L.bin[t] = myBin, L.fam[t] = myFam;
-    __syncthreads();
-
-    // statistics: active bins (segment heads) and the largest bin (rank of its last entry + 1)
-    const uint32_t prevBin = (j == 0) ? DEME_NULL_BINID_DEV : ((t == 0) ? keys[j - 1] : L.bin[t - 1]);
-    const bool head = valid && (myBin != prevBin);
-    {
-        const unsigned long long hm = __ballot(head);
-        if (lane == 0 && hm)
-            atomicAdd(&ctr->nActiveBins, (unsigned int)__popcll(hm));
-    }
-
-    uint32_t rank = 0;  // number of earlier entries in my bin
-    // ---- phase 1: partners inside this chunk (LDS)
-    int i = (int)t - 1;
-    while (true) {
-        const bool act = valid && (i >= 0) && (L.bin[i >= 0 ? i : 0] == myBin);
-        if (!__any(act))
-            break;
-        bool hit = false;
-        uint64_t key = 0;
-        if (act) {
-            rank++;
-            hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], mx, my, mz, mr, myOwner, myFam, myBin);
-            if (hit) {
-                const uint32_t a = L.sph[i];
-                key = (a < mySph) ? make_key(DEME_KEY_CLASS_SS, a, mySph) : make_key(DEME_KEY_CLASS_SS, mySph, a);
-            }
+    for (uint32_t win = blockIdx.x; win < nWin; win += gridDim.x) {
+        const uint32_t base = win * SW_T;
+        __syncthreads();  // everyone is done with the previous window's LDS contents
+        // ---- keys of [base, base + 2*SW_T) into LDS; heads mark first entries of bins
+        uint32_t k0 = DEME_NULL_BINID_DEV, k1 = DEME_NULL_BINID_DEV;
+        if (base + t < P)
+            k0 = keys[base + t];
+        if (base + SW_T + t < P)
+            k1 = keys[base + SW_T + t];
+        L.bin[t] = k0;
+        L.bin[SW_T + t] = k1;
+        if (t == 0) {
+            L.start = SW_W;
+            L.endIdx = SW_W;
+            L.giant = 0;
         }
-        const unsigned long long m = __ballot(hit);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t pos0 = 0;
-            if ((int)lane == leader)
-                pos0 = atomicAdd(&L.nOut, (uint32_t)__popcll(m));
-            pos0 = __shfl(pos0, leader);
-            if (hit) {
-                const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < SW_OUT) {
-                    L.out[pos] = key;
-                } else {  // LDS buffer full: spill straight to global
-                    const unsigned long long slot = atomicAdd(&ctr->nContactsRaw, 1ull);
-                    if (slot < cap)
-                        outKeys[slot] = key;
+        __syncthreads();
+        const uint32_t prev0 = (t == 0) ? (base == 0 ? DEME_NULL_BINID_DEV : keys[base - 1]) : L.bin[t - 1];
+        const bool head0 = (base + t < P) && (k0 != prev0);
+        const bool head1 = (base + SW_T + t >= P) ? (base + SW_T + t == P) : (k1 != L.bin[SW_T + t - 1]);
+        if (head0)
+            atomicMin(&L.start, t);  // first bin that begins in my window
+        if (head1)
+            atomicMin(&L.endIdx, SW_T + t);  // first bin (or list end) at or after the next window
+        if (base + t == P)
+            atomicMin(&L.endIdx, t);  // the list ends inside my own window
+        __syncthreads();
+        const uint32_t start = L.start;
+        if (start >= SW_T)
+            continue;  // no bin begins here: an earlier workgroup owns everything in this window
+        uint32_t end = L.endIdx;
+        uint32_t giantStart = SW_W;
+        if (end >= SW_W) {
+            // the last bin that begins in my window runs past the LDS window: a giant bin.  Bins before it
+            // are complete and handled in LDS; the giant one goes through the tiled path below.
+            // its first entry = the last head inside [start, SW_T): found with a max-reduction
+            if (head0)
+                atomicMax(&L.giant, t);
+            __syncthreads();
+            giantStart = L.giant;
+            end = giantStart;
+        }
+        const uint32_t n_rng = end - start;  // <= 2*SW_T - 1 entries, all complete bins
+        // ---- stage geometry of my range (two entries per thread)
+        __syncthreads();
+        for (uint32_t q = t; q < n_rng; q += SW_T) {
+            const uint32_t sph = sphIds[base + start + q];
+            const GeoRec g = geo[sph];
+            L.x[q] = g.x, L.y[q] = g.y, L.z[q] = g.z, L.r[q] = g.r;
+            L.owner[q] = g.owner, L.sph[q] = sph;
+            L.fam[q] = p.familyTrivial ? 0u : owners[g.owner].family;
+        }
+        // keys were loaded at offset `start`: shift so that L.bin[q] matches entry q of the range
+        uint32_t b0 = DEME_NULL_BINID_DEV, b1 = DEME_NULL_BINID_DEV;
+        if (t < n_rng)
+            b0 = L.bin[start + t];
+        if (SW_T + t < n_rng)
+            b1 = L.bin[start + SW_T + t];
+        __syncthreads();
+        L.bin[t] = b0;
+        L.bin[SW_T + t] = b1;
+        __syncthreads();
+        // ---- balanced cyclic pairing, entries q = t and q = t + SW_T
+        for (uint32_t q = t; q < SW_W; q += SW_T) {
+            const bool valid = q < n_rng;
+            uint32_t s = 0, n = 1, k = 0, myBin = DEME_NULL_BINID_DEV;
+            if (valid) {
+                myBin = L.bin[q];
+                uint32_t lo = 0, hi = q;  // first index with bin == myBin
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (L.bin[mid] < myBin)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
                 }
+                s = lo;
+                lo = q + 1, hi = n_rng;  // first index with bin > myBin
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (L.bin[mid] <= myBin)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                n = lo - s;
+                k = q - s;
+            }
+            const uint32_t half = valid ? (n - 1) / 2 : 0;
+            const uint32_t trips = half + ((valid && (n & 1u) == 0 && k < n / 2) ? 1u : 0u);
+            double mx = 0, my = 0, mz = 0;
+            float mr = 0;
+            uint32_t mo = 0, mf = 0, ms = 0;
+            if (valid)
+                mx = L.x[q], my = L.y[q], mz = L.z[q], mr = L.r[q], mo = L.owner[q], mf = L.fam[q], ms = L.sph[q];
+            for (uint32_t m = 1;; m++) {
+                const bool act = m <= trips;
+                if (!__any(act))
+                    break;
+                bool hit = false;
+                uint64_t key = 0;
+                if (act) {
+                    uint32_t qq = k + ((m <= half) ? m : n / 2);
+                    if (qq >= n)
+                        qq -= n;
+                    const uint32_t i = s + qq;
+                    hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf, myBin);
+                    if (hit)
+                        key = ss_key(L.sph[i], ms);
+                }
+                sweep_emit(L, hit, key, lane, outKeys, cap, ctr);
             }
         }
-        i--;
-    }
-    // ---- phase 2: my bin began in an earlier chunk (only lanes that ran off the front of LDS)
-    {
-        long long g = (long long)base - 1;
-        bool more = valid && (i < 0) && (base > 0) && (L.bin[0] == myBin);
-        while (true) {
-            bool act = more && (g >= 0);
-            uint32_t oSph = 0;
-            if (act) {
-                act = (keys[g] == myBin);
-                more = act;
+        // ---- giant bin: SW_T x SW_T tiles, A tile in LDS, each thread holds one B entry
+        if (giantStart < SW_W) {
+            const uint32_t gs = base + giantStart;
+            const uint32_t gbin = keys[gs];
+            uint32_t lo = gs + 1, hi = P;  // end of the giant bin: first index with key > gbin
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (keys[mid] <= gbin)
+                    lo = mid + 1;
+                else
+                    hi = mid;
             }
-            if (!__any(act))
-                break;
-            bool hit = false;
-            uint64_t key = 0;
-            if (act) {
-                rank++;
-                oSph = sphIds[g];
-                const GeoRec og = geo[oSph];
-                const uint32_t of = p.familyTrivial ? 0u : owners[og.owner].family;
-                hit = pair_test(p, og.x, og.y, og.z, og.r, og.owner, of, mx, my, mz, mr, myOwner, myFam, myBin);
-                if (hit)
-                    key = (oSph < mySph) ? make_key(DEME_KEY_CLASS_SS, oSph, mySph) : make_key(DEME_KEY_CLASS_SS, mySph, oSph);
-            }
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-                const int leader = __ffsll((long long)m) - 1;
-                uint32_t pos0 = 0;
-                if ((int)lane == leader)
-                    pos0 = atomicAdd(&L.nOut, (uint32_t)__popcll(m));
-                pos0 = __shfl(pos0, leader);
-                if (hit) {
-                    const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < SW_OUT) {
-                        L.out[pos] = key;
-                    } else {
-                        const unsigned long long slot = atomicAdd(&ctr->nContactsRaw, 1ull);
-                        if (slot < cap)
-                            outKeys[slot] = key;
+            const uint32_t ge = lo;
+            for (uint32_t ta = gs; ta < ge; ta += SW_T) {
+                __syncthreads();
+                const uint32_t na = min((uint32_t)SW_T, ge - ta);
+                if (t < na) {
+                    const uint32_t sph = sphIds[ta + t];
+                    const GeoRec g = geo[sph];
+                    L.x[t] = g.x, L.y[t] = g.y, L.z[t] = g.z, L.r[t] = g.r;
+                    L.owner[t] = g.owner, L.sph[t] = sph;
+                    L.fam[t] = p.familyTrivial ? 0u : owners[g.owner].family;
+                }
+                __syncthreads();
+                for (uint32_t tb = ta; tb < ge; tb += SW_T) {
+                    const uint32_t jb = tb + t;
+                    const bool valid = jb < ge;
+                    double mx = 0, my = 0, mz = 0;
+                    float mr = 0;
+                    uint32_t mo = 0, mf = 0, ms = 0;
+                    if (valid) {
+                        ms = sphIds[jb];
+                        const GeoRec g = geo[ms];
+                        mx = g.x, my = g.y, mz = g.z, mr = g.r, mo = g.owner;
+                        mf = p.familyTrivial ? 0u : owners[g.owner].family;
                     }
+                    for (uint32_t i = 0; i < na; i++) {  // uniform trip count
+                        const bool act = valid && (ta + i < jb);  // each unordered pair once
+                        bool hit = false;
+                        uint64_t key = 0;
+                        if (act) {
+                            hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf,
+                                            gbin);
+                            if (hit)
+                                key = ss_key(L.sph[i], ms);
+                        }
+                        sweep_emit(L, hit, key, lane, outKeys, cap, ctr);
+                    }
+                    __syncthreads();
+                    if (L.nOut >= SW_FLUSH)
+                        sweep_flush(L, t, outKeys, cap, ctr);
                 }
             }
-            g--;
+        }
+        __syncthreads();
+        if (L.nOut >= SW_FLUSH)  // uniform: read after the barrier
+            sweep_flush(L, t, outKeys, cap, ctr);
+    }
+    __syncthreads();
+    sweep_flush(L, t, outKeys, cap, ctr);
+}
+
+// Active-bin count and the largest bin population (numSpheresBinTouches statistics of
+// DEMCubContactDetection.cu:195-230; the population check feeds errOutBinSphNum).
+__global__ __launch_bounds__(256) void k_bin_stats(const uint32_t* __restrict__ keys, uint32_t P, DetectCounters* ctr) {
+    __shared__ uint32_t sHeads[4], sPop[4];
+    uint32_t heads = 0, pop = 0;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x) {
+        const uint32_t b = keys[j];
+        if ((j == 0) || (keys[j - 1] != b)) {
+            heads++;
+            uint32_t lo = j + 1, hi = P;  // first index with key > b; gallop first: bins are short
+            uint32_t step = 32;
+            while (lo + step < hi && keys[lo + step - 1] == b) {
+                lo += step;
+                step <<= 1;
+            }
+            hi = min(hi, lo + step);
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (keys[mid] <= b)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            pop = max(pop, lo - j);
         }
     }
-    // last entry of a bin knows the bin's population
-    {
-        const uint32_t nextBin = (j + 1 < P) ? ((t + 1 < SW_T) ? L.bin[t + 1] : keys[j + 1]) : DEME_NULL_BINID_DEV;
-        uint32_t pop = (valid && nextBin != myBin) ? rank + 1 : 0;
-        for (int off = 32; off > 0; off >>= 1)
-            pop = max(pop, (uint32_t)__shfl_xor((int)pop, off));
-        if (lane == 0 && pop > 1)
-            atomicMax(&ctr->maxInBin, pop);
+    for (int off = 32; off > 0; off >>= 1) {
+        heads += (uint32_t)__shfl_xor((int)heads, off);
+        pop = max(pop, (uint32_t)__shfl_xor((int)pop, off));
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        sHeads[threadIdx.x >> 6] = heads;
+        sPop[threadIdx.x >> 6] = pop;
     }
     __syncthreads();
-    const uint32_t nOut = min(L.nOut, (uint32_t)SW_OUT);
-    if (t == 0)
-        L.gBase = nOut ? atomicAdd(&ctr->nContactsRaw, (unsigned long long)nOut) : 0ull;
-    __syncthreads();
-    for (uint32_t k = t; k < nOut; k += SW_T) {
-        const unsigned long long slot = L.gBase + k;
-        if (slot < cap)
-            outKeys[slot] = L.out[k];
+    if (threadIdx.x == 0) {
+        const uint32_t h = sHeads[0] + sHeads[1] + sHeads[2] + sHeads[3];
+        const uint32_t m = max(max(sPop[0], sPop[1]), max(sPop[2], sPop[3]));
+        if (h)
+            atomicAdd(&ctr->nActiveBins, h);
+        if (m > 1)
+            atomicMax(&ctr->maxInBin, m);
     }
 }
 
@@ -586,8 +733,8 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         } else {
             gather_owner(g, o, a, al);
         }
-        ap[0] = a;  // kept for queries (GetOwnerAcc-style reads)
-        ap[1] = al;
+        // a/alpha are not stored in the stepping loop (32 B/owner of HBM writes per step saved); a state
+        // download re-derives them from the per-contact contributions (launch_full_reduction)
     } else {
         a = ap[0];
         al = ap[1];
