@@ -8,8 +8,17 @@
 // contract that makes contact / bin decisions bit-identical to the CPU oracle.
 // This translation unit is compiled with -ffp-contract=off.
 #pragma once
+#ifdef __HIPCC_RTC__
+// hipRTC: the HIP runtime declarations are built in; no system headers are available
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace deme_dev {
 

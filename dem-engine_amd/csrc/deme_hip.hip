@@ -19,6 +19,7 @@
 #include "../../include/deme_hip.h"
 #include "deme_device.h"
 #include "deme_force.h"
+#include "deme_jit.h"
 #include "deme_kernels.h"
 
 using namespace deme_dev;
@@ -60,6 +61,11 @@ struct deme_ctx {
     // per-contact contributions and the per-owner gather lists (built once per detection)
     DevBuf conA4, conA2, conB4, conB2, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
     uint32_t nHeavy = 0, nHeavyFree = 0;
+    // run-time compiled user force model
+    deme_jit::MaterialTables mt;
+    hipModule_t customMod = nullptr;
+    hipFunction_t customFn = nullptr;
+    std::map<size_t, std::vector<char>> jitCache;
     bool conValid = false;
     int keysCur = 0, wcCur = 0;
     size_t incCap = 0, cntCap = 0;
@@ -468,7 +474,7 @@ int launch_forces(deme_ctx* c) {
         c->conValid = true;
         return DEME_OK;
     }
-    if (c->hp.forceModel == DEME_FORCE_CUSTOM)
+    if (c->hp.forceModel == DEME_FORCE_CUSTOM && !c->customFn)
         return fail(c, DEME_ERR_INVALID, "custom force model selected but none compiled (deme_compile_force_model)");
     ForceArgs a{};
     a.owners = c->owners.as<OwnerRec>();
@@ -487,8 +493,12 @@ int launch_forces(deme_ctx* c) {
         ScopedTimer tm(c, "calc_forces");
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
             hipLaunchKernelGGL(k_calc_forces<0>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
-        else
+        else if (c->hp.forceModel == DEME_FORCE_HERTZIAN_FRICTIONLESS)
             hipLaunchKernelGGL(k_calc_forces<1>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
+        else {
+            void* args[] = {&c->dp, &a};
+            HIPCK(hipModuleLaunchKernel(c->customFn, grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+        }
     }
     c->conValid = true;
     return DEME_OK;
@@ -688,6 +698,12 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     }
     if (int rc = upload(c, c->anal, ha.data(), ha.size()))
         return rc;
+    c->mt.nMat = s->nMat;
+    c->mt.E.assign(s->E, s->E + s->nMat);
+    c->mt.nu.assign(s->nu, s->nu + s->nMat);
+    if (s->CoR) c->mt.CoR.assign(s->CoR, s->CoR + (size_t)s->nMat * s->nMat);
+    if (s->mu) c->mt.mu.assign(s->mu, s->mu + (size_t)s->nMat * s->nMat);
+    if (s->Crr) c->mt.Crr.assign(s->Crr, s->Crr + (size_t)s->nMat * s->nMat);
     std::vector<MatPair> hp;
     build_mat_pairs(s, hp);
     if (int rc = upload(c, c->matPair, hp.data(), hp.size()))
@@ -1034,8 +1050,61 @@ int deme_download_sphere_geometry(deme_ctx* c, double* X, double* Y, double* Z, 
     return DEME_OK;
 }
 
-int deme_compile_force_model(deme_ctx* c, const char*, size_t, const char* const*, uint32_t, const char*) {
-    return fail(c, DEME_ERR_COMPILE, "run-time force-model compilation is not built yet");
+int deme_compile_force_model(deme_ctx* c, const char* src, size_t len, const char* const* wildcardNames, uint32_t nWildcards,
+                             const char* prerequisites) {
+    if (!c || !src)
+        return DEME_ERR_INVALID;
+    if (!c->haveScene)
+        return fail(c, DEME_ERR_INVALID, "upload the scene first: material tables are compiled into the model");
+    if (nWildcards != c->hp.nContactWildcards)
+        return fail(c, DEME_ERR_INVALID, "%u wildcard names given but DemeParams.nContactWildcards is %u", nWildcards,
+                    c->hp.nContactWildcards);
+    std::vector<std::string> names;
+    for (uint32_t i = 0; i < nWildcards; i++)
+        names.emplace_back(wildcardNames[i] ? wildcardNames[i] : "");
+    std::string gen, err;
+    if (deme_jit::generate_source(std::string(src, len), names, prerequisites ? prerequisites : "", c->mt, gen, err))
+        return fail(c, DEME_ERR_COMPILE, "%s", err.c_str());
+    const size_t key = std::hash<std::string>{}(gen);
+    auto it = c->jitCache.find(key);
+    if (it == c->jitCache.end()) {
+        std::vector<char> code;
+        std::string log;
+        if (deme_jit::compile(gen, code, log))
+            return fail(c, DEME_ERR_COMPILE, "force model failed to compile:\n%.900s", log.c_str());
+        it = c->jitCache.emplace(key, std::move(code)).first;
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (c->customMod) {
+        (void)hipModuleUnload(c->customMod);
+        c->customMod = nullptr;
+        c->customFn = nullptr;
+    }
+    HIPCK(hipModuleLoadData(&c->customMod, it->second.data()));
+    HIPCK(hipModuleGetFunction(&c->customFn, c->customMod, "deme_custom_forces"));
+    return DEME_OK;
+}
+
+int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,
+                   char* log, size_t logCap) {
+    deme_jit::MaterialTables mt;
+    mt.nMat = 2;
+    mt.E = {1e8f, 1e9f}, mt.nu = {0.3f, 0.3f};
+    mt.CoR = {0.5f, 0.6f, 0.6f, 0.7f}, mt.mu = {0.2f, 0.3f, 0.3f, 0.4f}, mt.Crr = {0.f, 0.f, 0.f, 0.f};
+    std::vector<std::string> names;
+    for (uint32_t i = 0; i < nWildcards; i++)
+        names.emplace_back(wildcardNames[i] ? wildcardNames[i] : "");
+    std::string gen, err, clog;
+    std::vector<char> code;
+    int rc = deme_jit::generate_source(src ? src : "", names, prerequisites ? prerequisites : "", mt, gen, err);
+    if (!rc) {
+        rc = deme_jit::compile(gen, code, clog);
+        err = clog;
+    }
+    if (log && logCap) {
+        snprintf(log, logCap, "%s", err.c_str());
+    }
+    return rc ? DEME_ERR_COMPILE : DEME_OK;
 }
 
 int deme_set_timing(deme_ctx* c, int enable) {

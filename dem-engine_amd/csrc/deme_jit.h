@@ -1,0 +1,219 @@
+// deme_jit.h -- run-time compilation of user force-model fragments (hipRTC, gfx950).
+//
+// Replaces the reference's jitify/NVRTC path for the force kernel (core/utils/JitHelper.cpp:50-111,
+// DEM/APIPrivate.cpp:1381-1574 equipForceModel, DEM/Models.h:219-378).  The user's statement block is
+// spliced LITERALLY (no regex: SURVEY App. B notes the reference's regex_replace hazard) into a generated
+// deme_user_model() that pre-declares the reference's ingredient names with the reference's types; the
+// kernel around it is the same source as the built-in models (deme_force.h), handed to hipRTC as in-memory
+// headers.  Compiled code objects are cached by a hash of the generated source.
+#pragma once
+#include <hip/hiprtc.h>
+
+#include <functional>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "deme_embed.inc"  // kSrcDeviceH, kSrcForceH: the texts of deme_device.h / deme_force.h
+
+namespace deme_jit {
+
+// Names and helpers user fragments are written against (the reference gets them from DEM/Defines.h,
+// kernel/CUDAMathHelpers.cuh and kernel/DEMHelperKernels.cuh).  Own implementation, reference vocabulary.
+static const char* kVocabulary = R"DEMEVOC(
+#define DEME_TINY_FLOAT 1e-12
+#define DEME_HUGE_FLOAT 1e15
+#define DEME_MIN(a, b) ((a < b) ? a : b)
+#define DEME_MAX(a, b) ((a > b) ? a : b)
+namespace deme {
+typedef float oriQ_t;
+typedef unsigned int bodyID_t;
+typedef unsigned short materialsOffset_t;
+typedef unsigned char family_t;
+typedef unsigned char contact_t;
+constexpr double TWO_OVER_THREE = 2. / 3.;
+constexpr double FOUR_OVER_THREE = 4. / 3.;
+constexpr double FIVE_OVER_THREE = 5. / 3.;
+constexpr double TWO_TIMES_SQRT_FIVE_OVER_SIX = 1.825741858350554;
+constexpr double PI = 3.1415926535897932385;
+constexpr double PI_SQUARED = 9.869604401089358;
+const contact_t NOT_A_CONTACT = 0;
+const contact_t SPHERE_SPHERE_CONTACT = 1;
+const contact_t SPHERE_MESH_CONTACT = 2;
+const contact_t SPHERE_ANALYTICAL_CONTACT = 10;
+const contact_t SPHERE_PLANE_CONTACT = 11;
+const contact_t SPHERE_PLATE_CONTACT = 12;
+const contact_t SPHERE_CYL_CONTACT = 13;
+}
+__device__ inline float3 make_float3(float s) { return make_float3(s, s, s); }
+__device__ inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline double dot(double3 a, double3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline float3 cross(float3 a, float3 b) {
+    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ inline float length(float3 v) { return sqrtf(dot(v, v)); }
+__device__ inline double length(double3 v) { return sqrt(dot(v, v)); }
+__device__ inline float3 normalize(float3 v) { const float il = rsqrtf(dot(v, v)); return v * il; }
+__device__ inline float3 to_float3(double3 a) { return make_float3((float)a.x, (float)a.y, (float)a.z); }
+__device__ inline double3 to_double3(float3 a) { return make_double3(a.x, a.y, a.z); }
+template <typename T1, typename T2>
+__device__ inline void applyOriQToVector3(T1& X, T1& Y, T1& Z, const T2& Qw, const T2& Qx, const T2& Qy, const T2& Qz) {
+    const T1 oX = X, oY = Y, oZ = Z;
+    X = ((T2)2.0 * (Qw * Qw + Qx * Qx) - (T2)1.0) * oX + ((T2)2.0 * (Qx * Qy - Qw * Qz)) * oY + ((T2)2.0 * (Qx * Qz + Qw * Qy)) * oZ;
+    Y = ((T2)2.0 * (Qx * Qy + Qw * Qz)) * oX + ((T2)2.0 * (Qw * Qw + Qy * Qy) - (T2)1.0) * oY + ((T2)2.0 * (Qy * Qz - Qw * Qx)) * oZ;
+    Z = ((T2)2.0 * (Qx * Qz - Qw * Qy)) * oX + ((T2)2.0 * (Qy * Qz + Qw * Qx)) * oY + ((T2)2.0 * (Qw * Qw + Qz * Qz) - (T2)1.0) * oZ;
+}
+template <typename T1>
+__device__ inline void matProxy2ContactParam(T1& E_eff, T1& G_eff, const T1& Y1, const T1& nu1, const T1& Y2, const T1& nu2) {
+    const T1 invE = ((T1)1 - nu1 * nu1) / Y1 + ((T1)1 - nu2 * nu2) / Y2;
+    E_eff = (T1)1 / invE;
+    const T1 invG = (T1)2 * ((T1)2 - nu1) * ((T1)1 + nu1) / Y1 + (T1)2 * ((T1)2 - nu2) * ((T1)1 + nu2) / Y2;
+    G_eff = (T1)1 / invG;
+}
+template <typename T1>
+__device__ inline void matProxy2ContactParam(T1& E_eff, const T1& Y1, const T1& nu1, const T1& Y2, const T1& nu2) {
+    const T1 invE = ((T1)1 - nu1 * nu1) / Y1 + ((T1)1 - nu2 * nu2) / Y2;
+    E_eff = (T1)1 / invE;
+}
+)DEMEVOC";
+
+struct MaterialTables {
+    uint32_t nMat = 0;
+    std::vector<float> E, nu, CoR, mu, Crr;  // CoR/mu/Crr are nMat*nMat
+};
+
+inline std::string float_lit(float v) {
+    char b[64];
+    snprintf(b, sizeof(b), "%.9g", (double)v);
+    std::string s(b);
+    if (s.find_first_of(".eEn") == std::string::npos)  // "inf"/"nan" contain 'n'
+        s += ".0";
+    return s + "f";
+}
+
+inline void emit_array(std::ostringstream& o, const char* name, const std::vector<float>& v, uint32_t n, bool pair) {
+    if (v.empty())
+        return;
+    if (!pair) {
+        o << "__device__ const float " << name << "[] = {";
+        for (uint32_t i = 0; i < n; i++)
+            o << (i ? ", " : "") << float_lit(v[i]);
+        o << "};\n";
+    } else {  // _materialDefs_ pairwise form: float name[][nMat] (APIPrivate.cpp:1877-2026)
+        o << "__device__ const float " << name << "[][" << n << "] = {";
+        for (uint32_t a = 0; a < n; a++) {
+            o << (a ? ", {" : "{");
+            for (uint32_t b = 0; b < n; b++)
+                o << (b ? ", " : "") << float_lit(v[(size_t)a * n + b]);
+            o << "}";
+        }
+        o << "};\n";
+    }
+}
+
+// ingredient names a fragment may not redefine as wildcards (reference check: APIPrivate.cpp:1425-1465)
+inline bool reserved_name(const std::string& n) {
+    static const char* r[] = {"overlapDepth", "B2A", "contactPnt", "AOwnerPos", "BOwnerPos", "bodyAPos", "bodyBPos",
+                              "AOwnerMass", "BOwnerMass", "ARadius", "BRadius", "AOriQ", "BOriQ", "bodyAMatType",
+                              "bodyBMatType", "ContactType", "locCPA", "locCPB", "force", "torque_only_force",
+                              "AOwnerFamily", "BOwnerFamily", "ts", "time", "ALinVel", "BLinVel", "ARotVel", "BRotVel",
+                              "AOwner", "BOwner", "AGeo", "BGeo", "AOwnerMOI", "BOwnerMOI", "myContactID", "granData",
+                              "simParams", "E", "nu", "CoR", "mu", "Crr"};
+    for (const char* k : r)
+        if (n == k)
+            return true;
+    return false;
+}
+
+inline bool valid_identifier(const std::string& n) {
+    if (n.empty() || !(isalpha((unsigned char)n[0]) || n[0] == '_'))
+        return false;
+    for (char ch : n)
+        if (!(isalnum((unsigned char)ch) || ch == '_'))
+            return false;
+    return true;
+}
+
+inline int generate_source(const std::string& user, const std::vector<std::string>& wildcards, const std::string& prereq,
+                           const MaterialTables& mt, std::string& out, std::string& err) {
+    for (size_t i = 0; i < wildcards.size(); i++) {
+        if (!valid_identifier(wildcards[i]) || reserved_name(wildcards[i])) {
+            err = "contact wildcard name '" + wildcards[i] + "' is not a usable identifier (it clashes with a force-model ingredient)";
+            return 1;
+        }
+        for (size_t j = 0; j < i; j++)
+            if (wildcards[i] == wildcards[j]) {
+                err = "contact wildcard '" + wildcards[i] + "' is declared twice";
+                return 1;
+            }
+    }
+    std::ostringstream o;
+    o << "#define DEME_JIT 1\n#include \"deme_force.h\"\n" << kVocabulary << "\n";
+    emit_array(o, "E", mt.E, mt.nMat, false);
+    emit_array(o, "nu", mt.nu, mt.nMat, false);
+    emit_array(o, "CoR", mt.CoR, mt.nMat, true);
+    emit_array(o, "mu", mt.mu, mt.nMat, true);
+    emit_array(o, "Crr", mt.Crr, mt.nMat, true);
+    o << "// ---- _forceModelPrerequisites_\n" << prereq << "\n";
+    o << "namespace deme_dev {\n__device__ void deme_user_model(UserModelIO& io) {\n";
+    o << "    double overlapDepth = io.overlapDepth; float3 B2A = io.B2A; double3 contactPnt = io.contactPnt;\n"
+         "    double3 AOwnerPos = io.AOwnerPos, BOwnerPos = io.BOwnerPos, bodyAPos = io.bodyAPos, bodyBPos = io.bodyBPos;\n"
+         "    float AOwnerMass = io.AOwnerMass, BOwnerMass = io.BOwnerMass, ARadius = io.ARadius, BRadius = io.BRadius;\n"
+         "    float4 AOriQ = io.AOriQ, BOriQ = io.BOriQ;\n"
+         "    deme::materialsOffset_t bodyAMatType = io.bodyAMatType, bodyBMatType = io.bodyBMatType;\n"
+         "    deme::contact_t ContactType = io.ContactType; deme::family_t AOwnerFamily = io.AOwnerFamily, BOwnerFamily = io.BOwnerFamily;\n"
+         "    float3 locCPA = io.locCPA, locCPB = io.locCPB, force = io.force, torque_only_force = io.torque_only_force;\n"
+         "    float ts = io.ts; float time = io.time;\n"
+         "    float3 ALinVel = io.ALinVel, BLinVel = io.BLinVel, ARotVel = io.ARotVel, BRotVel = io.BRotVel;\n"
+         "    float3 AOwnerMOI = io.AOwnerMOI, BOwnerMOI = io.BOwnerMOI;\n"
+         "    deme::bodyID_t AOwner = io.AOwner, BOwner = io.BOwner, AGeo = io.AGeo, BGeo = io.BGeo; unsigned int myContactID = io.myContactID;\n"
+         "    (void)overlapDepth; (void)B2A; (void)contactPnt; (void)AOwnerPos; (void)BOwnerPos; (void)bodyAPos; (void)bodyBPos;\n"
+         "    (void)AOwnerMass; (void)BOwnerMass; (void)ARadius; (void)BRadius; (void)AOriQ; (void)BOriQ; (void)bodyAMatType;\n"
+         "    (void)bodyBMatType; (void)ContactType; (void)AOwnerFamily; (void)BOwnerFamily; (void)locCPA; (void)locCPB; (void)ts;\n"
+         "    (void)time; (void)ALinVel; (void)BLinVel; (void)ARotVel; (void)BRotVel; (void)AOwnerMOI; (void)BOwnerMOI; (void)AOwner;\n"
+         "    (void)BOwner; (void)AGeo; (void)BGeo; (void)myContactID;\n";
+    for (size_t i = 0; i < wildcards.size(); i++)  // _forceModelContactWildcardAcq_
+        o << "    float " << wildcards[i] << " = io.wc[" << i << "];\n";
+    o << "    // ---- _DEMForceModel_ (user statement block, spliced literally)\n    {\n" << user << "\n    }\n";
+    for (size_t i = 0; i < wildcards.size(); i++)  // _forceModelContactWildcardWrite_
+        o << "    io.wc[" << i << "] = " << wildcards[i] << ";\n";
+    o << "    io.force = force; io.torque_only_force = torque_only_force;\n}\n}  // namespace deme_dev\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void deme_custom_forces(const deme_dev::DevParams p, "
+         "const deme_dev::ForceArgs a) {\n    deme_dev::calc_forces_body<2>(p, a);\n}\n";
+    out = o.str();
+    return 0;
+}
+
+// hipRTC: source -> gfx950 code object.  Needs no GPU (used by the CPU test through deme_jit_probe).
+inline int compile(const std::string& src, std::vector<char>& code, std::string& log) {
+    hiprtcProgram prog;
+    const char* hdrs[] = {kSrcDeviceH, kSrcForceH};
+    const char* names[] = {"deme_device.h", "deme_force.h"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "deme_custom_force_model.hip", 2, hdrs, names) != HIPRTC_SUCCESS) {
+        log = "hiprtcCreateProgram failed";
+        return 1;
+    }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    if (ls > 1) {
+        log.resize(ls);
+        hiprtcGetProgramLog(prog, &log[0]);
+    }
+    if (rc != HIPRTC_SUCCESS) {
+        if (log.empty())
+            log = hiprtcGetErrorString(rc);
+        hiprtcDestroyProgram(&prog);
+        return 1;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code.resize(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return 0;
+}
+
+}  // namespace deme_jit

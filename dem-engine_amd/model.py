@@ -275,9 +275,53 @@ class SceneBuilder:
     def UseFrictionlessHertzianModel(self):
         self.force_model = abi.FORCE_HERTZIAN_FRICTIONLESS
 
-    def UseCustomModel(self, n_wildcards):
+    # ---- user force model (DEMForceModel, AuxClasses.h:422-485) -----------------------------------
+    def DefineContactForceModel(self, src):
+        """DEMSolver::DefineContactForceModel (APIPublic.cpp:906): a C++ statement block written against the
+        reference's ingredient names; compiled at run time through deme_compile_force_model (hipRTC)."""
         self.force_model = abi.FORCE_CUSTOM
-        self.n_custom_wildcards = int(n_wildcards)
+        self.force_src = src
+        return self
+
+    def ReadContactForceModel(self, path):
+        return self.DefineContactForceModel(open(path).read())
+
+    def SetPerContactWildcards(self, names):
+        """std::set<std::string> in the reference (Models.h:363): indices follow sorted order."""
+        self.contact_wildcards = sorted(set(names))
+        self.n_custom_wildcards = len(self.contact_wildcards)
+
+    def SetMustPairwiseMatProp(self, names):
+        self.pairwise_props = set(names) | {"CoR", "mu", "Crr"}
+
+    def DefineCustomModelPrerequisites(self, code):
+        self.user_prerequisites = code
+
+    def force_model_prerequisites(self):
+        """_materialDefs_ for the properties beyond E/nu/CoR/mu/Crr + the user's prerequisites text."""
+        nm = max(1, len(self.materials))
+        extra = sorted({k for m in self.materials for k in m} - {"E", "nu", "CoR", "mu", "Crr"})
+        out = []
+        lit = lambda v: repr(float(np.float32(v))) + "f"
+        for name in extra:
+            v = np.array([m.get(name, 0.0) for m in self.materials], np.float32)
+            if name in getattr(self, "pairwise_props", set()):
+                M = ((v[:, None] + v[None, :]) / np.float32(2.0)).astype(np.float32)
+                for i in range(nm):
+                    M[i, i] = v[i]
+                for (n_, a, b), val in self.pair_overrides.items():
+                    if n_ == name:
+                        M[a, b] = np.float32(val)
+                rows = ", ".join("{" + ", ".join(lit(x) for x in r) + "}" for r in M)
+                out.append(f"__device__ const float {name}[][{nm}] = {{{rows}}};")
+            else:
+                out.append(f"__device__ const float {name}[] = {{{', '.join(lit(x) for x in v)}}};")
+        return "\n".join(out) + "\n" + getattr(self, "user_prerequisites", "")
+
+    def compile_into(self, ctx):
+        """Call after ctx.upload_scene(): builds the user model into the context."""
+        if self.force_model == abi.FORCE_CUSTOM:
+            ctx.compile_force_model(self.force_src, getattr(self, "contact_wildcards", []), self.force_model_prerequisites())
 
     def SetFamilyFixed(self, fam):
         self.family_flags[int(fam)] |= abi.FAMILY_FIXED

@@ -218,6 +218,11 @@ int deme_download_sphere_geometry(deme_ctx* ctx, double* X, double* Y, double* Z
 int deme_compile_force_model(deme_ctx* ctx, const char* src, size_t len, const char* const* wildcardNames,
                              uint32_t nWildcards, const char* prerequisites);
 
+/* compile-only check of a fragment (no context, no GPU needed): same generator and hipRTC options,
+ * 2 dummy materials; the compiler log is copied into `log`. */
+int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,
+                   char* log, size_t logCap);
+
 /* timing of the kernels this library launched (HIP events on the context stream);
  * names: "calc_forces", "integrate", "detect"; returns avg ms per launch since last reset */
 int deme_kernel_time_ms(deme_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches);

@@ -1,0 +1,112 @@
+"""The jitified contact-model hook: user statement blocks written against the reference's
+ingredient names compile through hipRTC.  CPU tests cover generation + compilation for gfx950 (no GPU
+needed); GPU tests run the compiled model through the C-ABI."""
+import numpy as np
+import pytest
+
+FRICTIONLESS = r"""
+if (overlapDepth > 0) {
+    float E_cnt;
+    matProxy2ContactParam<float>(E_cnt, E[bodyAMatType], nu[bodyAMatType], E[bodyBMatType], nu[bodyBMatType]);
+    const float CoR_cnt = CoR[bodyAMatType][bodyBMatType];
+    float3 rotVelCPA = cross(ARotVel, locCPA), rotVelCPB = cross(BRotVel, locCPB);
+    applyOriQToVector3<float, deme::oriQ_t>(rotVelCPA.x, rotVelCPA.y, rotVelCPA.z, AOriQ.w, AOriQ.x, AOriQ.y, AOriQ.z);
+    applyOriQToVector3<float, deme::oriQ_t>(rotVelCPB.x, rotVelCPB.y, rotVelCPB.z, BOriQ.w, BOriQ.x, BOriQ.y, BOriQ.z);
+    const float3 velB2A = (ALinVel + rotVelCPA) - (BLinVel + rotVelCPB);
+    const float projection = dot(velB2A, B2A);
+    const float mass_eff = (AOwnerMass * BOwnerMass) / (AOwnerMass + BOwnerMass);
+    const float sqrt_Rd = sqrt(overlapDepth * (ARadius * BRadius) / (ARadius + BRadius));
+    const float Sn = 2. * E_cnt * sqrt_Rd;
+    const float loge = (CoR_cnt < DEME_TINY_FLOAT) ? log(DEME_TINY_FLOAT) : log(CoR_cnt);
+    const float beta = loge / sqrt(loge * loge + deme::PI_SQUARED);
+    const float k_n = deme::TWO_OVER_THREE * Sn;
+    const float gamma_n = deme::TWO_TIMES_SQRT_FIVE_OVER_SIX * beta * sqrt(Sn * mass_eff);
+    force += (k_n * overlapDepth + gamma_n * projection) * B2A;
+"""
+COHESIVE = FRICTIONLESS + """
+    force += -Cohesion[bodyAMatType][bodyBMatType] * B2A;   // pairwise user property
+    contact_age += ts;                                        // a user contact wildcard
+}
+"""
+PLAIN = FRICTIONLESS + "}\n"
+
+
+def test_fragment_compiles_for_gfx950_without_a_gpu(pkg):
+    pre = "__device__ const float Cohesion[][2] = {{0.01f, 0.02f}, {0.02f, 0.03f}};\n"
+    ok, log = pkg.abi.jit_probe(COHESIVE, ["contact_age"], pre)
+    assert ok, log
+    ok, log = pkg.abi.jit_probe(PLAIN, [], "")
+    assert ok, log
+
+
+def test_name_clash_and_syntax_errors_are_reported(pkg):
+    ok, log = pkg.abi.jit_probe(PLAIN, ["force"], "")  # APIPrivate.cpp:1425-1465: wildcard clashes with an ingredient
+    assert not ok and "force" in log
+    ok, log = pkg.abi.jit_probe(PLAIN, ["a", "a"], "")
+    assert not ok and "twice" in log
+    ok, log = pkg.abi.jit_probe("force = undeclared_thing;", [], "")
+    assert not ok and "undeclared_thing" in log
+
+
+def test_builder_emits_material_arrays(pkg):
+    b = pkg.SceneBuilder()
+    b.LoadMaterial({"E": 1e8, "nu": 0.3, "CoR": 0.6, "Cohesion": 0.01, "Gamma": 2.0})
+    b.LoadMaterial({"E": 1e9, "nu": 0.3, "CoR": 0.6, "Cohesion": 0.03, "Gamma": 4.0})
+    b.SetMustPairwiseMatProp(["Cohesion"])
+    b.SetMaterialPropertyPair("Cohesion", 0, 1, 0.5)
+    pre = b.force_model_prerequisites()
+    assert "Cohesion[][2]" in pre and "0.5f" in pre and "Gamma[] = {2.0f, 4.0f}" in pre
+    b.SetPerContactWildcards(["zeta", "alpha"])
+    assert b.contact_wildcards == ["alpha", "zeta"]  # std::set order
+
+
+@pytest.mark.gpu
+def test_custom_model_matches_builtin_and_adds_cohesion(pkg):
+    def run(kind):
+        b = pkg.model.packed_bed(2000, seed=31, cd_freq=0, spacing_mult=2.5, init_vz=-0.4, force_model=1)
+        b.materials[0]["Cohesion"] = 0.004
+        b.SetMustPairwiseMatProp(["Cohesion"])
+        if kind == "plain":
+            b.DefineContactForceModel(PLAIN)
+            b.SetPerContactWildcards([])
+        elif kind == "cohesive":
+            b.DefineContactForceModel(COHESIVE)
+            b.SetPerContactWildcards(["contact_age"])
+        p, sc = b.Initialize()
+        ctx = pkg.Context(0)
+        ctx.set_params(p)
+        ctx.upload_scene(sc)
+        b.compile_into(ctx)
+        ctx.set_record_contacts(True)
+        ctx.detect()
+        ctx.calc_forces()
+        F = ctx.contact_records()[0]
+        age = ctx.wildcard(0) if kind == "cohesive" else None
+        return F, age, ctx.contacts(), p
+
+    F0, _, c0, p = run("builtin")
+    F1, _, c1, _ = run("plain")
+    F2, age, c2, _ = run("cohesive")
+    assert (c0[0] == c1[0]).all() and (c0[1] == c2[1]).all()
+    scale = np.abs(F0).max()
+    assert scale > 0 and np.abs(F1 - F0).max() <= 2e-6 * scale  # float vs double sqrt/log overloads: <= 1 ulp
+    touching = np.linalg.norm(F0, axis=1) > 0
+    d = np.linalg.norm(F2 - F1, axis=1)
+    assert touching.sum() > 500
+    assert np.allclose(d[touching], 0.004, rtol=1e-3) and (d[~touching] == 0).all()
+    assert np.allclose(age[touching], p.h) and (age[~touching] == 0).all()
+
+
+@pytest.mark.gpu
+def test_custom_model_requires_compilation(pkg):
+    b = pkg.model.packed_bed(300, seed=1, cd_freq=0, spacing_mult=2.5)
+    b.DefineContactForceModel(PLAIN)
+    b.SetPerContactWildcards([])
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p)
+    ctx.upload_scene(sc)
+    with pytest.raises(pkg.abi.DemeError, match="none compiled"):
+        ctx.step(1)
+    with pytest.raises(pkg.abi.DemeError, match="compile"):
+        ctx.compile_force_model("force = nonsense;", [], "")
