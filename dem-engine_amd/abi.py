@@ -261,6 +261,10 @@ class Context:
         self._ck(self.lib.deme_download_owner_state(self.h, C.byref(st)), "deme_download_owner_state")
         return out
 
+    def update_tri_nodes(self, n1, n2, n3):
+        arrs = [np.ascontiguousarray(x, np.float32).reshape(-1) for x in (n1, n2, n3)]
+        self._ck(self.lib.deme_update_tri_nodes(self.h, *[_ptr(x) for x in arrs]), "deme_update_tri_nodes")
+
     def compute_margins(self, drift):
         self._ck(self.lib.deme_compute_margins(self.h, int(drift)), "deme_compute_margins")
 

@@ -96,6 +96,8 @@ struct DevParams {
     const uint8_t* familyMasks;
     const float* familyExtra;
     const uint8_t* familyFlags;
+    const void* tris;  // TriRec[nTri] (deme_mesh.h)
+    uint32_t nTri;
 };
 
 // contact key: sphere A (31 bits) | type class (2 bits) | B (31 bits).  Sorting keys ascending yields the

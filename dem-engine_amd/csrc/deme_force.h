@@ -12,6 +12,7 @@
 // reference's meaning.  Self-contained so the same text compiles under hipRTC.
 #pragma once
 #include "deme_device.h"
+#include "deme_mesh.h"
 
 namespace deme_dev {
 
@@ -254,12 +255,41 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
         ContactType = (ob.type == 0) ? 11u : 13u;
         if (in.overlapDepth < -extraMarginSize)
             ContactType = 0u;
-    } else {
-        ContactType = 0u;  // sphere-mesh contacts: see deme_mesh.h
-        oB = oA;
-        mpB = mpA;
-        in.RB = in.RA;
-        BOwnerPos = AOwnerPos;
+    } else {  // sphere-mesh, DEMCalcForceKernels.cu:138-183: exact test in fp64 against the ORIGINAL triangle
+        const TriRec tr = reinterpret_cast<const TriRec*>(p.tris)[BGeo];
+        BOwner = tr.owner;
+        oB = load_owner(a.owners, BOwner);
+        mpB = p.massProps[oB.inertiaOff];
+        in.BOwnerMass = mpB.x;
+        in.BRadius = 1e15f;  // DEME_HUGE_FLOAT
+        bodyBMatType = tr.mat;
+        if (!p.familyTrivial) {
+            const float eB = p.familyExtra[oB.family];
+            extraMarginSize = (extraMarginSize > eB) ? extraMarginSize : eB;
+        }
+        BOwnerPos = decode_pos(oB.voxelID, oB.locX, oB.locY, oB.locZ, p);
+        BOwnerPos.x += p.LBFX;
+        BOwnerPos.y += p.LBFY;
+        BOwnerPos.z += p.LBFZ;
+        in.RB = rot_coeffs(oB.qw, oB.qx, oB.qy, oB.qz);
+        v3<double> nd[3];
+        const float* src[3] = {tr.n1, tr.n2, tr.n3};
+        for (int k = 0; k < 3; k++) {
+            const d3 r = rot_apply_d(in.RB, d3{(double)src[k][0], (double)src[k][1], (double)src[k][2]});
+            nd[k] = {BOwnerPos.x + r.x, BOwnerPos.y + r.y, BOwnerPos.z + r.z};
+        }
+        bodyBPos = {(nd[0].x + nd[1].x + nd[2].x) / 3., (nd[0].y + nd[1].y + nd[2].y) / 3., (nd[0].z + nd[1].z + nd[2].z) / 3.};
+        v3<double> cn, cpt;
+        double depth;
+        const bool in_contact = tri_sphere_cd<double, false>(nd[0], nd[1], nd[2], v3<double>{bodyAPos.x, bodyAPos.y, bodyAPos.z},
+                                                             (double)in.ARadius, cn, depth, cpt);
+        in.B2A = mk3((float)cn.x, (float)cn.y, (float)cn.z);
+        contactPnt = {cpt.x, cpt.y, cpt.z};
+        ContactType = 2u;
+        // the extra margin only counts on the positive side of the facet (DEMCalcForceKernels.cu:176-181)
+        if ((depth > extraMarginSize) || (!in_contact && depth < 0.))
+            ContactType = 0u;
+        in.overlapDepth = -depth;
     }
     in.BLinVel = mk3(oB.vx, oB.vy, oB.vz);
     in.BRotVel = mk3(oB.wx, oB.wy, oB.wz);

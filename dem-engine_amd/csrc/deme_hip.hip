@@ -21,6 +21,7 @@
 #include "deme_force.h"
 #include "deme_jit.h"
 #include "deme_kernels.h"
+#include "deme_mesh_kernels.h"
 
 using namespace deme_dev;
 
@@ -61,6 +62,11 @@ struct deme_ctx {
     // per-contact contributions and the per-owner gather lists (built once per detection)
     DevBuf conA4, conA2, conB4, conB2, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
     uint32_t nHeavy = 0, nHeavyFree = 0;
+    // triangles (mesh path)
+    uint32_t nTri = 0;
+    DevBuf tris, triWorld, triLo, triHi, triCounts, triOffsets, triKeys[2], triVals[2];
+    size_t triCap = 0;
+    uint64_t nTriInc = 0;
     // run-time compiled user force model
     deme_jit::MaterialTables mt;
     hipModule_t customMod = nullptr;
@@ -208,6 +214,8 @@ void refresh_dev_params(deme_ctx* c) {
     d.familyMasks = c->famMasks.as<uint8_t>();
     d.familyExtra = c->famExtra.as<float>();
     d.familyFlags = c->famFlags.as<uint8_t>();
+    d.tris = c->tris.p;
+    d.nTri = c->nTri;
 }
 
 int check_ready(deme_ctx* c) {
@@ -359,6 +367,53 @@ int do_detect(deme_ctx* c) {
                                c->ctr.as<DetectCounters>());
         }
         (void)sortedIdx;
+        // ---- sphere-triangle contacts (only when a mesh is loaded and some sphere is registered in a bin)
+        c->nTriInc = 0;
+        if (c->nTri && P) {
+            const uint32_t nT = c->nTri;
+            hipLaunchKernelGGL(k_tri_prep, dim3(grid_for(nT)), dim3(256), 0, c->stream, c->dp, nT, c->tris.as<TriRec>(),
+                               c->owners.as<OwnerRec>(), c->triWorld.as<TriWorld>(), c->triLo.as<int4>(),
+                               c->triHi.as<int4>(), c->triCounts.as<uint32_t>());
+            size_t tmp = c->scanTmp.bytes;
+            HIPCK(rocprim::exclusive_scan(c->scanTmp.p, tmp, c->triCounts.as<uint32_t>(), c->triOffsets.as<uint32_t>(), 0u,
+                                          (size_t)nT + 1, rocprim::plus<uint32_t>(), c->stream));
+            uint32_t TP = 0;
+            HIPCK(hipMemcpyAsync(&TP, c->triOffsets.as<uint32_t>() + nT, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipStreamSynchronize(c->stream));
+            if (TP > c->triCap) {
+                const size_t cap = (size_t)TP + TP / 4 + 1024;
+                for (int k = 0; k < 2; k++)
+                    if (ensure(c, c->triKeys[k], cap * 4) || ensure(c, c->triVals[k], cap * 4))
+                        return c->lastStatus;
+                c->triCap = cap;
+            }
+            c->nTriInc = TP;
+            if (TP) {
+                hipLaunchKernelGGL(k_tri_fill, dim3(grid_for(nT)), dim3(256), 0, c->stream, c->dp, nT,
+                                   c->triWorld.as<TriWorld>(), c->triLo.as<int4>(), c->triHi.as<int4>(),
+                                   c->triOffsets.as<uint32_t>(), c->triKeys[0].as<uint32_t>(), c->triVals[0].as<uint32_t>(),
+                                   (uint64_t)c->triCap);
+                const uint64_t nBins = (uint64_t)c->hp.nbX * c->hp.nbY * c->hp.nbZ;
+                unsigned bits = 1;
+                while (bits < 32 && (1ull << bits) < nBins)
+                    bits++;
+                size_t need = 0;
+                HIPCK(rocprim::radix_sort_pairs(nullptr, need, c->triKeys[0].as<uint32_t>(), c->triKeys[1].as<uint32_t>(),
+                                                c->triVals[0].as<uint32_t>(), c->triVals[1].as<uint32_t>(), (size_t)TP, 0, bits,
+                                                c->stream));
+                if (int rc = ensure(c, c->sortTmp, need))
+                    return rc;
+                need = c->sortTmp.bytes;
+                HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, need, c->triKeys[0].as<uint32_t>(), c->triKeys[1].as<uint32_t>(),
+                                                c->triVals[0].as<uint32_t>(), c->triVals[1].as<uint32_t>(), (size_t)TP, 0, bits,
+                                                c->stream));
+                hipLaunchKernelGGL(k_tri_sweep, dim3(grid_for(TP)), dim3(256), 0, c->stream, c->dp, TP,
+                                   c->triKeys[1].as<uint32_t>(), c->triVals[1].as<uint32_t>(), c->triWorld.as<TriWorld>(), P,
+                                   c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), c->geo.as<GeoRec>(),
+                                   c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
+                                   c->ctr.as<DetectCounters>());
+            }
+        }
         HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
         if (hc.nContactsRaw > c->cntCap) {  // arena too small: grow and redo the emitting kernels
@@ -563,7 +618,7 @@ void deme_ctx_destroy(deme_ctx* c) {
     drain_timers(c);
     for (auto e : c->eventPool)
         hipEventDestroy(e);
-    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -740,6 +795,37 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         return rc;
     if (int rc = grow_contact_arena(c, std::max<size_t>(6 * nS, 4096)))
         return rc;
+    // triangles
+    c->nTri = s->nTri;
+    if (s->nTri) {
+        if (!s->ownerMesh || !s->triNode1 || !s->triNode2 || !s->triNode3)
+            return fail(c, DEME_ERR_INVALID, "nTri > 0 but triangle arrays are missing");
+        std::vector<TriRec> ht(s->nTri);
+        for (uint32_t t = 0; t < s->nTri; t++) {
+            for (int k = 0; k < 3; k++) {
+                ht[t].n1[k] = s->triNode1[3 * t + k];
+                ht[t].n2[k] = s->triNode2[3 * t + k];
+                ht[t].n3[k] = s->triNode3[3 * t + k];
+            }
+            ht[t].owner = s->ownerMesh[t];
+            ht[t].mat = s->triMaterialOffset ? s->triMaterialOffset[t] : 0;
+            ht[t].pad = 0;
+            if (ht[t].owner >= s->nOwners)
+                return fail(c, DEME_ERR_INVALID, "triangle %u refers to owner %u of %u", t, ht[t].owner, s->nOwners);
+        }
+        if (int rc = upload(c, c->tris, ht.data(), ht.size()))
+            return rc;
+        const size_t nT = s->nTri;
+        if (ensure(c, c->triWorld, nT * sizeof(TriWorld)) || ensure(c, c->triLo, nT * 16) || ensure(c, c->triHi, nT * 16) ||
+            ensure(c, c->triCounts, (nT + 1) * 4) || ensure(c, c->triOffsets, (nT + 1) * 4))
+            return c->lastStatus;
+        size_t need = 0;
+        HIPCK(rocprim::exclusive_scan(nullptr, need, c->triCounts.as<uint32_t>(), c->triOffsets.as<uint32_t>(), 0u, nT + 1,
+                                      rocprim::plus<uint32_t>(), c->stream));
+        if (int rc = ensure(c, c->scanTmp, need))
+            return rc;
+        HIPCK(hipStreamSynchronize(c->stream));
+    }
     c->haveScene = true;
     c->haveList = false;
     c->mapFresh = false;
@@ -814,8 +900,22 @@ static int owner_state_io(deme_ctx* c, const DemeOwnerState* st, int dir) {
 int deme_upload_owner_state(deme_ctx* c, const DemeOwnerState* st) { return owner_state_io(c, st, 0); }
 int deme_download_owner_state(deme_ctx* c, DemeOwnerState* st) { return owner_state_io(c, st, 1); }
 
-int deme_update_tri_nodes(deme_ctx* c, const float*, const float*, const float*) {
-    return fail(c, DEME_ERR_INVALID, "mesh path not built yet");
+int deme_update_tri_nodes(deme_ctx* c, const float* n1, const float* n2, const float* n3) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (!c->nTri || !n1 || !n2 || !n3)
+        return fail(c, DEME_ERR_INVALID, "no triangles loaded or null node arrays");
+    const size_t bytes = (size_t)c->nTri * 12;
+    if (int rc = ensure(c, c->stage, bytes * 3))
+        return rc;
+    float* d = c->stage.as<float>();
+    HIPCK(hipMemcpyAsync(d, n1, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(d + 3 * (size_t)c->nTri, n2, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(d + 6 * (size_t)c->nTri, n3, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pack_tris, dim3(grid_for(c->nTri)), dim3(256), 0, c->stream, c->nTri, c->tris.as<TriRec>(), d,
+                       d + 3 * (size_t)c->nTri, d + 6 * (size_t)c->nTri);
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
 }
 
 int deme_compute_margins(deme_ctx* c, uint32_t drift) {

@@ -188,9 +188,9 @@ inline int generate_source(const std::string& user, const std::vector<std::strin
 // hipRTC: source -> gfx950 code object.  Needs no GPU (used by the CPU test through deme_jit_probe).
 inline int compile(const std::string& src, std::vector<char>& code, std::string& log) {
     hiprtcProgram prog;
-    const char* hdrs[] = {kSrcDeviceH, kSrcForceH};
-    const char* names[] = {"deme_device.h", "deme_force.h"};
-    if (hiprtcCreateProgram(&prog, src.c_str(), "deme_custom_force_model.hip", 2, hdrs, names) != HIPRTC_SUCCESS) {
+    const char* hdrs[] = {kSrcDeviceH, kSrcMeshH, kSrcForceH};
+    const char* names[] = {"deme_device.h", "deme_mesh.h", "deme_force.h"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "deme_custom_force_model.hip", 3, hdrs, names) != HIPRTC_SUCCESS) {
         log = "hiprtcCreateProgram failed";
         return 1;
     }

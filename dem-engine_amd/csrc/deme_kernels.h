@@ -661,6 +661,8 @@ __global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint3
         ob = spheres[key_b(k)].owner;
     else if (cls == DEME_KEY_CLASS_SA)
         ob = p.anal[key_b(k)].owner;
+    else  // sphere-mesh: TriRec is 48 bytes with the owner id at byte 36 (deme_mesh.h)
+        ob = reinterpret_cast<const uint32_t*>(p.tris)[12 * (size_t)key_b(k) + 9];
     ownerB[c] = ob;
     idx[c] = c;
 }

@@ -132,6 +132,47 @@ class ExternObj:
         self.mass = float(m)
 
 
+class MeshObj:
+    """DEMMeshConnected (DEM/BdrsAndObjs.h): vertices + triangle index triples, owner-local frame."""
+
+    def __init__(self, vertices, faces, material):
+        self.vertices = np.asarray(vertices, np.float32).reshape(-1, 3)
+        self.faces = np.asarray(faces, np.int64).reshape(-1, 3)
+        self.material = material
+        self.family = RESERVED_FAMILY_NUM
+        self.init_pos = (0.0, 0.0, 0.0)
+        self.init_oriq = (0.0, 0.0, 0.0, 1.0)  # x y z w
+        self.mass = 1.0
+        self.moi = (1.0, 1.0, 1.0)
+        self.vel = (0.0, 0.0, 0.0)
+
+    def Scale(self, s):
+        self.vertices = (self.vertices * np.asarray(s, np.float32)).astype(np.float32)
+        return self
+
+    def SetInitPos(self, p):
+        self.init_pos = tuple(float(x) for x in p)
+
+    def SetInitQuat(self, q_xyzw):
+        self.init_oriq = tuple(float(x) for x in q_xyzw)
+
+    def SetMass(self, m):
+        self.mass = float(m)
+
+    def SetMOI(self, moi):
+        self.moi = tuple(float(x) for x in moi)
+
+    def SetFamily(self, f):
+        self.family = int(f)
+
+    def GetNumTriangles(self):
+        return len(self.faces)
+
+    def nodes(self):
+        v = self.vertices
+        return v[self.faces[:, 0]], v[self.faces[:, 1]], v[self.faces[:, 2]]
+
+
 class SceneBuilder:
     """Python mirror of the DEMSolver set-up surface needed by the hot path."""
 
@@ -141,6 +182,7 @@ class SceneBuilder:
         self.templates = []
         self.batches = []
         self.ext_objs = []
+        self.meshes = []
         self.user_box_min = np.array([-10, -10, -10], np.float32)
         self.user_box_max = np.array([10, 10, 10], np.float32)
         self.target_box_min = self.user_box_min * np.float32(1.2)
@@ -225,6 +267,12 @@ class SceneBuilder:
         o = ExternObj()
         self.ext_objs.append(o)
         return o
+
+    def AddMeshObject(self, vertices, faces, material):
+        """AddWavefrontMeshObject without the OBJ reader (API.h:638-645): vertices (n,3), faces (m,3)."""
+        m = MeshObj(vertices, faces, material)
+        self.meshes.append(m)
+        return m
 
     def AddBCPlane(self, pos, normal, material):
         o = self.AddExternalObject()
@@ -440,7 +488,7 @@ class SceneBuilder:
 
         # owners: clumps (batch load order) then analytical objects
         n_clumps = sum(len(b.xyz) for b in self.batches)
-        n_owners = n_clumps + len(ext)
+        n_owners = n_clumps + len(ext) + len(self.meshes)
         xyz = np.zeros((n_owners, 3), np.float32)
         oriq = np.tile(np.array([0, 0, 0, 1], np.float32), (n_owners, 1))
         vel = np.zeros((n_owners, 3), np.float32)
@@ -492,6 +540,21 @@ class SceneBuilder:
                 obj["rx"].append(rot[0]), obj["ry"].append(rot[1]), obj["rz"].append(rot[2])
                 obj["s1"].append(s1), obj["s2"].append(s2), obj["s3"].append(s3), obj["mass"].append(e.mass)
 
+        # meshes: one owner each after the analytical owners; triangles mesh-major (APIPrivate.cpp:756-810)
+        tri_owner, tri_n1, tri_n2, tri_n3, tri_mat = [], [], [], [], []
+        for mi, me in enumerate(self.meshes):
+            owner = n_clumps + len(ext) + mi
+            xyz[owner] = np.asarray(me.init_pos, np.float32)
+            oriq[owner] = np.asarray(me.init_oriq, np.float32)
+            vel[owner] = np.asarray(me.vel, np.float32)
+            fam[owner] = me.family
+            inert[owner] = n_tmpl + len(ext) + mi
+            mass.append(me.mass)
+            moi.append(me.moi)
+            a, b_, c_ = me.nodes()
+            tri_owner.append(np.full(len(a), owner, np.uint32))
+            tri_n1.append(a), tri_n2.append(b_), tri_n3.append(c_)
+            tri_mat.append(np.full(len(a), me.material, np.uint16))
         shifted = (xyz - lbf[None, :]).astype(np.float32).astype(np.float64)  # float3 subtraction, dT.cpp:745
         vid, lx, ly, lz = encode_positions(shifted, nv[0], nv[1], voxel, l)
 
@@ -555,11 +618,32 @@ class SceneBuilder:
             "familyMasks": self.family_masks, "familyExtraMarginSize": self.family_extra,
             "familyFlags": self.family_flags,
         }
+        n_tri = int(sum(len(x) for x in tri_owner))
+        if n_tri:
+            arrays.update({"ownerMesh": np.concatenate(tri_owner), "triNode1": np.concatenate(tri_n1).reshape(-1),
+                           "triNode2": np.concatenate(tri_n2).reshape(-1), "triNode3": np.concatenate(tri_n3).reshape(-1),
+                           "triMaterialOffset": np.concatenate(tri_mat)})
         counts = {"nOwners": n_owners, "nOwnerClumps": n_clumps, "nSpheres": len(arrays["ownerClumpBody"]),
-                  "nAnal": len(obj["type"]), "nTri": 0, "nMat": nm, "nComp": len(radii), "nMassProps": len(mass)}
+                  "nAnal": len(obj["type"]), "nTri": n_tri, "nMat": nm, "nComp": len(radii), "nMassProps": len(mass)}
         self.params, self.arrays, self.counts = p, arrays, counts
         self.scene = abi.make_scene_struct(arrays, counts)
         return p, self.scene
+
+
+def plate_mesh(nx, ny, size_x, size_y, z=0.0, wavy=0.0):
+    """A tessellated rectangular plate (2*nx*ny triangles, normals +z), optionally with a sinusoidal relief."""
+    xs = np.linspace(-size_x / 2, size_x / 2, nx + 1, dtype=np.float32)
+    ys = np.linspace(-size_y / 2, size_y / 2, ny + 1, dtype=np.float32)
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    Z = z + wavy * np.sin(6.0 * X / max(size_x, 1e-9)) * np.cos(5.0 * Y / max(size_y, 1e-9))
+    v = np.stack([X.ravel(), Y.ravel(), Z.ravel().astype(np.float32)], 1).astype(np.float32)
+    idx = lambda i, j: i * (ny + 1) + j
+    f = []
+    for i in range(nx):
+        for j in range(ny):
+            f.append((idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)))
+            f.append((idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)))
+    return v, np.asarray(f, np.int64)
 
 
 def hcp_points(lo, hi, sep):

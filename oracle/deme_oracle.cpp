@@ -23,6 +23,7 @@
  * build on the host.
  */
 #include <algorithm>
+#include <cfenv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -361,9 +362,206 @@ inline void force_hertz_frictionless(const ForceIn& in, V3f& force) {
 }
 
 // ---------------------------------------------------------------------------
-// Triangle-sphere narrow phase (UNPINNED restatement; kernel/DEMCollisionKernels.cu:16-236).
-// Implemented in oracle_tri.inc once the mesh path lands.
+// Triangle-sphere path.  PARITY UNPINNED: kernel/DEMCollisionKernels.cu is __device__-only (round-up
+// intrinsics) and kernel/DEMTriangleBoxIntersect.cu / DEMBinTriangleKernels.cu are __device__-only or
+// carry placeholders, so none of them can be built on the host here; these restatements are checked
+// only against analytic cases (tests/test_oracle_mesh.py).
 // ---------------------------------------------------------------------------
+// __drcp_ru / __dmul_ru (kernel/DEMCollisionKernels.cu:76-78): round-toward-+inf reciprocal and product,
+// emulated with one fma-based correction step (exact for finite, non-zero, non-subnormal operands).
+inline double rcp_ru(double x) {
+    double r = 1.0 / x;
+    const double e = fma(-x, r, 1.0);  // 1 - x*r, exact sign of the rounding error
+    // true value 1/x = r + e/x: below means r < 1/x -> bump toward +inf
+    if ((e > 0.0 && x > 0.0) || (e < 0.0 && x < 0.0))
+        r = nextafter(r, INFINITY);
+    return r;
+}
+inline double mul_ru(double a, double b) {
+    double p = a * b;
+    const double e = fma(a, b, -p);  // exact a*b - p
+    if (e > 0.0)
+        p = nextafter(p, INFINITY);
+    return p;
+}
+
+template <typename T>
+struct V3 {
+    T x, y, z;
+};
+template <typename T>
+inline V3<T> vsub(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T>
+inline V3<T> vadd(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T>
+inline V3<T> vscale(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename T>
+inline T vdot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T>
+inline V3<T> vcross(V3<T> a, V3<T> b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// normalize(): float3 -> v * rsqrtf(dot); double3 -> v * (double)rsqrtf(dot) (CUDAMathHelpers.cuh:1090, 1402);
+// host form of rsqrtf = 1.0f / sqrtf(x) (CUDAMathHelpers.cuh:66-68)
+template <typename T>
+inline V3<T> vnormalize(V3<T> v) {
+    const T il = (T)(1.0f / sqrtf((float)vdot(v, v)));
+    return {v.x * il, v.y * il, v.z * il};
+}
+inline float vlen(V3<float> v) { return sqrtf(vdot(v, v)); }
+inline double vlen(V3<double> v) { return sqrt(vdot(v, v)); }
+
+// kernel/DEMCollisionKernels.cu:16-82 (snap_to_face; Ericson, Real-Time Collision Detection p.141).
+// VT = component type of the points, ST = scalar type of the barycentric arithmetic (the reference's T2:
+// float inside triangle_sphere_CD<float3,float>, double when called with defaulted template arguments
+// from the bin sweep, DEMContactKernels_SphereTriangle.cu:247).
+template <typename VT, typename ST>
+inline bool snap_to_face(V3<VT> A, V3<VT> B, V3<VT> C, V3<VT> P, V3<VT>& res) {
+    const V3<VT> AB = vsub(B, A), AC = vsub(C, A), AP = vsub(P, A);
+    const ST d1 = vdot(AB, AP), d2 = vdot(AC, AP);
+    if (d1 <= 0 && d2 <= 0) {
+        res = A;
+        return true;
+    }
+    const V3<VT> BP = vsub(P, B);
+    const ST d3 = vdot(AB, BP), d4 = vdot(AC, BP);
+    if (d3 >= 0 && d4 <= d3) {
+        res = B;
+        return true;
+    }
+    const ST vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+        const ST v = d1 / (d1 - d3);
+        res = vadd(A, vscale((VT)v, AB));
+        return true;
+    }
+    const V3<VT> CP = vsub(P, C);
+    const ST d5 = vdot(AB, CP), d6 = vdot(AC, CP);
+    if (d6 >= 0 && d5 <= d6) {
+        res = C;
+        return true;
+    }
+    const ST vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+        const ST w = d2 / (d2 - d6);
+        res = vadd(A, vscale((VT)w, AC));
+        return true;
+    }
+    const ST va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+        const ST w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        res = vadd(B, vscale((VT)w, vsub(C, B)));
+        return true;
+    }
+    const ST denom = (ST)rcp_ru((double)(va + vb + vc));
+    const ST v = (ST)mul_ru((double)vb, (double)denom);
+    const ST w = (ST)mul_ru((double)vc, (double)denom);
+    res = vadd(vadd(A, vscale((VT)v, AB)), vscale((VT)w, AC));
+    return false;
+}
+
+// kernel/DEMCollisionKernels.cu:99-159 (triangle_sphere_CD) and :177-236 (directional flavour)
+template <typename T, bool DIRECTIONAL>
+inline bool tri_sphere_cd(V3<T> A, V3<T> B, V3<T> C, V3<T> sp, T radius, V3<T>& normal, T& depth, V3<T>& pt1) {
+    const V3<T> face_n = vnormalize(vcross(vsub(B, A), vsub(C, A)));
+    const T h = vdot(vsub(sp, A), face_n);
+    V3<T> faceLoc;
+    bool in_contact;
+    if (!snap_to_face<T, T>(A, B, C, sp, faceLoc)) {
+        depth = h - radius;
+        normal = face_n;
+        pt1 = faceLoc;
+        if (DIRECTIONAL)
+            in_contact = !(depth >= 0.);
+        else
+            in_contact = !(h >= radius || h <= -radius);
+    } else {
+        normal = vsub(sp, faceLoc);
+        const T dist = vlen(normal);
+        depth = dist - radius;
+        normal = vscale((T)(1.0 / dist), normal);  // (1.0 / dist) is double, narrowed for float3 (CUDAMathHelpers.cuh:677)
+        pt1 = faceLoc;
+        if (DIRECTIONAL)
+            in_contact = !(depth >= 0. || h >= radius);
+        else
+            in_contact = !(depth >= 0. || h >= radius || h <= -radius);
+    }
+    return in_contact;
+}
+
+// kernel/DEMTriangleBoxIntersect.cu:176-374 (Akenine-Moller triangle/AABB separating-axis test, fp32)
+inline bool plane_box_overlap(const float n[3], const float vert[3], const float maxbox[3]) {
+    float vmin[3], vmax[3];
+    for (int q = 0; q < 3; q++) {
+        const float v = vert[q];
+        if (n[q] > 0.0f) {
+            vmin[q] = -maxbox[q] - v;
+            vmax[q] = maxbox[q] - v;
+        } else {
+            vmin[q] = maxbox[q] - v;
+            vmax[q] = -maxbox[q] - v;
+        }
+    }
+    if (n[0] * vmin[0] + n[1] * vmin[1] + n[2] * vmin[2] > 0.0f)
+        return false;
+    return n[0] * vmax[0] + n[1] * vmax[1] + n[2] * vmax[2] >= 0.0f;
+}
+inline bool axis_sep(float pa, float pb, float rad) {
+    const float mn = (pa < pb) ? pa : pb, mx = (pa < pb) ? pb : pa;
+    return mn > rad || mx < -rad;
+}
+using T3f = V3<float>;
+using T3d = V3<double>;
+inline bool tri_box_overlap(const float bc[3], const float bh[3], T3f vA, T3f vB, T3f vC) {
+    const float v0[3] = {vA.x - bc[0], vA.y - bc[1], vA.z - bc[2]};
+    const float v1[3] = {vB.x - bc[0], vB.y - bc[1], vB.z - bc[2]};
+    const float v2[3] = {vC.x - bc[0], vC.y - bc[1], vC.z - bc[2]};
+    const float e0[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    const float e1[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+    const float e2[3] = {v0[0] - v2[0], v0[1] - v2[1], v0[2] - v2[2]};
+    float fex, fey, fez;
+    // edge 0: X01, Y02, Z12
+    fex = fabsf(e0[0]), fey = fabsf(e0[1]), fez = fabsf(e0[2]);
+    if (axis_sep(e0[2] * v0[1] - e0[1] * v0[2], e0[2] * v2[1] - e0[1] * v2[2], fez * bh[1] + fey * bh[2])) return false;
+    if (axis_sep(-e0[2] * v0[0] + e0[0] * v0[2], -e0[2] * v2[0] + e0[0] * v2[2], fez * bh[0] + fex * bh[2])) return false;
+    if (axis_sep(e0[1] * v1[0] - e0[0] * v1[1], e0[1] * v2[0] - e0[0] * v2[1], fey * bh[0] + fex * bh[1])) return false;
+    // edge 1: X01, Y02, Z0
+    fex = fabsf(e1[0]), fey = fabsf(e1[1]), fez = fabsf(e1[2]);
+    if (axis_sep(e1[2] * v0[1] - e1[1] * v0[2], e1[2] * v2[1] - e1[1] * v2[2], fez * bh[1] + fey * bh[2])) return false;
+    if (axis_sep(-e1[2] * v0[0] + e1[0] * v0[2], -e1[2] * v2[0] + e1[0] * v2[2], fez * bh[0] + fex * bh[2])) return false;
+    if (axis_sep(e1[1] * v0[0] - e1[0] * v0[1], e1[1] * v1[0] - e1[0] * v1[1], fey * bh[0] + fex * bh[1])) return false;
+    // edge 2: X2, Y1, Z12
+    fex = fabsf(e2[0]), fey = fabsf(e2[1]), fez = fabsf(e2[2]);
+    if (axis_sep(e2[2] * v0[1] - e2[1] * v0[2], e2[2] * v1[1] - e2[1] * v1[2], fez * bh[1] + fey * bh[2])) return false;
+    if (axis_sep(-e2[2] * v0[0] + e2[0] * v0[2], -e2[2] * v1[0] + e2[0] * v1[2], fez * bh[0] + fex * bh[2])) return false;
+    if (axis_sep(e2[1] * v1[0] - e2[0] * v1[1], e2[1] * v2[0] - e2[0] * v2[1], fey * bh[0] + fex * bh[1])) return false;
+    // AABB of the triangle against the box
+    for (int d = 0; d < 3; d++) {
+        float mn = v0[d], mx = v0[d];
+        if (v1[d] < mn) mn = v1[d];
+        if (v1[d] > mx) mx = v1[d];
+        if (v2[d] < mn) mn = v2[d];
+        if (v2[d] > mx) mx = v2[d];
+        if (mn > bh[d] || mx < -bh[d])
+            return false;
+    }
+    const float nrm[3] = {e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2], e0[0] * e1[1] - e0[1] * e1[0]};
+    return plane_box_overlap(nrm, v0, bh);
+}
+
+// kernel/DEMBinTriangleKernels.cu:7-20 (sandwichVertex) and DEMHelperKernels.cuh:215-225 (triangleIncenter)
+inline T3f sandwich_vertex(T3f vertex, T3f incenter, T3f side, T3f normal, float beta) {
+    const T3f ev = vnormalize(vsub(vertex, incenter));
+    const T3f nev{-ev.x, -ev.y, -ev.z};
+    const float cos_half = vdot(nev, side) / vlen(side);
+    const float enlarge = (float)(beta / sqrt(1. - cos_half * cos_half));
+    vertex = vadd(vertex, vscale(enlarge, ev));  // expandVec * enlarge_dist: float3 * float
+    vertex = vadd(vertex, vscale(beta, normal));
+    return vertex;
+}
+inline T3f tri_incenter(T3f p1, T3f p2, T3f p3) {
+    const float a = vlen(vsub(p2, p3)), b = vlen(vsub(p1, p3)), c = vlen(vsub(p1, p2));
+    return {(a * p1.x + b * p2.x + c * p3.x) / (a + b + c), (a * p1.y + b * p2.y + c * p3.y) / (a + b + c),
+            (a * p1.z + b * p2.z + c * p3.z) / (a + b + c)};
+}
 
 // ===========================================================================
 // Simulation object mirroring the C-ABI context, one stage per entry point.
@@ -381,6 +579,12 @@ struct Sim {
     // spheres
     std::vector<uint32_t> ownerOfSphere;
     std::vector<uint16_t> compOff, sphMat;
+    // triangles (mesh-major, owner-local nodes)
+    uint32_t nTri = 0;
+    std::vector<uint32_t> ownerMesh;
+    std::vector<float> tri1, tri2, tri3;  // xyz interleaved
+    std::vector<uint16_t> triMat;
+    std::vector<uint32_t> triIncBin, triIncTri;  // bin-sorted (stable) triangle incidence list
     // tables
     std::vector<float> Radii, relX, relY, relZ, mass, moiX, moiY, moiZ;
     std::vector<uint8_t> objType;
@@ -593,6 +797,109 @@ int detect(Sim& s) {
             }
         }
     }
+    // ---- sphere vs triangle (kernel/DEMBinTriangleKernels.cu:22-201, DEMContactKernels_SphereTriangle.cu:116-258)
+    s.triIncBin.clear();
+    s.triIncTri.clear();
+    if (s.nTri) {
+        struct TriW {
+            T3f a1, a2, a3, b1, b2, b3;
+        };
+        std::vector<TriW> tw(s.nTri);
+        std::vector<uint32_t> tb, tt;
+        const float bhs = (float)(s.p.binSize / 2. + 0.001 * s.p.binSize);  // DEME_BIN_ENLARGE_RATIO_FOR_FACETS
+        const float bh[3] = {bhs, bhs, bhs};
+        for (uint32_t t = 0; t < s.nTri; t++) {
+            const uint32_t o = s.ownerMesh[t];
+            const T3f p1{s.tri1[3 * t], s.tri1[3 * t + 1], s.tri1[3 * t + 2]};
+            const T3f p2{s.tri2[3 * t], s.tri2[3 * t + 1], s.tri2[3 * t + 2]};
+            const T3f p3{s.tri3[3 * t], s.tri3[3 * t + 1], s.tri3[3 * t + 2]};
+            const T3f inc = tri_incenter(p1, p2, p3);
+            const T3f n = vnormalize(vcross(vsub(p2, p1), vsub(p3, p1)));  // face_normal, DEMHelperKernels.cuh:352
+            const T3f nn{-n.x, -n.y, -n.z};
+            const float beta = s.margin[o];
+            T3f loc[6] = {sandwich_vertex(p1, inc, vsub(p2, p1), n, beta), sandwich_vertex(p2, inc, vsub(p3, p2), n, beta),
+                          sandwich_vertex(p3, inc, vsub(p1, p3), n, beta), sandwich_vertex(p1, inc, vsub(p2, p1), nn, beta),
+                          sandwich_vertex(p3, inc, vsub(p1, p3), nn, beta), sandwich_vertex(p2, inc, vsub(p3, p2), nn, beta)};
+            double oX, oY, oZ;
+            decode_pos(s.voxelID[o], s.locX[o], s.locY[o], s.locZ[o], s.p.nvXp2, s.p.nvYp2, s.p.voxelSize, s.p.l, oX, oY, oZ);
+            const RotM m = rot_coeffs(s.oriQw[o], s.oriQx[o], s.oriQy[o], s.oriQz[o]);
+            T3f w[6];
+            for (int k = 0; k < 6; k++) {
+                const V3f r = rotate_f(m, {loc[k].x, loc[k].y, loc[k].z});
+                w[k] = {(float)(oX + r.x), (float)(oY + r.y), (float)(oZ + r.z)};  // double3 + float3 -> float3
+            }
+            tw[t] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+            // boundingBoxIntersectBin (DEMHelperKernels.cuh:528-565) on both sandwich triangles, merged
+            int L[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, U[3] = {-1, -1, -1};
+            const int nbm[3] = {(int)s.p.nbX - 1, (int)s.p.nbY - 1, (int)s.p.nbZ - 1};
+            for (int half = 0; half < 2; half++) {
+                const T3f* v = w + 3 * half;
+                const float mn[3] = {std::min(v[0].x, std::min(v[1].x, v[2].x)), std::min(v[0].y, std::min(v[1].y, v[2].y)),
+                                     std::min(v[0].z, std::min(v[1].z, v[2].z))};
+                const float mx[3] = {std::max(v[0].x, std::max(v[1].x, v[2].x)), std::max(v[0].y, std::max(v[1].y, v[2].y)),
+                                     std::max(v[0].z, std::max(v[1].z, v[2].z))};
+                for (int d = 0; d < 3; d++) {
+                    const float lo = (float)(mn[d] - 0.001 * s.p.binSize), hi = (float)(mx[d] + 0.001 * s.p.binSize);
+                    const float ql = (float)(lo / s.p.binSize), qh = (float)(hi / s.p.binSize);
+                    const float cl = std::min(std::max(ql, 0.f), (float)nbm[d]), ch = std::min(std::max(qh, 0.f), (float)nbm[d]);
+                    L[d] = std::min(L[d], (int)cl);
+                    U[d] = std::max(U[d], (int)ch);
+                }
+            }
+            for (int i = L[0]; i <= U[0]; i++)
+                for (int j = L[1]; j <= U[1]; j++)
+                    for (int k = L[2]; k <= U[2]; k++) {
+                        const float bc[3] = {(float)(s.p.binSize * i + s.p.binSize / 2.), (float)(s.p.binSize * j + s.p.binSize / 2.),
+                                             (float)(s.p.binSize * k + s.p.binSize / 2.)};
+                        if (tri_box_overlap(bc, bh, {w[0].x, w[0].y, w[0].z}, {w[1].x, w[1].y, w[1].z}, {w[2].x, w[2].y, w[2].z}) ||
+                            tri_box_overlap(bc, bh, {w[3].x, w[3].y, w[3].z}, {w[4].x, w[4].y, w[4].z}, {w[5].x, w[5].y, w[5].z})) {
+                            tb.push_back((uint32_t)i + (uint32_t)j * s.p.nbX + (uint32_t)k * s.p.nbX * s.p.nbY);
+                            tt.push_back(t);
+                        }
+                    }
+        }
+        const size_t TP = tb.size();
+        std::vector<uint32_t> tperm(TP);
+        for (size_t i = 0; i < TP; i++)
+            tperm[i] = (uint32_t)i;
+        std::stable_sort(tperm.begin(), tperm.end(), [&](uint32_t x, uint32_t y) { return tb[x] < tb[y]; });
+        s.triIncBin.resize(TP);
+        s.triIncTri.resize(TP);
+        for (size_t i = 0; i < TP; i++) {
+            s.triIncBin[i] = tb[tperm[i]];
+            s.triIncTri[i] = tt[tperm[i]];
+        }
+        // per (bin, triangle) incidence: every sphere registered in that bin
+        for (size_t e = 0; e < TP; e++) {
+            const uint32_t bin = s.triIncBin[e], t = s.triIncTri[e];
+            const auto lo = std::lower_bound(s.incBin.begin(), s.incBin.end(), bin) - s.incBin.begin();
+            const auto hi = std::upper_bound(s.incBin.begin(), s.incBin.end(), bin) - s.incBin.begin();
+            const uint32_t oT = s.ownerMesh[t];
+            const unsigned fT = s.familyID[oT];
+            for (auto x = lo; x < hi; x++) {
+                const uint32_t sp = s.incSph[x];
+                const uint32_t oS = s.ownerOfSphere[sp];
+                if (oS == oT)
+                    continue;
+                const unsigned fS = s.familyID[oS];
+                if (s.masks[mask_pair(fS, fT)] != 0)
+                    continue;
+                const float am = (s.famExtra[fS] < s.famExtra[fT]) ? s.famExtra[fS] : s.famExtra[fT];
+                const T3f sph{(float)s.sphX[sp], (float)s.sphY[sp], (float)s.sphZ[sp]};
+                T3f cp, nr;
+                float depth;
+                bool inA = tri_sphere_cd<float, true>(tw[t].a1, tw[t].a2, tw[t].a3, sph, s.sphR[sp], nr, depth, cp);
+                inA = inA && (-depth > am);
+                bool inB = tri_sphere_cd<float, true>(tw[t].b1, tw[t].b2, tw[t].b3, sph, s.sphR[sp], nr, depth, cp);
+                inB = inB && (-depth > am);
+                if (inA || inB) {
+                    snap_to_face<float, double>(tw[t].a1, tw[t].a2, tw[t].a3, sph, cp);
+                    if (point_bin((double)cp.x, (double)cp.y, (double)cp.z, s.p.binSize, s.p.nbX, s.p.nbY) == bin)
+                        keys.push_back({sp, t, DEME_SPHERE_MESH_CONTACT});
+                }
+            }
+        }
+    }
     for (auto& v : perThread)
         keys.insert(keys.end(), v.begin(), v.end());
     std::sort(keys.begin(), keys.end(), key_less);
@@ -729,8 +1036,36 @@ void calc_forces(Sim& s, bool record) {
                           s.objNormal[ob], 0.0f, contactPnt, in.B2A, in.overlapDepth);
             if (in.overlapDepth < -extraMargin)
                 type = DEME_NOT_A_CONTACT;
+        } else if (type == DEME_SPHERE_MESH_CONTACT) {  // DEMCalcForceKernels.cu:138-183
+            const uint32_t t = s.cB[c];
+            oB = s.ownerMesh[t];
+            in.BRadius = kHugeF;
+            matB = s.triMat[t];
+            const float eB = s.famExtra[s.familyID[oB]];
+            extraMargin = (extraMargin > eB) ? extraMargin : eB;
+            in.BOwnerMass = s.mass[s.inertiaOff[oB]];
+            in.BLinVel = {s.vX[oB], s.vY[oB], s.vZ[oB]};
+            in.BRotVel = {s.omgX[oB], s.omgY[oB], s.omgZ[oB]};
+            owner_pose(s, oB, BOwnerPos, in.BOriQ);
+            const RotM m = rot_coeffs(in.BOriQ.w, in.BOriQ.x, in.BOriQ.y, in.BOriQ.z);
+            T3d nd[3];
+            const float* src[3] = {&s.tri1[3 * t], &s.tri2[3 * t], &s.tri3[3 * t]};
+            for (int k = 0; k < 3; k++) {
+                const V3d r = rotate_d(m, {(double)src[k][0], (double)src[k][1], (double)src[k][2]});
+                nd[k] = {BOwnerPos.x + r.x, BOwnerPos.y + r.y, BOwnerPos.z + r.z};
+            }
+            bodyBPos = {(nd[0].x + nd[1].x + nd[2].x) / 3., (nd[0].y + nd[1].y + nd[2].y) / 3., (nd[0].z + nd[1].z + nd[2].z) / 3.};
+            T3d cn, cpt;
+            double depth;
+            const bool in_contact = tri_sphere_cd<double, false>(nd[0], nd[1], nd[2], {bodyAPos.x, bodyAPos.y, bodyAPos.z},
+                                                                 (double)in.ARadius, cn, depth, cpt);
+            in.B2A = {(float)cn.x, (float)cn.y, (float)cn.z};
+            contactPnt = {cpt.x, cpt.y, cpt.z};
+            if ((depth > extraMargin) || (!in_contact && depth < 0.))
+                type = DEME_NOT_A_CONTACT;
+            in.overlapDepth = -depth;
         } else {
-            type = DEME_NOT_A_CONTACT;  // mesh contacts handled by the mesh extension
+            type = DEME_NOT_A_CONTACT;
         }
         ownB[c] = oB;
         ForceHist h{};
@@ -1046,6 +1381,73 @@ void orc_el_force(size_t n, int model, const double* depth, const float* fin, co
     }
 }
 
+// ---- mesh helpers (parity unpinned; checked against analytic cases and fenv rounding) -------------
+void orc_el_rcp_mul_ru(size_t n, const double* x, const double* y, double* rcp, double* mul) {
+    for (size_t i = 0; i < n; i++) {
+        rcp[i] = rcp_ru(x[i]);
+        mul[i] = mul_ru(x[i], y[i]);
+    }
+}
+// the same two operations done by the FPU in round-upward mode
+void orc_el_rcp_mul_fenv(size_t n, const double* x, const double* y, double* rcp, double* mul) {
+    const int old = fegetround();
+    fesetround(FE_UPWARD);
+    for (size_t i = 0; i < n; i++) {
+        volatile double a = x[i], b = y[i], one = 1.0;
+        volatile double r = one / a, m = a * b;
+        rcp[i] = r;
+        mul[i] = m;
+    }
+    fesetround(old);
+}
+// triangle_sphere_CD<double3,double> (directional = 0) or the fp32 directional flavour (directional = 1)
+void orc_el_tri_sphere(size_t n, int directional, const double* A, const double* B, const double* C, const double* P,
+                       const double* r, uint8_t* hit, double* normal, double* depth, double* pt) {
+    for (size_t i = 0; i < n; i++) {
+        if (!directional) {
+            T3d nr, cp;
+            double d;
+            hit[i] = tri_sphere_cd<double, false>({A[3 * i], A[3 * i + 1], A[3 * i + 2]}, {B[3 * i], B[3 * i + 1], B[3 * i + 2]},
+                                                  {C[3 * i], C[3 * i + 1], C[3 * i + 2]}, {P[3 * i], P[3 * i + 1], P[3 * i + 2]},
+                                                  r[i], nr, d, cp);
+            normal[3 * i] = nr.x, normal[3 * i + 1] = nr.y, normal[3 * i + 2] = nr.z;
+            pt[3 * i] = cp.x, pt[3 * i + 1] = cp.y, pt[3 * i + 2] = cp.z;
+            depth[i] = d;
+        } else {
+            T3f nr, cp;
+            float d;
+            hit[i] = tri_sphere_cd<float, true>({(float)A[3 * i], (float)A[3 * i + 1], (float)A[3 * i + 2]},
+                                                {(float)B[3 * i], (float)B[3 * i + 1], (float)B[3 * i + 2]},
+                                                {(float)C[3 * i], (float)C[3 * i + 1], (float)C[3 * i + 2]},
+                                                {(float)P[3 * i], (float)P[3 * i + 1], (float)P[3 * i + 2]}, (float)r[i], nr, d, cp);
+            normal[3 * i] = nr.x, normal[3 * i + 1] = nr.y, normal[3 * i + 2] = nr.z;
+            pt[3 * i] = cp.x, pt[3 * i + 1] = cp.y, pt[3 * i + 2] = cp.z;
+            depth[i] = d;
+        }
+    }
+}
+void orc_el_tri_box(size_t n, const float* center, const float* half, const float* A, const float* B, const float* C,
+                    uint8_t* out) {
+    for (size_t i = 0; i < n; i++) {
+        const float bh[3] = {half[i], half[i], half[i]};
+        out[i] = tri_box_overlap(center + 3 * i, bh, {A[3 * i], A[3 * i + 1], A[3 * i + 2]}, {B[3 * i], B[3 * i + 1], B[3 * i + 2]},
+                                 {C[3 * i], C[3 * i + 1], C[3 * i + 2]});
+    }
+}
+size_t orc_sim_get_tri_incidence(void* h, uint32_t* bins, uint32_t* tris, size_t cap) {
+    Sim* s = (Sim*)h;
+    const size_t n = std::min(cap, s->triIncBin.size());
+    std::copy(s->triIncBin.begin(), s->triIncBin.begin() + n, bins);
+    std::copy(s->triIncTri.begin(), s->triIncTri.begin() + n, tris);
+    return s->triIncBin.size();
+}
+void orc_sim_set_tri_nodes(void* h, const float* n1, const float* n2, const float* n3) {
+    Sim* s = (Sim*)h;
+    s->tri1.assign(n1, n1 + 3 * (size_t)s->nTri);
+    s->tri2.assign(n2, n2 + 3 * (size_t)s->nTri);
+    s->tri3.assign(n3, n3 + 3 * (size_t)s->nTri);
+}
+
 // ---- simulation object ------------------------------------------------------
 void* orc_sim_create(const DemeParams* p, const DemeScene* sc) {
     Sim* s = new Sim();
@@ -1084,6 +1486,11 @@ void* orc_sim_create(const DemeParams* p, const DemeScene* sc) {
     assign(s->masks, sc->familyMasks, (size_t)DEME_FAMILY_MASK_ENTRIES);
     assign(s->famExtra, sc->familyExtraMarginSize, (size_t)DEME_NUM_FAMILIES);
     assign(s->famFlags, sc->familyFlags, (size_t)DEME_NUM_FAMILIES);
+    s->nTri = sc->nTri;
+    assign(s->ownerMesh, sc->ownerMesh, (size_t)sc->nTri);
+    assign(s->tri1, sc->triNode1, (size_t)sc->nTri * 3), assign(s->tri2, sc->triNode2, (size_t)sc->nTri * 3),
+        assign(s->tri3, sc->triNode3, (size_t)sc->nTri * 3);
+    assign(s->triMat, sc->triMaterialOffset, (size_t)sc->nTri);
     return s;
 }
 void orc_sim_destroy(void* h) { delete (Sim*)h; }

@@ -294,6 +294,10 @@ class OracleSim:
         self.L.orc_sim_get_records(C.c_void_p(self.h), *[_p(a) for a in arrs], C.c_size_t(n))
         return arrs
 
+    def update_tri_nodes(self, n1, n2, n3):
+        arrs = [np.ascontiguousarray(x, np.float32).reshape(-1) for x in (n1, n2, n3)]
+        self.L.orc_sim_set_tri_nodes(C.c_void_p(self.h), *[_p(a) for a in arrs])
+
     def sphere_geometry(self):
         n = self.n_spheres
         X, Y, Z = (np.zeros(n) for _ in range(3))
@@ -305,6 +309,32 @@ class OracleSim:
 def make_sim(pkg, p, sc):
     """Oracle twin of a dem_engine_amd.Context built from the same params/scene structs."""
     return OracleSim(p, sc, pkg.abi.STATE_DTYPES, pkg.DemeCounts, pkg.abi.make_state_struct)
+
+
+def rcp_mul(x, y, fenv=False):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.ascontiguousarray(y, np.float64)
+    r, m = np.zeros_like(x), np.zeros_like(x)
+    fn = lib().orc_el_rcp_mul_fenv if fenv else lib().orc_el_rcp_mul_ru
+    fn(C.c_size_t(len(x)), _p(x), _p(y), _p(r), _p(m))
+    return r, m
+
+
+def tri_sphere(A, B, Cc, P, r, directional=False):
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (A, B, Cc, P, r)]
+    n = len(arrs[4])
+    hit = np.zeros(n, np.uint8)
+    nr, pt = np.zeros((n, 3)), np.zeros((n, 3))
+    d = np.zeros(n)
+    lib().orc_el_tri_sphere(C.c_size_t(n), C.c_int(int(directional)), *[_p(a) for a in arrs], _p(hit), _p(nr), _p(d), _p(pt))
+    return hit, nr, d, pt
+
+
+def tri_box(center, half, A, B, Cc):
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (center, half, A, B, Cc)]
+    out = np.zeros(len(arrs[1]), np.uint8)
+    lib().orc_el_tri_box(C.c_size_t(len(out)), *[_p(a) for a in arrs], _p(out))
+    return out
 
 
 def num_threads():

@@ -93,7 +93,8 @@ def test_custom_model_matches_builtin_and_adds_cohesion(pkg):
     touching = np.linalg.norm(F0, axis=1) > 0
     d = np.linalg.norm(F2 - F1, axis=1)
     assert touching.sum() > 500
-    assert np.allclose(d[touching], 0.004, rtol=1e-3) and (d[~touching] == 0).all()
+    # |F| is O(10 N) in fp32, so the 0.004 N shift is resolved to ~1e-5 N
+    assert np.allclose(d[touching], 0.004, atol=5e-5) and (d[~touching] == 0).all()
     assert np.allclose(age[touching], p.h) and (age[~touching] == 0).all()
 
 

@@ -1,0 +1,129 @@
+"""Sphere-triangle path (BASELINE configs[3]).  The reference's triangle code cannot be built on
+the host (device-only intrinsics / placeholders), so the oracle restatement is PARITY UNPINNED: the CPU tests
+check it against analytic cases, one reference output recorded in SURVEY App. E, and the FPU's own
+round-upward mode; the GPU tests check the HIP path against the oracle bit for bit (contact sets)."""
+import numpy as np
+import pytest
+
+
+def mesh_bed(pkg, n=1500, seed=3, cd_freq=0, plate_z=0.0195, wavy=0.003, fixed=True):
+    b = pkg.model.packed_bed(n, seed=seed, cd_freq=cd_freq, spacing_mult=2.8, init_vz=-1.0)
+    lo, hi = b.user_box_min, b.user_box_max
+    v, f = pkg.model.plate_mesh(20, 20, float(hi[0] - lo[0]) * 0.9, float(hi[1] - lo[1]) * 0.9, z=0.0, wavy=wavy)
+    m = b.AddMeshObject(v, f, 0)
+    m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, plate_z))
+    m.SetMass(0.5)
+    m.SetMOI((1e-3, 1e-3, 2e-3))
+    if not fixed:
+        m.SetFamily(7)
+    return b
+
+
+def test_round_up_emulation_matches_the_fpu(orc):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(1e-12, 1e3, 20000), -rng.uniform(1e-12, 1e3, 20000), [1.0, 2.0, 3.0, 0.1, -0.1, 1e300]])
+    y = np.concatenate([rng.standard_normal(40000) * 1e3, [1.0, 0.5, 1.0 / 3, 0.1, 0.1, 1e-300]])
+    r0, m0 = orc.rcp_mul(x, y)
+    r1, m1 = orc.rcp_mul(x, y, fenv=True)
+    assert (r0 == r1).all() and (m0 == m1).all()
+    assert (r0 >= 1.0 / x).all()  # rounded toward +inf
+
+
+def test_triangle_sphere_analytic_cases(orc):
+    A, B, C = np.array([[0., 0, 0]]), np.array([[1., 0, 0]]), np.array([[0., 1, 0]])
+    # SURVEY App. E anchor (reference output): r 0.1 at height 0.05 over a unit right triangle -> face contact, depth -0.05
+    hit, nr, d, pt = orc.tri_sphere(A, B, C, np.array([[0.25, 0.25, 0.05]]), np.array([0.1]))
+    assert hit[0] == 1 and abs(d[0] + 0.05) < 1e-7 and np.allclose(nr[0], [0, 0, 1], atol=1e-7)
+    assert np.allclose(pt[0], [0.25, 0.25, 0.0], atol=1e-12)
+    # above the face but too far; below the face (two-sided test fails beyond -r); past an edge; past a vertex
+    P = np.array([[0.25, 0.25, 0.2], [0.25, 0.25, -0.2], [0.5, -0.05, 0.0], [-0.03, -0.04, 0.0], [2.0, 2.0, 0.0]])
+    n = len(P)
+    hit, nr, d, pt = orc.tri_sphere(np.repeat(A, n, 0), np.repeat(B, n, 0), np.repeat(C, n, 0), P, np.full(n, 0.1))
+    assert list(hit) == [0, 0, 1, 1, 0]
+    assert np.allclose(pt[2], [0.5, 0, 0]) and abs(d[2] + 0.05) < 1e-12  # edge region
+    assert np.allclose(pt[3], [0, 0, 0]) and abs(d[3] + 0.05) < 1e-12   # vertex region
+    # directional flavour keeps a sphere that sank below the facet
+    hit_d, *_ = orc.tri_sphere(A, B, C, np.array([[0.25, 0.25, -0.2]]), np.array([0.1]), directional=True)
+    assert hit_d[0] == 1
+
+
+def test_triangle_box_overlap_cases(orc):
+    A = np.array([[0., 0, 0]] * 4, np.float32)
+    B = np.array([[1., 0, 0]] * 4, np.float32)
+    C = np.array([[0., 1, 0]] * 4, np.float32)
+    centers = np.array([[0.2, 0.2, 0.0], [0.2, 0.2, 0.5], [0.9, 0.9, 0.0], [0.55, 0.55, 0.0]], np.float32)
+    half = np.array([0.1, 0.1, 0.1, 0.1], np.float32)
+    out = orc.tri_box(centers, half, A, B, C)
+    assert list(out) == [1, 0, 0, 1]  # inside; off-plane; beyond the hypotenuse; straddling the hypotenuse
+
+
+def test_oracle_mesh_pipeline_runs(pkg, orc):
+    b = mesh_bed(pkg, 600)
+    p, sc = b.Initialize()
+    assert sc.nTri == 800 and sc.nOwners == 600 + 1 + 1
+    sim = orc.make_sim(pkg, p, sc)
+    sim.step(150)
+    a, bb, t, _ = sim.contacts()
+    assert (t == 2).sum() > 20 and bb[t == 2].max() < sc.nTri
+    st = sim.download_state()
+    assert st["vZ"][-1] == 0  # the plate is in the fixed family by default
+
+
+@pytest.mark.gpu
+def test_mesh_contacts_and_forces_match_oracle(pkg, orc):
+    b = mesh_bed(pkg, 1500)
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p)
+    ctx.upload_scene(sc)
+    sim = orc.make_sim(pkg, p, sc)
+    for chunk in range(3):
+        ctx.step(60), sim.step(60)
+        a, bb, t, m = ctx.contacts()
+        oa, ob, ot, om = sim.contacts()
+        assert len(a) == len(oa) and (a == oa).all() and (bb == ob).all() and (t == ot).all() and (m == om).all()
+    assert (t == 2).sum() > 50
+    gs, os_ = ctx.download_state(), sim.download_state()
+    X = pkg.model.decode_positions(gs["voxelID"], gs["locX"], gs["locY"], gs["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    Y = pkg.model.decode_positions(os_["voxelID"], os_["locX"], os_["locY"], os_["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    assert np.abs(X - Y).max() < 1e-7
+    # staged force pass on the same state: per-contact records
+    ctx.set_record_contacts(True)
+    ctx.compute_margins(0), sim.compute_margins(0)
+    ctx.detect(), sim.detect()
+    ctx.migrate(), sim.migrate()
+    for w in range(4):
+        ctx.set_wildcard(w, sim.wildcard(w))
+    ctx.calc_forces(), sim.calc_forces(record=True)
+    F, T, PA, PB = ctx.contact_records()
+    oF, oT, oPA, oPB = sim.contact_records()
+    tri = ctx.contacts()[2] == 2
+    assert tri.sum() > 50 and np.abs(oF[tri]).max() > 0
+    assert np.abs(F - oF).max() <= 2e-6 * np.abs(oF).max()
+    assert np.abs(PB - oPB).max() <= 1e-6 * max(1.0, np.abs(oPB).max())
+
+
+@pytest.mark.gpu
+def test_deforming_free_mesh(pkg, orc):
+    """A non-fixed mesh body (integrated like any owner) whose nodes are rewritten between steps
+    (DEMTracker::UpdateMesh -> SetTriNodeRelPos, APIPublic.cpp:709-730)."""
+    b = mesh_bed(pkg, 800, seed=9, fixed=False)
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p)
+    ctx.upload_scene(sc)
+    sim = orc.make_sim(pkg, p, sc)
+    n1, n2, n3 = (b.arrays[k].reshape(-1, 3).copy() for k in ("triNode1", "triNode2", "triNode3"))
+    for k in range(3):
+        ctx.step(40), sim.step(40)
+        for n in (n1, n2, n3):
+            n[:, 2] += np.float32(2e-4) * np.sin(40.0 * n[:, 0] + k).astype(np.float32)
+        ctx.update_tri_nodes(n1, n2, n3)
+        sim.update_tri_nodes(n1, n2, n3)
+    ctx.step(40), sim.step(40)
+    assert ctx.counts().nContacts == sim.counts().nContacts
+    a, bb, t, _ = ctx.contacts()
+    oa, ob, ot, _ = sim.contacts()
+    assert (a == oa).all() and (bb == ob).all() and (t == ot).all() and (t == 2).sum() > 10
+    gs, os_ = ctx.download_state(), sim.download_state()
+    assert gs["vZ"][-1] != 0 and abs(gs["vZ"][-1] - os_["vZ"][-1]) <= 1e-4 * max(1.0, abs(os_["vZ"][-1]))
