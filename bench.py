@@ -6,11 +6,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over the whole bed: (contact detection every --cd-freq steps:
-margins, binning, bin-sorted sweep, history map) + contact forces + integration.  State is resident in
-HBM before the timed region.  Prints ONE JSON line on rank 0.
+margins, binning, bin-sorted sweep, history map) + contact forces + fused accumulation/integration.
+State is resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
-N > 1: the bed is cut into N slabs along x (weak scaling: every rank simulates its own
---clumps-sized slab); see DESIGN.md section "Multi-GPU" for what is and is not exchanged.
+N > 1 (weak scaling): ONE bed N times as long in x is cut into N slabs (dem-engine_amd/decomp.py); each rank
+steps its slab and, every step, exchanges ghost-clump records (56 B each: pose, velocities) with its face
+neighbours over RCCL (torch.distributed P2P, backend nccl).  See DESIGN.md section 6.
 """
 import argparse
 import json
@@ -26,10 +27,11 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
 README_CLUMP_STEPS_PER_S = 1e6 * 1e6 / 3600.0  # reference README.md:48, two RTX 3080 ("around 1 hour")
+HALO = 0.03  # ghost layer thickness [m]: two lattice spacings (clump reach 7.3 mm)
 
 
-def build_bed(pkg, n_clumps, seed, cd_freq, rank=0):
-    b = pkg.model.packed_bed(n_clumps, seed=seed + rank, cd_freq=cd_freq, aspect=(1.0, 1.0, 0.05),
+def build_bed(pkg, n_clumps, seed, cd_freq, x_mult=1):
+    b = pkg.model.packed_bed(n_clumps * x_mult, seed=seed, cd_freq=cd_freq, aspect=(1.0 * x_mult, 1.0, 0.05),
                              spacing_mult=3.0, jitter=0.05, bin_multiple=4.0, init_vz=-1.0)
     b.SetExpandSafetyMultiplier(1.2)
     b.SetExpandSafetyAdder(0.02)
@@ -37,7 +39,7 @@ def build_bed(pkg, n_clumps, seed, cd_freq, rank=0):
 
 
 def force_kernel_bytes(n_owners, n_spheres, n_contacts, n_w):
-    """Algorithmic HBM bytes of ONE contact-force launch (SURVEY 8d / DESIGN.md):
+    """Algorithmic HBM bytes of ONE contact-force launch (SURVEY 8d / DESIGN.md 3.2):
     N_c*(9 + 8*n_w) + N_o*57 + N_s*7  (contact ids+type, wildcards read+write, owner and sphere state
     once each).  The per-contact contribution records this design writes instead of atomics are
     implementation traffic and are NOT counted."""
@@ -45,13 +47,21 @@ def force_kernel_bytes(n_owners, n_spheres, n_contacts, n_w):
 
 
 def cpu_baseline(pkg, seed, budget_s=15.0):
-    """The CPU oracle (oracle/, a port: the reference has no CPU path) on a bounded sample of the
-    same workload recipe, all host cores via OpenMP."""
+    """The CPU oracle (oracle/, a port: the reference has no CPU path) on a bounded sample of the same
+    workload: 20 000 clumps of the same recipe, pre-settled on the GPU so the bed is packed like the
+    measured one, then timed on all host cores (OpenMP)."""
     orc = entry.load_oracle()
     n = 20000
     b = build_bed(pkg, n, seed, cd_freq=10)
     p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p)
+    ctx.upload_scene(sc)
+    ctx.step(20000)
+    st = ctx.download_state()
+    ctx.close()
     sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state({k: st[k] for k in st if k not in ("aX", "aY", "aZ", "alphaX", "alphaY", "alphaZ")})
     sim.step(10)  # first detection + page-in
     t0 = time.perf_counter()
     steps = 0
@@ -60,8 +70,38 @@ def cpu_baseline(pkg, seed, budget_s=15.0):
         steps += 10
     dt = time.perf_counter() - t0
     return {"value": n * steps / dt, "unit": "clump*steps/s", "cores": int(orc.num_threads()), "kind": "port",
-            "sample": f"{n} three-sphere clumps x {steps} steps (same recipe, cd every 10), oracle/deme_oracle.cpp -O2 OpenMP, "
-                      f"{int(sim.counts().nContacts)} contacts at end"}
+            "sample": f"{n} three-sphere clumps x {steps} steps, packed state ({int(sim.counts().nContacts)} contacts), "
+                      f"cd every 10; oracle/deme_oracle.cpp -O2 OpenMP (list building and accumulation are serial)"}
+
+
+class Halo:
+    """Per-step ghost exchange with the face neighbours (RCCL P2P through torch.distributed)."""
+
+    def __init__(self, pkg, ctx, part, rank, world, torch, dist):
+        self.ctx, self.rank, self.world, self.torch, self.dist = ctx, rank, world, torch, dist
+        dev = torch.device("cuda", torch.cuda.current_device())
+        keys = ("send_left", "send_right", "recv_left", "recv_right")
+        self.ids = {k: torch.from_numpy(part[k].astype(np.int32)).to(dev) for k in keys}
+        gb = pkg.abi.GHOST_BYTES
+        self.buf = {k: torch.empty(max(1, len(part[k])) * gb, dtype=torch.uint8, device=dev) for k in keys}
+        self.n = {k: len(part[k]) for k in keys}
+        self.bytes_per_step = gb * (self.n["send_left"] + self.n["send_right"])
+
+    def exchange(self):
+        c, d = self.ctx, self.dist
+        ops = []
+        sides = [(s, nb) for s, nb in (("left", self.rank - 1), ("right", self.rank + 1)) if 0 <= nb < self.world]
+        for side, nb in sides:
+            s, r = "send_" + side, "recv_" + side
+            c.halo_pack(self.ids[s].data_ptr(), self.n[s], self.buf[s].data_ptr())
+            ops.append(d.P2POp(d.isend, self.buf[s], nb))
+            ops.append(d.P2POp(d.irecv, self.buf[r], nb))
+        if ops:
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        for side, nb in sides:
+            r = "recv_" + side
+            c.halo_unpack(self.ids[r].data_ptr(), self.n[r], self.buf[r].data_ptr())
 
 
 def main():
@@ -71,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--clumps", type=int, default=1_000_000, help="clumps per GPU")
     ap.add_argument("--cd-freq", type=int, default=10, help="contact detection every K steps (0: every step)")
-    ap.add_argument("--presettle", type=int, default=30000, help="untimed steps that let the lattice start settling")
+    ap.add_argument("--presettle", type=int, default=30000, help="untimed steps that let the lattice settle")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -92,11 +132,35 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     pkg = entry.load_package()
-    b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, rank)
+    b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world)
     p, sc = b.Initialize()
+    halo, part = None, None
+    if world > 1:
+        x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+        part = pkg.decomp.decompose(b.arrays, b.counts, x, world, HALO)[rank]
+        sc = part["scene"]
+        n_own = part["n_own"]
+    else:
+        n_own = int(sc.nOwnerClumps)
     ctx = pkg.Context(local_rank)
+    if world > 1:
+        # ghost traffic (RCCL, ordered against torch's current stream) and the DEM kernels share one
+        # non-default torch stream, so pack -> send/recv -> unpack -> step need no host synchronisation
+        side = torch.cuda.Stream()
+        torch.cuda.set_stream(side)
+        ctx.set_stream(side.cuda_stream)
     ctx.set_params(p)
     ctx.upload_scene(sc)
+    if world > 1:
+        halo = Halo(pkg, ctx, part, rank, world, torch, dist)
+
+    def run(n):
+        if halo is None:
+            ctx.step(n)
+        else:
+            for _ in range(n):
+                halo.exchange()
+                ctx.step(1)
 
     def barrier():
         ctx.sync()
@@ -104,55 +168,56 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # untimed pre-settling: the lattice (no contacts at t=0) is dropped at 1 m/s and compacts; stop when the
-    # contact count has plateaued or the step budget is spent
-    done, last_nc, log = 0, -1, []
+    # untimed pre-settling: the lattice (no contacts at t=0) is dropped at 1 m/s and compacts; single-GPU runs
+    # stop early once the contact count has plateaued
+    done, last_nc = 0, -1
     t_pre = time.perf_counter()
     while done < args.presettle:
         chunk = min(1000, args.presettle - done)
-        ctx.step(chunk)
+        run(chunk)
         done += chunk
         nc = int(ctx.counts().nContacts)
-        log.append((done, nc))
         if rank == 0 and args.verbose:
-            st = ctx.download_state()
-            vmax = float(np.sqrt(st["vX"] ** 2 + st["vY"] ** 2 + st["vZ"] ** 2).max())
-            print(f"[presettle] step {done} contacts {nc} vmax {vmax:.3f} t {time.perf_counter() - t_pre:.1f}s",
-                  file=sys.stderr, flush=True)
+            print(f"[presettle] step {done} contacts {nc} t {time.perf_counter() - t_pre:.1f}s", file=sys.stderr, flush=True)
         if world == 1 and done >= 4000 and last_nc > 0 and abs(nc - last_nc) < 0.002 * nc:
             break
         last_nc = nc
     args.presettle = done
-    ctx.step(args.warmup)
+    run(args.warmup)
     ctx.set_timing(True)
     ctx.kernel_time_reset()
     barrier()
     t0 = time.perf_counter()
-    ctx.step(args.steps)
+    run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    total_clumps = n_own
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        tot = torch.tensor([float(n_own)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt, total_clumps = float(tmax.item()), int(tot.item())
     f_ms, f_n = ctx.kernel_time_ms("calc_forces")
-    i_ms, i_n = ctx.kernel_time_ms("integrate")
+    i_ms, _ = ctx.kernel_time_ms("integrate")
     d_ms, d_n = ctx.kernel_time_ms("detect")
     c = ctx.counts()
-    n_clumps = int(sc.nOwnerClumps)
-    total_clumps = n_clumps * world
     value = total_clumps * args.steps / dt
     fbytes = force_kernel_bytes(int(sc.nOwners), int(sc.nSpheres), int(c.nContacts), int(p.nContactWildcards))
     achieved = fbytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
+    par = f"{world} x-slab(s)"
+    if halo:
+        par += f", ghost exchange every step over RCCL ({halo.bytes_per_step} B sent per step by rank 0)"
     out = {
         "metric": "clump*steps/s", "value": value, "unit": "clump*steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 1M three-sphere clumps (3_clump.csv x0.005) in a box, gravity settling",
-                   "clumps_per_gpu": n_clumps, "spheres_per_gpu": int(sc.nSpheres), "contacts": int(c.nContacts),
-                   "bin_sphere_touches": int(c.nBinSphereTouches), "cd_every": args.cd_freq,
-                   "presettle_steps": args.presettle, "force_model": "Hertzian (history, 4 wildcards)",
-                   "integrator": "extended Taylor", "h": p.h, "parallelism": f"slab x{world}",
+        "config": {"workload": "BASELINE configs[1]: 1M three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling",
+                   "clumps_total": total_clumps, "owners_this_rank": int(sc.nOwners), "spheres_this_rank": int(sc.nSpheres),
+                   "contacts_this_rank": int(c.nContacts), "bin_sphere_touches": int(c.nBinSphereTouches),
+                   "cd_every": args.cd_freq, "presettle_steps": args.presettle,
+                   "force_model": "Hertzian (history, 4 wildcards)", "integrator": "extended Taylor", "h": p.h,
+                   "parallelism": par,
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
         "roofline": {"kernel": "k_calc_forces<0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -160,10 +225,7 @@ def main():
         "kernels_ms": {"calc_forces": f_ms, "integrate": i_ms, "detect_update": d_ms, "detect_updates": int(d_n)},
     }
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pkg, args.seed)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_baseline(pkg, args.seed) if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

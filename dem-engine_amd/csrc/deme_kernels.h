@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_
     const uint32_t b0 = lower_bound_u32(ownerBSorted, nC, o), b1 = lower_bound_u32(ownerBSorted, nC, o + 1);
     aStart[o] = a0;
     bStart[o] = b0;
-    const bool isFixed = (p.familyFlags[owners[o].family] & 1u) != 0;
+    const bool isFixed = (p.familyFlags[owners[o].family] & 3u) != 0;  // fixed or ghost: a/alpha never integrated here
     fixedFlag[o] = isFixed ? 1 : 0;
     const bool hv = (a1 - a0) + (b1 - b0) > DEME_HEAVY_THRESHOLD;
     heavy[o] = hv ? 1 : 0;
@@ -725,9 +725,12 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
     if (o >= p.nOwners)
         return;
     OwnerRec r = load_owner(owners, o);
+    const uint32_t fflags = p.familyFlags[r.family];
+    if (fflags & 2u)
+        return;  // ghost: its owner rank integrates it; refreshed by deme_halo_unpack
     float4* ap = reinterpret_cast<float4*>(acc + o);
     float4 a, al;
-    const bool fixed = (p.familyFlags[r.family] & 1u) != 0;
+    const bool fixed = (fflags & 1u) != 0;
     if (FUSED && !g.heavy[o]) {
         if (fixed) {  // a fixed owner's a/alpha never feed the integrator; they are reduced on demand
             a = make_float4(0, 0, 0, 0);

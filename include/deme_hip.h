@@ -51,6 +51,8 @@ extern "C" {
  * reference JIT-compiles into integrateOwners (DEMIntegrationKernels.cu:26-33,
  * APIPublic.cpp:980-1011 SetFamilyFixed). */
 #define DEME_FAMILY_FIXED 1
+/* copy of a clump that another rank owns and integrates (slab decomposition): never integrated here */
+#define DEME_FAMILY_GHOST 2
 
 /* status codes */
 #define DEME_OK 0

@@ -1151,6 +1151,8 @@ void integrate(Sim& s) {
 #pragma omp parallel for schedule(static)
     for (int64_t oi = 0; oi < (int64_t)s.nOwners; oi++) {
         const uint32_t o = (uint32_t)oi;
+        if (s.famFlags[s.familyID[o]] & DEME_FAMILY_GHOST)
+            continue;  // ghost of a clump another rank integrates (slab decomposition)
         const bool fixed = (s.famFlags[s.familyID[o]] & DEME_FAMILY_FIXED) != 0;
         V3f old_v{s.vX[o], s.vY[o], s.vZ[o]};
         V3f old_w{s.omgX[o], s.omgY[o], s.omgZ[o]};

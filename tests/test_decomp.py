@@ -1,0 +1,137 @@
+"""Multi-GPU slab decomposition.  CPU tests: bookkeeping, a two-slab run with the ghost exchange
+done in host memory, and the same exchange over torch.distributed (gloo, world_size 2, one process per slab)
+-- each slab stepped by the CPU oracle -- against a single-domain run.  The GPU test does the two-slab run with
+two HIP contexts and the device-side pack/unpack kernels."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GKEYS = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY",
+         "omgBarZ")
+
+
+def build_global(pkg, n=1600, seed=4, cd_freq=0):
+    b = pkg.model.packed_bed(n, seed=seed, cd_freq=cd_freq, spacing_mult=2.5, init_vz=-0.4, aspect=(2.0, 1.0, 0.5))
+    p, sc = b.Initialize()
+    x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+    return b, p, sc, x
+
+
+def test_decomposition_bookkeeping(pkg):
+    b, p, sc, x = build_global(pkg)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=0.03)
+    assert sum(pt["n_own"] for pt in parts) == sc.nOwnerClumps
+    all_own = np.sort(np.concatenate([pt["global_ids"] for pt in parts]))
+    assert (all_own == np.arange(sc.nOwnerClumps)).all()  # every clump owned exactly once
+    for r, pt in enumerate(parts):
+        a, c = pt["arrays"], pt["counts"]
+        assert len(a["voxelID"]) == c["nOwners"] and len(a["ownerClumpBody"]) == c["nSpheres"] == 3 * c["nOwnerClumps"]
+        assert (a["familyID"][pt["n_own"]:c["nOwnerClumps"]] == pkg.decomp.GHOST_FAMILY).all()
+        assert a["objOwner"].min() >= c["nOwnerClumps"]  # walls renumbered behind the clumps
+        if r + 1 < len(parts):  # what I send right is what my right neighbour receives from its left, same order
+            nb = parts[r + 1]
+            assert len(pt["send_right"]) == len(nb["recv_left"]) > 0
+            assert (pt["global_ids"][pt["send_right"]] == nb["ghost_left_g"]).all()
+            assert (a["voxelID"][pt["send_right"]] == nb["arrays"]["voxelID"][nb["recv_left"]]).all()
+
+
+def run_slabs(pkg, make_sim, parts, p, steps, exchange):
+    sims = [make_sim(p, pt["scene"]) for pt in parts]
+    for _ in range(steps):
+        exchange(sims)
+        for s in sims:
+            s.step(1)
+    return sims
+
+
+def gather_positions(pkg, parts, sims, p, n_clumps):
+    X = np.zeros((n_clumps, 3))
+    V = np.zeros((n_clumps, 3))
+    for pt, s in zip(parts, sims):
+        st = s.download_state()
+        n = pt["n_own"]
+        X[pt["global_ids"]] = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2,
+                                                         p.voxelSize, p.l)[:n]
+        V[pt["global_ids"]] = np.stack([st["vX"], st["vY"], st["vZ"]], 1)[:n]
+    return X, V
+
+
+def host_exchange(pkg, parts):
+    def ex(sims):
+        states = [s.download_state() for s in sims]
+        pkg.decomp.exchange_host(parts, states)
+        for s, st in zip(sims, states):
+            s.upload_state({k: st[k] for k in GKEYS})
+    return ex
+
+
+def test_two_slabs_equal_single_domain_oracle(pkg, orc):
+    b, p, sc, x = build_global(pkg)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
+    steps = 120
+    sims = run_slabs(pkg, lambda pp, s: orc.make_sim(pkg, pp, s), parts, p, steps, host_exchange(pkg, parts))
+    X, V = gather_positions(pkg, parts, sims, p, sc.nOwnerClumps)
+    one = orc.make_sim(pkg, p, sc)
+    one.step(steps)
+    st = one.download_state()
+    n = sc.nOwnerClumps
+    X1 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
+    V1 = np.stack([st["vX"], st["vY"], st["vZ"]], 1)[:n]
+    assert one.counts().nContacts > 200
+    # contacts across the cut exist, so this really exercises the ghosts
+    a, bb, t, _ = sims[0].contacts()
+    own = parts[0]["arrays"]["ownerClumpBody"]
+    cross = ((own[a] < parts[0]["n_own"]) != (own[bb] < parts[0]["n_own"])) & (t == 1)
+    assert cross.sum() > 5
+    assert np.abs(X - X1).max() < 2e-7 and np.abs(V - V1).max() < 2e-3
+
+
+def test_gloo_world2_halo_exchange(pkg):
+    """One process per slab, ghost records moved with torch.distributed (gloo) send/recv."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gloo_halo_worker.py")], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GLOO_HALO_OK" in out.stdout
+
+
+@pytest.mark.gpu
+def test_two_slabs_on_gpu_match_single_domain(pkg):
+    import ctypes as C
+    b, p, sc, x = build_global(pkg, n=3000, seed=6)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
+
+    def make(pp, s):
+        ctx = pkg.Context(0)
+        ctx.set_params(pp)
+        ctx.upload_scene(s)
+        return ctx
+
+    ctxs = [make(p, pt["scene"]) for pt in parts]
+    import torch
+    dev = torch.device("cuda", 0)
+    ids = [{k: torch.from_numpy(pt[k].astype(np.int32)).to(dev) for k in ("send_left", "send_right", "recv_left", "recv_right")}
+           for pt in parts]
+    n01 = len(parts[0]["send_right"])
+    n10 = len(parts[1]["send_left"])
+    buf01 = torch.empty(n01 * pkg.abi.GHOST_BYTES, dtype=torch.uint8, device=dev)
+    buf10 = torch.empty(n10 * pkg.abi.GHOST_BYTES, dtype=torch.uint8, device=dev)
+    steps = 100
+    for _ in range(steps):
+        ctxs[0].halo_pack(ids[0]["send_right"].data_ptr(), n01, buf01.data_ptr())
+        ctxs[1].halo_pack(ids[1]["send_left"].data_ptr(), n10, buf10.data_ptr())
+        ctxs[0].sync(), ctxs[1].sync()
+        ctxs[1].halo_unpack(ids[1]["recv_left"].data_ptr(), n01, buf01.data_ptr())
+        ctxs[0].halo_unpack(ids[0]["recv_right"].data_ptr(), n10, buf10.data_ptr())
+        ctxs[0].step(1), ctxs[1].step(1)
+    X, V = gather_positions(pkg, parts, ctxs, p, sc.nOwnerClumps)
+    one = make(p, sc)
+    one.step(steps)
+    st = one.download_state()
+    n = sc.nOwnerClumps
+    X1 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
+    assert one.counts().nContacts > 300
+    assert np.abs(X - X1).max() < 2e-7
