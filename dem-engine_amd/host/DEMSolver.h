@@ -1,0 +1,721 @@
+// DEMSolver.h -- header-only C++ shell of deme::DEMSolver above the C-ABI (include/deme_hip.h).
+//
+// Same class / method names and argument meaning as the reference's scripting API for the set-up and
+// stepping calls the BASELINE configurations use (reference: src/DEM/API.h:50-1300, APIPublic.cpp,
+// BdrsAndObjs.h, Structs.h, AuxClasses.h:422-485), so demo-style programs compile against this header and
+// run on libdeme_hip.so.  What it does NOT carry: writers, trackers/inspectors, OBJ/CSV mesh loaders,
+// family prescriptions other than "fixed" (SURVEY 8f).  Errors are std::runtime_error thrown from the
+// calling thread, as in the reference (Structs.h:285-295).
+//
+// Host-side preprocessing follows the reference where it defines kernel inputs:
+//   voxel bit split / l          APIPrivate.cpp:373-487 (figureOutNV)
+//   bin size / counts            APIPrivate.cpp:489-566, HostSideHelpers.hpp:195-207
+//   world bounding planes        APIPrivate.cpp:955-1014
+//   template order, owner order  APIPrivate.cpp:696-742, dT.cpp:700-800
+//   pairwise material matrices   APIPrivate.cpp:1877-2026
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "deme_hip.h"
+
+#ifndef DEME_HOST_VECTOR_TYPES
+#define DEME_HOST_VECTOR_TYPES
+struct float3 {
+    float x, y, z;
+};
+struct float4 {
+    float x, y, z, w;
+};
+inline float3 make_float3(float x, float y, float z) { return {x, y, z}; }
+inline float3 make_float3(float s) { return {s, s, s}; }
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline float3 operator*(float3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float3 operator+(float3 a, float3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline float3 operator-(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+#endif
+
+namespace deme {
+
+enum class TIME_INTEGRATOR { FORWARD_EULER, CENTERED_DIFFERENCE, EXTENDED_TAYLOR };
+enum class FORCE_MODEL { HERTZIAN, HERTZIAN_FRICTIONLESS, CUSTOM };
+enum VERBOSITY { QUIET = 0, ERR = 10, WARNING = 20, INFO = 30, STEP_METRIC = 35, DEBUG = 40 };
+constexpr unsigned int RESERVED_FAMILY_NUM = 255;
+const bool ENTITY_NORMAL_INWARD = false;
+const bool ENTITY_NORMAL_OUTWARD = true;
+
+struct DEMMaterial {
+    std::unordered_map<std::string, float> mat_prop;
+    unsigned int load_order = 0;
+};
+
+struct DEMClumpTemplate {
+    float mass = 0;
+    float3 MOI{0, 0, 0};
+    std::vector<float> radii;
+    std::vector<float3> relPos;
+    std::vector<std::shared_ptr<DEMMaterial>> materials;
+    unsigned int nComp = 0, mark = 0;
+    // x,y,z,r rows, '#' comments (data/clumps/*.csv in the reference)
+    void ReadComponentFromFile(const std::string& file) {
+        std::ifstream in(file);
+        if (!in)
+            throw std::runtime_error("clump file " + file + " not found");
+        std::string line;
+        while (std::getline(in, line)) {
+            if (line.empty() || line[0] == '#' || line[0] == 'x')
+                continue;
+            std::replace(line.begin(), line.end(), ',', ' ');
+            std::istringstream ss(line);
+            float x, y, z, r;
+            if (ss >> x >> y >> z >> r) {
+                relPos.push_back({x, y, z});
+                radii.push_back(r);
+            }
+        }
+        nComp = (unsigned)radii.size();
+    }
+    void Scale(float s) {  // Structs.h: lengths*s, mass*s^3, MOI*s^5
+        mass *= s * s * s;
+        const float s5 = s * s * s * s * s;
+        MOI = {MOI.x * s5, MOI.y * s5, MOI.z * s5};
+        for (auto& r : radii)
+            r *= s;
+        for (auto& p : relPos)
+            p = p * s;
+    }
+};
+
+struct DEMClumpBatch {
+    std::vector<std::shared_ptr<DEMClumpTemplate>> types;
+    std::vector<float3> xyz, vel, angVel;
+    std::vector<float4> oriQ;
+    std::vector<unsigned int> families;
+    size_t nClumps = 0;
+    explicit DEMClumpBatch(size_t n) : nClumps(n) {
+        vel.assign(n, {0, 0, 0});
+        angVel.assign(n, {0, 0, 0});
+        oriQ.assign(n, {0, 0, 0, 1});
+        families.assign(n, 0);
+    }
+    void SetVel(const std::vector<float3>& v) { vel = v; }
+    void SetVel(float3 v) { vel.assign(nClumps, v); }
+    void SetAngVel(const std::vector<float3>& v) { angVel = v; }
+    void SetOriQ(const std::vector<float4>& q) { oriQ = q; }
+    void SetFamilies(const std::vector<unsigned int>& f) { families = f; }
+    void SetFamily(unsigned int f) { families.assign(nClumps, f); }
+    size_t GetNumClumps() const { return nClumps; }
+};
+
+struct DEMExternObj {
+    struct Comp {
+        uint8_t type;
+        float3 pos, dir;
+        float size1;
+        float normal_sign;
+        std::shared_ptr<DEMMaterial> mat;
+    };
+    std::vector<Comp> comps;
+    unsigned int family_code = RESERVED_FAMILY_NUM;
+    float3 init_pos{0, 0, 0};
+    float4 init_oriQ{0, 0, 0, 1};
+    float mass = 1e6f;
+    float3 MOI{1e6f, 1e6f, 1e6f};
+    static float3 unit(float3 n) {  // normalize(): v * rsqrtf(dot)
+        const float il = 1.0f / std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+        return {n.x * il, n.y * il, n.z * il};
+    }
+    void AddPlane(float3 pos, float3 normal, const std::shared_ptr<DEMMaterial>& m) {
+        comps.push_back({DEME_ANAL_OBJ_TYPE_PLANE, pos, unit(normal), 0.f, 1.f, m});
+    }
+    void AddCylinder(float3 pos, float3 axis, float rad, const std::shared_ptr<DEMMaterial>& m, bool normal = ENTITY_NORMAL_INWARD) {
+        comps.push_back({DEME_ANAL_OBJ_TYPE_CYL_INF, pos, unit(axis), rad, normal == ENTITY_NORMAL_INWARD ? 1.f : -1.f, m});
+    }
+    void AddZCylinder(float3 pos, float rad, const std::shared_ptr<DEMMaterial>& m, bool normal = ENTITY_NORMAL_INWARD) {
+        AddCylinder(pos, {0, 0, 1}, rad, m, normal);
+    }
+    void SetFamily(unsigned int f) { family_code = f; }
+    void SetInitPos(float3 p) { init_pos = p; }
+    void SetMass(float m) { mass = m; }
+    void SetMOI(float3 m) { MOI = m; }
+};
+
+struct DEMMeshConnected {
+    std::vector<float3> vertices;
+    std::vector<std::array<int, 3>> faces;
+    std::shared_ptr<DEMMaterial> mat;
+    unsigned int family_code = RESERVED_FAMILY_NUM;
+    float3 init_pos{0, 0, 0};
+    float4 init_oriQ{0, 0, 0, 1};
+    float mass = 1.f;
+    float3 MOI{1, 1, 1};
+    size_t GetNumTriangles() const { return faces.size(); }
+    void Scale(float s) {
+        for (auto& v : vertices)
+            v = v * s;
+    }
+    void SetFamily(unsigned int f) { family_code = f; }
+    void SetInitPos(float3 p) { init_pos = p; }
+    void SetMass(float m) { mass = m; }
+    void SetMOI(float3 m) { MOI = m; }
+};
+
+class DEMForceModel {
+  public:
+    FORCE_MODEL type = FORCE_MODEL::HERTZIAN;
+    std::string code, prerequisites;
+    std::set<std::string> contact_wildcards;  // std::set: alphabetical indices, as in the reference (Models.h:363)
+    std::set<std::string> pairwise_props{"CoR", "mu", "Crr"};
+    void SetForceModelType(FORCE_MODEL t) {
+        type = t;
+        contact_wildcards.clear();
+        if (t == FORCE_MODEL::HERTZIAN)
+            contact_wildcards = {"delta_tan_x", "delta_tan_y", "delta_tan_z", "delta_time"};
+    }
+    void DefineCustomModel(const std::string& model) {
+        type = FORCE_MODEL::CUSTOM;
+        code = model;
+    }
+    int ReadCustomModelFile(const std::string& path) {
+        std::ifstream in(path);
+        if (!in)
+            return 1;
+        std::stringstream ss;
+        ss << in.rdbuf();
+        DefineCustomModel(ss.str());
+        return 0;
+    }
+    void DefineCustomModelPrerequisites(const std::string& util) { prerequisites = util; }
+    void SetMustPairwiseMatProp(const std::set<std::string>& props) { pairwise_props.insert(props.begin(), props.end()); }
+    void SetPerContactWildcards(const std::set<std::string>& wc) { contact_wildcards = wc; }
+};
+
+class DEMSolver {
+  public:
+    explicit DEMSolver(unsigned int nGPUs = 1) {
+        (void)nGPUs;  // one context per process; multi-GPU runs use one process per GPU
+        if (deme_ctx_create(0, &m_ctx) != DEME_OK)
+            throw std::runtime_error("DEMSolver: no usable HIP device");  // GpuManager.cpp:64-68
+        m_force_model = std::make_shared<DEMForceModel>();
+        m_force_model->SetForceModelType(FORCE_MODEL::HERTZIAN);
+        m_family_flags[RESERVED_FAMILY_NUM] = DEME_FAMILY_FIXED;
+    }
+    ~DEMSolver() {
+        if (m_ctx)
+            deme_ctx_destroy(m_ctx);
+    }
+    DEMSolver(const DEMSolver&) = delete;
+    DEMSolver& operator=(const DEMSolver&) = delete;
+
+    void SetVerbosity(int) {}
+    void SetVerbosity(const std::string&) {}
+
+    // ---- domain (APIPublic.cpp:845-904)
+    void InstructBoxDomainDimension(float x, float y, float z) {
+        InstructBoxDomainDimension({-x / 2, x / 2}, {-y / 2, y / 2}, {-z / 2, z / 2});
+    }
+    void InstructBoxDomainDimension(std::pair<float, float> x, std::pair<float, float> y, std::pair<float, float> z) {
+        m_user_min = {std::min(x.first, x.second), std::min(y.first, y.second), std::min(z.first, z.second)};
+        m_user_max = {std::max(x.first, x.second), std::max(y.first, y.second), std::max(z.first, z.second)};
+        const float3 e = {(m_user_max.x - m_user_min.x) * 0.1f, (m_user_max.y - m_user_min.y) * 0.1f, (m_user_max.z - m_user_min.z) * 0.1f};
+        m_target_min = m_user_min - e;
+        m_target_max = m_user_max + e;
+    }
+    void InstructBoxDomainBoundingBC(const std::string& inst, const std::shared_ptr<DEMMaterial>& mat) {
+        m_bounding = inst;
+        m_bounding_mat = mat;
+    }
+
+    // ---- materials
+    std::shared_ptr<DEMMaterial> LoadMaterial(const std::unordered_map<std::string, float>& props) {
+        auto m = std::make_shared<DEMMaterial>();
+        m->mat_prop = props;
+        m->load_order = (unsigned)m_materials.size();
+        m_materials.push_back(m);
+        return m;
+    }
+    void SetMaterialPropertyPair(const std::string& name, const std::shared_ptr<DEMMaterial>& a, const std::shared_ptr<DEMMaterial>& b, float v) {
+        m_pair_overrides[name][{a->load_order, b->load_order}] = v;
+        m_pair_overrides[name][{b->load_order, a->load_order}] = v;
+    }
+
+    // ---- templates
+    std::shared_ptr<DEMClumpTemplate> LoadClumpType(float mass, float3 moi, const std::vector<float>& radii,
+                                                    const std::vector<float3>& relPos, const std::shared_ptr<DEMMaterial>& mat) {
+        auto t = std::make_shared<DEMClumpTemplate>();
+        t->mass = mass, t->MOI = moi, t->radii = radii, t->relPos = relPos, t->nComp = (unsigned)radii.size();
+        t->materials.assign(radii.size(), mat);
+        m_templates.push_back(t);
+        return t;
+    }
+    std::shared_ptr<DEMClumpTemplate> LoadClumpType(float mass, float3 moi, const std::string& file, const std::shared_ptr<DEMMaterial>& mat) {
+        auto t = std::make_shared<DEMClumpTemplate>();
+        t->mass = mass, t->MOI = moi;
+        t->ReadComponentFromFile(file);
+        t->materials.assign(t->radii.size(), mat);
+        m_templates.push_back(t);
+        return t;
+    }
+    std::shared_ptr<DEMClumpTemplate> LoadSphereType(float mass, float radius, const std::shared_ptr<DEMMaterial>& mat) {
+        const float I = 2.f / 5.f * mass * radius * radius;
+        return LoadClumpType(mass, {I, I, I}, std::vector<float>{radius}, std::vector<float3>{{0, 0, 0}}, mat);
+    }
+
+    // ---- entities
+    std::shared_ptr<DEMClumpBatch> AddClumps(const std::vector<std::shared_ptr<DEMClumpTemplate>>& types, const std::vector<float3>& xyz) {
+        if (types.size() != xyz.size())
+            throw std::runtime_error("AddClumps: type and position arrays differ in length");
+        auto b = std::make_shared<DEMClumpBatch>(xyz.size());
+        b->types = types, b->xyz = xyz;
+        m_batches.push_back(b);
+        return b;
+    }
+    std::shared_ptr<DEMClumpBatch> AddClumps(const std::shared_ptr<DEMClumpTemplate>& type, const std::vector<float3>& xyz) {
+        return AddClumps(std::vector<std::shared_ptr<DEMClumpTemplate>>(xyz.size(), type), xyz);
+    }
+    std::shared_ptr<DEMExternObj> AddExternalObject() {
+        m_ext.push_back(std::make_shared<DEMExternObj>());
+        return m_ext.back();
+    }
+    std::shared_ptr<DEMExternObj> AddBCPlane(float3 pos, float3 normal, const std::shared_ptr<DEMMaterial>& mat) {
+        auto o = AddExternalObject();
+        o->AddPlane(pos, normal, mat);
+        return o;
+    }
+    std::shared_ptr<DEMMeshConnected> AddMeshObject(const std::vector<float3>& vertices, const std::vector<std::array<int, 3>>& faces,
+                                                    const std::shared_ptr<DEMMaterial>& mat) {
+        auto m = std::make_shared<DEMMeshConnected>();
+        m->vertices = vertices, m->faces = faces, m->mat = mat;
+        m_meshes.push_back(m);
+        return m;
+    }
+
+    // ---- force model (APIPublic.cpp:906-933)
+    std::shared_ptr<DEMForceModel> UseFrictionalHertzianModel() {
+        m_force_model->SetForceModelType(FORCE_MODEL::HERTZIAN);
+        return m_force_model;
+    }
+    std::shared_ptr<DEMForceModel> UseFrictionlessHertzianModel() {
+        m_force_model->SetForceModelType(FORCE_MODEL::HERTZIAN_FRICTIONLESS);
+        return m_force_model;
+    }
+    std::shared_ptr<DEMForceModel> DefineContactForceModel(const std::string& model) {
+        m_force_model = std::make_shared<DEMForceModel>();
+        m_force_model->DefineCustomModel(model);
+        return m_force_model;
+    }
+    std::shared_ptr<DEMForceModel> ReadContactForceModel(const std::string& file) {
+        m_force_model = std::make_shared<DEMForceModel>();
+        if (m_force_model->ReadCustomModelFile(file))
+            throw std::runtime_error("The force model file " + file + " is not found.");
+        return m_force_model;
+    }
+
+    // ---- knobs
+    void SetInitTimeStep(double h) { m_h = (float)h; }
+    void SetGravitationalAcceleration(float3 g) { m_G = g; }
+    void SetCDUpdateFreq(int k) { m_cd_freq = k < 0 ? 0 : (unsigned)k; }
+    void SetInitBinSize(double s) { m_bin_size = s; }
+    void SetInitBinSizeAsMultipleOfSmallestSphere(float m) { m_bin_multiple = m, m_bin_size = -1; }
+    void SetExpandSafetyMultiplier(float m) { m_safety_multi = m; }
+    void SetExpandSafetyAdder(float a) { m_safety_adder = a; }
+    void SetMaxVelocity(float v) { m_max_vel = v; }
+    void SetErrorOutVelocity(float v) { m_err_vel = v; }
+    void SetIntegrator(TIME_INTEGRATOR i) { m_integrator = i; }
+    void SetFamilyFixed(unsigned int f) { m_family_flags[f & 255] |= DEME_FAMILY_FIXED; }
+    void DisableContactBetweenFamilies(unsigned int a, unsigned int b) {
+        if (a > b)
+            std::swap(a, b);
+        m_family_masks[(1 + b) * b / 2 + a] = 1;  // locateMaskPair, DEMHelperKernels.cuh:57-62
+    }
+    void SetFamilyExtraMargin(unsigned int f, float m) { m_family_extra[f & 255] = m; }
+    void DisableAdaptiveBinSize() {}
+    void UseAdaptiveUpdateFreq(bool) {}
+    void SetNoForceRecord(bool = true) {}
+    void SetCollectAccRightAfterForceCalc(bool = true) {}
+
+    // ---- run
+    void Initialize() { initialize_impl(); }
+    void DoDynamics(double t) { step((uint32_t)std::llround(t / (double)m_h)); }
+    void DoDynamicsThenSync(double t) {
+        DoDynamics(t);
+        check(deme_sync(m_ctx));
+    }
+    void DoStepDynamics(unsigned int n = 1) { step(n); }
+    double GetSimTime() const { return m_time; }
+
+    // ---- queries (subset of DEMTracker / GetOwner* getters)
+    size_t GetNumClumps() const { return m_n_clumps; }
+    size_t GetNumContacts() {
+        DemeCounts c{};
+        check(deme_get_counts(m_ctx, &c));
+        return (size_t)c.nContacts;
+    }
+    float3 GetOwnerPosition(unsigned int owner) {
+        refresh_state();
+        return m_pos.at(owner);
+    }
+    float3 GetOwnerVelocity(unsigned int owner) {
+        refresh_state();
+        return {m_st_v[0].at(owner), m_st_v[1].at(owner), m_st_v[2].at(owner)};
+    }
+    float GetMaxOwnerSpeed() {
+        refresh_state();
+        float m = 0;
+        for (size_t i = 0; i < m_n_clumps; i++)
+            m = std::max(m, std::sqrt(m_st_v[0][i] * m_st_v[0][i] + m_st_v[1][i] * m_st_v[1][i] + m_st_v[2][i] * m_st_v[2][i]));
+        return m;
+    }
+    deme_ctx* GetContext() { return m_ctx; }
+
+  private:
+    deme_ctx* m_ctx = nullptr;
+    std::vector<std::shared_ptr<DEMMaterial>> m_materials;
+    std::map<std::string, std::map<std::pair<unsigned, unsigned>, float>> m_pair_overrides;
+    std::vector<std::shared_ptr<DEMClumpTemplate>> m_templates;
+    std::vector<std::shared_ptr<DEMClumpBatch>> m_batches;
+    std::vector<std::shared_ptr<DEMExternObj>> m_ext;
+    std::vector<std::shared_ptr<DEMMeshConnected>> m_meshes;
+    std::shared_ptr<DEMForceModel> m_force_model;
+    float3 m_user_min{-10, -10, -10}, m_user_max{10, 10, 10}, m_target_min{-12, -12, -12}, m_target_max{12, 12, 12};
+    std::string m_bounding = "none";
+    std::shared_ptr<DEMMaterial> m_bounding_mat;
+    float m_h = 1e-5f;
+    float3 m_G{0, 0, -9.81f};
+    unsigned m_cd_freq = 20;
+    double m_bin_size = -1;
+    float m_bin_multiple = 8.0f, m_safety_multi = 1.f, m_safety_adder = 0.f, m_max_vel = 1e15f, m_err_vel = 1e15f;
+    TIME_INTEGRATOR m_integrator = TIME_INTEGRATOR::EXTENDED_TAYLOR;
+    uint8_t m_family_masks[DEME_FAMILY_MASK_ENTRIES] = {0};
+    float m_family_extra[DEME_NUM_FAMILIES] = {0};
+    uint8_t m_family_flags[DEME_NUM_FAMILIES] = {0};
+    DemeParams m_p{};
+    size_t m_n_clumps = 0, m_n_owners = 0;
+    double m_time = 0;
+    bool m_state_fresh = false;
+    std::vector<float3> m_pos;
+    std::vector<float> m_st_v[3];
+
+    void check(int rc) {
+        if (rc)
+            throw std::runtime_error(deme_last_error(m_ctx));
+    }
+    void step(uint32_t n) {
+        check(deme_step(m_ctx, n));
+        m_time += (double)n * (double)m_h;
+        m_state_fresh = false;
+    }
+
+    void refresh_state() {
+        if (m_state_fresh)
+            return;
+        std::vector<uint64_t> vid(m_n_owners);
+        std::vector<uint16_t> lx(m_n_owners), ly(m_n_owners), lz(m_n_owners);
+        for (auto& v : m_st_v)
+            v.resize(m_n_owners);
+        DemeOwnerState st{};
+        st.voxelID = vid.data(), st.locX = lx.data(), st.locY = ly.data(), st.locZ = lz.data();
+        st.vX = m_st_v[0].data(), st.vY = m_st_v[1].data(), st.vZ = m_st_v[2].data();
+        check(deme_download_owner_state(m_ctx, &st));
+        m_pos.resize(m_n_owners);
+        for (size_t i = 0; i < m_n_owners; i++) {  // voxelIDToPosition + LBF, DEMHelperKernels.cuh:116-134
+            const uint64_t vx = vid[i] & ((1ull << m_p.nvXp2) - 1), vy = (vid[i] >> m_p.nvXp2) & ((1ull << m_p.nvYp2) - 1),
+                           vz = vid[i] >> (m_p.nvXp2 + m_p.nvYp2);
+            m_pos[i] = {(float)((double)vx * m_p.voxelSize + (double)lx[i] * m_p.l + m_p.LBFX),
+                        (float)((double)vy * m_p.voxelSize + (double)ly[i] * m_p.l + m_p.LBFY),
+                        (float)((double)vz * m_p.voxelSize + (double)lz[i] * m_p.l + m_p.LBFZ)};
+        }
+        m_state_fresh = true;
+    }
+
+    void figure_out_nv(unsigned nv[3], double& l, double& voxel) {
+        float xyz[3] = {m_target_max.x - m_target_min.x, m_target_max.y - m_target_min.y, m_target_max.z - m_target_min.z};
+        int rank[3] = {0, 1, 2};
+        for (int i = 0; i < 2; i++)
+            for (int j = i + 1; j < 3; j++)
+                if (xyz[i] > xyz[j]) {
+                    std::swap(xyz[i], xyz[j]);
+                    std::swap(rank[i], rank[j]);
+                }
+        const float user321[3] = {xyz[0], xyz[1], xyz[2]};
+        int more[2] = {0, 0};
+        while (xyz[0] < xyz[1]) {
+            if (std::sqrt(2.) * xyz[0] > xyz[1])
+                break;
+            more[0]++;
+            xyz[0] *= 2.;
+        }
+        while (xyz[1] < xyz[2]) {
+            if (std::sqrt(2.) * xyz[1] > xyz[2])
+                break;
+            more[1]++;
+            xyz[1] *= 2.;
+        }
+        const int budget = 64 - 2 * more[0] - more[1];
+        int b3 = budget / 3, left = budget % 3;
+        int b2 = b3 + more[0], b1 = b2 + more[1];
+        while (left-- > 0) {
+            if (b3 < b2)
+                b3++;
+            else if (b2 < b1)
+                b2++;
+            else
+                b1++;
+        }
+        const int bits[3] = {b3, b2, b1};
+        l = 0;
+        for (int k = 0; k < 3; k++)
+            l = std::max(l, (double)user321[k] / std::pow(2., 16) / std::pow(2., bits[k]));
+        for (int k = 0; k < 3; k++)
+            nv[rank[k]] = (unsigned)bits[k];
+        voxel = 65536.0 * l;
+    }
+
+    void initialize_impl() {
+        unsigned nv[3];
+        double l, voxel;
+        figure_out_nv(nv, l, voxel);
+        const float3 lbf = m_target_min;
+        // templates by component count (stable), marks renumbered
+        std::vector<std::shared_ptr<DEMClumpTemplate>> ts = m_templates;
+        std::stable_sort(ts.begin(), ts.end(), [](const auto& a, const auto& b) { return a->nComp < b->nComp; });
+        std::vector<float> Radii, rx, ry, rz, mass, moix, moiy, moiz;
+        std::vector<unsigned> prefix(ts.size());
+        float smallest = 1e30f;
+        for (size_t i = 0; i < ts.size(); i++) {
+            ts[i]->mark = (unsigned)i;
+            prefix[i] = (unsigned)Radii.size();
+            for (size_t k = 0; k < ts[i]->radii.size(); k++) {
+                Radii.push_back(ts[i]->radii[k]);
+                rx.push_back(ts[i]->relPos[k].x), ry.push_back(ts[i]->relPos[k].y), rz.push_back(ts[i]->relPos[k].z);
+                smallest = std::min(smallest, ts[i]->radii[k]);
+            }
+            mass.push_back(ts[i]->mass), moix.push_back(ts[i]->MOI.x), moiy.push_back(ts[i]->MOI.y), moiz.push_back(ts[i]->MOI.z);
+        }
+        if (Radii.size() > 65535)
+            throw std::runtime_error("more than 65535 clump components");
+        double bin = m_bin_size > 0 ? m_bin_size : (double)m_bin_multiple * smallest;
+        auto nbins = [&](uint32_t nb[3]) {
+            for (int k = 0; k < 3; k++)
+                nb[k] = (uint32_t)(voxel * (double)(1ull << nv[k]) / bin) + 1;
+            return (uint64_t)nb[0] * nb[1] * nb[2];
+        };
+        uint32_t nb[3];
+        while (nbins(nb) > 0xFFFFFFFEull)
+            bin *= 1.5;
+        // bounding box planes
+        std::vector<std::shared_ptr<DEMExternObj>> ext = m_ext;
+        if (m_bounding != "none") {
+            const bool bottom = m_bounding == "only_bottom" || m_bounding == "top_open" || m_bounding == "all";
+            const bool sides = m_bounding == "only_sides" || m_bounding == "top_open" || m_bounding == "all";
+            const bool top = m_bounding == "all";
+            if (!bottom && !sides)
+                throw std::runtime_error("Domain bounding BC instruction " + m_bounding + " is unknown.");
+            auto box = std::make_shared<DEMExternObj>();
+            const float3 c = {(m_user_min.x + m_user_max.x) / 2.f, (m_user_min.y + m_user_max.y) / 2.f, (m_user_min.z + m_user_max.z) / 2.f};
+            if (bottom)
+                box->AddPlane({c.x, c.y, m_user_min.z}, {0, 0, 1}, m_bounding_mat);
+            if (sides) {
+                box->AddPlane({m_user_min.x, c.y, c.z}, {1, 0, 0}, m_bounding_mat);
+                box->AddPlane({m_user_max.x, c.y, c.z}, {-1, 0, 0}, m_bounding_mat);
+                box->AddPlane({c.x, m_user_min.y, c.z}, {0, 1, 0}, m_bounding_mat);
+                box->AddPlane({c.x, m_user_max.y, c.z}, {0, -1, 0}, m_bounding_mat);
+            }
+            if (top)
+                box->AddPlane({c.x, c.y, m_user_max.z}, {0, 0, -1}, m_bounding_mat);
+            ext.push_back(box);
+        }
+        // owners
+        size_t nC = 0;
+        for (auto& b : m_batches)
+            nC += b->nClumps;
+        const size_t nO = nC + ext.size() + m_meshes.size();
+        std::vector<uint64_t> vid(nO);
+        std::vector<uint16_t> lx(nO), ly(nO), lz(nO), inert(nO);
+        std::vector<float> qw(nO, 1.f), qx(nO, 0.f), qy(nO, 0.f), qz(nO, 0.f), vx(nO, 0.f), vy(nO, 0.f), vz(nO, 0.f), wx(nO, 0.f),
+            wy(nO, 0.f), wz(nO, 0.f);
+        std::vector<uint8_t> fam(nO, 0);
+        std::vector<uint32_t> sphOwner;
+        std::vector<uint16_t> sphComp, sphMat;
+        auto encode = [&](size_t o, float3 pos) {  // positionToVoxelID of (pos - LBF), dT.cpp:745-782
+            const float3 d = pos - lbf;
+            const double P[3] = {(double)d.x, (double)d.y, (double)d.z};
+            uint64_t n[3];
+            uint16_t s[3];
+            for (int k = 0; k < 3; k++) {
+                n[k] = (uint64_t)(P[k] / voxel);
+                s[k] = (uint16_t)((P[k] - (double)n[k] * voxel) / l);
+            }
+            vid[o] = n[0] + (n[1] << nv[0]) + (n[2] << (nv[0] + nv[1]));
+            lx[o] = s[0], ly[o] = s[1], lz[o] = s[2];
+        };
+        size_t o = 0;
+        for (auto& b : m_batches)
+            for (size_t i = 0; i < b->nClumps; i++, o++) {
+                encode(o, b->xyz[i]);
+                qw[o] = b->oriQ[i].w, qx[o] = b->oriQ[i].x, qy[o] = b->oriQ[i].y, qz[o] = b->oriQ[i].z;
+                vx[o] = b->vel[i].x, vy[o] = b->vel[i].y, vz[o] = b->vel[i].z;
+                wx[o] = b->angVel[i].x, wy[o] = b->angVel[i].y, wz[o] = b->angVel[i].z;
+                fam[o] = (uint8_t)b->families[i];
+                const auto& t = b->types[i];
+                inert[o] = (uint16_t)t->mark;
+                for (unsigned k = 0; k < t->nComp; k++) {
+                    sphOwner.push_back((uint32_t)o);
+                    sphComp.push_back((uint16_t)(prefix[t->mark] + k));
+                    sphMat.push_back((uint16_t)t->materials[k]->load_order);
+                }
+            }
+        std::vector<uint8_t> objType;
+        std::vector<uint32_t> objOwner;
+        std::vector<uint16_t> objMat;
+        std::vector<float> objN, opx, opy, opz, orx, ory, orz, os1, os2, os3, om;
+        for (size_t e = 0; e < ext.size(); e++, o++) {
+            encode(o, ext[e]->init_pos);
+            qw[o] = ext[e]->init_oriQ.w, qx[o] = ext[e]->init_oriQ.x, qy[o] = ext[e]->init_oriQ.y, qz[o] = ext[e]->init_oriQ.z;
+            fam[o] = (uint8_t)ext[e]->family_code;
+            inert[o] = (uint16_t)(ts.size() + e);
+            mass.push_back(ext[e]->mass), moix.push_back(ext[e]->MOI.x), moiy.push_back(ext[e]->MOI.y), moiz.push_back(ext[e]->MOI.z);
+            for (auto& cmp : ext[e]->comps) {
+                objType.push_back(cmp.type), objOwner.push_back((uint32_t)o), objMat.push_back((uint16_t)cmp.mat->load_order);
+                objN.push_back(cmp.normal_sign);
+                opx.push_back(cmp.pos.x), opy.push_back(cmp.pos.y), opz.push_back(cmp.pos.z);
+                orx.push_back(cmp.dir.x), ory.push_back(cmp.dir.y), orz.push_back(cmp.dir.z);
+                os1.push_back(cmp.size1), os2.push_back(0.f), os3.push_back(0.f), om.push_back(ext[e]->mass);
+            }
+        }
+        std::vector<uint32_t> triOwner;
+        std::vector<float> t1, t2, t3;
+        std::vector<uint16_t> triMat;
+        for (size_t mI = 0; mI < m_meshes.size(); mI++, o++) {
+            auto& me = m_meshes[mI];
+            encode(o, me->init_pos);
+            qw[o] = me->init_oriQ.w, qx[o] = me->init_oriQ.x, qy[o] = me->init_oriQ.y, qz[o] = me->init_oriQ.z;
+            fam[o] = (uint8_t)me->family_code;
+            inert[o] = (uint16_t)(ts.size() + ext.size() + mI);
+            mass.push_back(me->mass), moix.push_back(me->MOI.x), moiy.push_back(me->MOI.y), moiz.push_back(me->MOI.z);
+            for (auto& f : me->faces) {
+                const float3 a = me->vertices.at(f[0]), b = me->vertices.at(f[1]), c = me->vertices.at(f[2]);
+                triOwner.push_back((uint32_t)o), triMat.push_back((uint16_t)me->mat->load_order);
+                t1.insert(t1.end(), {a.x, a.y, a.z}), t2.insert(t2.end(), {b.x, b.y, b.z}), t3.insert(t3.end(), {c.x, c.y, c.z});
+            }
+        }
+        // materials
+        const size_t nM = std::max<size_t>(1, m_materials.size());
+        auto prop = [&](const std::string& name) {
+            std::vector<float> v(nM, 0.f);
+            for (size_t i = 0; i < m_materials.size(); i++) {
+                auto it = m_materials[i]->mat_prop.find(name);
+                if (it != m_materials[i]->mat_prop.end())
+                    v[i] = it->second;
+            }
+            return v;
+        };
+        auto pair = [&](const std::string& name) {
+            const std::vector<float> v = prop(name);
+            std::vector<float> M(nM * nM);
+            for (size_t a = 0; a < nM; a++)
+                for (size_t b = 0; b < nM; b++)
+                    M[a * nM + b] = (a == b) ? v[a] : (v[a] + v[b]) / 2.f;
+            auto it = m_pair_overrides.find(name);
+            if (it != m_pair_overrides.end())
+                for (auto& kv : it->second)
+                    M[kv.first.first * nM + kv.first.second] = kv.second;
+            return M;
+        };
+        const std::vector<float> E = prop("E"), nu = prop("nu"), CoR = pair("CoR"), mu = pair("mu"), Crr = pair("Crr");
+
+        DemeParams& p = m_p;
+        p = DemeParams{};
+        p.nvXp2 = nv[0], p.nvYp2 = nv[1], p.nvZp2 = nv[2];
+        p.nbX = nb[0], p.nbY = nb[1], p.nbZ = nb[2];
+        p.l = l, p.voxelSize = voxel, p.binSize = bin;
+        p.LBFX = lbf.x, p.LBFY = lbf.y, p.LBFZ = lbf.z;
+        p.Gx = m_G.x, p.Gy = m_G.y, p.Gz = m_G.z;
+        p.h = m_h;
+        p.approxMaxVel = m_max_vel, p.expSafetyMulti = m_safety_multi, p.expSafetyAdder = m_safety_adder;
+        p.integrator = m_integrator == TIME_INTEGRATOR::FORWARD_EULER ? DEME_INTEGRATOR_FORWARD_EULER
+                       : m_integrator == TIME_INTEGRATOR::CENTERED_DIFFERENCE ? DEME_INTEGRATOR_CENTERED_DIFFERENCE
+                                                                               : DEME_INTEGRATOR_EXTENDED_TAYLOR;
+        p.forceModel = m_force_model->type == FORCE_MODEL::HERTZIAN ? DEME_FORCE_HERTZIAN
+                       : m_force_model->type == FORCE_MODEL::HERTZIAN_FRICTIONLESS ? DEME_FORCE_HERTZIAN_FRICTIONLESS
+                                                                                     : DEME_FORCE_CUSTOM;
+        p.nContactWildcards = (uint32_t)m_force_model->contact_wildcards.size();
+        p.cdUpdateFreq = m_cd_freq;
+        p.errOutBinSphNum = 32768;
+        p.errOutVel = m_err_vel;
+
+        DemeScene s{};
+        s.nOwners = (uint32_t)nO, s.nOwnerClumps = (uint32_t)nC, s.nSpheres = (uint32_t)sphOwner.size();
+        s.nAnal = (uint32_t)objType.size(), s.nTri = (uint32_t)triOwner.size(), s.nMat = (uint32_t)nM;
+        s.nComp = (uint32_t)Radii.size(), s.nMassProps = (uint32_t)mass.size();
+        s.voxelID = vid.data(), s.locX = lx.data(), s.locY = ly.data(), s.locZ = lz.data();
+        s.oriQw = qw.data(), s.oriQx = qx.data(), s.oriQy = qy.data(), s.oriQz = qz.data();
+        s.vX = vx.data(), s.vY = vy.data(), s.vZ = vz.data(), s.omgBarX = wx.data(), s.omgBarY = wy.data(), s.omgBarZ = wz.data();
+        s.familyID = fam.data(), s.inertiaPropOffsets = inert.data();
+        s.ownerClumpBody = sphOwner.data(), s.clumpComponentOffset = sphComp.data(), s.sphereMaterialOffset = sphMat.data();
+        s.Radii = Radii.data(), s.CDRelPosX = rx.data(), s.CDRelPosY = ry.data(), s.CDRelPosZ = rz.data();
+        s.MassProperties = mass.data(), s.moiX = moix.data(), s.moiY = moiy.data(), s.moiZ = moiz.data();
+        s.objType = objType.data(), s.objOwner = objOwner.data(), s.objNormal = objN.data(), s.objMaterial = objMat.data();
+        s.objRelPosX = opx.data(), s.objRelPosY = opy.data(), s.objRelPosZ = opz.data();
+        s.objRotX = orx.data(), s.objRotY = ory.data(), s.objRotZ = orz.data();
+        s.objSize1 = os1.data(), s.objSize2 = os2.data(), s.objSize3 = os3.data(), s.objMass = om.data();
+        s.E = E.data(), s.nu = nu.data(), s.CoR = CoR.data(), s.mu = mu.data(), s.Crr = Crr.data();
+        s.familyMasks = m_family_masks, s.familyExtraMarginSize = m_family_extra, s.familyFlags = m_family_flags;
+        s.ownerMesh = triOwner.data(), s.triNode1 = t1.data(), s.triNode2 = t2.data(), s.triNode3 = t3.data();
+        s.triMaterialOffset = triMat.data();
+        check(deme_set_params(m_ctx, &p));
+        check(deme_upload_scene(m_ctx, &s));
+        if (m_force_model->type == FORCE_MODEL::CUSTOM) {
+            // _materialDefs_ for properties beyond the five built-in ones (APIPrivate.cpp:1877-2026)
+            std::set<std::string> extra;
+            for (auto& m : m_materials)
+                for (auto& kv : m->mat_prop)
+                    if (kv.first != "E" && kv.first != "nu" && kv.first != "CoR" && kv.first != "mu" && kv.first != "Crr")
+                        extra.insert(kv.first);
+            std::ostringstream pre;
+            pre.precision(9);
+            for (auto& name : extra) {
+                if (m_force_model->pairwise_props.count(name)) {
+                    const std::vector<float> M = pair(name);
+                    pre << "__device__ const float " << name << "[][" << nM << "] = {";
+                    for (size_t a = 0; a < nM; a++) {
+                        pre << (a ? ", {" : "{");
+                        for (size_t b = 0; b < nM; b++)
+                            pre << (b ? ", " : "") << std::scientific << M[a * nM + b] << "f";
+                        pre << "}";
+                    }
+                    pre << "};\n";
+                } else {
+                    const std::vector<float> v = prop(name);
+                    pre << "__device__ const float " << name << "[] = {";
+                    for (size_t a = 0; a < nM; a++)
+                        pre << (a ? ", " : "") << std::scientific << v[a] << "f";
+                    pre << "};\n";
+                }
+            }
+            pre << m_force_model->prerequisites;
+            std::vector<const char*> names;
+            for (auto& n : m_force_model->contact_wildcards)
+                names.push_back(n.c_str());
+            const std::string prereq = pre.str();
+            check(deme_compile_force_model(m_ctx, m_force_model->code.c_str(), m_force_model->code.size(), names.data(),
+                                           (uint32_t)names.size(), prereq.c_str()));
+        }
+        m_n_clumps = nC, m_n_owners = nO;
+        m_state_fresh = false;
+    }
+};
+
+}  // namespace deme

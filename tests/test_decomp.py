@@ -111,14 +111,27 @@ def test_two_slabs_on_gpu_match_single_domain(pkg):
         return ctx
 
     ctxs = [make(p, pt["scene"]) for pt in parts]
-    import torch
-    dev = torch.device("cuda", 0)
-    ids = [{k: torch.from_numpy(pt[k].astype(np.int32)).to(dev) for k in ("send_left", "send_right", "recv_left", "recv_right")}
+    # device buffers through the HIP runtime the library itself is linked against (no torch here: importing
+    # torch after libdeme_hip.so would pull a second ROCm runtime into the process)
+    hip = C.CDLL("libamdhip64.so")
+
+    class DevArr:
+        def __init__(self, host=None, nbytes=0):
+            self.ptr = C.c_void_p()
+            nbytes = host.nbytes if host is not None else nbytes
+            assert hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(nbytes, 16))) == 0
+            if host is not None and host.nbytes:
+                assert hip.hipMemcpy(self.ptr, C.c_void_p(host.ctypes.data), C.c_size_t(host.nbytes), 1) == 0
+
+        def data_ptr(self):
+            return self.ptr.value
+
+    ids = [{k: DevArr(np.ascontiguousarray(pt[k].astype(np.uint32))) for k in ("send_left", "send_right", "recv_left", "recv_right")}
            for pt in parts]
     n01 = len(parts[0]["send_right"])
     n10 = len(parts[1]["send_left"])
-    buf01 = torch.empty(n01 * pkg.abi.GHOST_BYTES, dtype=torch.uint8, device=dev)
-    buf10 = torch.empty(n10 * pkg.abi.GHOST_BYTES, dtype=torch.uint8, device=dev)
+    buf01 = DevArr(nbytes=n01 * pkg.abi.GHOST_BYTES)
+    buf10 = DevArr(nbytes=n10 * pkg.abi.GHOST_BYTES)
     steps = 100
     for _ in range(steps):
         ctxs[0].halo_pack(ids[0]["send_right"].data_ptr(), n01, buf01.data_ptr())
