@@ -19,7 +19,12 @@ namespace deme_dev {
 struct ForceArgs {
     const OwnerRec* owners;
     const SphereRec* spheres;
-    const uint64_t* keys;  // sorted contact keys
+    const uint64_t* keys;  // sorted contact keys (sphere ids; only user models read them, as AGeo/BGeo)
+    // per-contact gather record written once per detection (k_contact_owners): x = A's owner | class << 30,
+    // y = B's owner, z = A's component | material << 16, w = B's component | material << 16 (sphere) or the
+    // analytical-object / triangle index.  One coalesced 16-byte load replaces the key load and two dependent
+    // SphereRec gathers, so the owner records are the only gathers left on the critical path.
+    const uint4* info;
     float* wc;             // contact wildcards, AoS: wc[c*nW + w]
     // per-contact, per-side contributions to the owners' a and alpha (no atomics: the integrator
     // gathers them per owner in contact order).  side A: conA4 = (ax, ay, az, alx), conA2 = (aly, alz)
@@ -165,21 +170,29 @@ __device__ void deme_user_model(UserModelIO& io);
 #endif
 
 // One thread per contact.  MODEL: 0 full Hertzian (4 wildcards), 1 frictionless (none), 2 user model (JIT).
-template <int MODEL>
+// CLS selects the geometry branches that are compiled in: 0 = sphere-sphere and sphere-analytical (the hot
+// variant), 1 = sphere-mesh only.  Both scan the whole list and threads of the other classes exit at once; the
+// mesh variant is only launched when triangles are loaded.  Keeping the fp64 triangle code out of the hot
+// variant saves ~40 VGPRs (3 -> 4 waves per SIMD; measured 174 -> 148 us at 4.2 M contacts).  Measured and
+// rejected: a third variant for analytical contacts (no occupancy gain, one more pass), per-class index lists
+// (their same-address atomics cost 1.7 ms per detection), register caps of 96 / 80 VGPRs (spills: 231 / 385 us).
+template <int MODEL, int CLS>
 __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) {
     const uint32_t myContactID = blockIdx.x * blockDim.x + threadIdx.x;
     if (myContactID >= a.nContacts)
         return;
-    const uint64_t key = a.keys[myContactID];
-    const uint32_t cls = key_class(key);
+    const uint4 ci = a.info[myContactID];
+    const uint32_t cls = ci.x >> 30;
+    if ((CLS == 1) != (cls == DEME_KEY_CLASS_SM))
+        return;
     uint32_t ContactType = (cls == DEME_KEY_CLASS_SS) ? 1u : 0u;
 
     HertzIn in;
     in.ts = p.h;
     d3 contactPnt{0, 0, 0}, AOwnerPos, BOwnerPos, bodyAPos, bodyBPos;
     // ---- A: always a sphere (DEMCalcForceKernels.cu:63-94)
-    const uint32_t AGeo = key_a(key);
-    const SphereRec sA = load_sphere(a.spheres, AGeo);
+    SphereRec sA;
+    sA.owner = ci.x & 0x3FFFFFFFu, sA.comp = (uint16_t)(ci.z & 0xFFFFu), sA.mat = (uint16_t)(ci.z >> 16);
     const uint32_t AOwner = sA.owner;
     const OwnerRec oA = load_owner(a.owners, AOwner);
     const float4 mpA = p.massProps[oA.inertiaOff];
@@ -200,13 +213,14 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
     const uint32_t AOwnerFamily = oA.family;
     float extraMarginSize = p.familyTrivial ? 0.f : p.familyExtra[AOwnerFamily];
     const uint32_t bodyAMatType = sA.mat;
-    uint32_t bodyBMatType = 0, BOwner = 0;
-    const uint32_t BGeo = key_b(key);
+    uint32_t bodyBMatType = 0;
+    const uint32_t BOwner = ci.y;
+    const uint32_t BIdx = ci.w;  // analytical-object or triangle index for the non-sphere classes
     float4 mpB;
     OwnerRec oB;
-    if (cls == DEME_KEY_CLASS_SS) {  // DEMCalcForceKernels.cu:97-136
-        const SphereRec sB = load_sphere(a.spheres, BGeo);
-        BOwner = sB.owner;
+    if (CLS == 0 && cls == DEME_KEY_CLASS_SS) {  // DEMCalcForceKernels.cu:97-136
+        SphereRec sB;
+        sB.owner = BOwner, sB.comp = (uint16_t)(ci.w & 0xFFFFu), sB.mat = (uint16_t)(ci.w >> 16);
         oB = load_owner(a.owners, BOwner);
         mpB = p.massProps[oB.inertiaOff];
         in.BOwnerMass = mpB.x;
@@ -228,9 +242,8 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
                         (double)in.BRadius, contactPnt, in.B2A, in.overlapDepth);
         if (in.overlapDepth < -extraMarginSize)
             ContactType = 0u;
-    } else if (cls == DEME_KEY_CLASS_SA) {  // DEMCalcForceKernels.cu:184-232
-        const AnalObj ob = p.anal[BGeo];
-        BOwner = ob.owner;
+    } else if (CLS == 0) {  // DEMCalcForceKernels.cu:184-232
+        const AnalObj ob = p.anal[BIdx];
         oB = load_owner(a.owners, BOwner);
         mpB = p.massProps[oB.inertiaOff];
         bodyBMatType = ob.mat;
@@ -256,8 +269,7 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
         if (in.overlapDepth < -extraMarginSize)
             ContactType = 0u;
     } else {  // sphere-mesh, DEMCalcForceKernels.cu:138-183: exact test in fp64 against the ORIGINAL triangle
-        const TriRec tr = reinterpret_cast<const TriRec*>(p.tris)[BGeo];
-        BOwner = tr.owner;
+        const TriRec tr = reinterpret_cast<const TriRec*>(p.tris)[BIdx];
         oB = load_owner(a.owners, BOwner);
         mpB = p.massProps[oB.inertiaOff];
         in.BOwnerMass = mpB.x;
@@ -338,7 +350,11 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
             io.ARotVel = make_float3(in.ARotVel.x, in.ARotVel.y, in.ARotVel.z);
             io.BRotVel = make_float3(in.BRotVel.x, in.BRotVel.y, in.BRotVel.z);
             io.AOwnerMOI = make_float3(mpA.y, mpA.z, mpA.w), io.BOwnerMOI = make_float3(mpB.y, mpB.z, mpB.w);
-            io.AOwner = AOwner, io.BOwner = BOwner, io.AGeo = AGeo, io.BGeo = BGeo, io.myContactID = myContactID;
+            io.AOwner = AOwner, io.BOwner = BOwner, io.myContactID = myContactID;
+            {
+                const uint64_t key = a.keys[myContactID];
+                io.AGeo = key_a(key), io.BGeo = key_b(key);
+            }
             io.wc = a.wc + (size_t)myContactID * p.nW;
             deme_user_model(io);
             force = mk3(io.force.x, io.force.y, io.force.z);
@@ -388,9 +404,8 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
         *wcp = hist;  // _forceModelContactWildcardWrite_
 }
 
-template <int MODEL>
+template <int MODEL, int CLS>
 __global__ __launch_bounds__(256) void k_calc_forces(const DevParams p, const ForceArgs a) {
-    calc_forces_body<MODEL>(p, a);
+    calc_forces_body<MODEL, CLS>(p, a);
 }
-
 }  // namespace deme_dev

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -61,7 +62,8 @@ struct deme_ctx {
         scanTmp, sortTmp, rec[4], stage;
     // per-contact contributions and the per-owner gather lists (built once per detection)
     DevBuf conA4, conA2, conB4, conB2, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
-    uint32_t nHeavy = 0, nHeavyFree = 0;
+    uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
+    DevBuf info;
     // triangles (mesh path)
     uint32_t nTri = 0;
     DevBuf tris, triWorld, triLo, triHi, triCounts, triOffsets, triKeys[2], triVals[2];
@@ -70,7 +72,7 @@ struct deme_ctx {
     // run-time compiled user force model
     deme_jit::MaterialTables mt;
     hipModule_t customMod = nullptr;
-    hipFunction_t customFn = nullptr;
+    hipFunction_t customFn[3] = {nullptr, nullptr, nullptr};
     std::map<size_t, std::vector<char>> jitCache;
     bool conValid = false;
     int keysCur = 0, wcCur = 0;
@@ -272,6 +274,7 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
         rc |= ensure(c, c->ownerB[k], cap * 4);
         rc |= ensure(c, c->bIdx[k], cap * 4);
     }
+    rc |= ensure(c, c->info, cap * 16);
     if (rc)
         return rc;
     c->cntCap = cap;
@@ -361,7 +364,7 @@ int do_detect(deme_ctx* c) {
             sortedIdx = 1;
             hipLaunchKernelGGL(k_bin_stats, dim3(std::min<unsigned>(grid_for(P), 1024u)), dim3(256), 0, c->stream, c->incKeys[1].as<uint32_t>(), P,
                                c->ctr.as<DetectCounters>());
-            hipLaunchKernelGGL(k_sweep, dim3(std::min<unsigned>(grid_for(P, SW_T), 4096u)), dim3(SW_T), 0, c->stream, c->dp,
+            hipLaunchKernelGGL(k_sweep, dim3((grid_for(P, SW_T) + 3) / 4), dim3(SW_T), 0, c->stream, c->dp,
                                c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
                                c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
                                c->ctr.as<DetectCounters>());
@@ -448,7 +451,7 @@ int do_detect(deme_ctx* c) {
         if (nC) {
             hipLaunchKernelGGL(k_contact_owners, dim3(grid_for(nC)), dim3(256), 0, c->stream, c->dp, (uint32_t)nC,
                                c->keysSorted[next].as<uint64_t>(), c->spheres.as<SphereRec>(), c->ownerA.as<uint32_t>(),
-                               c->ownerB[0].as<uint32_t>(), c->bIdx[0].as<uint32_t>());
+                               c->ownerB[0].as<uint32_t>(), c->bIdx[0].as<uint32_t>(), c->info.as<uint4>());
             unsigned obits = 1;
             while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
                 obits++;
@@ -475,6 +478,8 @@ int do_detect(deme_ctx* c) {
             return fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", hr.nHeavy);
         c->nHeavy = hr.nHeavy;
         c->nHeavyFree = hr.nHeavyFree;
+        c->nSA = hr.nSA;
+        c->nSM = hr.nSM;
         c->conValid = false;
         c->nPrev = c->haveList ? c->nContacts : 0;
         c->nContacts = nC;
@@ -529,12 +534,13 @@ int launch_forces(deme_ctx* c) {
         c->conValid = true;
         return DEME_OK;
     }
-    if (c->hp.forceModel == DEME_FORCE_CUSTOM && !c->customFn)
+    if (c->hp.forceModel == DEME_FORCE_CUSTOM && !c->customFn[0])
         return fail(c, DEME_ERR_INVALID, "custom force model selected but none compiled (deme_compile_force_model)");
     ForceArgs a{};
     a.owners = c->owners.as<OwnerRec>();
     a.spheres = c->spheres.as<SphereRec>();
     a.keys = c->keysSorted[c->keysCur].as<uint64_t>();
+    a.info = c->info.as<uint4>();
     a.wc = c->wc[c->wcCur].as<float>();
     a.conA4 = c->conA4.as<float4>(), a.conA2 = c->conA2.as<float2>();
     a.conB4 = c->conB4.as<float4>(), a.conB2 = c->conB2.as<float2>();
@@ -546,13 +552,22 @@ int launch_forces(deme_ctx* c) {
     }
     {
         ScopedTimer tm(c, "calc_forces");
-        if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
-            hipLaunchKernelGGL(k_calc_forces<0>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
-        else if (c->hp.forceModel == DEME_FORCE_HERTZIAN_FRICTIONLESS)
-            hipLaunchKernelGGL(k_calc_forces<1>, dim3(grid_for(a.nContacts)), dim3(256), 0, c->stream, c->dp, a);
-        else {
-            void* args[] = {&c->dp, &a};
-            HIPCK(hipModuleLaunchKernel(c->customFn, grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+        const dim3 g(grid_for(a.nContacts)), b(256);
+        const bool hasSM = c->nTri > 0;
+        if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
+            hipLaunchKernelGGL((k_calc_forces<0, 0>), g, b, 0, c->stream, c->dp, a);
+            if (hasSM)
+                hipLaunchKernelGGL((k_calc_forces<0, 1>), g, b, 0, c->stream, c->dp, a);
+        } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN_FRICTIONLESS) {
+            hipLaunchKernelGGL((k_calc_forces<1, 0>), g, b, 0, c->stream, c->dp, a);
+            if (hasSM)
+                hipLaunchKernelGGL((k_calc_forces<1, 1>), g, b, 0, c->stream, c->dp, a);
+        }
+        else {  // user model: two entry points of the same code object (hot variant, mesh variant)
+            void* args0[] = {&c->dp, &a};
+            HIPCK(hipModuleLaunchKernel(c->customFn[0], grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args0, nullptr));
+            if (hasSM)
+                HIPCK(hipModuleLaunchKernel(c->customFn[1], grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args0, nullptr));
         }
     }
     c->conValid = true;
@@ -618,7 +633,7 @@ void deme_ctx_destroy(deme_ctx* c) {
     drain_timers(c);
     for (auto e : c->eventPool)
         hipEventDestroy(e);
-    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -682,6 +697,8 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         return fail(c, DEME_ERR_INVALID, "call deme_set_params before deme_upload_scene");
     if (s->nSpheres >= (1u << 31))
         return fail(c, DEME_ERR_INVALID, "sphere ids must fit 31 bits");
+    if (s->nOwners >= (1u << 30))
+        return fail(c, DEME_ERR_INVALID, "owner ids must fit 30 bits");
     hipSetDevice(c->device);
     c->nOwners = s->nOwners, c->nOwnerClumps = s->nOwnerClumps, c->nSpheres = s->nSpheres, c->nAnal = s->nAnal;
     c->nMat = s->nMat, c->nComp = s->nComp, c->nMassProps = s->nMassProps;
@@ -1178,10 +1195,12 @@ int deme_compile_force_model(deme_ctx* c, const char* src, size_t len, const cha
     if (c->customMod) {
         (void)hipModuleUnload(c->customMod);
         c->customMod = nullptr;
-        c->customFn = nullptr;
+        c->customFn[0] = c->customFn[1] = c->customFn[2] = nullptr;
     }
     HIPCK(hipModuleLoadData(&c->customMod, it->second.data()));
-    HIPCK(hipModuleGetFunction(&c->customFn, c->customMod, "deme_custom_forces"));
+    HIPCK(hipModuleGetFunction(&c->customFn[0], c->customMod, "deme_custom_forces_ss"));
+    HIPCK(hipModuleGetFunction(&c->customFn[1], c->customMod, "deme_custom_forces_sm"));
+
     return DEME_OK;
 }
 

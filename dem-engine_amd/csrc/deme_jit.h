@@ -179,8 +179,11 @@ inline int generate_source(const std::string& user, const std::vector<std::strin
     for (size_t i = 0; i < wildcards.size(); i++)  // _forceModelContactWildcardWrite_
         o << "    io.wc[" << i << "] = " << wildcards[i] << ";\n";
     o << "    io.force = force; io.torque_only_force = torque_only_force;\n}\n}  // namespace deme_dev\n";
-    o << "extern \"C\" __global__ __launch_bounds__(256) void deme_custom_forces(const deme_dev::DevParams p, "
-         "const deme_dev::ForceArgs a) {\n    deme_dev::calc_forces_body<2>(p, a);\n}\n";
+    const char* ent[2] = {"ss", "sm"};
+    for (int cls = 0; cls < 2; cls++)
+        o << "extern \"C\" __global__ __launch_bounds__(256) void deme_custom_forces_" << ent[cls]
+          << "(const deme_dev::DevParams p, const deme_dev::ForceArgs a) {\n    deme_dev::calc_forces_body<2, " << cls
+          << ">(p, a);\n}\n";
     out = o.str();
     return 0;
 }

@@ -551,9 +551,10 @@ __global__ __launch_bounds__(256) void k_migrate(uint32_t nNew, uint32_t nW, con
 // forceToAcc + integrateOwners, DEMPrepForceKernels.cu:32, DEMCollectForceKernels_Compact.cu:13).
 // ---------------------------------------------------------------------------
 // Per-owner gather of the per-contact contributions written by k_calc_forces (atomics-free, and in
-// contact-list order so the fp32 sum is reproducible run to run and equals the oracle's list-order sum).
+// a fixed order -- A-side run, then B-side list, both by ascending contact index -- so the fp32 sum is
+// reproducible run to run; it differs from a pure list-order sum only in rounding).
 // An owner's A-side contacts are the contiguous run [aStart[o], aStart[o+1]); its B-side contacts are
-// bIdx[bStart[o] .. bStart[o+1]) (ascending).  The two ascending sequences are merged by contact index.
+// bIdx[bStart[o] .. bStart[o+1]) (ascending).
 struct GatherArgs {
     const uint32_t* aStart;  // nOwners+1
     const uint32_t* bStart;  // nOwners+1
@@ -566,27 +567,46 @@ struct GatherArgs {
 };
 
 __device__ inline void gather_owner(const GatherArgs& g, uint32_t o, float4& a, float4& al) {
+    // fixed order: the A-side run (ascending contact index), then the B-side list (ascending contact index).
+    // Loads are issued four at a time so that their latencies overlap; the fp32 sum is reproducible run to run.
     float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
-    uint32_t ia = g.aStart[o];
     const uint32_t ea = g.aStart[o + 1];
-    uint32_t ib = g.bStart[o];
-    const uint32_t eb = g.bStart[o + 1];
-    uint32_t cb = (ib < eb) ? g.bIdx[ib] : 0xFFFFFFFFu;
-    while (ia < ea || ib < eb) {
-        float4 c4;
-        float2 c2;
-        if (ia < ea && ia < cb) {
-            c4 = g.conA4[ia];
-            c2 = g.conA2[ia];
-            ia++;
-        } else {
-            c4 = g.conB4[cb];
-            c2 = g.conB2[cb];
-            ib++;
-            cb = (ib < eb) ? g.bIdx[ib] : 0xFFFFFFFFu;
+    const uint32_t ib0 = g.bStart[o], eb = g.bStart[o + 1];
+    for (uint32_t ia = g.aStart[o]; ia < ea; ia += 4) {
+        float4 c4[4];
+        float2 c2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool ok = ia + k < ea;
+            c4[k] = ok ? g.conA4[ia + k] : make_float4(0, 0, 0, 0);
+            c2[k] = ok ? g.conA2[ia + k] : make_float2(0, 0);
         }
-        ax += c4.x, ay += c4.y, az += c4.z;
-        lx += c4.w, ly += c2.x, lz += c2.y;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ia + k < ea) {
+                ax += c4[k].x, ay += c4[k].y, az += c4[k].z;
+                lx += c4[k].w, ly += c2[k].x, lz += c2[k].y;
+            }
+    }
+    for (uint32_t ib = ib0; ib < eb; ib += 4) {
+        uint32_t idx[4];
+        float4 c4[4];
+        float2 c2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            idx[k] = (ib + k < eb) ? g.bIdx[ib + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool ok = ib + k < eb;
+            c4[k] = ok ? g.conB4[idx[k]] : make_float4(0, 0, 0, 0);
+            c2[k] = ok ? g.conB2[idx[k]] : make_float2(0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ib + k < eb) {
+                ax += c4[k].x, ay += c4[k].y, az += c4[k].z;
+                lx += c4[k].w, ly += c2[k].x, lz += c2[k].y;
+            }
     }
     a = make_float4(ax, ay, az, 0.f);
     al = make_float4(lx, ly, lz, 0.f);
@@ -645,26 +665,33 @@ __global__ __launch_bounds__(256) void k_reduce_heavy(const GatherArgs g, const 
     }
 }
 
-// Owner of each contact's B side (sort key for the B-side lists) and of its A side.
+// Once per detection: each contact's gather record for the force kernel (see ForceArgs::info), A's owner
+// (ascending: the list is sorted by sphere A and spheres are clump-major) and B's owner (sort key of the
+// B-side lists).
 __global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint32_t nC, const uint64_t* __restrict__ keys,
                                                         const SphereRec* __restrict__ spheres,
                                                         uint32_t* __restrict__ ownerA, uint32_t* __restrict__ ownerB,
-                                                        uint32_t* __restrict__ idx) {
+                                                        uint32_t* __restrict__ idx, uint4* __restrict__ info) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nC)
         return;
     const uint64_t k = keys[c];
-    ownerA[c] = spheres[key_a(k)].owner;
+    const SphereRec sa = load_sphere(spheres, key_a(k));
     const uint32_t cls = key_class(k);
-    uint32_t ob = 0;
-    if (cls == DEME_KEY_CLASS_SS)
-        ob = spheres[key_b(k)].owner;
-    else if (cls == DEME_KEY_CLASS_SA)
+    uint32_t ob = 0, w = key_b(k);
+    if (cls == DEME_KEY_CLASS_SS) {
+        const SphereRec sb = load_sphere(spheres, key_b(k));
+        ob = sb.owner;
+        w = (uint32_t)sb.comp | ((uint32_t)sb.mat << 16);
+    } else if (cls == DEME_KEY_CLASS_SA) {
         ob = p.anal[key_b(k)].owner;
-    else  // sphere-mesh: TriRec is 48 bytes with the owner id at byte 36 (deme_mesh.h)
+    } else {  // sphere-mesh: TriRec is 48 bytes with the owner id at byte 36 (deme_mesh.h)
         ob = reinterpret_cast<const uint32_t*>(p.tris)[12 * (size_t)key_b(k) + 9];
+    }
+    ownerA[c] = sa.owner;
     ownerB[c] = ob;
     idx[c] = c;
+    info[c] = make_uint4(sa.owner | (cls << 30), ob, (uint32_t)sa.comp | ((uint32_t)sa.mat << 16), w);
 }
 
 __device__ inline uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t v) {
@@ -683,7 +710,8 @@ __device__ inline uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32
 struct RangeCounters {
     unsigned int nHeavy;
     unsigned int nHeavyFree;  // heavy owners that are not fixed (they must be reduced every step)
-    unsigned int pad[14];
+    unsigned int nSA, nSM;    // sphere-analytical / sphere-mesh contacts in the list
+    unsigned int pad[12];
 };
 
 // aStart / bStart by binary search (once per detection), plus the heavy-owner list.

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < n_side; k++)
         for (int j = 0; j < n_side; j++)
             for (int i = 0; i < n_side; i++)
-                xyz.push_back(make_float3(0.03f + i * 0.016f + jit(rng), 0.03f + j * 0.016f + jit(rng), 0.03f + k * 0.016f + jit(rng)));
+                xyz.push_back(make_float3(0.03f + i * 0.016f + jit(rng), 0.03f + j * 0.016f + jit(rng), 0.0085f + k * 0.0135f + jit(rng)));
     auto batch = DEMSim.AddClumps(tmpl, xyz);
     batch->SetVel(make_float3(0.f, 0.f, -0.5f));
 
