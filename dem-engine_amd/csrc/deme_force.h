@@ -72,7 +72,7 @@ __device__ inline void hertz_full(const HertzIn& in, const MatPair& mp, float& d
         const float Sn = (float)(2. * mp.E_cnt * sqrt_Rd);
         const float beta = mp.beta;
         const float k_n = (float)((2. / 3.) * Sn);
-        const float gamma_n = (float)(1.825741858350554 * beta * sqrt((double)(Sn * mass_eff)));
+        const float gamma_n = (float)(1.825741858350554 * beta * sqrtf(Sn * mass_eff));
         force = force + (float)(k_n * in.overlapDepth + gamma_n * projection) * in.B2A;
 
         if (mp.Crr > 0.0f) {
@@ -96,7 +96,7 @@ __device__ inline void hertz_full(const HertzIn& in, const MatPair& mp, float& d
         }
         if (mp.mu > 0.0f) {
             const float kt = (float)(8. * mp.G_cnt * sqrt_Rd);
-            const float gt = (float)(-1.825741858350554 * beta * sqrt((double)(mass_eff * kt)));
+            const float gt = (float)(-1.825741858350554 * beta * sqrtf(mass_eff * kt));
             f3 tangent_force = (-kt) * delta_tan - gt * vrel_tan;
             const float ft = len3(tangent_force);
             if (ft > 1e-12) {
@@ -133,7 +133,7 @@ __device__ inline void hertz_frictionless(const HertzIn& in, const MatPair& mp, 
             (float)sqrt(in.overlapDepth * (double)(in.ARadius * in.BRadius) / (double)(in.ARadius + in.BRadius));
         const float Sn = (float)(2. * mp.E_cnt * sqrt_Rd);
         const float k_n = (float)((2. / 3.) * Sn);
-        const float gamma_n = (float)(1.825741858350554 * mp.beta * sqrt((double)(Sn * mass_eff)));
+        const float gamma_n = (float)(1.825741858350554 * mp.beta * sqrtf(Sn * mass_eff));
         force = force + (float)(k_n * in.overlapDepth + gamma_n * projection) * in.B2A;
     }
 }

@@ -246,7 +246,7 @@ void build_mat_pairs(const DemeScene* s, std::vector<MatPair>& out) {
             m.CoR = s->CoR ? s->CoR[a * n + b] : 0.f;
             m.mu = s->mu ? s->mu[a * n + b] : 0.f;
             m.Crr = s->Crr ? s->Crr[a * n + b] : 0.f;
-            const float loge = (float)((m.CoR < 1e-12) ? log(1e-12) : log((double)m.CoR));
+            const float loge = (float)((m.CoR < 1e-12) ? log(1e-12) : logf(m.CoR));  // log(float) -> float overload
             m.beta = (float)(loge / sqrt(loge * loge + 9.869604401089358));
             out[(size_t)a * n + b] = m;
         }

@@ -243,11 +243,11 @@ inline void mat_proxy(float& E_eff, float& G_eff, float Y1, float nu1, float Y2,
 // FrictionlessHertzianForceModel.cu:3-42.  Mixed precision is deliberate in the
 // reference: overlapDepth is fp64, most physics fp32, with double literals
 // promoting a few products before they are narrowed on assignment.
-// Overload note: the pinned reference build (oracle/_ref) is a HOST compile, where the
-// unqualified `sqrt(x)` / `log(x)` of a float argument resolve to the double overloads
-// (under NVRTC they resolve to the float ones).  The restatement follows the host
-// resolution so it can be pinned bit-for-bit; the two differ by <= 1 ulp(fp32) in
-// gamma_n, g_t and beta.
+// Overload note: the fragments call unqualified `sqrt(x)` / `log(x)`.  With the C++ overload set
+// in scope (CUDA device code; the pinned oracle/_ref host build, whose translation unit includes
+// <math.h> through the reference's own DEMTriangleBoxIntersect.cu) a float argument selects the
+// float overload: log(CoR_cnt), sqrt(Sn * mass_eff) and sqrt(mass_eff * kt) are fp32 operations,
+// while sqrt(overlapDepth * ...) and sqrt(loge * loge + PI_SQUARED) have double arguments and stay fp64.
 // ---------------------------------------------------------------------------
 struct ForceIn {
     double overlapDepth;
@@ -288,10 +288,10 @@ inline void force_hertz_full(const ForceIn& in, ForceHist& h, V3f& force, V3f& t
         const float sqrt_Rd =
             (float)sqrt(in.overlapDepth * (double)(in.ARadius * in.BRadius) / (double)(in.ARadius + in.BRadius));
         const float Sn = (float)(2. * E_cnt * sqrt_Rd);
-        const float loge = (float)((in.CoR < kTiny) ? log(kTiny) : log((double)in.CoR));
+        const float loge = (float)((in.CoR < kTiny) ? log(kTiny) : logf(in.CoR));
         const float beta = (float)(loge / sqrt(loge * loge + kPiSq));
         const float k_n = (float)(kTwoThirds * Sn);
-        const float gamma_n = (float)(kTwoSqrt56 * beta * sqrt((double)(Sn * mass_eff)));
+        const float gamma_n = (float)(kTwoSqrt56 * beta * sqrtf(Sn * mass_eff));
         force = force + (float)(k_n * in.overlapDepth + gamma_n * projection) * in.B2A;
 
         if (in.Crr > 0.0) {
@@ -316,7 +316,7 @@ inline void force_hertz_full(const ForceIn& in, ForceHist& h, V3f& force, V3f& t
 
         if (in.mu > 0.0) {
             const float kt = (float)(8. * G_cnt * sqrt_Rd);
-            const float gt = (float)(-kTwoSqrt56 * beta * sqrt((double)(mass_eff * kt)));
+            const float gt = (float)(-kTwoSqrt56 * beta * sqrtf(mass_eff * kt));
             V3f tangent_force = (-kt) * delta_tan - gt * vrel_tan;
             const float ft = lenf(tangent_force);
             if (ft > kTiny) {
@@ -353,10 +353,10 @@ inline void force_hertz_frictionless(const ForceIn& in, V3f& force) {
         const float sqrt_Rd =
             (float)sqrt(in.overlapDepth * (double)(in.ARadius * in.BRadius) / (double)(in.ARadius + in.BRadius));
         const float Sn = (float)(2. * E_cnt * sqrt_Rd);
-        const float loge = (float)((in.CoR < kTiny) ? log(kTiny) : log((double)in.CoR));
+        const float loge = (float)((in.CoR < kTiny) ? log(kTiny) : logf(in.CoR));
         const float beta = (float)(loge / sqrt(loge * loge + kPiSq));
         const float k_n = (float)(kTwoThirds * Sn);
-        const float gamma_n = (float)(kTwoSqrt56 * beta * sqrt((double)(Sn * mass_eff)));
+        const float gamma_n = (float)(kTwoSqrt56 * beta * sqrtf(Sn * mass_eff));
         force = force + (float)(k_n * in.overlapDepth + gamma_n * projection) * in.B2A;
     }
 }

@@ -330,10 +330,11 @@ def tri_sphere(A, B, Cc, P, r, directional=False):
     return hit, nr, d, pt
 
 
-def tri_box(center, half, A, B, Cc):
+def tri_box(center, half, A, B, Cc, which="orc"):
+    L, pre = _pick(which)
     arrs = [np.ascontiguousarray(a, np.float32) for a in (center, half, A, B, Cc)]
     out = np.zeros(len(arrs[1]), np.uint8)
-    lib().orc_el_tri_box(C.c_size_t(len(out)), *[_p(a) for a in arrs], _p(out))
+    getattr(L, pre + "tri_box")(C.c_size_t(len(out)), *[_p(a) for a in arrs], _p(out))
     return out
 
 

@@ -21,6 +21,9 @@
 #include <cstdint>
 
 #include "kernel/DEMHelperKernels.cuh"
+// check_TriangleBoxOverlap (SAT triangle / axis-aligned box test used by the mesh broad phase): the file is
+// __device__-only, which the genuine CUDA headers define away for a host compiler
+#include "kernel/DEMTriangleBoxIntersect.cu"
 
 extern "C" {
 
@@ -174,6 +177,18 @@ void ref_vel_pass_on(size_t n, int scheme, const float* old_v_in, const float* v
         }
         (void)omgBar;
         v_out[3 * i] = v.x, v_out[3 * i + 1] = v.y, v_out[3 * i + 2] = v.z;
+    }
+}
+
+// G7: check_TriangleBoxOverlap (DEMTriangleBoxIntersect.cu:295), cubic box of half-size half[i]
+void ref_tri_box(size_t n, const float* center, const float* half, const float* A, const float* B, const float* C,
+                 uint8_t* out) {
+    for (size_t i = 0; i < n; i++) {
+        float bc[3] = {center[3 * i], center[3 * i + 1], center[3 * i + 2]};
+        float bh[3] = {half[i], half[i], half[i]};
+        out[i] = check_TriangleBoxOverlap(bc, bh, make_float3(A[3 * i], A[3 * i + 1], A[3 * i + 2]),
+                                          make_float3(B[3 * i], B[3 * i + 1], B[3 * i + 2]),
+                                          make_float3(C[3 * i], C[3 * i + 1], C[3 * i + 2]));
     }
 }
 

@@ -151,6 +151,25 @@ def main():
     out.update(g8_A=A, g8_radA=radA, g8_typeB=typeB, g8_B=Bp, g8_dirB=dirB, g8_size1=size1, g8_nsign=nsign,
                g8_beta=beta, g8_type=t, g8_CP=CP, g8_nrm=nrm, g8_depth=d)
 
+    # G7 check_TriangleBoxOverlap: triangles around a cubic bin, many of them grazing a face / edge / corner
+    n = 6000
+    half = rng.choice([0.004, 0.0075, 0.02], n).astype(np.float32)
+    center = (rng.integers(0, 40, (n, 3)) * 2 + 1).astype(np.float32) * half[:, None]
+    base = center + rng.uniform(-2.2, 2.2, (n, 3)).astype(np.float32) * half[:, None]
+    ext = rng.choice([0.3, 1.0, 4.0], n).astype(np.float32)[:, None] * half[:, None]
+    tA = base
+    tB = base + rng.uniform(-1, 1, (n, 3)).astype(np.float32) * ext
+    tC = base + rng.uniform(-1, 1, (n, 3)).astype(np.float32) * ext
+    flat = rng.random(n) < 0.3  # axis-parallel triangles lying exactly in a box face plane or just off it
+    ax = rng.integers(0, 3, n)
+    off = rng.choice([-1.0, 1.0], n).astype(np.float32) * half * rng.choice([1.0, 1.0 + 1e-6, 1.0 - 1e-6], n).astype(np.float32)
+    for k in range(3):
+        sel = flat & (ax == k)
+        for t in (tA, tB, tC):
+            t[sel, k] = center[sel, k] + off[sel]
+    hit = orc.tri_box(center, half, tA, tB, tC, which="ref")
+    out.update(g7_center=center, g7_half=half, g7_A=tA, g7_B=tB, g7_C=tC, g7_hit=hit)
+
     # G9 integrator velocity pass-on fragments
     ov = rng.uniform(-2, 2, (1000, 3)).astype(np.float32)
     vu = rng.uniform(-1e-3, 1e-3, (1000, 3)).astype(np.float32)

@@ -116,3 +116,10 @@ def test_ref_build_agrees_when_present(orc, golden):
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     v = rng.standard_normal((n, 3)).astype(np.float32)
     same(orc.rotate("orc", v, q), orc.rotate("ref", v, q))
+
+
+def test_g7_triangle_box_overlap(orc, golden):
+    """check_TriangleBoxOverlap (DEMTriangleBoxIntersect.cu:295), bit-exact verdicts incl. face-plane grazing cases."""
+    hit = orc.tri_box(golden["g7_center"], golden["g7_half"], golden["g7_A"], golden["g7_B"], golden["g7_C"])
+    assert 0.15 < golden["g7_hit"].mean() < 0.85
+    assert (hit == golden["g7_hit"]).all()
