@@ -487,6 +487,23 @@ inline bool tri_sphere_cd(V3<T> A, V3<T> B, V3<T> C, V3<T> sp, T radius, V3<T>& 
     return in_contact;
 }
 
+// boundingBoxIntersectBin (DEMHelperKernels.cuh:528-565): bin range of one triangle's bounding box, enlarged by
+// DEME_BIN_ENLARGE_RATIO_FOR_FACETS * binSize (float -= double, narrowed), divided in fp64, narrowed to fp32,
+// clamped as a float against [0, nb-1] and truncated (clampBetween3Comp<float3,int3>, :73-80).
+inline void tri_bbox_bins(const V3<float> v[3], double binSize, const int nbm[3], int L[3], int U[3]) {
+    const float mn[3] = {std::min(v[0].x, std::min(v[1].x, v[2].x)), std::min(v[0].y, std::min(v[1].y, v[2].y)),
+                         std::min(v[0].z, std::min(v[1].z, v[2].z))};
+    const float mx[3] = {std::max(v[0].x, std::max(v[1].x, v[2].x)), std::max(v[0].y, std::max(v[1].y, v[2].y)),
+                         std::max(v[0].z, std::max(v[1].z, v[2].z))};
+    for (int d = 0; d < 3; d++) {
+        const float lo = (float)(mn[d] - 0.001 * binSize), hi = (float)(mx[d] + 0.001 * binSize);
+        const float ql = (float)(lo / binSize), qh = (float)(hi / binSize);
+        const float cl = std::min(std::max(ql, 0.f), (float)nbm[d]), ch = std::min(std::max(qh, 0.f), (float)nbm[d]);
+        L[d] = (int)cl;
+        U[d] = (int)ch;
+    }
+}
+
 // kernel/DEMTriangleBoxIntersect.cu:176-374 (Akenine-Moller triangle/AABB separating-axis test, fp32)
 inline bool plane_box_overlap(const float n[3], const float vert[3], const float maxbox[3]) {
     float vmin[3], vmax[3];
@@ -833,17 +850,11 @@ int detect(Sim& s) {
             int L[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, U[3] = {-1, -1, -1};
             const int nbm[3] = {(int)s.p.nbX - 1, (int)s.p.nbY - 1, (int)s.p.nbZ - 1};
             for (int half = 0; half < 2; half++) {
-                const T3f* v = w + 3 * half;
-                const float mn[3] = {std::min(v[0].x, std::min(v[1].x, v[2].x)), std::min(v[0].y, std::min(v[1].y, v[2].y)),
-                                     std::min(v[0].z, std::min(v[1].z, v[2].z))};
-                const float mx[3] = {std::max(v[0].x, std::max(v[1].x, v[2].x)), std::max(v[0].y, std::max(v[1].y, v[2].y)),
-                                     std::max(v[0].z, std::max(v[1].z, v[2].z))};
+                int l3[3], u3[3];
+                tri_bbox_bins(w + 3 * half, s.p.binSize, nbm, l3, u3);
                 for (int d = 0; d < 3; d++) {
-                    const float lo = (float)(mn[d] - 0.001 * s.p.binSize), hi = (float)(mx[d] + 0.001 * s.p.binSize);
-                    const float ql = (float)(lo / s.p.binSize), qh = (float)(hi / s.p.binSize);
-                    const float cl = std::min(std::max(ql, 0.f), (float)nbm[d]), ch = std::min(std::max(qh, 0.f), (float)nbm[d]);
-                    L[d] = std::min(L[d], (int)cl);
-                    U[d] = std::max(U[d], (int)ch);
+                    L[d] = std::min(L[d], l3[d]);
+                    U[d] = std::max(U[d], u3[d]);
                 }
             }
             for (int i = L[0]; i <= U[0]; i++)
@@ -1434,6 +1445,14 @@ void orc_el_tri_box(size_t n, const float* center, const float* half, const floa
         const float bh[3] = {half[i], half[i], half[i]};
         out[i] = tri_box_overlap(center + 3 * i, bh, {A[3 * i], A[3 * i + 1], A[3 * i + 2]}, {B[3 * i], B[3 * i + 1], B[3 * i + 2]},
                                  {C[3 * i], C[3 * i + 1], C[3 * i + 2]});
+    }
+}
+void orc_el_tri_bbox(size_t n, const float* A, const float* B, const float* C, double binSize, uint32_t nbX, uint32_t nbY,
+                     uint32_t nbZ, int32_t* L, int32_t* U) {
+    const int nbm[3] = {(int)nbX - 1, (int)nbY - 1, (int)nbZ - 1};
+    for (size_t i = 0; i < n; i++) {
+        const T3f v[3] = {{A[3 * i], A[3 * i + 1], A[3 * i + 2]}, {B[3 * i], B[3 * i + 1], B[3 * i + 2]}, {C[3 * i], C[3 * i + 1], C[3 * i + 2]}};
+        tri_bbox_bins(v, binSize, nbm, L + 3 * i, U + 3 * i);
     }
 }
 size_t orc_sim_get_tri_incidence(void* h, uint32_t* bins, uint32_t* tris, size_t cap) {

@@ -338,6 +338,16 @@ def tri_box(center, half, A, B, Cc, which="orc"):
     return out
 
 
+def tri_bbox(A, B, Cc, binSize, nb, which="orc"):
+    L_, pre = _pick(which)
+    arrs = [np.ascontiguousarray(a, np.float32) for a in (A, B, Cc)]
+    n = len(arrs[0])
+    lo, hi = np.zeros((n, 3), np.int32), np.zeros((n, 3), np.int32)
+    getattr(L_, pre + "tri_bbox")(C.c_size_t(n), *[_p(a) for a in arrs], C.c_double(binSize), C.c_uint32(nb[0]), C.c_uint32(nb[1]),
+                                  C.c_uint32(nb[2]), _p(lo), _p(hi))
+    return lo, hi
+
+
 def num_threads():
     return lib().orc_num_threads()
 

@@ -192,4 +192,23 @@ void ref_tri_box(size_t n, const float* center, const float* half, const float* 
     }
 }
 
+// boundingBoxIntersectBin (DEMHelperKernels.cuh:528): bin range of a triangle's enlarged bounding box
+void ref_tri_bbox(size_t n, const float* A, const float* B, const float* C, double binSize, uint32_t nbX, uint32_t nbY,
+                  uint32_t nbZ, int32_t* L, int32_t* U) {
+    deme::DEMSimParams sp{};
+    sp.binSize = binSize;
+    sp.nbX = nbX;
+    sp.nbY = nbY;
+    sp.nbZ = nbZ;
+    for (size_t i = 0; i < n; i++) {
+        deme::binID_t l3[3], u3[3];
+        boundingBoxIntersectBin(l3, u3, make_float3(A[3 * i], A[3 * i + 1], A[3 * i + 2]), make_float3(B[3 * i], B[3 * i + 1], B[3 * i + 2]),
+                                make_float3(C[3 * i], C[3 * i + 1], C[3 * i + 2]), &sp);
+        for (int d = 0; d < 3; d++) {
+            L[3 * i + d] = (int32_t)l3[d];
+            U[3 * i + d] = (int32_t)u3[d];
+        }
+    }
+}
+
 }  // extern "C"

@@ -170,6 +170,18 @@ def main():
     hit = orc.tri_box(center, half, tA, tB, tC, which="ref")
     out.update(g7_center=center, g7_half=half, g7_A=tA, g7_B=tB, g7_C=tC, g7_hit=hit)
 
+    # G7b boundingBoxIntersectBin: bin ranges of triangle bounding boxes, incl. vertices outside the world and on bin faces
+    n = 4000
+    bs = 0.0125
+    nb = (40, 24, 16)
+    bA = rng.uniform(-0.05, 0.55, (n, 3)).astype(np.float32)
+    bB = bA + rng.uniform(-0.03, 0.03, (n, 3)).astype(np.float32)
+    bC = bA + rng.uniform(-0.03, 0.03, (n, 3)).astype(np.float32)
+    onface = rng.random(n) < 0.4
+    bA[onface] = (rng.integers(0, 16, (int(onface.sum()), 3)) * bs).astype(np.float32)
+    lo, hi = orc.tri_bbox(bA, bB, bC, bs, nb, which="ref")
+    out.update(g7b_A=bA, g7b_B=bB, g7b_C=bC, g7b_binSize=np.float64(bs), g7b_nb=np.array(nb, np.uint32), g7b_L=lo, g7b_U=hi)
+
     # G9 integrator velocity pass-on fragments
     ov = rng.uniform(-2, 2, (1000, 3)).astype(np.float32)
     vu = rng.uniform(-1e-3, 1e-3, (1000, 3)).astype(np.float32)

@@ -123,3 +123,11 @@ def test_g7_triangle_box_overlap(orc, golden):
     hit = orc.tri_box(golden["g7_center"], golden["g7_half"], golden["g7_A"], golden["g7_B"], golden["g7_C"])
     assert 0.15 < golden["g7_hit"].mean() < 0.85
     assert (hit == golden["g7_hit"]).all()
+
+
+def test_g7b_triangle_bbox_bins(orc, golden):
+    """boundingBoxIntersectBin (DEMHelperKernels.cuh:528-565): integer bin ranges, bit-exact."""
+    lo, hi = orc.tri_bbox(golden["g7b_A"], golden["g7b_B"], golden["g7b_C"], float(golden["g7b_binSize"]),
+                          [int(x) for x in golden["g7b_nb"]])
+    assert (lo == golden["g7b_L"]).all() and (hi == golden["g7b_U"]).all()
+    assert (hi > lo).any()
