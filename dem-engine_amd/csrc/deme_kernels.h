@@ -612,6 +612,84 @@ __device__ inline void gather_owner(const GatherArgs& g, uint32_t o, float4& a, 
     al = make_float4(lx, ly, lz, 0.f);
 }
 
+// Workgroup-cooperative form of gather_owner for 256 consecutive owners (the integrator's fused path).
+// The A-side runs of consecutive owners are one contiguous range of the contribution arrays, and so are
+// their B-side index lists: the range is streamed through LDS in tiles with fully coalesced loads (A side)
+// or with one independent gather per lane (B side), and every owner then sums its own slice out of LDS in
+// the same order as gather_owner (A run ascending, then B list ascending) -- bit-identical results, but no
+// lane walks a chain of dependent global loads any more.  `want` is false for lanes that do not need a sum
+// (beyond the end, fixed, ghost, heavy); all lanes of the workgroup must call.
+#define DEME_GATHER_TILE 1024
+struct GatherLds {
+    float4 c4[DEME_GATHER_TILE];
+    float2 c2[DEME_GATHER_TILE];
+};
+__device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint32_t o, bool want, GatherLds& L, float4& a,
+                                    float4& al) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t oFirst = blockIdx.x * blockDim.x;
+    const uint32_t oEnd = (oFirst + blockDim.x < nOwners) ? oFirst + blockDim.x : nOwners;
+    const uint32_t loA = g.aStart[oFirst], hiA = g.aStart[oEnd];
+    const uint32_t loB = g.bStart[oFirst], hiB = g.bStart[oEnd];
+    if (hiA - loA > 8u * DEME_GATHER_TILE || hiB - loB > 8u * DEME_GATHER_TILE) {  // workgroup-uniform: a giant run inside
+        if (want)
+            gather_owner(g, o, a, al);
+        return;
+    }
+    float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
+    uint32_t sA = 0, eA = 0, sB = 0, eB = 0;
+    if (want) {
+        sA = g.aStart[o], eA = g.aStart[o + 1];
+        sB = g.bStart[o], eB = g.bStart[o + 1];
+    }
+    for (uint32_t base = loA; base < hiA; base += DEME_GATHER_TILE) {
+#pragma unroll
+        for (int k = 0; k < DEME_GATHER_TILE / 256; k++) {
+            const uint32_t j = base + k * 256 + t;
+            if (j < hiA) {
+                L.c4[k * 256 + t] = g.conA4[j];
+                L.c2[k * 256 + t] = g.conA2[j];
+            }
+        }
+        __syncthreads();
+        const uint32_t s = (sA > base) ? sA : base;
+        const uint32_t e = (eA < base + DEME_GATHER_TILE) ? eA : base + DEME_GATHER_TILE;
+        for (uint32_t i = s; i < e; i++) {
+            const float4 c4 = L.c4[i - base];
+            const float2 c2 = L.c2[i - base];
+            ax += c4.x, ay += c4.y, az += c4.z;
+            lx += c4.w, ly += c2.x, lz += c2.y;
+        }
+        __syncthreads();
+    }
+    for (uint32_t base = loB; base < hiB; base += DEME_GATHER_TILE) {
+        uint32_t idx[DEME_GATHER_TILE / 256];
+#pragma unroll
+        for (int k = 0; k < DEME_GATHER_TILE / 256; k++) {
+            const uint32_t j = base + k * 256 + t;
+            idx[k] = (j < hiB) ? g.bIdx[j] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < DEME_GATHER_TILE / 256; k++)
+            if (idx[k] != 0xFFFFFFFFu) {
+                L.c4[k * 256 + t] = g.conB4[idx[k]];
+                L.c2[k * 256 + t] = g.conB2[idx[k]];
+            }
+        __syncthreads();
+        const uint32_t s = (sB > base) ? sB : base;
+        const uint32_t e = (eB < base + DEME_GATHER_TILE) ? eB : base + DEME_GATHER_TILE;
+        for (uint32_t i = s; i < e; i++) {
+            const float4 c4 = L.c4[i - base];
+            const float2 c2 = L.c2[i - base];
+            ax += c4.x, ay += c4.y, az += c4.z;
+            lx += c4.w, ly += c2.x, lz += c2.y;
+        }
+        __syncthreads();
+    }
+    a = make_float4(ax, ay, az, 0.f);
+    al = make_float4(lx, ly, lz, 0.f);
+}
+
 // stand-alone reduction (deme_calc_forces): a/alpha of every non-heavy owner
 __global__ __launch_bounds__(256) void k_gather_acc(const DevParams p, const GatherArgs g, AccRec* __restrict__ acc) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -750,25 +828,30 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* __restrict__ owners,
                                                    AccRec* __restrict__ acc, const GatherArgs g) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= p.nOwners)
-        return;
-    OwnerRec r = load_owner(owners, o);
+    const bool valid = o < p.nOwners;
+    OwnerRec r = load_owner(owners, valid ? o : 0u);
     const uint32_t fflags = p.familyFlags[r.family];
-    if (fflags & 2u)
-        return;  // ghost: its owner rank integrates it; refreshed by deme_halo_unpack
-    float4* ap = reinterpret_cast<float4*>(acc + o);
-    float4 a, al;
+    const bool ghost = (fflags & 2u) != 0;  // its owner rank integrates it; refreshed by deme_halo_unpack
     const bool fixed = (fflags & 1u) != 0;
-    if (FUSED && !g.heavy[o]) {
-        if (fixed) {  // a fixed owner's a/alpha never feed the integrator; they are reduced on demand
-            a = make_float4(0, 0, 0, 0);
-            al = a;
-        } else {
-            gather_owner(g, o, a, al);
+    float4 a = make_float4(0, 0, 0, 0), al = a;
+    if (FUSED) {
+        // a fixed owner's a/alpha never feed the integrator (they are reduced on demand); a/alpha are not stored in
+        // the stepping loop either (32 B/owner of HBM writes per step saved): a state download re-derives them from
+        // the per-contact contributions (launch_full_reduction)
+        __shared__ GatherLds lds;
+        const bool hv = valid && g.heavy[o];
+        gather_block(g, p.nOwners, o, valid && !ghost && !fixed && !hv, lds, a, al);
+        if (!valid || ghost)
+            return;
+        if (hv) {
+            const float4* ap = reinterpret_cast<const float4*>(acc + o);
+            a = ap[0];
+            al = ap[1];
         }
-        // a/alpha are not stored in the stepping loop (32 B/owner of HBM writes per step saved); a state
-        // download re-derives them from the per-contact contributions (launch_full_reduction)
     } else {
+        if (!valid || ghost)
+            return;
+        const float4* ap = reinterpret_cast<const float4*>(acc + o);
         a = ap[0];
         al = ap[1];
     }

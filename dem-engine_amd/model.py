@@ -672,9 +672,20 @@ def random_unit_quaternions(n, rng):
     return q.astype(np.float32)  # x y z w
 
 
+def morton_codes(pts, cell):
+    """Z-order code of the cell (edge `cell`) each point falls in; 21 bits per axis."""
+    q = np.floor(np.asarray(pts, np.float64) / cell).astype(np.int64)
+    q -= q.min(axis=0)
+    code = np.zeros(len(q), np.uint64)
+    for bit in range(21):
+        for ax in range(3):
+            code |= ((q[:, ax].astype(np.uint64) >> np.uint64(bit)) & np.uint64(1)) << np.uint64(3 * bit + ax)
+    return code
+
+
 def packed_bed(n_target, seed=2024, scale=0.005, spacing_mult=3.0, jitter=0.05, aspect=(1.0, 1.0, 0.45),
                three_sphere=True, cd_freq=0, E=1e8, nu=0.3, CoR=0.6, mu=0.2, Crr=0.0, h=5e-6, bin_multiple=4.0,
-               radii_poly=None, force_model=abi.FORCE_HERTZIAN, init_vz=0.0):
+               radii_poly=None, force_model=abi.FORCE_HERTZIAN, init_vz=0.0, order="lattice"):
     """BASELINE.md config-2 recipe: three-sphere clumps (3_clump.csv * scale) on an HCP lattice of
     spacing 3*scale with seeded jitter and random orientations inside a box with 5 wall planes."""
     rng = np.random.default_rng(seed)
@@ -693,6 +704,10 @@ def packed_bed(n_target, seed=2024, scale=0.005, spacing_mult=3.0, jitter=0.05, 
     pts = hcp_points([pad, pad, pad], [pad + dims[0], pad + dims[1], pad + dims[2]], sep)
     if len(pts) > n_target:
         pts = pts[:n_target]  # keep the lowest layers (z-major ordering)
+    if order == "random":  # input order of the clumps: the engine keeps the caller's numbering
+        pts = pts[rng.permutation(len(pts))]
+    elif order == "morton":
+        pts = pts[np.argsort(morton_codes(pts, 2.0 * sep), kind="stable")]
     pts = pts + ((rng.random(pts.shape) * 2 - 1) * (jitter * sep)).astype(np.float32)
     if three_sphere:
         tmpl = b.LoadThreeSphereClump(scale, 2.6e3, mat)
