@@ -77,8 +77,9 @@ def cpu_baseline(pkg, seed, budget_s=15.0):
 class Halo:
     """Per-step ghost exchange with the face neighbours (RCCL P2P through torch.distributed)."""
 
-    def __init__(self, pkg, ctx, part, rank, world, torch, dist):
+    def __init__(self, pkg, ctx, part, rank, world, torch, dist, via_host=False):
         self.ctx, self.rank, self.world, self.torch, self.dist = ctx, rank, world, torch, dist
+        self.via_host = via_host  # plumbing test on a box with fewer GPUs than ranks: gloo, staged through host memory
         dev = torch.device("cuda", torch.cuda.current_device())
         keys = ("send_left", "send_right", "recv_left", "recv_right")
         self.ids = {k: torch.from_numpy(part[k].astype(np.int32)).to(dev) for k in keys}
@@ -94,9 +95,24 @@ class Halo:
         for side, nb in sides:
             s, r = "send_" + side, "recv_" + side
             c.halo_pack(self.ids[s].data_ptr(), self.n[s], self.buf[s].data_ptr())
+            if self.via_host:
+                continue
             ops.append(d.P2POp(d.isend, self.buf[s], nb))
             ops.append(d.P2POp(d.irecv, self.buf[r], nb))
-        if ops:
+        if self.via_host:
+            c.sync()
+            host = {}
+            for side, nb in sides:
+                host["send_" + side] = self.buf["send_" + side].cpu()
+                host["recv_" + side] = self.torch.empty(self.buf["recv_" + side].numel(), dtype=self.torch.uint8)
+                ops.append(d.P2POp(d.isend, host["send_" + side], nb))
+                ops.append(d.P2POp(d.irecv, host["recv_" + side], nb))
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+            for side, nb in sides:
+                self.buf["recv_" + side].copy_(host["recv_" + side])
+            self.torch.cuda.current_stream().synchronize()
+        elif ops:
             for w in d.batch_isend_irecv(ops):
                 w.wait()
         for side, nb in sides:
@@ -110,8 +126,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--clumps", type=int, default=1_000_000, help="clumps per GPU")
-    ap.add_argument("--cd-freq", type=int, default=20,
-                    help="contact detection every K steps (0: every step); 20 = the reference default m_updateFreq (API.h:1509)")
+    ap.add_argument("--cd-freq", type=int, default=40,
+                    help="contact detection every K steps (0: every step); 40 = the setting of the demo the config-2 recipe "
+                         "comes from (DEMdemo_Mixer.cpp:87); the reference's built-in default is 20 (API.h:1509)")
     ap.add_argument("--presettle", type=int, default=30000, help="untimed steps that let the lattice settle")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--order", default="lattice", choices=["lattice", "morton", "random"],
@@ -128,10 +145,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # DEME_BENCH_VIA_HOST=1: plumbing test of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs,
+    # ghosts travel over gloo through host memory); never set for a measurement
+    via_host = os.environ.get("DEME_BENCH_VIA_HOST") == "1"
+    if via_host:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if via_host:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if via_host else "cuda"
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     pkg = entry.load_package()
@@ -155,7 +181,7 @@ def main():
     ctx.set_params(p)
     ctx.upload_scene(sc)
     if world > 1:
-        halo = Halo(pkg, ctx, part, rank, world, torch, dist)
+        halo = Halo(pkg, ctx, part, rank, world, torch, dist, via_host=via_host)
 
     def run(n):
         if halo is None:
@@ -196,9 +222,9 @@ def main():
     dt = time.perf_counter() - t0
     total_clumps = n_own
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = torch.tensor([float(n_own)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(n_own)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt, total_clumps = float(tmax.item()), int(tot.item())
     f_ms, f_n = ctx.kernel_time_ms("calc_forces")
@@ -210,7 +236,7 @@ def main():
     achieved = fbytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
     par = f"{world} x-slab(s)"
     if halo:
-        par += f", ghost exchange every step over RCCL ({halo.bytes_per_step} B sent per step by rank 0)"
+        par += f", ghost exchange every step over {'gloo via host memory (PLUMBING TEST, not a measurement)' if via_host else 'RCCL'} ({halo.bytes_per_step} B sent per step by rank 0)"
     out = {
         "metric": "clump*steps/s", "value": value, "unit": "clump*steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
