@@ -74,6 +74,38 @@ def cpu_baseline(pkg, seed, budget_s=15.0):
                       f"cd every 20; oracle/deme_oracle.cpp -O2 OpenMP (list building and accumulation are serial)"}
 
 
+def pmc_traffic(n_contacts):
+    """roofline.traffic: HBM bytes per launch of the force kernel from the rocprofv3 PMC passes of this same
+    command (FETCH_SIZE and WRITE_SIZE in separate passes, corrected with the factors calibrated in the same
+    passes; profiles/<round>/traffic.json written by profiles/make_traffic.py).  Counters cannot be read from
+    inside the process, so the committed summary is quoted -- only when it was taken on the same workload."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    if not os.path.exists(path):
+        return {"traffic": None}
+    t = json.load(open(path))
+    if abs(t["contacts"] - n_contacts) > 0.05 * n_contacts:
+        return {"traffic": None, "traffic_note": "profiles/r01/traffic.json was taken on a different workload"}
+    return {"traffic": t["traffic_bytes_per_launch"], "traffic_source": "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE, "
+            "WRITE_SIZE; calibrated)"}
+
+
+def pmc_calibration(torch):
+    """Known-byte kernels for calibrating FETCH_SIZE / WRITE_SIZE inside a rocprofv3 --pmc pass
+    (MI355X_MICROARCH.md, HBM section): a 1 GiB streaming copy and 4 M random 64-byte row gathers out of
+    a 512 MiB table (both beyond the 256 MiB Infinity Cache)."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_(generator=g)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)  # 1 GiB read + 1 GiB written per launch
+    table = src.view(-1, 16)[: 1 << 23]  # 8 Mi rows x 64 B
+    idx = torch.randint(0, table.shape[0], (1 << 22,), device="cuda", generator=g)
+    out = torch.empty((1 << 22, 16), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        torch.index_select(table, 0, idx, out=out)  # 256 MiB gathered in 64 B rows + 32 MiB of indices; 256 MiB written
+    torch.cuda.synchronize()
+
+
 class Halo:
     """Per-step ghost exchange with the face neighbours (RCCL P2P through torch.distributed)."""
 
@@ -253,6 +285,9 @@ def main():
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n)},
         "kernels_ms": {"calc_forces": f_ms, "integrate": i_ms, "detect_update": d_ms, "detect_updates": int(d_n)},
     }
+    out["roofline"].update(pmc_traffic(int(c.nContacts)))
+    if os.environ.get("DEME_PMC_CALIB") == "1":
+        pmc_calibration(torch)
     if rank == 0:
         out["cpu_baseline"] = cpu_baseline(pkg, args.seed) if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out))
