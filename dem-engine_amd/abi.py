@@ -130,7 +130,8 @@ def make_state_struct(n_owners, arrays=None):
 
 
 def library_path():
-    return os.path.join(_HERE, "csrc", "libdeme_hip.so")
+    # DEME_HIP_LIB: another build of the same library (kernel A/B experiments); never a different implementation
+    return os.environ.get("DEME_HIP_LIB") or os.path.join(_HERE, "csrc", "libdeme_hip.so")
 
 
 _lib = None

@@ -174,6 +174,13 @@ __device__ inline RotM rot_coeffs(float w, float x, float y, float z) {
     m.zz = 2.0f * (w * w + z * z) - 1.0f;
     return m;
 }
+__device__ inline RotM rot_transpose(const RotM& m) {
+    RotM t;
+    t.xx = m.xx, t.xy = m.yx, t.xz = m.zx;
+    t.yx = m.xy, t.yy = m.yy, t.yz = m.zy;
+    t.zx = m.xz, t.zy = m.yz, t.zz = m.zz;
+    return t;
+}
 __device__ inline f3 rot_apply(const RotM& m, f3 v) {
     f3 r;
     r.x = m.xx * v.x + m.xy * v.y + m.xz * v.z;

@@ -28,10 +28,15 @@ struct ForceArgs {
     float* wc;             // contact wildcards, AoS: wc[c*nW + w]
     // per-contact, per-side contributions to the owners' a and alpha (no atomics: the integrator
     // gathers them per owner in contact order).  side A: conA4 = (ax, ay, az, alx), conA2 = (aly, alz)
+    // A side is reduced inside the workgroup whenever an owner's whole A run lies in one 256-contact block (see
+    // calc_forces_block): then only aSum[owner] = {ax, ay, az, 0 | alx, aly, alz, 0} is written; the per-contact
+    // conA records are written only for runs that straddle a block boundary and for sphere-mesh contacts.
     float4* conA4;
     float2* conA2;
     float4* conB4;
     float2* conB2;
+    float4* aSum;            // two float4 per owner
+    const uint32_t* aStart;  // nOwners+1: first contact of each owner's A run
     float* recForce;       // optional per-contact records (3 floats each), may be null
     float* recTorque;
     float* recCPA;
@@ -39,6 +44,36 @@ struct ForceArgs {
     uint32_t nContacts;
     float timeElapsed;
 };
+
+// Physics-only arithmetic (force model, per-side contributions).  Contact / bin DECISIONS never go through these.
+// DEME_FAST_PHYSICS: 1-ulp hardware reciprocal / square root instead of the correctly rounded sequences
+// (~10 instructions each); results stay deterministic, within a few fp32 ulp of the exact form.
+#ifndef DEME_FAST_PHYSICS
+#define DEME_FAST_PHYSICS 0
+#endif
+__device__ inline float pdiv(float a, float b) {
+#if DEME_FAST_PHYSICS
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+__device__ inline float psqrt(float x) {
+#if DEME_FAST_PHYSICS
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+__device__ inline float plen3(f3 a) { return psqrt(dot3(a, a)); }
+__device__ inline f3 pdiv3(f3 a, float s) {
+#if DEME_FAST_PHYSICS
+    const float r = __builtin_amdgcn_rcpf(s);
+    return mk3(a.x * r, a.y * r, a.z * r);
+#else
+    return a / s;
+#endif
+}
 
 struct HertzIn {
     double overlapDepth;
@@ -66,13 +101,13 @@ __device__ inline void hertz_full(const HertzIn& in, const MatPair& mp, float& d
         delta_tan = delta_tan - disp_proj * in.B2A;
         dtime += in.ts;
 
-        const float mass_eff = (in.AOwnerMass * in.BOwnerMass) / (in.AOwnerMass + in.BOwnerMass);
+        const float mass_eff = pdiv(in.AOwnerMass * in.BOwnerMass, in.AOwnerMass + in.BOwnerMass);
         const float sqrt_Rd =
             (float)sqrt(in.overlapDepth * (double)(in.ARadius * in.BRadius) / (double)(in.ARadius + in.BRadius));
         const float Sn = (float)(2. * mp.E_cnt * sqrt_Rd);
         const float beta = mp.beta;
         const float k_n = (float)((2. / 3.) * Sn);
-        const float gamma_n = (float)(1.825741858350554 * beta * sqrtf(Sn * mass_eff));
+        const float gamma_n = (float)(1.825741858350554 * beta * psqrt(Sn * mass_eff));
         force = force + (float)(k_n * in.overlapDepth + gamma_n * projection) * in.B2A;
 
         if (mp.Crr > 0.0f) {
@@ -89,21 +124,21 @@ __device__ inline void hertz_full(const HertzIn& in, const MatPair& mp, float& d
             }
             if (roll) {
                 const f3 v_rot = rotVelCPB - rotVelCPA;
-                const float v_rot_mag = len3(v_rot);
+                const float v_rot_mag = plen3(v_rot);
                 if (v_rot_mag > 1e-12)
-                    torque_only = (v_rot / v_rot_mag) * (mp.Crr * len3(force));
+                    torque_only = pdiv3(v_rot, v_rot_mag) * (mp.Crr * plen3(force));
             }
         }
         if (mp.mu > 0.0f) {
             const float kt = (float)(8. * mp.G_cnt * sqrt_Rd);
-            const float gt = (float)(-1.825741858350554 * beta * sqrtf(mass_eff * kt));
+            const float gt = (float)(-1.825741858350554 * beta * psqrt(mass_eff * kt));
             f3 tangent_force = (-kt) * delta_tan - gt * vrel_tan;
-            const float ft = len3(tangent_force);
+            const float ft = plen3(tangent_force);
             if (ft > 1e-12) {
-                const float ft_max = len3(force) * mp.mu;
+                const float ft_max = plen3(force) * mp.mu;
                 if (ft > ft_max) {
-                    tangent_force = (ft_max / ft) * tangent_force;
-                    delta_tan = (tangent_force + gt * vrel_tan) / (-kt);
+                    tangent_force = pdiv(ft_max, ft) * tangent_force;
+                    delta_tan = pdiv3(tangent_force + gt * vrel_tan, -kt);
                 }
             } else {
                 tangent_force = mk3(0, 0, 0);
@@ -144,8 +179,14 @@ __device__ inline void side_contribution(f3 F, f3 Ftot, float mass, f3 moi, cons
                                          float2& c2) {
     const f3 myF = rot_apply(Rinv, Ftot);
     const f3 cr = cross3(locCP, myF);
+#if DEME_FAST_PHYSICS
+    const float rm = __builtin_amdgcn_rcpf(mass);
+    c4 = make_float4(F.x * rm, F.y * rm, F.z * rm, cr.x * __builtin_amdgcn_rcpf(moi.x));
+    c2 = make_float2(cr.y * __builtin_amdgcn_rcpf(moi.y), cr.z * __builtin_amdgcn_rcpf(moi.z));
+#else
     c4 = make_float4(F.x / mass, F.y / mass, F.z / mass, cr.x / moi.x);
     c2 = make_float2(cr.y / moi.y, cr.z / moi.z);
+#endif
 }
 
 #ifdef DEME_JIT
@@ -177,14 +218,9 @@ __device__ void deme_user_model(UserModelIO& io);
 // rejected: a third variant for analytical contacts (no occupancy gain, one more pass), per-class index lists
 // (their same-address atomics cost 1.7 ms per detection), register caps of 96 / 80 VGPRs (spills: 231 / 385 us).
 template <int MODEL, int CLS>
-__device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) {
-    const uint32_t myContactID = blockIdx.x * blockDim.x + threadIdx.x;
-    if (myContactID >= a.nContacts)
-        return;
-    const uint4 ci = a.info[myContactID];
+__device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, const uint32_t myContactID, const uint4 ci,
+                                        float4& outA4, float2& outA2) {
     const uint32_t cls = ci.x >> 30;
-    if ((CLS == 1) != (cls == DEME_KEY_CLASS_SM))
-        return;
     uint32_t ContactType = (cls == DEME_KEY_CLASS_SS) ? 1u : 0u;
 
     HertzIn in;
@@ -315,8 +351,10 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
     }
     if (ContactType != 0u) {
         f3 force = mk3(0, 0, 0), torque_only_force = mk3(0, 0, 0);
-        const RotM RAinv = rot_coeffs(oA.qw, -oA.qx, -oA.qy, -oA.qz);
-        const RotM RBinv = rot_coeffs(oB.qw, -oB.qx, -oB.qy, -oB.qz);
+        // rotation by the conjugate quaternion: its nine coefficients are, bit for bit, the transposed forward ones
+        // ((-x)(-y) = xy, w(-z) = -(wz), a - (-b) = a + b are all exact), so they are not recomputed
+        const RotM RAinv = rot_transpose(in.RA);
+        const RotM RBinv = rot_transpose(in.RB);
         in.locCPA = rot_apply(RAinv, mk3((float)(contactPnt.x - AOwnerPos.x), (float)(contactPnt.y - AOwnerPos.y),
                                          (float)(contactPnt.z - AOwnerPos.z)));
         in.locCPB = rot_apply(RBinv, mk3((float)(contactPnt.x - BOwnerPos.x), (float)(contactPnt.y - BOwnerPos.y),
@@ -376,15 +414,15 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
         float4 c4;
         float2 c2;
         side_contribution(force, tot, in.AOwnerMass, mk3(mpA.y, mpA.z, mpA.w), RAinv, in.locCPA, c4, c2);
-        a.conA4[myContactID] = c4;
-        a.conA2[myContactID] = c2;
+        outA4 = c4;
+        outA2 = c2;
         const f3 nF = mk3(-force.x, -force.y, -force.z);
         side_contribution(nF, -1.f * tot, in.BOwnerMass, mk3(mpB.y, mpB.z, mpB.w), RBinv, in.locCPB, c4, c2);
         a.conB4[myContactID] = c4;
         a.conB2[myContactID] = c2;
     } else {
-        a.conA4[myContactID] = make_float4(0, 0, 0, 0);
-        a.conA2[myContactID] = make_float2(0, 0);
+        outA4 = make_float4(0, 0, 0, 0);
+        outA2 = make_float2(0, 0);
         a.conB4[myContactID] = make_float4(0, 0, 0, 0);
         a.conB2[myContactID] = make_float2(0, 0);
         hist = make_float4(0, 0, 0, 0);  // _forceModelContactWildcardDestroy_
@@ -404,8 +442,98 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a) 
         *wcp = hist;  // _forceModelContactWildcardWrite_
 }
 
+// an owner's A run [s, e) is reduced in-workgroup iff it lies inside one block of DEME_FORCE_BLOCK contacts
+#define DEME_FORCE_BLOCK 256
+#ifndef DEME_FV
+#define DEME_FV 1
+#endif
+#if DEME_FV == 2
+#define DEME_ARUN_SPAN 64  // wavefront-level reduction: no workgroup barrier
+#else
+#define DEME_ARUN_SPAN DEME_FORCE_BLOCK
+#endif
+__host__ __device__ inline bool a_run_in_one_block(uint32_t s, uint32_t e) {
+    return s < e && (s / DEME_ARUN_SPAN) == ((e - 1) / DEME_ARUN_SPAN);
+}
+
+// Workgroup = DEME_FORCE_BLOCK consecutive contacts.  The list is sorted by A's owner, so an owner's A-side
+// contributions sit in consecutive lanes: they go to LDS and the lane of the run's first contact sums them in
+// list order (the order the integrator and the oracle use) and writes ONE 32-byte record per owner instead of
+// 24 bytes per contact (-0.2 GB of HBM traffic per step at 4.3 M contacts, half here, half in the integrator).
+// Runs that straddle a block boundary (~1 owner in 60) keep the per-contact records.  The mesh-only variant
+// (CLS 1) is launched BEFORE the hot variant and leaves its A-side records in conA; the hot variant folds them
+// into the same in-order sum.
 template <int MODEL, int CLS>
-__global__ __launch_bounds__(256) void k_calc_forces(const DevParams p, const ForceArgs a) {
-    calc_forces_body<MODEL, CLS>(p, a);
+__device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a) {
+    const uint32_t c = blockIdx.x * DEME_FORCE_BLOCK + threadIdx.x;
+    const bool valid = c < a.nContacts;
+    uint4 ci = make_uint4(0, 0, 0, 0);
+    bool mine = false;
+    float4 c4 = make_float4(0, 0, 0, 0);
+    float2 c2 = make_float2(0, 0);
+    uint32_t s = 0, e = 0;
+    if (valid) {
+        ci = a.info[c];
+        mine = (CLS == 1) == ((ci.x >> 30) == DEME_KEY_CLASS_SM);
+#if DEME_FV >= 1
+        if (CLS == 0) {  // issued before the force evaluation so that their latency is hidden behind it
+            s = a.aStart[ci.x & 0x3FFFFFFFu];
+            e = a.aStart[(ci.x & 0x3FFFFFFFu) + 1];
+        }
+#endif
+        if (mine)
+            calc_forces_body<MODEL, CLS>(p, a, c, ci, c4, c2);
+    }
+    if (CLS == 1) {
+        if (mine) {
+            a.conA4[c] = c4;
+            a.conA2[c] = c2;
+        }
+        return;
+    }
+    __shared__ float4 s4[DEME_FORCE_BLOCK];
+    __shared__ float2 s2[DEME_FORCE_BLOCK];
+    if (valid && !mine) {  // sphere-mesh contact: evaluated by the mesh variant
+        c4 = a.conA4[c];
+        c2 = a.conA2[c];
+    }
+    s4[threadIdx.x] = c4;
+    s2[threadIdx.x] = c2;
+#if DEME_FV == 2
+    // producer and consumer lanes belong to the same wavefront: LDS operations of one wavefront complete in
+    // order, so only the compiler has to be kept from reordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    __syncthreads();
+#endif
+    if (!valid)
+        return;
+    const uint32_t AOwner = ci.x & 0x3FFFFFFFu;
+#if DEME_FV == 0
+    s = a.aStart[AOwner], e = a.aStart[AOwner + 1];
+#endif
+    if (a_run_in_one_block(s, e)) {
+        if (c == s) {
+            float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
+            for (uint32_t i = s % DEME_FORCE_BLOCK; i <= (e - 1) % DEME_FORCE_BLOCK; i++) {
+                const float4 v4 = s4[i];
+                const float2 v2 = s2[i];
+                ax += v4.x, ay += v4.y, az += v4.z;
+                lx += v4.w, ly += v2.x, lz += v2.y;
+            }
+            a.aSum[2 * (size_t)AOwner] = make_float4(ax, ay, az, 0.f);
+            a.aSum[2 * (size_t)AOwner + 1] = make_float4(lx, ly, lz, 0.f);
+        }
+    } else if (mine) {
+        a.conA4[c] = c4;
+        a.conA2[c] = c2;
+    }
+}
+
+template <int MODEL, int CLS>
+__global__ __launch_bounds__(DEME_FORCE_BLOCK) void k_calc_forces(const DevParams p, const ForceArgs a) {
+    calc_forces_block<MODEL, CLS>(p, a);
 }
 }  // namespace deme_dev

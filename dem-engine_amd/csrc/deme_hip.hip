@@ -61,7 +61,7 @@ struct deme_ctx {
     DevBuf geo, binLo, binN, counts, offsets, incKeys[2], incVals[2], keysRaw, keysSorted[2], mapping, wc[2], ctr,
         scanTmp, sortTmp, rec[4], stage;
     // per-contact contributions and the per-owner gather lists (built once per detection)
-    DevBuf conA4, conA2, conB4, conB2, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
+    DevBuf conA4, conA2, conB4, conB2, aSum, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
     // triangles (mesh path)
@@ -517,6 +517,7 @@ GatherArgs gather_args(deme_ctx* c) {
     g.heavy = c->heavy.as<uint8_t>();
     g.conA4 = c->conA4.as<float4>(), g.conA2 = c->conA2.as<float2>();
     g.conB4 = c->conB4.as<float4>(), g.conB2 = c->conB2.as<float2>();
+    g.aSum = c->aSum.as<float4>();
     return g;
 }
 
@@ -544,6 +545,8 @@ int launch_forces(deme_ctx* c) {
     a.wc = c->wc[c->wcCur].as<float>();
     a.conA4 = c->conA4.as<float4>(), a.conA2 = c->conA2.as<float2>();
     a.conB4 = c->conB4.as<float4>(), a.conB2 = c->conB2.as<float2>();
+    a.aSum = c->aSum.as<float4>();
+    a.aStart = c->aStart.as<uint32_t>();
     a.nContacts = (uint32_t)c->nContacts;
     a.timeElapsed = (float)c->timeElapsed;
     if (c->record) {
@@ -555,19 +558,19 @@ int launch_forces(deme_ctx* c) {
         const dim3 g(grid_for(a.nContacts)), b(256);
         const bool hasSM = c->nTri > 0;
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
-            hipLaunchKernelGGL((k_calc_forces<0, 0>), g, b, 0, c->stream, c->dp, a);
-            if (hasSM)
+            if (hasSM)  // mesh variant first: the hot variant folds its A-side records into the in-block sums
                 hipLaunchKernelGGL((k_calc_forces<0, 1>), g, b, 0, c->stream, c->dp, a);
+            hipLaunchKernelGGL((k_calc_forces<0, 0>), g, b, 0, c->stream, c->dp, a);
         } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN_FRICTIONLESS) {
-            hipLaunchKernelGGL((k_calc_forces<1, 0>), g, b, 0, c->stream, c->dp, a);
             if (hasSM)
                 hipLaunchKernelGGL((k_calc_forces<1, 1>), g, b, 0, c->stream, c->dp, a);
+            hipLaunchKernelGGL((k_calc_forces<1, 0>), g, b, 0, c->stream, c->dp, a);
         }
         else {  // user model: two entry points of the same code object (hot variant, mesh variant)
             void* args0[] = {&c->dp, &a};
-            HIPCK(hipModuleLaunchKernel(c->customFn[0], grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args0, nullptr));
             if (hasSM)
                 HIPCK(hipModuleLaunchKernel(c->customFn[1], grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args0, nullptr));
+            HIPCK(hipModuleLaunchKernel(c->customFn[0], grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args0, nullptr));
         }
     }
     c->conValid = true;
@@ -633,7 +636,7 @@ void deme_ctx_destroy(deme_ctx* c) {
     drain_timers(c);
     for (auto e : c->eventPool)
         hipEventDestroy(e);
-    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -723,7 +726,7 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     if (int rc = ensure(c, c->acc, std::max<size_t>(nO, 1) * sizeof(AccRec)))
         return rc;
     HIPCK(hipMemsetAsync(c->acc.p, 0, c->acc.bytes, c->stream));
-    if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
+    if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->aSum, (nO + 1) * 32) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
         ensure(c, c->fixedFlag, nO + 1) || ensure(c, c->heavyList, 4096 * 4) || ensure(c, c->rangeCtr, sizeof(RangeCounters)))
         return c->lastStatus;
     HIPCK(hipMemsetAsync(c->aStart.p, 0, c->aStart.bytes, c->stream));

@@ -182,7 +182,7 @@ inline int generate_source(const std::string& user, const std::vector<std::strin
     const char* ent[2] = {"ss", "sm"};
     for (int cls = 0; cls < 2; cls++)
         o << "extern \"C\" __global__ __launch_bounds__(256) void deme_custom_forces_" << ent[cls]
-          << "(const deme_dev::DevParams p, const deme_dev::ForceArgs a) {\n    deme_dev::calc_forces_body<2, " << cls
+          << "(const deme_dev::DevParams p, const deme_dev::ForceArgs a) {\n    deme_dev::calc_forces_block<2, " << cls
           << ">(p, a);\n}\n";
     out = o.str();
     return 0;

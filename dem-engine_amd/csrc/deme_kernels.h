@@ -560,34 +560,46 @@ struct GatherArgs {
     const uint32_t* bStart;  // nOwners+1
     const uint32_t* bIdx;    // contact indices sorted by B's owner (stable)
     const uint8_t* heavy;    // 1: too many contacts for one thread; summed by k_reduce_heavy into acc
-    const float4* conA4;
+    const float4* conA4;     // per-contact A-side records: only valid for runs that straddle a force-kernel block
     const float2* conA2;
     const float4* conB4;
     const float2* conB2;
+    const float4* aSum;      // in-order sum of an A run that lies inside one force-kernel block (deme_force.h)
 };
 
-__device__ inline void gather_owner(const GatherArgs& g, uint32_t o, float4& a, float4& al) {
-    // fixed order: the A-side run (ascending contact index), then the B-side list (ascending contact index).
-    // Loads are issued four at a time so that their latencies overlap; the fp32 sum is reproducible run to run.
-    float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
-    const uint32_t ea = g.aStart[o + 1];
-    const uint32_t ib0 = g.bStart[o], eb = g.bStart[o + 1];
-    for (uint32_t ia = g.aStart[o]; ia < ea; ia += 4) {
+// A-side sum of one owner: the force kernel's in-workgroup result when the run lay inside one block, else the
+// same in-order sum over the per-contact records (loads issued four at a time).
+__device__ inline void a_side_sum(const GatherArgs& g, uint32_t o, uint32_t s, uint32_t e, float& ax, float& ay, float& az,
+                                  float& lx, float& ly, float& lz) {
+    if (a_run_in_one_block(s, e)) {
+        const float4 v = g.aSum[2 * (size_t)o], w = g.aSum[2 * (size_t)o + 1];
+        ax = v.x, ay = v.y, az = v.z, lx = w.x, ly = w.y, lz = w.z;
+        return;
+    }
+    for (uint32_t ia = s; ia < e; ia += 4) {
         float4 c4[4];
         float2 c2[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const bool ok = ia + k < ea;
+            const bool ok = ia + k < e;
             c4[k] = ok ? g.conA4[ia + k] : make_float4(0, 0, 0, 0);
             c2[k] = ok ? g.conA2[ia + k] : make_float2(0, 0);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (ia + k < ea) {
+            if (ia + k < e) {
                 ax += c4[k].x, ay += c4[k].y, az += c4[k].z;
                 lx += c4[k].w, ly += c2[k].x, lz += c2[k].y;
             }
     }
+}
+
+__device__ inline void gather_owner(const GatherArgs& g, uint32_t o, float4& a, float4& al) {
+    // fixed order: the A-side run (ascending contact index), then the B-side list (ascending contact index).
+    // Loads are issued four at a time so that their latencies overlap; the fp32 sum is reproducible run to run.
+    float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
+    const uint32_t ib0 = g.bStart[o], eb = g.bStart[o + 1];
+    a_side_sum(g, o, g.aStart[o], g.aStart[o + 1], ax, ay, az, lx, ly, lz);
     for (uint32_t ib = ib0; ib < eb; ib += 4) {
         uint32_t idx[4];
         float4 c4[4];
@@ -629,9 +641,8 @@ __device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint3
     const uint32_t t = threadIdx.x;
     const uint32_t oFirst = blockIdx.x * blockDim.x;
     const uint32_t oEnd = (oFirst + blockDim.x < nOwners) ? oFirst + blockDim.x : nOwners;
-    const uint32_t loA = g.aStart[oFirst], hiA = g.aStart[oEnd];
     const uint32_t loB = g.bStart[oFirst], hiB = g.bStart[oEnd];
-    if (hiA - loA > 8u * DEME_GATHER_TILE || hiB - loB > 8u * DEME_GATHER_TILE) {  // workgroup-uniform: a giant run inside
+    if (hiB - loB > 8u * DEME_GATHER_TILE) {  // workgroup-uniform: a giant run inside
         if (want)
             gather_owner(g, o, a, al);
         return;
@@ -642,26 +653,8 @@ __device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint3
         sA = g.aStart[o], eA = g.aStart[o + 1];
         sB = g.bStart[o], eB = g.bStart[o + 1];
     }
-    for (uint32_t base = loA; base < hiA; base += DEME_GATHER_TILE) {
-#pragma unroll
-        for (int k = 0; k < DEME_GATHER_TILE / 256; k++) {
-            const uint32_t j = base + k * 256 + t;
-            if (j < hiA) {
-                L.c4[k * 256 + t] = g.conA4[j];
-                L.c2[k * 256 + t] = g.conA2[j];
-            }
-        }
-        __syncthreads();
-        const uint32_t s = (sA > base) ? sA : base;
-        const uint32_t e = (eA < base + DEME_GATHER_TILE) ? eA : base + DEME_GATHER_TILE;
-        for (uint32_t i = s; i < e; i++) {
-            const float4 c4 = L.c4[i - base];
-            const float2 c2 = L.c2[i - base];
-            ax += c4.x, ay += c4.y, az += c4.z;
-            lx += c4.w, ly += c2.x, lz += c2.y;
-        }
-        __syncthreads();
-    }
+    if (want)
+        a_side_sum(g, o, sA, eA, ax, ay, az, lx, ly, lz);
     for (uint32_t base = loB; base < hiB; base += DEME_GATHER_TILE) {
         uint32_t idx[DEME_GATHER_TILE / 256];
 #pragma unroll
@@ -714,10 +707,18 @@ __global__ __launch_bounds__(256) void k_reduce_heavy(const GatherArgs g, const 
         if (skip && skip[o])
             continue;
         float s[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t c = g.aStart[o] + threadIdx.x; c < g.aStart[o + 1]; c += 256) {
-            const float4 c4 = g.conA4[c];
-            const float2 c2 = g.conA2[c];
-            s[0] += c4.x, s[1] += c4.y, s[2] += c4.z, s[3] += c4.w, s[4] += c2.x, s[5] += c2.y;
+        const uint32_t a0 = g.aStart[o], a1 = g.aStart[o + 1];
+        if (a_run_in_one_block(a0, a1)) {
+            if (threadIdx.x == 0) {
+                const float4 v = g.aSum[2 * (size_t)o], w = g.aSum[2 * (size_t)o + 1];
+                s[0] = v.x, s[1] = v.y, s[2] = v.z, s[3] = w.x, s[4] = w.y, s[5] = w.z;
+            }
+        } else {
+            for (uint32_t c = a0 + threadIdx.x; c < a1; c += 256) {
+                const float4 c4 = g.conA4[c];
+                const float2 c2 = g.conA2[c];
+                s[0] += c4.x, s[1] += c4.y, s[2] += c4.z, s[3] += c4.w, s[4] += c2.x, s[5] += c2.y;
+            }
         }
         for (uint32_t i = g.bStart[o] + threadIdx.x; i < g.bStart[o + 1]; i += 256) {
             const uint32_t c = g.bIdx[i];
