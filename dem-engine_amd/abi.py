@@ -172,6 +172,7 @@ def load_library():
         "deme_download_contacts": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_download_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_upload_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
+        "deme_seed_contacts": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_set_record_contacts": [_P, C.c_int],
         "deme_download_contact_records": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_download_sphere_geometry": [_P, _P, _P, _P, _P, C.c_size_t],
@@ -322,6 +323,16 @@ class Context:
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         self._ck(self.lib.deme_upload_contact_wildcard(self.h, int(w), _ptr(arr), arr.size),
                  "deme_upload_contact_wildcard")
+
+    def seed_contacts(self, idA, idB, ctype, wildcards=None):
+        """Restart: saved contact pairs (geometry ids) + wildcards [n, nW] feed the next history map."""
+        a = np.ascontiguousarray(idA, dtype=np.uint32)
+        b = np.ascontiguousarray(idB, dtype=np.uint32)
+        t = np.ascontiguousarray(ctype, dtype=np.uint8)
+        w = None if wildcards is None else np.ascontiguousarray(wildcards, dtype=np.float32)
+        self._keep_seed = (a, b, t, w)
+        self._ck(self.lib.deme_seed_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), None if w is None else _ptr(w), a.size),
+                 "deme_seed_contacts")
 
     def set_record_contacts(self, enable=True):
         self._ck(self.lib.deme_set_record_contacts(self.h, int(bool(enable))), "deme_set_record_contacts")

@@ -81,6 +81,7 @@ struct deme_ctx {
     uint64_t nActiveBins = 0;
     uint32_t maxInBin = 0;
     bool haveList = false, mapFresh = false;
+    bool seeded = false;  // the list was loaded by deme_seed_contacts: it only feeds the next history map
     bool record = false;
     uint64_t nSteps = 0, nDetections = 0;
     uint32_t stepsSinceCD = 0;
@@ -485,6 +486,7 @@ int do_detect(deme_ctx* c) {
         c->nContacts = nC;
         c->keysCur = next;
         c->haveList = true;
+        c->seeded = false;
         c->mapFresh = true;
         c->nDetections++;
         return DEME_OK;
@@ -976,7 +978,7 @@ int deme_calc_forces(deme_ctx* c) {
     if (c->mapFresh)
         if (int rc = do_migrate(c))
             return rc;
-    if (!c->haveList)
+    if (!c->haveList || c->seeded)
         return fail(c, DEME_ERR_INVALID, "no contact list yet: call deme_detect_contacts first");
     if (int rc = launch_forces(c))
         return rc;
@@ -999,7 +1001,7 @@ int deme_step(deme_ctx* c, uint32_t nsteps) {
         return rc;
     const uint32_t K = c->hp.cdUpdateFreq;
     for (uint32_t i = 0; i < nsteps; i++) {
-        if (!c->haveList || K == 0 || c->stepsSinceCD >= K) {
+        if (!c->haveList || c->seeded || K == 0 || c->stepsSinceCD >= K) {
             if (int rc = do_margins(c, K))
                 return rc;
             if (int rc = do_detect(c))
@@ -1121,6 +1123,54 @@ int deme_upload_contact_wildcard(deme_ctx* c, uint32_t w, const float* in, size_
     if (n)
         HIPCK(hipMemcpyAsync(c->wc[c->wcCur].p, h.data(), n * nW * 4, hipMemcpyHostToDevice, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_seed_contacts(deme_ctx* c, const uint32_t* idA, const uint32_t* idB, const uint8_t* type, const float* wildcards,
+                       size_t n) {
+    if (int rc = check_ready(c))
+        return rc;
+    const uint32_t nW = c->hp.nContactWildcards;
+    if (n && (!idA || !idB || !type || (nW && !wildcards)))
+        return fail(c, DEME_ERR_INVALID, "deme_seed_contacts: null input");
+    std::vector<uint64_t> keys(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t cls = (type[i] == 1) ? DEME_KEY_CLASS_SS : (type[i] == 2) ? DEME_KEY_CLASS_SM : DEME_KEY_CLASS_SA;
+        const uint32_t nB = (cls == DEME_KEY_CLASS_SS) ? c->dp.nSpheres : (cls == DEME_KEY_CLASS_SM) ? c->dp.nTri : c->dp.nAnal;
+        if (idA[i] >= c->dp.nSpheres || idB[i] >= nB)
+            return fail(c, DEME_ERR_INVALID, "deme_seed_contacts: pair %zu (%u, %u, type %u) is out of range", i, idA[i], idB[i],
+                        (unsigned)type[i]);
+        keys[i] = make_key(cls, idA[i], idB[i]);
+    }
+    std::vector<uint32_t> perm(n);
+    for (size_t i = 0; i < n; i++)
+        perm[i] = (uint32_t)i;
+    std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return keys[x] < keys[y]; });
+    std::vector<uint64_t> ks(n);
+    std::vector<float> ws(n * (size_t)nW);
+    for (size_t i = 0; i < n; i++) {
+        ks[i] = keys[perm[i]];
+        if (i && ks[i] == ks[i - 1])
+            return fail(c, DEME_ERR_INVALID, "deme_seed_contacts: duplicate pair (%u, %u)", idA[perm[i]], idB[perm[i]]);
+        for (uint32_t w = 0; w < nW; w++)
+            ws[i * nW + w] = wildcards[(size_t)perm[i] * nW + w];
+    }
+    if (n > c->cntCap)
+        if (int rc = grow_contact_arena(c, n + n / 4 + 1024))
+            return rc;
+    if (n) {
+        HIPCK(hipMemcpyAsync(c->keysSorted[c->keysCur].p, ks.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+        if (nW)
+            HIPCK(hipMemcpyAsync(c->wc[c->wcCur].p, ws.data(), n * nW * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
+    c->nContacts = n;
+    c->nPrev = 0;
+    c->nWcStored = n;
+    c->haveList = true;
+    c->seeded = true;
+    c->mapFresh = false;
+    c->conValid = false;
     return DEME_OK;
 }
 

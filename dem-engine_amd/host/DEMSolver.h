@@ -52,6 +52,14 @@ namespace deme {
 enum class TIME_INTEGRATOR { FORWARD_EULER, CENTERED_DIFFERENCE, EXTENDED_TAYLOR };
 enum class FORCE_MODEL { HERTZIAN, HERTZIAN_FRICTIONLESS, CUSTOM };
 enum VERBOSITY { QUIET = 0, ERR = 10, WARNING = 20, INFO = 30, STEP_METRIC = 35, DEBUG = 40 };
+// output content flags and file column names: DEM/Defines.h:152-183, DEM/Structs.h:41-97
+enum OUTPUT_CONTENT { XYZ = 0, QUAT = 1, ABSV = 2, VEL = 4, ANG_VEL = 8, ABS_ACC = 16, ACC = 32, ANG_ACC = 64, FAMILY = 128, MAT = 256,
+                      OWNER_WILDCARD = 512, GEO_WILDCARD = 1024 };
+enum CNT_OUTPUT_CONTENT { CNT_TYPE = 0, FORCE = 1, CNT_POINT = 2, COMPONENT = 4, NORMAL = 8, TORQUE = 16, CNT_WILDCARD = 32, OWNER = 64,
+                          GEO_ID = 128, NICKNAME = 256 };
+enum class OUTPUT_FORMAT { CSV, BINARY, CHPF };
+typedef unsigned int bodyID_t;
+constexpr float DEME_TINY_FLOAT_HOST = 1e-12f;
 constexpr unsigned int RESERVED_FAMILY_NUM = 255;
 const bool ENTITY_NORMAL_INWARD = false;
 const bool ENTITY_NORMAL_OUTWARD = true;
@@ -68,6 +76,8 @@ struct DEMClumpTemplate {
     std::vector<float3> relPos;
     std::vector<std::shared_ptr<DEMMaterial>> materials;
     unsigned int nComp = 0, mark = 0;
+    std::string m_name;  // AssignName (Structs.h:697); default "%04d" of the load order (APIPublic.cpp:1751-1755)
+    void AssignName(const std::string& n) { m_name = n; }
     // x,y,z,r rows, '#' comments (data/clumps/*.csv in the reference)
     void ReadComponentFromFile(const std::string& file) {
         std::ifstream in(file);
@@ -117,6 +127,17 @@ struct DEMClumpBatch {
     void SetFamilies(const std::vector<unsigned int>& f) { families = f; }
     void SetFamily(unsigned int f) { families.assign(nClumps, f); }
     size_t GetNumClumps() const { return nClumps; }
+    // restart data (Structs.h:857-880): sphere-sphere pairs by geometry id within this batch + their wildcards
+    void SetExistingContacts(const std::vector<std::pair<bodyID_t, bodyID_t>>& pairs) { contact_pairs = pairs; }
+    void SetExistingContactWildcards(const std::unordered_map<std::string, std::vector<float>>& w) {
+        for (auto& kv : w)
+            if (kv.second.size() != contact_pairs.size())
+                throw std::runtime_error("SetExistingContactWildcards needs to be called after SetExistingContacts, with each "
+                                         "wildcard array having the same length as the number of contact pairs.");
+        contact_wildcards = w;
+    }
+    std::vector<std::pair<bodyID_t, bodyID_t>> contact_pairs;
+    std::unordered_map<std::string, std::vector<float>> contact_wildcards;
 };
 
 struct DEMExternObj {
@@ -380,6 +401,153 @@ class DEMSolver {
     }
     deme_ctx* GetContext() { return m_ctx; }
 
+    // ---- output (API.h:1096-1122, 1318-1324); formats of dT.cpp:1254-1405, 1491-1618, 1620-1848
+    void SetOutputFormat(OUTPUT_FORMAT f) { require_csv(f); }
+    void SetContactOutputFormat(OUTPUT_FORMAT f) { require_csv(f); }
+    void SetOutputContent(unsigned int content) { m_out_content = content; }
+    void SetContactOutputContent(unsigned int content) { m_cnt_out_content = content; }
+    void WriteSphereFile(const std::string& outfilename) {
+        const Snapshot sn = snapshot(false);
+        std::ostringstream o;
+        o << "X,Y,Z,r";
+        owner_header(o);
+        o << "\n";
+        for (size_t i = 0; i < m_keep.sphOwner.size(); i++) {
+            const uint32_t ow = m_keep.sphOwner[i];
+            const uint16_t cp = m_keep.sphComp[i];
+            float3 d = {m_keep.rx[cp], m_keep.ry[cp], m_keep.rz[cp]};
+            rotate(d, sn.q[ow]);
+            const float3 pos = sn.com[ow] + d;
+            o << pos.x << "," << pos.y << "," << pos.z << "," << m_keep.Radii[cp];
+            owner_columns(o, sn, ow);
+            o << "\n";
+        }
+        flush(outfilename, o);
+    }
+    void WriteClumpFile(const std::string& outfilename, unsigned int accuracy = 10) {
+        const Snapshot sn = snapshot(false);
+        std::ostringstream o;
+        o.precision(accuracy);
+        o << "X,Y,Z,Qw,Qx,Qy,Qz,clump_type";
+        owner_header(o);
+        o << "\n";
+        for (size_t i = 0; i < m_n_clumps; i++) {
+            o << sn.com[i].x << "," << sn.com[i].y << "," << sn.com[i].z;
+            o << "," << sn.q[i].w << "," << sn.q[i].x << "," << sn.q[i].y << "," << sn.q[i].z;
+            o << "," << m_keep.templateName.at(m_keep.inert[i]);
+            owner_columns(o, sn, i);
+            o << "\n";
+        }
+        flush(outfilename, o);
+    }
+    /// Contacts whose |force + torque-only force| reaches force_thres; needs SetContactOutputContent before Initialize if the
+    /// force / point / torque columns are wanted (per-contact records are switched on at Initialize).
+    void WriteContactFile(const std::string& outfilename, float force_thres = DEME_TINY_FLOAT_HOST) {
+        const Snapshot sn = snapshot(true);
+        const unsigned fl = m_cnt_out_content;
+        std::ostringstream o;
+        o << "contact_type";
+        if (fl & OWNER) o << ",A,B";
+        if (fl & GEO_ID) o << ",geoA,geoB";
+        if (fl & FORCE) o << ",f_x,f_y,f_z";
+        if (fl & CNT_POINT) o << ",X,Y,Z";
+        if (fl & NORMAL) o << ",n_x,n_y,n_z";
+        if (fl & TORQUE) o << ",torque_x,torque_y,torque_z";
+        if (fl & CNT_WILDCARD)
+            for (auto& n : m_force_model->contact_wildcards) o << "," << n;
+        o << "\n";
+        for (size_t c = 0; c < sn.idA.size(); c++) {
+            const float3 F = {sn.F[3 * c], sn.F[3 * c + 1], sn.F[3 * c + 2]}, T = {sn.T[3 * c], sn.T[3 * c + 1], sn.T[3 * c + 2]};
+            const float3 tot = F + T;
+            if (std::sqrt(tot.x * tot.x + tot.y * tot.y + tot.z * tot.z) < force_thres)
+                continue;
+            const uint8_t ty = sn.type[c];
+            const uint32_t oA = m_keep.sphOwner[sn.idA[c]];
+            const uint32_t oB = ty == 1 ? m_keep.sphOwner[sn.idB[c]] : ty == 2 ? m_keep.triOwner[sn.idB[c]] : m_keep.objOwner[sn.idB[c]];
+            o << (ty == 1 ? "SS" : ty == 2 ? "SM" : "SA");
+            if (fl & OWNER) o << "," << oA << "," << oB;
+            if (fl & GEO_ID) o << "," << sn.idA[c] << "," << sn.idB[c];
+            if (fl & FORCE) o << "," << F.x << "," << F.y << "," << F.z;
+            const float3 loc = {sn.cpA[3 * c], sn.cpA[3 * c + 1], sn.cpA[3 * c + 2]};
+            float3 pnt = loc;
+            rotate(pnt, sn.q[oA]);
+            pnt = pnt + sn.com[oA];
+            if (fl & CNT_POINT) o << "," << pnt.x << "," << pnt.y << "," << pnt.z;
+            if (fl & NORMAL) {
+                const uint16_t cp = m_keep.sphComp[sn.idA[c]];
+                float3 d = {m_keep.rx[cp], m_keep.ry[cp], m_keep.rz[cp]};
+                rotate(d, sn.q[oA]);
+                const float3 n = pnt - (sn.com[oA] + d);
+                const float inv = 1.0f / std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+                o << "," << n.x * inv << "," << n.y * inv << "," << n.z * inv;
+            }
+            if (fl & TORQUE) {
+                float3 t = T;
+                const float4 qa = sn.q[oA];
+                rotate(t, {-qa.x, -qa.y, -qa.z, qa.w});
+                t = {loc.y * t.z - loc.z * t.y, loc.z * t.x - loc.x * t.z, loc.x * t.y - loc.y * t.x};
+                rotate(t, qa);
+                o << "," << t.x << "," << t.y << "," << t.z;
+            }
+            if (fl & CNT_WILDCARD)
+                for (size_t w = 0; w < sn.wc.size(); w++) o << "," << sn.wc[w][c];
+            o << "\n";
+        }
+        flush(outfilename, o);
+    }
+
+    // ---- CSV readers (static members of the reference's DEMSolver, API.h:1153-1250)
+    static std::unordered_map<std::string, std::vector<float3>> ReadClumpXyzFromCsv(const std::string& f) {
+        return read_float3_by_type(f, "X", "Y", "Z");
+    }
+    static std::unordered_map<std::string, std::vector<float3>> ReadClumpVelFromCsv(const std::string& f) {
+        return read_float3_by_type(f, "v_x", "v_y", "v_z");
+    }
+    static std::unordered_map<std::string, std::vector<float3>> ReadClumpAngVelFromCsv(const std::string& f) {
+        return read_float3_by_type(f, "w_x", "w_y", "w_z");
+    }
+    static std::unordered_map<std::string, std::vector<float4>> ReadClumpQuatFromCsv(const std::string& f) {
+        const Table t = read_table(f);
+        const size_t ty = t.col("clump_type"), w = t.col("Qw"), x = t.col("Qx"), y = t.col("Qy"), z = t.col("Qz");
+        std::unordered_map<std::string, std::vector<float4>> out;
+        for (auto& r : t.rows)
+            out[r[ty]].push_back({std::stof(r[x]), std::stof(r[y]), std::stof(r[z]), std::stof(r[w])});
+        return out;
+    }
+    static std::vector<std::pair<bodyID_t, bodyID_t>> ReadContactPairsFromCsv(const std::string& f, const std::string& cntType = "SS",
+                                                                             const std::string& cntColName = "contact_type",
+                                                                             const std::string& first_name = "geoA",
+                                                                             const std::string& second_name = "geoB") {
+        const Table t = read_table(f);
+        const size_t ty = t.col(cntColName), a = t.col(first_name), b = t.col(second_name);
+        std::vector<std::pair<bodyID_t, bodyID_t>> out;
+        for (auto& r : t.rows)
+            if (r[ty] == cntType)
+                out.push_back({(bodyID_t)std::stoul(r[a]), (bodyID_t)std::stoul(r[b])});
+        return out;
+    }
+    /// Every column that is not a known contact-file column is a wildcard -- which includes X, Y, Z, as in the reference
+    /// (CNT_FILE_KNOWN_COL_NAMES, Structs.h:75-84).
+    static std::unordered_map<std::string, std::vector<float>> ReadContactWildcardsFromCsv(const std::string& f,
+                                                                                          const std::string& cntType = "SS",
+                                                                                          const std::string& cntColName = "contact_type") {
+        static const std::set<std::string> known = {"A", "B", "compA", "compB", "geoA", "geoB", "nameA", "nameB", "contact_type",
+                                                    "f_x", "f_y", "f_z", "torque_x", "torque_y", "torque_z", "n_x", "n_y", "n_z",
+                                                    "SS", "SA", "SM"};
+        const Table t = read_table(f);
+        const size_t ty = t.col(cntColName);
+        std::unordered_map<std::string, std::vector<float>> out;
+        for (size_t c = 0; c < t.header.size(); c++) {
+            if (known.count(t.header[c]))
+                continue;
+            auto& v = out[t.header[c]];
+            for (auto& r : t.rows)
+                if (r[ty] == cntType)
+                    v.push_back(std::stof(r[c]));
+        }
+        return out;
+    }
+
   private:
     deme_ctx* m_ctx = nullptr;
     std::vector<std::shared_ptr<DEMMaterial>> m_materials;
@@ -407,6 +575,156 @@ class DEMSolver {
     bool m_state_fresh = false;
     std::vector<float3> m_pos;
     std::vector<float> m_st_v[3];
+
+
+    unsigned int m_out_content = QUAT | ABSV;                                      // API.h:1418
+    unsigned int m_cnt_out_content = OWNER | GEO_ID | FORCE | CNT_POINT | CNT_WILDCARD;  // API.h:1422-1424
+    struct Keep {  // scene arrays the writers need after Initialize
+        std::vector<uint32_t> sphOwner, objOwner, triOwner;
+        std::vector<uint16_t> sphComp, inert;
+        std::vector<float> Radii, rx, ry, rz;
+        std::map<unsigned, std::string> templateName;
+    } m_keep;
+    struct Snapshot {
+        std::vector<float3> com, v, w, a, al;
+        std::vector<float4> q;
+        std::vector<uint8_t> fam;
+        std::vector<uint32_t> idA, idB;
+        std::vector<uint8_t> type;
+        std::vector<float> F, T, cpA;
+        std::vector<std::vector<float>> wc;
+    };
+    static void require_csv(OUTPUT_FORMAT f) {
+        if (f != OUTPUT_FORMAT::CSV)
+            throw std::runtime_error("only OUTPUT_FORMAT::CSV is implemented");
+    }
+    // applyOriQToVector3<float, float> (DEMHelperKernels.cuh:162-173); float4 is (x, y, z, w)
+    static void rotate(float3& v, float4 q) {
+        const float w = q.w, x = q.x, y = q.y, z = q.z;
+        const float ox = (2.0f * (w * w + x * x) - 1.0f) * v.x + (2.0f * (x * y - w * z)) * v.y + (2.0f * (x * z + w * y)) * v.z;
+        const float oy = (2.0f * (x * y + w * z)) * v.x + (2.0f * (w * w + y * y) - 1.0f) * v.y + (2.0f * (y * z - w * x)) * v.z;
+        const float oz = (2.0f * (x * z - w * y)) * v.x + (2.0f * (y * z + w * x)) * v.y + (2.0f * (w * w + z * z) - 1.0f) * v.z;
+        v = {ox, oy, oz};
+    }
+    void owner_header(std::ostringstream& o) const {
+        const unsigned fl = m_out_content;
+        if (fl & ABSV) o << ",absv";
+        if (fl & VEL) o << ",v_x,v_y,v_z";
+        if (fl & ANG_VEL) o << ",w_x,w_y,w_z";
+        if (fl & ABS_ACC) o << ",abs_acc";
+        if (fl & ACC) o << ",a_x,a_y,a_z";
+        if (fl & ANG_ACC) o << ",alpha_x,alpha_y,alpha_z";
+        if (fl & FAMILY) o << ",family";
+    }
+    void owner_columns(std::ostringstream& o, const Snapshot& sn, size_t i) const {
+        const unsigned fl = m_out_content;
+        auto len = [](float3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); };
+        if (fl & ABSV) o << "," << len(sn.v[i]);
+        if (fl & VEL) o << "," << sn.v[i].x << "," << sn.v[i].y << "," << sn.v[i].z;
+        if (fl & ANG_VEL) o << "," << sn.w[i].x << "," << sn.w[i].y << "," << sn.w[i].z;
+        if (fl & ABS_ACC) o << "," << len(sn.a[i]);
+        if (fl & ACC) o << "," << sn.a[i].x << "," << sn.a[i].y << "," << sn.a[i].z;
+        if (fl & ANG_ACC) o << "," << sn.al[i].x << "," << sn.al[i].y << "," << sn.al[i].z;
+        if (fl & FAMILY) o << "," << +sn.fam[i];
+    }
+    static void flush(const std::string& path, const std::ostringstream& o) {
+        std::ofstream f(path, std::ios::out);
+        if (!f)
+            throw std::runtime_error("cannot open " + path + " for writing");
+        f << o.str();
+    }
+    Snapshot snapshot(bool contacts) {
+        const size_t n = m_n_owners;
+        std::vector<uint64_t> vid(n);
+        std::vector<uint16_t> lx(n), ly(n), lz(n);
+        std::vector<float> f[16];
+        for (auto& v : f)
+            v.resize(n);
+        Snapshot sn;
+        sn.fam.resize(n);
+        DemeOwnerState st{};
+        st.voxelID = vid.data(), st.locX = lx.data(), st.locY = ly.data(), st.locZ = lz.data();
+        st.oriQw = f[0].data(), st.oriQx = f[1].data(), st.oriQy = f[2].data(), st.oriQz = f[3].data();
+        st.vX = f[4].data(), st.vY = f[5].data(), st.vZ = f[6].data();
+        st.omgBarX = f[7].data(), st.omgBarY = f[8].data(), st.omgBarZ = f[9].data();
+        st.aX = f[10].data(), st.aY = f[11].data(), st.aZ = f[12].data();
+        st.alphaX = f[13].data(), st.alphaY = f[14].data(), st.alphaZ = f[15].data();
+        st.familyID = sn.fam.data();
+        check(deme_download_owner_state(m_ctx, &st));
+        sn.com.resize(n), sn.q.resize(n), sn.v.resize(n), sn.w.resize(n), sn.a.resize(n), sn.al.resize(n);
+        const float vs = (float)m_p.voxelSize, l = (float)m_p.l;
+        for (size_t i = 0; i < n; i++) {  // voxelIDToPosition<float, ...> then + LBF, all fp32 (dT.cpp:1312-1320)
+            const uint64_t vx = vid[i] & ((1ull << m_p.nvXp2) - 1), vy = (vid[i] >> m_p.nvXp2) & ((1ull << m_p.nvYp2) - 1),
+                           vz = vid[i] >> (m_p.nvXp2 + m_p.nvYp2);
+            sn.com[i] = {((float)vx * vs + (float)lx[i] * l) + m_p.LBFX, ((float)vy * vs + (float)ly[i] * l) + m_p.LBFY,
+                         ((float)vz * vs + (float)lz[i] * l) + m_p.LBFZ};
+            sn.q[i] = {f[1][i], f[2][i], f[3][i], f[0][i]};
+            sn.v[i] = {f[4][i], f[5][i], f[6][i]};
+            sn.w[i] = {f[7][i], f[8][i], f[9][i]};
+            sn.a[i] = {f[10][i], f[11][i], f[12][i]};
+            sn.al[i] = {f[13][i], f[14][i], f[15][i]};
+        }
+        if (contacts) {
+            DemeCounts c{};
+            check(deme_get_counts(m_ctx, &c));
+            const size_t nc = (size_t)c.nContacts;
+            sn.idA.resize(nc), sn.idB.resize(nc), sn.type.resize(nc);
+            std::vector<uint32_t> map(nc);
+            check(deme_download_contacts(m_ctx, sn.idA.data(), sn.idB.data(), sn.type.data(), map.data(), nc));
+            sn.F.assign(3 * nc, 0.f), sn.T.assign(3 * nc, 0.f), sn.cpA.assign(3 * nc, 0.f);
+            std::vector<float> cpB(3 * nc);
+            check(deme_download_contact_records(m_ctx, sn.F.data(), sn.T.data(), sn.cpA.data(), cpB.data(), nc));
+            sn.wc.assign(m_p.nContactWildcards, std::vector<float>(nc));
+            for (uint32_t w = 0; w < m_p.nContactWildcards; w++)
+                check(deme_download_contact_wildcard(m_ctx, w, sn.wc[w].data(), nc));
+        }
+        return sn;
+    }
+    struct Table {
+        std::vector<std::string> header;
+        std::vector<std::vector<std::string>> rows;
+        size_t col(const std::string& name) const {
+            for (size_t i = 0; i < header.size(); i++)
+                if (header[i] == name)
+                    return i;
+            throw std::runtime_error("column " + name + " not found");
+        }
+    };
+    static Table read_table(const std::string& path) {
+        std::ifstream f(path);
+        if (!f)
+            throw std::runtime_error("cannot open " + path);
+        Table t;
+        std::string line;
+        auto split = [](const std::string& ln) {
+            std::vector<std::string> out;
+            std::stringstream ss(ln);
+            std::string tok;
+            while (std::getline(ss, tok, ',')) {
+                const size_t a = tok.find_first_not_of(" \t\r"), b = tok.find_last_not_of(" \t\r");
+                out.push_back(a == std::string::npos ? std::string() : tok.substr(a, b - a + 1));
+            }
+            return out;
+        };
+        while (std::getline(f, line)) {
+            if (line.find_first_not_of(" \t\r") == std::string::npos || line[line.find_first_not_of(" \t")] == '#')
+                continue;
+            if (t.header.empty())
+                t.header = split(line);
+            else
+                t.rows.push_back(split(line));
+        }
+        return t;
+    }
+    static std::unordered_map<std::string, std::vector<float3>> read_float3_by_type(const std::string& f, const char* x, const char* y,
+                                                                                    const char* z) {
+        const Table t = read_table(f);
+        const size_t ty = t.col("clump_type"), cx = t.col(x), cy = t.col(y), cz = t.col(z);
+        std::unordered_map<std::string, std::vector<float3>> out;
+        for (auto& r : t.rows)
+            out[r[ty]].push_back({std::stof(r[cx]), std::stof(r[cy]), std::stof(r[cz])});
+        return out;
+    }
 
     void check(int rc) {
         if (rc)
@@ -715,6 +1033,38 @@ class DEMSolver {
         }
         m_n_clumps = nC, m_n_owners = nO;
         m_state_fresh = false;
+        m_keep.sphOwner = sphOwner, m_keep.sphComp = sphComp, m_keep.inert = inert, m_keep.objOwner = objOwner, m_keep.triOwner = triOwner;
+        m_keep.Radii = Radii, m_keep.rx = rx, m_keep.ry = ry, m_keep.rz = rz;
+        for (size_t i = 0; i < m_templates.size(); i++) {
+            char nm[32];
+            snprintf(nm, sizeof nm, "%04d", (int)i);
+            m_keep.templateName[m_templates[i]->mark] = m_templates[i]->m_name.empty() ? std::string(nm) : m_templates[i]->m_name;
+        }
+        if (m_cnt_out_content & (FORCE | CNT_POINT | NORMAL | TORQUE))
+            check(deme_set_record_contacts(m_ctx, 1));
+        // restart: existing sphere-sphere contacts of the batches (geometry ids are batch-relative, Structs.h:857)
+        {
+            std::vector<uint32_t> a, b;
+            std::vector<float> w;
+            const uint32_t nW = p.nContactWildcards;
+            size_t sphBase = 0;
+            for (auto& bt : m_batches) {
+                for (size_t k = 0; k < bt->contact_pairs.size(); k++) {
+                    a.push_back((uint32_t)(sphBase + bt->contact_pairs[k].first));
+                    b.push_back((uint32_t)(sphBase + bt->contact_pairs[k].second));
+                    for (auto& name : m_force_model->contact_wildcards) {
+                        auto it = bt->contact_wildcards.find(name);
+                        w.push_back(it == bt->contact_wildcards.end() ? 0.f : it->second[k]);
+                    }
+                }
+                for (size_t i = 0; i < bt->nClumps; i++)
+                    sphBase += bt->types[i]->nComp;
+            }
+            if (!a.empty()) {
+                const std::vector<uint8_t> ty(a.size(), 1);
+                check(deme_seed_contacts(m_ctx, a.data(), b.data(), ty.data(), nW ? w.data() : nullptr, a.size()));
+            }
+        }
     }
 };
 

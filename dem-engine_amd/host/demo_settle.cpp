@@ -2,7 +2,8 @@
 // written against dem-engine_amd/host/DEMSolver.h: three-sphere clumps dropped into a box with a cohesive
 // user force model on top of the built-in frictional Hertzian for comparison.
 //
-//   ./demo_settle [n_per_side] [steps]       prints "<time> <contacts> <max speed> <mean z>" lines
+//   ./demo_settle [n_per_side] [steps] [outdir]   prints "<time> <contacts> <max speed> <mean z>" lines; with outdir it
+//   writes sphere / clump / contact files, restarts a second solver from them and runs both for 200 more steps
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,44 @@ int main(int argc, char** argv) {
             zsum += DEMSim.GetOwnerPosition((unsigned)i).z;
         std::printf("t=%.5f contacts=%zu vmax=%.4f zmean=%.5f\n", DEMSim.GetSimTime(), DEMSim.GetNumContacts(),
                     DEMSim.GetMaxOwnerSpeed(), zsum / (double)DEMSim.GetNumClumps());
+    }
+    if (argc > 3) {  // output + restart round trip (cf. DEMdemo_Repose.cpp's checkpoint use of WriteClumpFile / ReadClump*FromCsv)
+        const std::string dir = argv[3];
+        DEMSim.SetOutputContent(ABSV | VEL | ANG_VEL | FAMILY);
+        DEMSim.WriteSphereFile(dir + "/spheres.csv");
+        DEMSim.WriteClumpFile(dir + "/clumps.csv");
+        DEMSim.WriteContactFile(dir + "/contacts.csv");
+        DEMSolver Again;
+        auto mat2 = Again.LoadMaterial({{"E", 1e8f}, {"nu", 0.3f}, {"CoR", 0.6f}, {"mu", 0.2f}, {"Crr", 0.0f}});
+        Again.InstructBoxDomainDimension({0.f, 0.25f}, {0.f, 0.25f}, {0.f, 0.4f});
+        Again.InstructBoxDomainBoundingBC("top_open", mat2);
+        auto tmpl2 = Again.LoadClumpType(mass, MOI, std::vector<float>{0.8f, 0.8f, 0.8f},
+                                         std::vector<float3>{{0.5f, 0.341729f, 0.f}, {0.f, -0.658271f, 0.f}, {-0.5f, 0.341729f, 0.f}}, mat2);
+        tmpl2->Scale(r);
+        auto b2 = Again.AddClumps(tmpl2, DEMSolver::ReadClumpXyzFromCsv(dir + "/clumps.csv").at("0000"));
+        b2->SetOriQ(DEMSolver::ReadClumpQuatFromCsv(dir + "/clumps.csv").at("0000"));
+        b2->SetVel(DEMSolver::ReadClumpVelFromCsv(dir + "/clumps.csv").at("0000"));
+        b2->SetAngVel(DEMSolver::ReadClumpAngVelFromCsv(dir + "/clumps.csv").at("0000"));
+        b2->SetExistingContacts(DEMSolver::ReadContactPairsFromCsv(dir + "/contacts.csv"));
+        b2->SetExistingContactWildcards(DEMSolver::ReadContactWildcardsFromCsv(dir + "/contacts.csv"));
+        Again.UseFrictionalHertzianModel();
+        Again.SetInitTimeStep(5e-6);
+        Again.SetGravitationalAcceleration(make_float3(0, 0, -9.81f));
+        Again.SetCDUpdateFreq(10);
+        Again.SetExpandSafetyMultiplier(1.2f);
+        Again.SetExpandSafetyAdder(0.02f);
+        Again.SetMaxVelocity(10.f);
+        Again.SetErrorOutVelocity(100.f);
+        Again.SetInitBinSizeAsMultipleOfSmallestSphere(4.f);
+        Again.Initialize();
+        DEMSim.DoDynamicsThenSync(200 * 5e-6);
+        Again.DoDynamicsThenSync(200 * 5e-6);
+        double dmax = 0;
+        for (size_t i = 0; i < DEMSim.GetNumClumps(); i++) {
+            const float3 a = DEMSim.GetOwnerPosition((unsigned)i), b = Again.GetOwnerPosition((unsigned)i);
+            dmax = std::max({dmax, (double)std::fabs(a.x - b.x), (double)std::fabs(a.y - b.y), (double)std::fabs(a.z - b.z)});
+        }
+        std::printf("RESTART contacts=%zu/%zu max_pos_diff=%.3e\n", DEMSim.GetNumContacts(), Again.GetNumContacts(), dmax);
     }
     std::printf("DEMO_OK clumps=%zu\n", DEMSim.GetNumClumps());
     return 0;

@@ -66,6 +66,11 @@ class ClumpTemplate:
         self.relpos = np.asarray(relpos, np.float32).reshape(-1, 3)
         self.materials = list(materials)
         self.mark = None
+        self.name = None  # AssignName (Structs.h:697); default "%04d" of the load order (APIPublic.cpp:1751-1755)
+
+    def AssignName(self, name):
+        self.name = str(name)
+        return self
 
     def Scale(self, s):
         """DEMClumpTemplate::Scale (DEM/Structs.h): lengths*s, mass*s^3, MOI*s^5."""
@@ -626,6 +631,8 @@ class SceneBuilder:
         counts = {"nOwners": n_owners, "nOwnerClumps": n_clumps, "nSpheres": len(arrays["ownerClumpBody"]),
                   "nAnal": len(obj["type"]), "nTri": n_tri, "nMat": nm, "nComp": len(radii), "nMassProps": len(mass)}
         self.params, self.arrays, self.counts = p, arrays, counts
+        # clump mark -> type name for the clump output file (m_template_number_name_map, APIPrivate.cpp:721)
+        self.template_names = {t.mark: (t.name if t.name is not None else "%04d" % self.templates.index(t)) for t in self.templates}
         self.scene = abi.make_scene_struct(arrays, counts)
         return p, self.scene
 

@@ -206,6 +206,13 @@ int deme_download_contacts(deme_ctx* ctx, uint32_t* idA, uint32_t* idB, uint8_t*
 /* contact wildcards, array w (0..nContactWildcards-1), length nContacts */
 int deme_download_contact_wildcard(deme_ctx* ctx, uint32_t w, float* out, size_t cap);
 int deme_upload_contact_wildcard(deme_ctx* ctx, uint32_t w, const float* in, size_t n);
+/* Restart: load a saved contact list with its wildcards (DEMClumpBatch::SetExistingContacts /
+ * SetExistingContactWildcards, Structs.h:857-880; loaded by dT at initialisation).  The
+ * pairs are geometry ids (sphere A; sphere / triangle / analytical component B), `type` the reference's
+ * contact_t (1 SS, 2 SM, other: analytical); `wildcards` is float[n][nContactWildcards].  The list only feeds
+ * the history map of the next detection, which therefore always runs before the next force evaluation. */
+int deme_seed_contacts(deme_ctx* ctx, const uint32_t* idA, const uint32_t* idB, const uint8_t* type, const float* wildcards,
+                       size_t n);
 /* per-contact records (ContactInfoWriteBack.cu): force, torque-only force, local contact
  * points; each nContacts*3 floats; any pointer may be NULL. Recording must have been enabled. */
 int deme_set_record_contacts(deme_ctx* ctx, int enable);

@@ -22,12 +22,21 @@ def test_demo_builds_and_fails_loudly_without_a_gpu():
 
 
 @pytest.mark.gpu
-def test_demo_runs_and_settles():
+def test_demo_runs_and_settles(tmp_path):
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
-    out = subprocess.run([os.path.join(HOST, "demo_settle"), "10", "3000"], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([os.path.join(HOST, "demo_settle"), "10", "3000", str(tmp_path)], capture_output=True, text=True,
+                         timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DEMO_OK clumps=1000" in out.stdout
     rows = [l for l in out.stdout.splitlines() if l.startswith("t=")]
     z = [float(l.split("zmean=")[1]) for l in rows]
     c = [int(l.split("contacts=")[1].split()[0]) for l in rows]
     assert z[-1] < z[0] and c[-1] > 100  # the bed drops and contacts form
+    # output files in the reference's formats, and the restart built from them tracks the original run
+    assert open(tmp_path / "spheres.csv").readline().strip() == "X,Y,Z,r,absv,v_x,v_y,v_z,w_x,w_y,w_z,family"
+    assert open(tmp_path / "clumps.csv").readline().strip() == "X,Y,Z,Qw,Qx,Qy,Qz,clump_type,absv,v_x,v_y,v_z,w_x,w_y,w_z,family"
+    assert open(tmp_path / "contacts.csv").readline().strip() == ("contact_type,A,B,geoA,geoB,f_x,f_y,f_z,X,Y,Z,delta_tan_x,"
+                                                                  "delta_tan_y,delta_tan_z,delta_time")
+    assert len(open(tmp_path / "spheres.csv").readlines()) == 3001 and len(open(tmp_path / "clumps.csv").readlines()) == 1001
+    rs = [l for l in out.stdout.splitlines() if l.startswith("RESTART")][0]
+    assert float(rs.split("max_pos_diff=")[1]) < 5e-5, rs
