@@ -173,6 +173,7 @@ def load_library():
         "deme_download_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_upload_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_seed_contacts": [_P, _P, _P, _P, _P, C.c_size_t],
+        "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)], "deme_inspect_values": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_set_record_contacts": [_P, C.c_int],
         "deme_download_contact_records": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_download_sphere_geometry": [_P, _P, _P, _P, _P, C.c_size_t],
@@ -323,6 +324,24 @@ class Context:
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         self._ck(self.lib.deme_upload_contact_wildcard(self.h, int(w), _ptr(arr), arr.size),
                  "deme_upload_contact_wildcard")
+
+    # DEMInspector quantity names (AuxClasses.cpp:94-170)
+    INSPECT_CODES = {"clump_max_z": 0, "clump_min_z": 1, "clump_max_absv": 2, "clump_mass": 3, "max_absv": 4,
+                     "clump_kinetic_energy": 5, "absv": 6}
+
+    def inspect(self, quantity):
+        """DEMInspector::GetValue of a named quantity (reduced on the device)."""
+        if quantity not in self.INSPECT_CODES:
+            raise DemeError(f"{quantity} is not a known query type.")
+        out = C.c_float(0)
+        self._ck(self.lib.deme_inspect(self.h, self.INSPECT_CODES[quantity], C.byref(out)), "deme_inspect")
+        return float(out.value)
+
+    def inspect_values(self, quantity, n):
+        """DEMInspector::GetValues: the unreduced per-sphere / per-owner array (n elements)."""
+        out = np.zeros(int(n), np.float32)
+        self._ck(self.lib.deme_inspect_values(self.h, self.INSPECT_CODES[quantity], _ptr(out), out.size), "deme_inspect_values")
+        return out
 
     def seed_contacts(self, idA, idB, ctype, wildcards=None):
         """Restart: saved contact pairs (geometry ids) + wildcards [n, nW] feed the next history map."""

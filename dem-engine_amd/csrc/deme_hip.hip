@@ -1296,6 +1296,83 @@ int deme_kernel_time_reset(deme_ctx* c) {
     }
     return DEME_OK;
 }
+namespace {
+struct FMax {
+    __host__ __device__ float operator()(float a, float b) const { return a > b ? a : b; }
+};
+struct FMin {
+    __host__ __device__ float operator()(float a, float b) const { return a < b ? a : b; }
+};
+// fills c->stage with the per-element quantity; returns the element count through n
+int inspect_fill(deme_ctx* c, uint32_t q, float identity, size_t& n) {
+    if (q > DEME_INSPECT_ABSV)
+        return fail(c, DEME_ERR_INVALID, "unknown inspection quantity %u", q);
+    const bool perSphere = q <= DEME_INSPECT_CLUMP_MAX_ABSV;
+    n = perSphere ? c->nSpheres : c->nOwners;
+    if (int rc = ensure(c, c->stage, std::max<size_t>(n, 1) * 4 + 16))
+        return rc;
+    if (n == 0)
+        return DEME_OK;
+    if (perSphere)
+        hipLaunchKernelGGL(k_inspect_sphere, dim3(grid_for(n)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
+                           c->spheres.as<SphereRec>(), q, identity, c->stage.as<float>());
+    else
+        hipLaunchKernelGGL(k_inspect_owner, dim3(grid_for(n)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
+                           (uint32_t)c->nOwnerClumps, q, identity, c->stage.as<float>());
+    return DEME_OK;
+}
+}  // namespace
+
+int deme_inspect(deme_ctx* c, uint32_t q, float* out) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (!out || q == DEME_INSPECT_ABSV)
+        return fail(c, DEME_ERR_INVALID, "deme_inspect: quantity %u has no reduction (use deme_inspect_values)", q);
+    const bool isMax = q == DEME_INSPECT_CLUMP_MAX_Z || q == DEME_INSPECT_CLUMP_MAX_ABSV || q == DEME_INSPECT_MAX_ABSV;
+    const bool isMin = q == DEME_INSPECT_CLUMP_MIN_Z;
+    const float identity = isMax ? -3.402823466e38f : isMin ? 3.402823466e38f : 0.f;
+    size_t n = 0;
+    if (int rc = inspect_fill(c, q, identity, n))
+        return rc;
+    float* in = c->stage.as<float>();
+    float* res = in + n;  // one spare slot behind the values
+    size_t need = 0;
+    if (isMax) {
+        HIPCK(rocprim::reduce(nullptr, need, in, res, identity, n, FMax(), c->stream));
+    } else if (isMin) {
+        HIPCK(rocprim::reduce(nullptr, need, in, res, identity, n, FMin(), c->stream));
+    } else {
+        HIPCK(rocprim::reduce(nullptr, need, in, res, identity, n, rocprim::plus<float>(), c->stream));
+    }
+    if (int rc = ensure(c, c->sortTmp, need))
+        return rc;
+    need = c->sortTmp.bytes;
+    if (isMax) {
+        HIPCK(rocprim::reduce(c->sortTmp.p, need, in, res, identity, n, FMax(), c->stream));
+    } else if (isMin) {
+        HIPCK(rocprim::reduce(c->sortTmp.p, need, in, res, identity, n, FMin(), c->stream));
+    } else {
+        HIPCK(rocprim::reduce(c->sortTmp.p, need, in, res, identity, n, rocprim::plus<float>(), c->stream));
+    }
+    HIPCK(hipMemcpyAsync(out, res, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_inspect_values(deme_ctx* c, uint32_t q, float* out, size_t cap) {
+    if (int rc = check_ready(c))
+        return rc;
+    size_t n = 0;
+    if (int rc = inspect_fill(c, q, 0.f, n))
+        return rc;
+    if (!out || cap < n)
+        return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    if (n)
+        HIPCK(hipMemcpyAsync(out, c->stage.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
 int deme_kernel_time_ms(deme_ctx* c, const char* name, double* avg_ms, uint64_t* launches) {
     if (!c || !name)
         return DEME_ERR_INVALID;

@@ -989,6 +989,66 @@ __global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owner
     }
 }
 
+// ---- inspectors: DEMSphereQueryKernels.cu:13-54 / DEMOwnerQueryKernels.cu:11-63 with the quantity fragments of
+// AuxClasses.cpp:19-92.  Elements that do not take part get the reduction's identity.
+__global__ __launch_bounds__(256) void k_inspect_sphere(const DevParams p, const OwnerRec* __restrict__ owners,
+                                                       const SphereRec* __restrict__ spheres, uint32_t quantity, float identity,
+                                                       float* __restrict__ out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.nSpheres)
+        return;
+    const SphereRec sr = spheres[s];
+    const OwnerRec o = load_owner(owners, sr.owner);
+    if (p.familyFlags[o.family] & 2u) {  // ghost copy: its owner rank reports it
+        out[s] = identity;
+        return;
+    }
+    const float4 c = p.comp[sr.comp];
+    const RotM R = rot_coeffs(o.qw, o.qx, o.qy, o.qz);
+    const f3 rel = rot_apply(R, mk3(c.x, c.y, c.z));  // myRelPos, rotated in place
+    const d3 X = decode_pos(o.voxelID, o.locX, o.locY, o.locZ, p);
+    float q;
+    if (quantity == 0u) {
+        const float Z = (float)(X.z + (double)rel.z + (double)p.LBFZ);
+        q = Z + c.w;
+    } else if (quantity == 1u) {
+        const float Z = (float)(X.z + (double)rel.z + (double)p.LBFZ);
+        q = Z - c.w;
+    } else {  // INSP_CODE_SPHERE_HIGH_ABSV: cross(omgBar, rotated relPos), rotated once more, + v
+        const f3 pr = rot_apply(R, cross3(mk3(o.wx, o.wy, o.wz), rel));
+        q = len3(pr + mk3(o.vx, o.vy, o.vz));
+    }
+    out[s] = q;
+}
+
+__global__ __launch_bounds__(256) void k_inspect_owner(const DevParams p, const OwnerRec* __restrict__ owners, uint32_t nClumps,
+                                                      uint32_t quantity, float identity, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.nOwners)
+        return;
+    const OwnerRec o = load_owner(owners, i);
+    const bool clumpOnly = quantity == 3u || quantity == 5u;  // OWNER_T_CLUMP quantities
+    if ((p.familyFlags[o.family] & 2u) || (clumpOnly && i >= nClumps)) {
+        out[i] = identity;
+        return;
+    }
+    const float4 mp = p.massProps[o.inertiaOff];
+    float q;
+    if (quantity == 3u) {
+        q = mp.x;
+    } else if (quantity == 5u) {
+        double vx = o.vx, vy = o.vy, vz = o.vz;
+        double ke = 0.5 * mp.x * (vx * vx + vy * vy + vz * vz);
+        vx = o.wx, vy = o.wy, vz = o.wz;
+        ke += 0.5 * ((double)mp.y * vx * vx + (double)mp.z * vy * vy + (double)mp.w * vz * vz);
+        q = (float)ke;
+    } else {
+        const double vx = o.vx, vy = o.vy, vz = o.vz;
+        q = (float)sqrt(vx * vx + vy * vy + vz * vz);
+    }
+    out[i] = q;
+}
+
 // ghost-owner exchange records for the slab decomposition: pose + velocities + family
 struct __attribute__((aligned(8))) GhostRec {
     uint64_t voxelID;

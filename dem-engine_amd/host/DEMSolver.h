@@ -401,6 +401,14 @@ class DEMSolver {
     }
     deme_ctx* GetContext() { return m_ctx; }
 
+    // ---- inspectors and trackers (API.h:652-679, AuxClasses.h:26-420)
+    std::shared_ptr<class DEMInspector> CreateInspector(const std::string& quantity = "clump_max_z");
+    std::shared_ptr<class DEMTracker> Track(const std::shared_ptr<DEMClumpBatch>& batch);
+    std::shared_ptr<class DEMTracker> Track(const std::shared_ptr<DEMExternObj>& obj);
+    std::shared_ptr<class DEMTracker> Track(const std::shared_ptr<DEMMeshConnected>& mesh);
+    friend class DEMInspector;
+    friend class DEMTracker;
+
     // ---- output (API.h:1096-1122, 1318-1324); formats of dT.cpp:1254-1405, 1491-1618, 1620-1848
     void SetOutputFormat(OUTPUT_FORMAT f) { require_csv(f); }
     void SetContactOutputFormat(OUTPUT_FORMAT f) { require_csv(f); }
@@ -729,6 +737,40 @@ class DEMSolver {
     void check(int rc) {
         if (rc)
             throw std::runtime_error(deme_last_error(m_ctx));
+    }
+    // tracker setters: read-modify-write of the affected SoA columns (null columns keep their device values)
+    void set_owner(size_t o, const float3* pos, const float3* vel, const float3* angvel, const float4* q) {
+        const size_t n = m_n_owners;
+        std::vector<uint64_t> vid(n);
+        std::vector<uint16_t> lx(n), ly(n), lz(n);
+        std::vector<float> f[10];
+        for (auto& v : f)
+            v.resize(n);
+        DemeOwnerState st{};
+        st.voxelID = vid.data(), st.locX = lx.data(), st.locY = ly.data(), st.locZ = lz.data();
+        st.oriQw = f[0].data(), st.oriQx = f[1].data(), st.oriQy = f[2].data(), st.oriQz = f[3].data();
+        st.vX = f[4].data(), st.vY = f[5].data(), st.vZ = f[6].data();
+        st.omgBarX = f[7].data(), st.omgBarY = f[8].data(), st.omgBarZ = f[9].data();
+        check(deme_download_owner_state(m_ctx, &st));
+        if (pos) {  // positionToVoxelID of (pos - LBF), as at initialisation
+            const double P[3] = {(double)(pos->x - m_p.LBFX), (double)(pos->y - m_p.LBFY), (double)(pos->z - m_p.LBFZ)};
+            uint64_t nn[3];
+            uint16_t ss[3];
+            for (int k = 0; k < 3; k++) {
+                nn[k] = (uint64_t)(P[k] / m_p.voxelSize);
+                ss[k] = (uint16_t)((P[k] - (double)nn[k] * m_p.voxelSize) / m_p.l);
+            }
+            vid[o] = nn[0] + (nn[1] << m_p.nvXp2) + (nn[2] << (m_p.nvXp2 + m_p.nvYp2));
+            lx[o] = ss[0], ly[o] = ss[1], lz[o] = ss[2];
+        }
+        if (q)
+            f[0][o] = q->w, f[1][o] = q->x, f[2][o] = q->y, f[3][o] = q->z;
+        if (vel)
+            f[4][o] = vel->x, f[5][o] = vel->y, f[6][o] = vel->z;
+        if (angvel)
+            f[7][o] = angvel->x, f[8][o] = angvel->y, f[9][o] = angvel->z;
+        check(deme_upload_owner_state(m_ctx, &st));
+        m_state_fresh = false;
     }
     void step(uint32_t n) {
         check(deme_step(m_ctx, n));
@@ -1067,5 +1109,106 @@ class DEMSolver {
         }
     }
 };
+
+
+/// A named reduction over the spheres / owners, evaluated on the device (deme_inspect).  Quantities: clump_max_z,
+/// clump_min_z, clump_max_absv, clump_mass, max_absv, clump_kinetic_energy, absv (AuxClasses.cpp:94-170).
+class DEMInspector {
+  public:
+    DEMInspector(DEMSolver* sys, const std::string& quantity) : m_sys(sys) {
+        static const std::map<std::string, uint32_t> codes = {{"clump_max_z", DEME_INSPECT_CLUMP_MAX_Z},
+                                                              {"clump_min_z", DEME_INSPECT_CLUMP_MIN_Z},
+                                                              {"clump_max_absv", DEME_INSPECT_CLUMP_MAX_ABSV},
+                                                              {"clump_mass", DEME_INSPECT_CLUMP_MASS},
+                                                              {"max_absv", DEME_INSPECT_MAX_ABSV},
+                                                              {"clump_kinetic_energy", DEME_INSPECT_CLUMP_KINETIC_ENERGY},
+                                                              {"absv", DEME_INSPECT_ABSV}};
+        auto it = codes.find(quantity);
+        if (it == codes.end())
+            throw std::runtime_error(quantity + " is not a known query type.");
+        m_code = it->second;
+    }
+    float GetValue() {
+        float v = 0;
+        m_sys->check(deme_inspect(m_sys->m_ctx, m_code, &v));
+        return v;
+    }
+    std::vector<float> GetValues() {
+        std::vector<float> v(m_code <= DEME_INSPECT_CLUMP_MAX_ABSV ? m_sys->m_keep.sphOwner.size() : m_sys->m_n_owners);
+        m_sys->check(deme_inspect_values(m_sys->m_ctx, m_code, v.data(), v.size()));
+        return v;
+    }
+
+  private:
+    DEMSolver* m_sys;
+    uint32_t m_code = 0;
+};
+
+/// Access to the state of the owners of one loaded object (a batch of clumps, an analytical object, a mesh):
+/// getters read the current device state, setters write it back (DEMTracker, AuxClasses.h:93-420).
+class DEMTracker {
+  public:
+    DEMTracker(DEMSolver* sys, size_t first_owner, size_t n) : m_sys(sys), m_first(first_owner), m_n(n) {}
+    bodyID_t GetOwnerID(size_t offset = 0) const { return (bodyID_t)(m_first + in_range(offset)); }
+    size_t GetNumOwners() const { return m_n; }
+    float3 Pos(size_t offset = 0) { return m_sys->GetOwnerPosition(GetOwnerID(offset)); }
+    float3 Vel(size_t offset = 0) { return m_sys->GetOwnerVelocity(GetOwnerID(offset)); }
+    float3 AngVelLocal(size_t offset = 0) { return column3(offset, 2); }
+    float4 OriQ(size_t offset = 0) {
+        const DEMSolver::Snapshot sn = m_sys->snapshot(false);
+        return sn.q[GetOwnerID(offset)];
+    }
+    float3 ContactAcc(size_t offset = 0) { return column3(offset, 3); }
+    float3 ContactAngAccLocal(size_t offset = 0) { return column3(offset, 4); }
+    std::vector<float3> Positions() {
+        std::vector<float3> out(m_n);
+        for (size_t i = 0; i < m_n; i++)
+            out[i] = Pos(i);
+        return out;
+    }
+    void SetPos(float3 pos, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), &pos, nullptr, nullptr, nullptr); }
+    void SetVel(float3 vel, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, &vel, nullptr, nullptr); }
+    void SetAngVel(float3 w, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, nullptr, &w, nullptr); }
+    void SetOriQ(float4 q, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, nullptr, nullptr, &q); }
+
+  private:
+    DEMSolver* m_sys;
+    size_t m_first, m_n;
+    size_t in_range(size_t offset) const {
+        if (offset >= m_n)
+            throw std::runtime_error("tracker offset is out of range");
+        return offset;
+    }
+    float3 column3(size_t offset, int which) {
+        const DEMSolver::Snapshot sn = m_sys->snapshot(false);
+        const size_t o = GetOwnerID(offset);
+        return which == 2 ? sn.w[o] : which == 3 ? sn.a[o] : sn.al[o];
+    }
+};
+
+inline std::shared_ptr<DEMInspector> DEMSolver::CreateInspector(const std::string& quantity) {
+    return std::make_shared<DEMInspector>(this, quantity);
+}
+inline std::shared_ptr<DEMTracker> DEMSolver::Track(const std::shared_ptr<DEMClumpBatch>& batch) {
+    size_t first = 0;
+    for (auto& b : m_batches) {
+        if (b == batch)
+            return std::make_shared<DEMTracker>(this, first, b->nClumps);
+        first += b->nClumps;
+    }
+    throw std::runtime_error("Track: this batch was not loaded into this solver");
+}
+inline std::shared_ptr<DEMTracker> DEMSolver::Track(const std::shared_ptr<DEMExternObj>& obj) {
+    for (size_t e = 0; e < m_ext.size(); e++)
+        if (m_ext[e] == obj)
+            return std::make_shared<DEMTracker>(this, m_n_clumps + e, 1);
+    throw std::runtime_error("Track: this object was not loaded into this solver");
+}
+inline std::shared_ptr<DEMTracker> DEMSolver::Track(const std::shared_ptr<DEMMeshConnected>& mesh) {
+    for (size_t m = 0; m < m_meshes.size(); m++)
+        if (m_meshes[m] == mesh)
+            return std::make_shared<DEMTracker>(this, m_n_owners - m_meshes.size() + m, 1);
+    throw std::runtime_error("Track: this mesh was not loaded into this solver");
+}
 
 }  // namespace deme

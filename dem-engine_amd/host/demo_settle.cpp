@@ -52,6 +52,10 @@ int main(int argc, char** argv) {
     DEMSim.SetErrorOutVelocity(100.f);
     DEMSim.SetInitBinSizeAsMultipleOfSmallestSphere(4.f);
     DEMSim.Initialize();
+    auto max_z_finder = DEMSim.CreateInspector("clump_max_z");
+    auto total_mass_finder = DEMSim.CreateInspector("clump_mass");
+    auto ke_finder = DEMSim.CreateInspector("clump_kinetic_energy");
+    auto tracker = DEMSim.Track(batch);
 
     for (int done = 0; done < steps; done += 500) {
         DEMSim.DoDynamicsThenSync(500 * 5e-6);
@@ -61,6 +65,8 @@ int main(int argc, char** argv) {
         std::printf("t=%.5f contacts=%zu vmax=%.4f zmean=%.5f\n", DEMSim.GetSimTime(), DEMSim.GetNumContacts(),
                     DEMSim.GetMaxOwnerSpeed(), zsum / (double)DEMSim.GetNumClumps());
     }
+    std::printf("INSPECT max_z=%.6f mass=%.6e ke=%.6e tracked0_z=%.6f\n", max_z_finder->GetValue(), total_mass_finder->GetValue(),
+                ke_finder->GetValue(), tracker->Pos(0).z);
     if (argc > 3) {  // output + restart round trip (cf. DEMdemo_Repose.cpp's checkpoint use of WriteClumpFile / ReadClump*FromCsv)
         const std::string dir = argv[3];
         DEMSim.SetOutputContent(ABSV | VEL | ANG_VEL | FAMILY);

@@ -232,6 +232,20 @@ int deme_compile_force_model(deme_ctx* ctx, const char* src, size_t len, const c
 int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,
                    char* log, size_t logCap);
 
+/* Inspectors (DEMInspector, AuxClasses.cpp:19-170; kernels DEMSphereQueryKernels.cu:13-54,
+ * DEMOwnerQueryKernels.cu:11-63; reduction dT.cpp:2556-2640): a per-sphere or per-owner quantity evaluated on
+ * the device and reduced there.  Ghost owners of a slab decomposition are left out.  No region filter. */
+#define DEME_INSPECT_CLUMP_MAX_Z 0          /* "clump_max_z": max over spheres of Z + radius */
+#define DEME_INSPECT_CLUMP_MIN_Z 1          /* "clump_min_z" */
+#define DEME_INSPECT_CLUMP_MAX_ABSV 2       /* "clump_max_absv": sphere-centre speed incl. rotation */
+#define DEME_INSPECT_CLUMP_MASS 3           /* "clump_mass": sum over clump owners */
+#define DEME_INSPECT_MAX_ABSV 4             /* "max_absv": max owner speed, all owner kinds */
+#define DEME_INSPECT_CLUMP_KINETIC_ENERGY 5 /* "clump_kinetic_energy" */
+#define DEME_INSPECT_ABSV 6                 /* "absv": per-owner values only (deme_inspect_values) */
+int deme_inspect(deme_ctx* ctx, uint32_t quantity, float* out);
+/* unreduced values (DEMInspector::GetValues): one per sphere (quantities 0-2) or per owner (3-6) */
+int deme_inspect_values(deme_ctx* ctx, uint32_t quantity, float* out, size_t cap);
+
 /* timing of the kernels this library launched (HIP events on the context stream);
  * names: "calc_forces", "integrate", "detect"; returns avg ms per launch since last reset */
 int deme_kernel_time_ms(deme_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches);

@@ -1542,6 +1542,65 @@ void orc_sim_counts(void* h, DemeCounts* c) {
     c->nDetections = s->nDetections;
     c->maxSpheresInBin = s->maxInBin;
 }
+// Inspectors: DEMSphereQueryKernels.cu:13-54 / DEMOwnerQueryKernels.cu:11-63 with the quantity fragments of
+// AuxClasses.cpp:19-92.  values (may be null) receives the per-element quantity; the return value is the number
+// of elements; *reduced gets max / min / sum (sums accumulated in double, the reference reduces fp32 with CUB).
+size_t orc_sim_inspect(void* h, uint32_t q, float* reduced, float* values) {
+    Sim& s = *(Sim*)h;
+    const bool perSphere = q <= DEME_INSPECT_CLUMP_MAX_ABSV;
+    const size_t n = perSphere ? s.nSpheres : s.nOwners;
+    const bool isMax = q == DEME_INSPECT_CLUMP_MAX_Z || q == DEME_INSPECT_CLUMP_MAX_ABSV || q == DEME_INSPECT_MAX_ABSV;
+    const bool isMin = q == DEME_INSPECT_CLUMP_MIN_Z;
+    const float identity = isMax ? -3.402823466e38f : isMin ? 3.402823466e38f : 0.f;
+    double sum = 0;
+    float best = identity;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t o = perSphere ? s.ownerOfSphere[i] : (uint32_t)i;
+        float v;
+        const bool clumpOnly = q == DEME_INSPECT_CLUMP_MASS || q == DEME_INSPECT_CLUMP_KINETIC_ENERGY;
+        if ((s.famFlags[s.familyID[o]] & DEME_FAMILY_GHOST) || (clumpOnly && o >= s.nOwnerClumps)) {
+            v = identity;
+        } else if (perSphere) {
+            const uint16_t c = s.compOff[i];
+            const RotM m = rot_coeffs(s.oriQw[o], s.oriQx[o], s.oriQy[o], s.oriQz[o]);
+            const V3f rel = rotate_f(m, {s.relX[c], s.relY[c], s.relZ[c]});
+            double oX, oY, oZ;
+            decode_pos(s.voxelID[o], s.locX[o], s.locY[o], s.locZ[o], s.p.nvXp2, s.p.nvYp2, s.p.voxelSize, s.p.l, oX, oY, oZ);
+            if (q == DEME_INSPECT_CLUMP_MAX_ABSV) {
+                const V3f w{s.omgX[o], s.omgY[o], s.omgZ[o]};
+                const V3f cr{w.y * rel.z - w.z * rel.y, w.z * rel.x - w.x * rel.z, w.x * rel.y - w.y * rel.x};
+                const V3f pr = rotate_f(m, cr);
+                const V3f t{pr.x + s.vX[o], pr.y + s.vY[o], pr.z + s.vZ[o]};
+                v = lenf(t);
+            } else {
+                const float Z = (float)(oZ + (double)rel.z + (double)s.p.LBFZ);
+                v = (q == DEME_INSPECT_CLUMP_MAX_Z) ? Z + s.Radii[c] : Z - s.Radii[c];
+            }
+        } else {
+            const uint16_t io = s.inertiaOff[o];
+            if (q == DEME_INSPECT_CLUMP_MASS) {
+                v = s.mass[io];
+            } else if (q == DEME_INSPECT_CLUMP_KINETIC_ENERGY) {
+                double vx = s.vX[o], vy = s.vY[o], vz = s.vZ[o];
+                double ke = 0.5 * s.mass[io] * (vx * vx + vy * vy + vz * vz);
+                vx = s.omgX[o], vy = s.omgY[o], vz = s.omgZ[o];
+                ke += 0.5 * ((double)s.moiX[io] * vx * vx + (double)s.moiY[io] * vy * vy + (double)s.moiZ[io] * vz * vz);
+                v = (float)ke;
+            } else {
+                const double vx = s.vX[o], vy = s.vY[o], vz = s.vZ[o];
+                v = (float)sqrt(vx * vx + vy * vy + vz * vz);
+            }
+        }
+        if (values)
+            values[i] = v;
+        sum += v;
+        if (isMax ? v > best : v < best)
+            best = v;
+    }
+    if (reduced)
+        *reduced = (isMax || isMin) ? best : (float)sum;
+    return n;
+}
 void orc_sim_get_state(void* h, DemeOwnerState* st) {
     Sim* s = (Sim*)h;
     auto cp = [](auto& v, auto* dst) {

@@ -50,6 +50,10 @@ def lib():
     return _orc
 
 
+INSPECT_CODES = {"clump_max_z": 0, "clump_min_z": 1, "clump_max_absv": 2, "clump_mass": 3, "max_absv": 4,
+                 "clump_kinetic_energy": 5, "absv": 6}
+
+
 def ref_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libdeme_ref.so"))
 
@@ -263,6 +267,15 @@ class OracleSim:
     def upload_state(self, arrays):
         st, _ = self._state_factory(self.n_owners, arrays)
         self.L.orc_sim_set_state(C.c_void_p(self.h), C.byref(st))
+
+    def inspect(self, quantity, values=False):
+        q = INSPECT_CODES[quantity] if isinstance(quantity, str) else int(quantity)
+        n = self.n_spheres if q <= 2 else self.n_owners
+        red = C.c_float(0)
+        vals = np.zeros(n, np.float32) if values else None
+        self.L.orc_sim_inspect.restype = C.c_size_t
+        self.L.orc_sim_inspect(C.c_void_p(self.h), C.c_uint32(q), C.byref(red), None if vals is None else _p(vals))
+        return vals if values else float(red.value)
 
     def bin_incidence(self):
         n = int(self.counts().nBinSphereTouches)

@@ -40,3 +40,8 @@ def test_demo_runs_and_settles(tmp_path):
     assert len(open(tmp_path / "spheres.csv").readlines()) == 3001 and len(open(tmp_path / "clumps.csv").readlines()) == 1001
     rs = [l for l in out.stdout.splitlines() if l.startswith("RESTART")][0]
     assert float(rs.split("max_pos_diff=")[1]) < 5e-5, rs
+    # inspectors (device reductions) agree with what the per-clump getters printed
+    ins = [l for l in out.stdout.splitlines() if l.startswith("INSPECT")][0]
+    vals = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in ins.split()[1:]}
+    assert abs(vals["mass"] - 1000 * 2.6e3 * 5.5886717 * 0.005 ** 3) < 1e-6 * vals["mass"]
+    assert vals["max_z"] > z[-1] and vals["max_z"] < 0.4 and vals["ke"] >= 0.0 and 0.0 < vals["tracked0_z"] < 0.4
