@@ -9,8 +9,11 @@ their owner rank (56-byte ghost records: pose, velocities, family; deme_halo_pac
 A local-ghost contact is evaluated on both ranks, each applying the force to its own clump only;
 ghost-ghost contacts are masked out.
 
-Round-1 limitation (stated in DESIGN.md): ownership and ghost lists are fixed at set-up, so a clump must not
-drift further than `halo` minus its reach from its initial slab -- true for settling beds, not for flows.
+Ownership and ghost lists are fixed between re-decompositions, so a clump must not drift further than `halo`
+minus its reach before the next one.  `redecompose` (every few thousand steps, or when the maximum displacement
+since the last one approaches that bound) gathers the owned state and the contact history of all ranks, cuts the
+domain again at the current positions and re-seeds every rank's history through deme_seed_contacts -- clumps
+migrate between ranks there, with their contact wildcards.
 """
 import numpy as np
 
@@ -71,7 +74,8 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
         c = dict(counts)
         c.update({"nOwners": len(owners_g), "nOwnerClumps": len(clumps_here), "nSpheres": len(sph_idx)})
         out.append({"arrays": a, "counts": c, "n_own": len(own), "global_ids": own, "ghost_left_g": gl, "ghost_right_g": gr,
-                    "new_id": new_id, "edges": (edges[r], edges[r + 1])})
+                    "new_id": new_id, "edges": (edges[r], edges[r + 1]), "sphere_global": sph_idx.astype(np.int64),
+                    "owner_global": owners_g})
     # send lists: what my neighbour holds as ghosts, in the neighbour's slot order (ascending global id on both sides)
     for r in range(n_ranks):
         me = out[r]
@@ -104,3 +108,89 @@ def exchange_host(parts, states):
             assert len(src) == len(dst)
             for k in GHOST_STATE_KEYS:
                 states[nb][k][dst] = states[r][k][src]
+
+
+# ---- re-decomposition (migration of clumps and of their contact history between ranks) --------------------------
+def owned_payload(part, state, contacts, wildcards, flip_sign_wildcards=(0, 1, 2)):
+    """What one rank contributes to a re-decomposition: the state of its OWN clumps and its share of the contact
+    history in global ids.  A sphere-sphere pair is reported once, by the rank that owns the clump of the globally
+    smaller sphere id, stored (smaller, larger); where the local numbering had it the other way round the B-to-A
+    vector wildcards (flip_sign_wildcards) change sign.  Sphere-analytical contacts go with sphere A's owner.
+    contacts = (idA, idB, type[, map]) local; wildcards = float[n, nW]."""
+    n_own = part["n_own"]
+    own_state = {k: np.asarray(state[k])[:n_own].copy() for k in GHOST_STATE_KEYS}
+    idA, idB, ctype = (np.asarray(x) for x in contacts[:3])
+    W = np.asarray(wildcards, np.float32).reshape(len(idA), -1)
+    local_owner = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
+    sg = part["sphere_global"]
+    ss = ctype == 1
+    gA = sg[idA]
+    gB = np.where(ss, sg[np.where(ss, idB, 0)], idB.astype(np.int64))  # analytical component ids are global already
+    flipped = ss & (gA > gB)
+    lo_local = np.where(flipped, idB, idA)  # local id of the sphere that is sphere A in the global numbering
+    mine = local_owner[np.where(ss, lo_local, idA)] < n_own
+    gA2 = np.where(flipped, gB, gA)[mine]
+    gB2 = np.where(flipped, gA, gB)[mine]
+    Wm = W[mine].copy()
+    fm = flipped[mine]
+    for k in flip_sign_wildcards:
+        if k < Wm.shape[1]:
+            Wm[fm, k] = -Wm[fm, k]
+    return {"global_ids": np.asarray(part["global_ids"], np.int64), "state": own_state, "gA": gA2, "gB": gB2, "type": ctype[mine],
+            "wc": Wm}
+
+
+def redecompose(global_arrays, counts, payloads, n_ranks, halo, decode_x, flip_sign_wildcards=(0, 1, 2)):
+    """payloads: owned_payload() of every rank (in-process list, or the result of an all_gather_object).
+    decode_x(arrays) -> world x of every clump centre.  Returns (global_arrays_now, new_parts, seeds) where
+    seeds[r] = (idA, idB, type, wildcards) in rank r's new local sphere ids, ready for seed_contacts().
+    flip_sign_wildcards: wildcards that are vectors from B to A (the Hertzian model's delta_tan_x/y/z, indices 0-2 in
+    its alphabetical order): they change sign when a rank's local numbering stores the pair the other way round."""
+    g = dict(global_arrays)
+    for k in GHOST_STATE_KEYS:
+        g[k] = np.array(global_arrays[k], copy=True)
+    for pl in payloads:
+        for k in GHOST_STATE_KEYS:
+            g[k][pl["global_ids"]] = pl["state"][k]
+    parts = decompose(g, counts, decode_x(g), n_ranks, halo)
+    gA = np.concatenate([pl["gA"] for pl in payloads])
+    gB = np.concatenate([pl["gB"] for pl in payloads])
+    ty = np.concatenate([pl["type"] for pl in payloads])
+    wc = np.concatenate([pl["wc"] for pl in payloads]) if payloads else np.zeros((0, 0), np.float32)
+    n_sph_global = len(global_arrays["ownerClumpBody"])
+    seeds = []
+    for part in parts:
+        loc = np.full(n_sph_global, -1, np.int64)
+        loc[part["sphere_global"]] = np.arange(len(part["sphere_global"]))
+        owner_local = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
+        a = loc[gA]
+        ss = ty == 1
+        b = np.where(ss, loc[np.where(ss, gB, 0)], gB)
+        present = (a >= 0) & (b >= 0)
+        own_a = np.zeros(len(a), bool)
+        own_a[present] = owner_local[a[present]] < part["n_own"]
+        own_b = np.zeros(len(a), bool)
+        sel = present & ss
+        own_b[sel] = owner_local[b[sel]] < part["n_own"]
+        keep = present & (own_a | own_b)  # ghost-ghost pairs and contacts of foreign clumps stay with their owners
+        # a sphere-sphere pair is stored with the smaller sphere id first (DEMContactKernels_SphereSphere.cu:199-207):
+        # the local numbering may flip it
+        la, lb = a[keep].copy(), b[keep].copy()
+        flip = (ty[keep] == 1) & (la > lb)
+        la[flip], lb[flip] = lb[flip], la[flip].copy()
+        w = wc[keep].copy()
+        for k in flip_sign_wildcards:
+            if k < w.shape[1]:
+                w[flip, k] = -w[flip, k]
+        seeds.append((la.astype(np.uint32), lb.astype(np.uint32), ty[keep].astype(np.uint8), w))
+    return g, parts, seeds
+
+
+def redecompose_distributed(dist, rank, world, global_arrays, counts, part, state, contacts, wildcards, halo, decode_x, **kw):
+    """One process per rank: all-gather the owned payloads (torch.distributed object collective -- a few tens of MB
+    per million clumps, amortised over the thousands of steps between re-decompositions), cut again, and return
+    this rank's (global arrays, new part, seed)."""
+    payloads = [None] * world
+    dist.all_gather_object(payloads, owned_payload(part, state, contacts, wildcards))
+    g, parts, seeds = redecompose(global_arrays, counts, payloads, world, halo, decode_x, **kw)
+    return g, parts[rank], seeds[rank]

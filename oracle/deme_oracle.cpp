@@ -627,6 +627,7 @@ struct Sim {
     uint64_t nSteps = 0, nDetections = 0;
     uint32_t stepsSinceCD = 0;
     bool haveList = false;
+    bool seeded = false;  // list loaded by orc_sim_seed_contacts: only feeds the next history map
 };
 
 template <typename T>
@@ -937,6 +938,7 @@ int detect(Sim& s) {
             s.cMap[i] = (uint32_t)j;
     }
     s.haveList = true;
+    s.seeded = false;
     s.nDetections++;
     return DEME_OK;
 }
@@ -1239,7 +1241,7 @@ void integrate(Sim& s) {
 int step(Sim& s, uint32_t n) {
     const uint32_t K = s.p.cdUpdateFreq;
     for (uint32_t i = 0; i < n; i++) {
-        if (!s.haveList || K == 0 || s.stepsSinceCD >= K) {
+        if (!s.haveList || s.seeded || K == 0 || s.stepsSinceCD >= K) {
             compute_margins(s, K);
             const int rc = detect(s);
             if (rc)
@@ -1545,6 +1547,36 @@ void orc_sim_counts(void* h, DemeCounts* c) {
 // Inspectors: DEMSphereQueryKernels.cu:13-54 / DEMOwnerQueryKernels.cu:11-63 with the quantity fragments of
 // AuxClasses.cpp:19-92.  values (may be null) receives the per-element quantity; the return value is the number
 // of elements; *reduced gets max / min / sum (sums accumulated in double, the reference reduces fp32 with CUB).
+// restart / re-decomposition: mirror of deme_seed_contacts (include/deme_hip.h)
+int orc_sim_seed_contacts(void* h, const uint32_t* idA, const uint32_t* idB, const uint8_t* type, const float* wildcards, size_t n) {
+    Sim& s = *(Sim*)h;
+    const uint32_t nW = s.p.nContactWildcards;
+    std::vector<Key> keys(n);
+    std::vector<uint32_t> perm(n);
+    for (size_t i = 0; i < n; i++) {
+        keys[i] = {idA[i], idB[i], type[i]};
+        perm[i] = (uint32_t)i;
+    }
+    std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return key_less(keys[x], keys[y]); });
+    for (size_t i = 1; i < n; i++) {  // same rule as deme_seed_contacts: a pair may appear once
+        const Key &x = keys[perm[i - 1]], &y = keys[perm[i]];
+        if (x.a == y.a && x.b == y.b && x.t == y.t)
+            return DEME_ERR_INVALID;
+    }
+    s.cA.resize(n), s.cB.resize(n), s.cType.resize(n);
+    s.cMap.assign(n, DEME_NULL_MAPPING_PARTNER);
+    for (uint32_t w = 0; w < nW; w++)
+        s.wc[w].assign(n, 0.f);
+    for (size_t i = 0; i < n; i++) {
+        const Key& k = keys[perm[i]];
+        s.cA[i] = k.a, s.cB[i] = k.b, s.cType[i] = k.t;
+        for (uint32_t w = 0; w < nW; w++)
+            s.wc[w][i] = wildcards[(size_t)perm[i] * nW + w];
+    }
+    s.haveList = true;
+    s.seeded = true;
+    return DEME_OK;
+}
 size_t orc_sim_inspect(void* h, uint32_t q, float* reduced, float* values) {
     Sim& s = *(Sim*)h;
     const bool perSphere = q <= DEME_INSPECT_CLUMP_MAX_ABSV;

@@ -268,6 +268,15 @@ class OracleSim:
         st, _ = self._state_factory(self.n_owners, arrays)
         self.L.orc_sim_set_state(C.c_void_p(self.h), C.byref(st))
 
+    def seed_contacts(self, idA, idB, ctype, wildcards=None):
+        a = np.ascontiguousarray(idA, np.uint32)
+        b = np.ascontiguousarray(idB, np.uint32)
+        t = np.ascontiguousarray(ctype, np.uint8)
+        w = np.ascontiguousarray(wildcards if wildcards is not None else np.zeros((len(a), 0)), np.float32)
+        self.L.orc_sim_seed_contacts.restype = C.c_int
+        rc = self.L.orc_sim_seed_contacts(C.c_void_p(self.h), _p(a), _p(b), _p(t), _p(w), C.c_size_t(len(a)))
+        assert rc == 0, "duplicate contact pair in the seed list"
+
     def inspect(self, quantity, values=False):
         q = INSPECT_CODES[quantity] if isinstance(quantity, str) else int(quantity)
         n = self.n_spheres if q <= 2 else self.n_owners

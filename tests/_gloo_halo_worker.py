@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 GKEYS = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY",
          "omgBarZ")
 STEPS = 80
+STEPS_A, STEPS_B = 400, 20  # re-decomposition run: before / after the clumps change hands
 
 
 def pack(st, ids):
@@ -73,7 +74,70 @@ def worker(rank, world, port):
         assert err < 2e-7, err
         print(f"GLOO_HALO_OK max|dx|={err:.3e} contacts={one.counts().nContacts}")
     dist.barrier()
+    redecomposition_run(rank, world, dist, torch, pkg, orc)
+    dist.barrier()
     dist.destroy_process_group()
+
+
+def exchange_and_step(sim, me, rank, dist, torch, steps):
+    nb = 1 - rank
+    send_ids, recv_ids = (me["send_right"], me["recv_right"]) if rank == 0 else (me["send_left"], me["recv_left"])
+    for _ in range(steps):
+        st = sim.download_state()
+        out = torch.from_numpy(pack(st, send_ids))
+        inc = torch.empty(len(recv_ids) * len(GKEYS), dtype=torch.float64)
+        if rank == 0:
+            dist.send(out, nb), dist.recv(inc, nb)
+        else:
+            dist.recv(inc, nb), dist.send(out, nb)
+        unpack(st, recv_ids, inc.numpy())
+        sim.upload_state({k: st[k] for k in GKEYS})
+        sim.step(1)
+
+
+def redecomposition_run(rank, world, dist, torch, pkg, orc):
+    """sheared bed: clumps cross the cut; ownership and contact history migrate through
+    decomp.redecompose_distributed (all_gather_object) + seed_contacts"""
+    b = pkg.model.packed_bed(1200, seed=9, cd_freq=0, spacing_mult=2.5, init_vz=-0.4, aspect=(2.0, 1.0, 0.5))
+    p, sc = b.Initialize()
+    nC = int(sc.nOwnerClumps)
+    b.arrays["vX"][:nC] = np.where(np.arange(nC) % 2 == 0, 0.6, 0.3).astype(np.float32)
+    sc = pkg.abi.make_scene_struct(b.arrays, b.counts)
+    x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+    me = pkg.decomp.decompose(b.arrays, b.counts, x, world, halo=0.035)[rank]
+    sim = orc.make_sim(pkg, p, me["scene"])
+    exchange_and_step(sim, me, rank, dist, torch, STEPS_A)
+    cnt = sim.contacts()
+    W = np.stack([sim.wildcard(w) for w in range(int(p.nContactWildcards))], 1)
+
+    def decode_x(arrays):
+        return pkg.model.decode_positions(arrays["voxelID"], arrays["locX"], arrays["locY"], arrays["locZ"], p.nvXp2, p.nvYp2,
+                                          p.voxelSize, p.l)[:, 0] + p.LBFX
+
+    _, me2, seed = pkg.decomp.redecompose_distributed(dist, rank, world, b.arrays, b.counts, me, sim.download_state(), cnt, W,
+                                                      0.035, decode_x)
+    moved = len(np.setdiff1d(me2["global_ids"], me["global_ids"]))
+    sim2 = orc.make_sim(pkg, p, me2["scene"])
+    sim2.seed_contacts(*seed)
+    exchange_and_step(sim2, me2, rank, dist, torch, STEPS_B)
+    exchange_and_step(sim, me, rank, dist, torch, STEPS_B)  # the old decomposition simply continuing: the yardstick
+
+    def owned_x(s, part):
+        st = s.download_state()
+        return pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize,
+                                          p.l)[:part["n_own"]]
+
+    gathered = [None, None]
+    dist.all_gather_object(gathered, (me2["global_ids"], owned_x(sim2, me2), me["global_ids"], owned_x(sim, me), moved))
+    if rank == 0:
+        Xn, Xo = np.zeros((nC, 3)), np.zeros((nC, 3))
+        for ids2, x2, ids1, x1, _ in gathered:
+            Xn[ids2], Xo[ids1] = x2, x1
+        err = float(np.abs(Xn - Xo).max())
+        total_moved = sum(g[4] for g in gathered)
+        assert total_moved > 3, total_moved
+        assert err < 1e-9, err  # 5e-6 if the history is not carried (tests/test_decomp.py)
+        print(f"GLOO_REDECOMP_OK max|dx|={err:.3e} moved={total_moved}")
 
 
 if __name__ == "__main__":

@@ -96,6 +96,7 @@ def test_gloo_world2_halo_exchange(pkg):
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "GLOO_HALO_OK" in out.stdout
+    assert "GLOO_REDECOMP_OK" in out.stdout  # clumps and their contact history migrated between the two processes
 
 
 @pytest.mark.gpu
@@ -148,3 +149,75 @@ def test_two_slabs_on_gpu_match_single_domain(pkg):
     X1 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
     assert one.counts().nContacts > 300
     assert np.abs(X - X1).max() < 2e-7
+
+
+def _decode_x(pkg, p):
+    def f(arrays):
+        X = pkg.model.decode_positions(arrays["voxelID"], arrays["locX"], arrays["locY"], arrays["locZ"], p.nvXp2, p.nvYp2,
+                                       p.voxelSize, p.l)
+        return X[:, 0] + p.LBFX
+    return f
+
+
+def _run_with_redecomposition(pkg, make_sim, b, p, sc, x, steps_a, steps_b, n_ranks=2, halo=0.035):
+    """steps_a steps on the initial decomposition, then a re-decomposition at the current positions (clumps and their
+    contact history migrate) and steps_b more -- next to the SAME slabs simply continuing for steps_b (the drift is
+    far below the halo, so the static decomposition is still exact).  The two must agree to rounding: both continue
+    from bit-identical states, only the local numbering (hence the fp32 summation order) differs.  Comparing with a
+    single-domain run instead would measure the chaotic growth of those rounding differences over hundreds of steps."""
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, n_ranks, halo=halo)
+    sims = run_slabs(pkg, make_sim, parts, p, steps_a, host_exchange(pkg, parts))
+    nW = int(p.nContactWildcards)
+    payloads = []
+    for pt, s in zip(parts, sims):
+        cnt = s.contacts()
+        W = np.stack([s.wildcard(w) for w in range(nW)], 1) if nW else np.zeros((len(cnt[0]), 0), np.float32)
+        payloads.append(pkg.decomp.owned_payload(pt, s.download_state(), cnt, W))
+    g, parts2, seeds = pkg.decomp.redecompose(b.arrays, b.counts, payloads, n_ranks, halo, _decode_x(pkg, p))
+    moved = sum(len(np.setdiff1d(a["global_ids"], b_["global_ids"])) for a, b_ in zip(parts2, parts))
+    sims2 = []
+    for pt, sd in zip(parts2, seeds):
+        s = make_sim(p, pt["scene"])
+        s.seed_contacts(*sd)
+        sims2.append(s)
+    ex, ex2 = host_exchange(pkg, parts), host_exchange(pkg, parts2)
+    for _ in range(steps_b):
+        ex(sims), ex2(sims2)
+        for s in sims + sims2:
+            s.step(1)
+    X, V = gather_positions(pkg, parts2, sims2, p, sc.nOwnerClumps)
+    X0, V0 = gather_positions(pkg, parts, sims, p, sc.nOwnerClumps)
+    return X, V, X0, V0, moved, seeds
+
+
+def _sheared_bed(pkg, n, seed):
+    # neighbouring clumps start with different x-velocities: the bed shears and clumps cross the cut
+    b, p, sc, x = build_global(pkg, n=n, seed=seed)
+    nc = int(sc.nOwnerClumps)
+    b.arrays["vX"][:nc] = np.where(np.arange(nc) % 2 == 0, 0.6, 0.3).astype(np.float32)
+    return b, p, pkg.abi.make_scene_struct(b.arrays, b.counts), x
+
+
+def test_redecomposition_migrates_clumps_and_history_oracle(pkg, orc):
+    b, p, sc, x = _sheared_bed(pkg, 1200, 9)
+    X, V, X0, V0, moved, seeds = _run_with_redecomposition(pkg, lambda pp, s: orc.make_sim(pkg, pp, s), b, p, sc, x, 400, 20)
+    assert moved > 3  # ownership really changed hands
+    assert sum(len(s[0]) for s in seeds) > 200 and any((s[2] == 1).any() for s in seeds)
+    # measured: 1.5e-12 m / 3e-8 m/s with the history carried; 5.7e-6 m / 0.09 m/s when it is dropped, 1.6e-6 m /
+    # 0.02 m/s when the B-to-A vector wildcards of mirrored pairs are not negated
+    assert np.abs(X - X0).max() < 1e-9 and np.abs(V - V0).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_redecomposition_on_gpu(pkg):
+    b, p, sc, x = _sheared_bed(pkg, 3000, 6)
+
+    def make(pp, s):
+        ctx = pkg.Context(0)
+        ctx.set_params(pp)
+        ctx.upload_scene(s)
+        return ctx
+
+    X, V, X0, V0, moved, seeds = _run_with_redecomposition(pkg, make, b, p, sc, x, 400, 20)
+    assert moved > 5
+    assert np.abs(X - X0).max() < 1e-9 and np.abs(V - V0).max() < 1e-5
