@@ -14,6 +14,8 @@ NULL_MAPPING_PARTNER = 0xFFFFFFFF
 FAMILY_MASK_ENTRIES = 32896
 NUM_FAMILIES = 256
 FAMILY_FIXED = 1
+FAMILY_GHOST = 2
+FAMILY_PRESCRIBED = 4
 INTEGRATOR_FORWARD_EULER, INTEGRATOR_CENTERED_DIFFERENCE, INTEGRATOR_EXTENDED_TAYLOR = 0, 1, 2
 FORCE_HERTZIAN, FORCE_HERTZIAN_FRICTIONLESS, FORCE_CUSTOM = 0, 1, 2
 GHOST_BYTES = 56
@@ -173,6 +175,7 @@ def load_library():
         "deme_download_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_upload_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_seed_contacts": [_P, _P, _P, _P, _P, C.c_size_t],
+        "deme_compile_prescriptions": [_P, C.c_char_p, C.c_char_p, C.c_char_p],
         "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)], "deme_inspect_values": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_set_record_contacts": [_P, C.c_int],
         "deme_download_contact_records": [_P, _P, _P, _P, _P, C.c_size_t],
@@ -342,6 +345,11 @@ class Context:
         out = np.zeros(int(n), np.float32)
         self._ck(self.lib.deme_inspect_values(self.h, self.INSPECT_CODES[quantity], _ptr(out), out.size), "deme_inspect_values")
         return out
+
+    def compile_prescriptions(self, vel_cases, pos_cases, acc_cases):
+        """Family motion prescriptions: the three switch bodies of equipFamilyPrescribedMotions (see include/deme_hip.h)."""
+        self._ck(self.lib.deme_compile_prescriptions(self.h, vel_cases.encode(), pos_cases.encode(), acc_cases.encode()),
+                 "deme_compile_prescriptions")
 
     def seed_contacts(self, idA, idB, ctype, wildcards=None):
         """Restart: saved contact pairs (geometry ids) + wildcards [n, nW] feed the next history map."""

@@ -67,6 +67,20 @@ struct __attribute__((aligned(16))) AnalObj {  // AnalyticalCompDefJitify.cu:2-1
     uint32_t pad0, pad1;
 };
 
+// One record per owner whose family carries a motion prescription (DEME_FAMILY_PRESCRIBED): what the user's
+// prescription code (compiled at run time, deme_jit.h) decided for this step.  Consumed by k_integrate with the
+// per-component semantics of integrateVelPos (kernel/DEMIntegrationKernels.cu:100-236).
+struct __attribute__((aligned(8))) PrescRec {
+    double X, Y, Z;           // position after applyPrescribedPos (world frame, LBF included)
+    float vx, vy, vz;         // velocities after applyPrescribedVel
+    float wx, wy, wz;
+    float qw, qx, qy, qz;     // orientation after applyPrescribedPos
+    float ax, ay, az;         // applyAddedAcceleration
+    float lx, ly, lz;
+    uint32_t flags;           // bit 0-2 LinVelX/Y/Z, 3-5 RotVelX/Y/Z, 6-8 LinX/Y/Z, 9 Rot prescribed
+    uint32_t pad;
+};
+
 struct MatPair {  // per (matA, matB): everything the Hertzian models derive from materials alone
     float E_cnt, G_cnt, CoR, mu, Crr, beta, E_A_unused, pad;
 };

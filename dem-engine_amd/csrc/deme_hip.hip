@@ -81,7 +81,14 @@ struct deme_ctx {
     uint64_t nActiveBins = 0;
     uint32_t maxInBin = 0;
     bool haveList = false, mapFresh = false;
-    bool seeded = false;  // the list was loaded by deme_seed_contacts: it only feeds the next history map
+    bool seeded = false;
+    // family motion prescriptions: run-time compiled kernel + the owners it applies to
+    hipModule_t prescMod = nullptr;
+    hipFunction_t prescFn = nullptr;
+    DevBuf prescList, prescSlot, prescRec;
+    uint32_t nPresc = 0;
+    uint8_t hostFamFlags[DEME_NUM_FAMILIES] = {0};
+    bool prescDirty = true;  // owner -> family assignment changed: rebuild the list  // the list was loaded by deme_seed_contacts: it only feeds the next history map
     bool record = false;
     uint64_t nSteps = 0, nDetections = 0;
     uint32_t stepsSinceCD = 0;
@@ -579,15 +586,61 @@ int launch_forces(deme_ctx* c) {
     return DEME_OK;
 }
 
+// owners of prescribed families (rebuilt when families were uploaded); host-side: this is a set-up path
+int rebuild_presc_list(deme_ctx* c) {
+    c->prescDirty = false;
+    c->nPresc = 0;
+    if (!c->prescFn)
+        return DEME_OK;
+    std::vector<OwnerRec> h(c->nOwners);
+    HIPCK(hipMemcpyAsync(h.data(), c->owners.p, (size_t)c->nOwners * sizeof(OwnerRec), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> list, slot(c->nOwners, 0u);
+    for (uint32_t o = 0; o < c->nOwners; o++)
+        if (c->hostFamFlags[h[o].family & 255u] & DEME_FAMILY_PRESCRIBED) {
+            slot[o] = (uint32_t)list.size();
+            list.push_back(o);
+        }
+    c->nPresc = (uint32_t)list.size();
+    if (int rc = ensure(c, c->prescList, std::max<size_t>(list.size(), 1) * 4))
+        return rc;
+    if (int rc = ensure(c, c->prescSlot, std::max<size_t>(c->nOwners, 1) * 4))
+        return rc;
+    if (int rc = ensure(c, c->prescRec, std::max<size_t>(list.size(), 1) * sizeof(PrescRec)))
+        return rc;
+    if (!list.empty())
+        HIPCK(hipMemcpyAsync(c->prescList.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->prescSlot.p, slot.data(), slot.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
 int launch_integrate(deme_ctx* c, bool fused) {
     ScopedTimer tm(c, "integrate");
+    PrescArgs pa{nullptr, nullptr};
+    if (c->prescFn) {
+        if (c->prescDirty)
+            if (int rc = rebuild_presc_list(c))
+                return rc;
+        if (c->nPresc) {
+            const OwnerRec* ow = c->owners.as<OwnerRec>();
+            const uint32_t* list = c->prescList.as<uint32_t>();
+            PrescRec* rec = c->prescRec.as<PrescRec>();
+            uint32_t n = c->nPresc;
+            float t = (float)c->timeElapsed;
+            void* args[] = {&c->dp, &ow, &list, &n, &rec, &t};
+            HIPCK(hipModuleLaunchKernel(c->prescFn, grid_for(n), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+            pa.rec = rec;
+            pa.slot = c->prescSlot.as<uint32_t>();
+        }
+    }
     if (fused) {
         launch_reduce_heavy(c, true);
         hipLaunchKernelGGL(k_integrate<true>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
-                           c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c));
+                           c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c), pa);
     } else {
         hipLaunchKernelGGL(k_integrate<false>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
-                           c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c));
+                           c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c), pa);
     }
     return DEME_OK;
 }
@@ -638,7 +691,7 @@ void deme_ctx_destroy(deme_ctx* c) {
     drain_timers(c);
     for (auto e : c->eventPool)
         hipEventDestroy(e);
-    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -793,6 +846,10 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         upload(c, c->famExtra, s->familyExtraMarginSize, (size_t)DEME_NUM_FAMILIES) ||
         upload(c, c->famFlags, s->familyFlags, (size_t)DEME_NUM_FAMILIES))
         return c->lastStatus;
+    memset(c->hostFamFlags, 0, sizeof(c->hostFamFlags));
+    if (s->familyFlags)
+        memcpy(c->hostFamFlags, s->familyFlags, DEME_NUM_FAMILIES);
+    c->prescDirty = true;
     bool trivial = true;
     if (s->familyMasks)
         for (size_t i = 0; i < DEME_FAMILY_MASK_ENTRIES && trivial; i++)
@@ -919,7 +976,11 @@ static int owner_state_io(deme_ctx* c, const DemeOwnerState* st, int dir) {
     return DEME_OK;
 }
 
-int deme_upload_owner_state(deme_ctx* c, const DemeOwnerState* st) { return owner_state_io(c, st, 0); }
+int deme_upload_owner_state(deme_ctx* c, const DemeOwnerState* st) {
+    if (c && st && st->familyID)
+        c->prescDirty = true;  // owners may have changed family
+    return owner_state_io(c, st, 0);
+}
 int deme_download_owner_state(deme_ctx* c, DemeOwnerState* st) { return owner_state_io(c, st, 1); }
 
 int deme_update_tri_nodes(deme_ctx* c, const float* n1, const float* n2, const float* n3) {
@@ -1254,6 +1315,35 @@ int deme_compile_force_model(deme_ctx* c, const char* src, size_t len, const cha
     HIPCK(hipModuleGetFunction(&c->customFn[0], c->customMod, "deme_custom_forces_ss"));
     HIPCK(hipModuleGetFunction(&c->customFn[1], c->customMod, "deme_custom_forces_sm"));
 
+    return DEME_OK;
+}
+
+int deme_compile_prescriptions(deme_ctx* c, const char* velCases, const char* posCases, const char* accCases) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (c->prescMod) {
+        (void)hipModuleUnload(c->prescMod);
+        c->prescMod = nullptr;
+        c->prescFn = nullptr;
+    }
+    c->prescDirty = true;
+    const std::string v = velCases ? velCases : "", ps = posCases ? posCases : "", a = accCases ? accCases : "";
+    if (v.empty() && ps.empty() && a.empty())
+        return DEME_OK;
+    std::string gen;
+    deme_jit::generate_prescribe_source(v, ps, a, gen);
+    const size_t key = std::hash<std::string>{}(gen);
+    auto it = c->jitCache.find(key);
+    if (it == c->jitCache.end()) {
+        std::vector<char> code;
+        std::string log;
+        if (deme_jit::compile(gen, code, log))
+            return fail(c, DEME_ERR_COMPILE, "family prescriptions failed to compile:\n%.900s", log.c_str());
+        it = c->jitCache.emplace(key, std::move(code)).first;
+    }
+    HIPCK(hipModuleLoadData(&c->prescMod, it->second.data()));
+    HIPCK(hipModuleGetFunction(&c->prescFn, c->prescMod, "deme_prescribe"));
     return DEME_OK;
 }
 

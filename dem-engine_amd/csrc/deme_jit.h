@@ -188,6 +188,80 @@ inline int generate_source(const std::string& user, const std::vector<std::strin
     return 0;
 }
 
+// Family motion prescriptions (DEMSolver::SetFamilyPrescribedLinVel & co.; code generation of
+// DEM/APIPrivate.cpp:1600-1708 equipFamilyPrescribedMotions).  The three strings are the BODIES of the
+// `switch (family)` statements of applyPrescribedVel / applyPrescribedPos / applyAddedAcceleration
+// (kernel/DEMIntegrationKernels.cu:8-98), i.e. "case 3: { ... break; }" sequences written against the reference's
+// parameter names.  The generated kernel runs over the owners of prescribed families only and leaves one PrescRec
+// each for k_integrate.
+inline void generate_prescribe_source(const std::string& velCases, const std::string& posCases, const std::string& accCases,
+                                      std::string& out) {
+    std::ostringstream o;
+    o << "#include \"deme_device.h\"\n" << kVocabulary << R"DEMEPRE(
+namespace deme_dev {
+__device__ inline void applyPrescribedVel(bool& LinVelXPrescribed, bool& LinVelYPrescribed, bool& LinVelZPrescribed,
+                                          bool& RotVelXPrescribed, bool& RotVelYPrescribed, bool& RotVelZPrescribed, float& vX,
+                                          float& vY, float& vZ, float& omgBarX, float& omgBarY, float& omgBarZ, double X, double Y,
+                                          double Z, float oriQw, float oriQx, float oriQy, float oriQz, deme::bodyID_t ownerID,
+                                          const deme::family_t& family, const float& t) {
+    switch (family) {
+)DEMEPRE" << velCases << R"DEMEPRE(
+        default:
+            return;
+    }
+}
+__device__ inline void applyPrescribedPos(bool& LinXPrescribed, bool& LinYPrescribed, bool& LinZPrescribed, bool& RotPrescribed,
+                                          double& X, double& Y, double& Z, float& oriQw, float& oriQx, float& oriQy, float& oriQz,
+                                          float vX, float vY, float vZ, float omgBarX, float omgBarY, float omgBarZ,
+                                          deme::bodyID_t ownerID, const deme::family_t& family, const float& t) {
+    switch (family) {
+)DEMEPRE" << posCases << R"DEMEPRE(
+        default:
+            return;
+    }
+}
+__device__ inline void applyAddedAcceleration(float& accX, float& accY, float& accZ, float& angAccX, float& angAccY, float& angAccZ,
+                                              double X, double Y, double Z, float oriQw, float oriQx, float oriQy, float oriQz,
+                                              float vX, float vY, float vZ, float omgBarX, float omgBarY, float omgBarZ,
+                                              deme::bodyID_t ownerID, const deme::family_t& family, const float& t) {
+    switch (family) {
+)DEMEPRE" << accCases << R"DEMEPRE(
+        default:
+            return;
+    }
+}
+}  // namespace deme_dev
+extern "C" __global__ __launch_bounds__(256) void deme_prescribe(const deme_dev::DevParams p, const deme_dev::OwnerRec* owners,
+                                                                 const uint32_t* list, uint32_t n, deme_dev::PrescRec* out,
+                                                                 float t) {
+    using namespace deme_dev;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t ownerID = list[i];
+    OwnerRec r = load_owner(owners, ownerID);
+    const deme::family_t family = (deme::family_t)r.family;
+    d3 P = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);
+    double X = P.x + (double)p.LBFX, Y = P.y + (double)p.LBFY, Z = P.z + (double)p.LBFZ;
+    bool lvx = false, lvy = false, lvz = false, rvx = false, rvy = false, rvz = false, lx = false, ly = false, lz = false, rot = false;
+    applyPrescribedVel(lvx, lvy, lvz, rvx, rvy, rvz, r.vx, r.vy, r.vz, r.wx, r.wy, r.wz, X, Y, Z, r.qw, r.qx, r.qy, r.qz, ownerID, family, t);
+    applyPrescribedPos(lx, ly, lz, rot, X, Y, Z, r.qw, r.qx, r.qy, r.qz, r.vx, r.vy, r.vz, r.wx, r.wy, r.wz, ownerID, family, t);
+    PrescRec q;
+    q.ax = q.ay = q.az = q.lx = q.ly = q.lz = 0.f;
+    applyAddedAcceleration(q.ax, q.ay, q.az, q.lx, q.ly, q.lz, X, Y, Z, r.qw, r.qx, r.qy, r.qz, r.vx, r.vy, r.vz, r.wx, r.wy, r.wz,
+                           ownerID, family, t);
+    q.X = X, q.Y = Y, q.Z = Z;
+    q.vx = r.vx, q.vy = r.vy, q.vz = r.vz, q.wx = r.wx, q.wy = r.wy, q.wz = r.wz;
+    q.qw = r.qw, q.qx = r.qx, q.qy = r.qy, q.qz = r.qz;
+    q.flags = (lvx ? 1u : 0u) | (lvy ? 2u : 0u) | (lvz ? 4u : 0u) | (rvx ? 8u : 0u) | (rvy ? 16u : 0u) | (rvz ? 32u : 0u) |
+              (lx ? 64u : 0u) | (ly ? 128u : 0u) | (lz ? 256u : 0u) | (rot ? 512u : 0u);
+    q.pad = 0u;
+    out[i] = q;
+}
+)DEMEPRE";
+    out = o.str();
+}
+
 // hipRTC: source -> gfx950 code object.  Needs no GPU (used by the CPU test through deme_jit_probe).
 inline int compile(const std::string& src, std::vector<char>& code, std::string& log) {
     hiprtcProgram prog;

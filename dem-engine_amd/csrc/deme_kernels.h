@@ -825,9 +825,14 @@ __global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_
     }
 }
 
+struct PrescArgs {
+    const PrescRec* rec;    // null: no family carries a prescription
+    const uint32_t* slot;   // per owner: index into rec (only read for owners of a prescribed family)
+};
+
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* __restrict__ owners,
-                                                   AccRec* __restrict__ acc, const GatherArgs g) {
+                                                   AccRec* __restrict__ acc, const GatherArgs g, const PrescArgs pa) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = o < p.nOwners;
     OwnerRec r = load_owner(owners, valid ? o : 0u);
@@ -863,6 +868,20 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
     X.x += (double)p.LBFX;
     X.y += (double)p.LBFY;
     X.z += (double)p.LBFZ;
+    // prescribed motion (applyPrescribedVel / applyPrescribedPos / applyAddedAcceleration,
+    // DEMIntegrationKernels.cu:8-98): evaluated by the run-time compiled k_prescribe just before this kernel
+    uint32_t pf = 0u;
+    f3 extra_a = mk3(0, 0, 0), extra_al = mk3(0, 0, 0);
+    if (pa.rec && (fflags & 4u)) {
+        const PrescRec pr = pa.rec[pa.slot[o]];
+        pf = pr.flags;
+        r.vx = pr.vx, r.vy = pr.vy, r.vz = pr.vz;
+        r.wx = pr.wx, r.wy = pr.wy, r.wz = pr.wz;
+        r.qw = pr.qw, r.qx = pr.qx, r.qy = pr.qy, r.qz = pr.qz;
+        X = {pr.X, pr.Y, pr.Z};
+        extra_a = mk3(pr.ax, pr.ay, pr.az);
+        extra_al = mk3(pr.lx, pr.ly, pr.lz);
+    }
     f3 v_upd = mk3(0, 0, 0), w_upd = mk3(0, 0, 0);
     if (fixed) {
         r.vx = r.vy = r.vz = 0.f;
@@ -870,18 +889,42 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         old_v = mk3(0, 0, 0);
         old_w = mk3(0, 0, 0);
     } else {
-        v_upd.x = (a.x + 0.f + p.Gx) * h;
-        r.vx += v_upd.x;
-        v_upd.y = (a.y + 0.f + p.Gy) * h;
-        r.vy += v_upd.y;
-        v_upd.z = (a.z + 0.f + p.Gz) * h;
-        r.vz += v_upd.z;
-        w_upd.x = (al.x + 0.f) * h;
-        r.wx += w_upd.x;
-        w_upd.y = (al.y + 0.f) * h;
-        r.wy += w_upd.y;
-        w_upd.z = (al.z + 0.f) * h;
-        r.wz += w_upd.z;
+        if (!(pf & 1u)) {
+            v_upd.x = (a.x + extra_a.x + p.Gx) * h;
+            r.vx += v_upd.x;
+        } else {
+            old_v.x = r.vx;
+        }
+        if (!(pf & 2u)) {
+            v_upd.y = (a.y + extra_a.y + p.Gy) * h;
+            r.vy += v_upd.y;
+        } else {
+            old_v.y = r.vy;
+        }
+        if (!(pf & 4u)) {
+            v_upd.z = (a.z + extra_a.z + p.Gz) * h;
+            r.vz += v_upd.z;
+        } else {
+            old_v.z = r.vz;
+        }
+        if (!(pf & 8u)) {
+            w_upd.x = (al.x + extra_al.x) * h;
+            r.wx += w_upd.x;
+        } else {
+            old_w.x = r.wx;
+        }
+        if (!(pf & 16u)) {
+            w_upd.y = (al.y + extra_al.y) * h;
+            r.wy += w_upd.y;
+        } else {
+            old_w.y = r.wy;
+        }
+        if (!(pf & 32u)) {
+            w_upd.z = (al.z + extra_al.z) * h;
+            r.wz += w_upd.z;
+        } else {
+            old_w.z = r.wz;
+        }
     }
     f3 v, w;
     if (p.integrator == 0) {
@@ -895,15 +938,18 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         w = old_w + w_upd * 0.5f;
     }
     if (!fixed) {
-        X.x += (double)v.x * h;
-        X.y += (double)v.y * h;
-        X.z += (double)v.z * h;
+        if (!(pf & 64u))
+            X.x += (double)v.x * h;
+        if (!(pf & 128u))
+            X.y += (double)v.y * h;
+        if (!(pf & 256u))
+            X.z += (double)v.z * h;
     }
     X.x -= (double)p.LBFX;
     X.y -= (double)p.LBFY;
     X.z -= (double)p.LBFZ;
     encode_pos(X, p, r.voxelID, r.locX, r.locY, r.locZ);
-    if (!fixed) {
+    if (!fixed && !(pf & 512u)) {
         const float hh = (float)(0.5 * h);
         const f3 ha = hh * w;
         // HamiltonProduct(q, (1, ha)) : DEMHelperKernels.cuh:228-245

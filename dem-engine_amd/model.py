@@ -372,9 +372,131 @@ class SceneBuilder:
         return "\n".join(out) + "\n" + getattr(self, "user_prerequisites", "")
 
     def compile_into(self, ctx):
-        """Call after ctx.upload_scene(): builds the user model into the context."""
+        """Call after ctx.upload_scene(): builds the user model and the family prescriptions into the context."""
         if self.force_model == abi.FORCE_CUSTOM:
             ctx.compile_force_model(self.force_src, getattr(self, "contact_wildcards", []), self.force_model_prerequisites())
+        if getattr(self, "_presc_inputs", None):
+            ctx.compile_prescriptions(*self.prescription_cases())
+
+    # ---- family motion prescriptions (API.h:720-838; APIPublic.cpp:1013-1330) ---------------------------------
+    _PRESC_FIELDS = ("linPosX", "linPosY", "linPosZ", "linVelX", "linVelY", "linVelZ", "oriQ", "rotVelX", "rotVelY", "rotVelZ",
+                     "linPosPre", "linVelPre", "rotVelPre", "accX", "accY", "accZ", "angAccX", "angAccY", "angAccZ", "accPre",
+                     "angAccPre")
+    _PRESC_FLAGS = ("linVelXPrescribed", "linVelYPrescribed", "linVelZPrescribed", "rotVelXPrescribed", "rotVelYPrescribed",
+                    "rotVelZPrescribed", "rotPosPrescribed", "linPosXPrescribed", "linPosYPrescribed", "linPosZPrescribed")
+
+    def _presc(self, fam, **kw):
+        if int(fam) > 255:
+            raise ValueError(f"You applied prescribed motion to family {fam}, but family number should not be larger than 255.")
+        if not hasattr(self, "_presc_inputs"):
+            self._presc_inputs = []
+        info = {k: "none" for k in self._PRESC_FIELDS}
+        info.update({k: False for k in self._PRESC_FLAGS})
+        info["family"] = int(fam)
+        info.update(kw)
+        self._presc_inputs.append(info)
+        self.family_flags[int(fam)] |= abi.FAMILY_PRESCRIBED
+
+    def SetFamilyPrescribedLinVel(self, fam, velX="none", velY="none", velZ="none", dictate=True, pre="none"):
+        """Strings are C++ expressions of t (and X, Y, Z, vX ... as in the reference); "none": leave that component.  With
+        dictate the family ignores contact forces for its translation AND rotation (APIPublic.cpp:1013-1054)."""
+        f = {k: dictate for k in ("linVelXPrescribed", "linVelYPrescribed", "linVelZPrescribed", "rotVelXPrescribed",
+                                  "rotVelYPrescribed", "rotVelZPrescribed")}
+        for k, v in (("linVelXPrescribed", velX), ("linVelYPrescribed", velY), ("linVelZPrescribed", velZ)):
+            if v != "none":
+                f[k] = True
+        self._presc(fam, linVelX=velX, linVelY=velY, linVelZ=velZ, linVelPre=pre, **f)
+
+    def SetFamilyPrescribedAngVel(self, fam, velX="none", velY="none", velZ="none", dictate=True, pre="none"):
+        f = {k: dictate for k in ("linVelXPrescribed", "linVelYPrescribed", "linVelZPrescribed", "rotVelXPrescribed",
+                                  "rotVelYPrescribed", "rotVelZPrescribed")}
+        for k, v in (("rotVelXPrescribed", velX), ("rotVelYPrescribed", velY), ("rotVelZPrescribed", velZ)):
+            if v != "none":
+                f[k] = True
+        self._presc(fam, rotVelX=velX, rotVelY=velY, rotVelZ=velZ, rotVelPre=pre, **f)
+
+    def SetFamilyPrescribedPosition(self, fam, X="none", Y="none", Z="none", dictate=True, pre="none"):
+        f = {k: dictate for k in ("linPosXPrescribed", "linPosYPrescribed", "linPosZPrescribed", "rotPosPrescribed")}
+        for k, v in (("linPosXPrescribed", X), ("linPosYPrescribed", Y), ("linPosZPrescribed", Z)):
+            if v != "none":
+                f[k] = True
+        self._presc(fam, linPosX=X, linPosY=Y, linPosZ=Z, linPosPre=pre, **f)
+
+    def SetFamilyPrescribedQuaternion(self, fam, q_formula="none", dictate=True):
+        """q_formula: statements that `return` a float4 (x, y, z, w), e.g. "return make_float4(0, 0, sinf(t), cosf(t));"."""
+        f = {k: dictate for k in ("linPosXPrescribed", "linPosYPrescribed", "linPosZPrescribed", "rotPosPrescribed")}
+        if q_formula != "none":
+            f["rotPosPrescribed"] = True
+        self._presc(fam, oriQ=q_formula, **f)
+
+    def AddFamilyPrescribedAcc(self, fam, X="none", Y="none", Z="none", pre="none"):
+        self._presc(fam, accX=X, accY=Y, accZ=Z, accPre=pre)
+
+    def AddFamilyPrescribedAngAcc(self, fam, X="none", Y="none", Z="none", pre="none"):
+        self._presc(fam, angAccX=X, angAccY=Y, angAccZ=Z, angAccPre=pre)
+
+    def prescription_cases(self):
+        """The three switch bodies of equipFamilyPrescribedMotions (APIPrivate.cpp:1600-1708), after the per-family merge
+        of APIPrivate.cpp:843-937 (later strings replace earlier ones, flags are OR-ed)."""
+        merged = {}
+        for inp in self._presc_inputs:
+            m = merged.setdefault(inp["family"], dict({k: "none" for k in self._PRESC_FIELDS}, **{k: False for k in self._PRESC_FLAGS}))
+            for k in self._PRESC_FIELDS:
+                if inp[k] != "none":
+                    m[k] = inp[k]
+            for k in self._PRESC_FLAGS:
+                m[k] = m[k] or inp[k]
+        vel = pos = acc = " "
+        b = lambda v: "1" if v else "0"  # std::to_string(bool)
+        for fam in sorted(merged):
+            m = merged[fam]
+            head = f"case {fam}: {{"
+            v = head + "{"
+            if m["linVelPre"] != "none":
+                v += m["linVelPre"] + ";"
+            for name, key in (("vX", "linVelX"), ("vY", "linVelY"), ("vZ", "linVelZ")):
+                if m[key] != "none":
+                    v += f"{name} = {m[key]};"
+            v += "}{"
+            if m["rotVelPre"] != "none":
+                v += m["rotVelPre"] + ";"
+            for name, key in (("omgBarX", "rotVelX"), ("omgBarY", "rotVelY"), ("omgBarZ", "rotVelZ")):
+                if m[key] != "none":
+                    v += f"{name} = {m[key]};"
+            v += "}"
+            for name, key in (("LinVelXPrescribed", "linVelXPrescribed"), ("LinVelYPrescribed", "linVelYPrescribed"),
+                              ("LinVelZPrescribed", "linVelZPrescribed"), ("RotVelXPrescribed", "rotVelXPrescribed"),
+                              ("RotVelYPrescribed", "rotVelYPrescribed"), ("RotVelZPrescribed", "rotVelZPrescribed")):
+                v += f"{name} = {b(m[key])};"
+            vel += v + "break; }"
+            q = head + "{"
+            if m["linPosPre"] != "none":
+                q += m["linPosPre"] + ";"
+            for name, key in (("X", "linPosX"), ("Y", "linPosY"), ("Z", "linPosZ")):
+                if m[key] != "none":
+                    q += f"{name} = {m[key]};"
+            q += "}"
+            if m["oriQ"] != "none":
+                q += "{" + m["oriQ"].replace("return", "float4 DEME_Presc_OriQ = ") + ";"
+                q += "oriQw = DEME_Presc_OriQ.w; oriQx = DEME_Presc_OriQ.x; oriQy = DEME_Presc_OriQ.y; oriQz = DEME_Presc_OriQ.z;}"
+            for name, key in (("LinXPrescribed", "linPosXPrescribed"), ("LinYPrescribed", "linPosYPrescribed"),
+                              ("LinZPrescribed", "linPosZPrescribed"), ("RotPrescribed", "rotPosPrescribed")):
+                q += f"{name} = {b(m[key])};"
+            pos += q + "break; }"
+            a = head + "{"
+            if m["accPre"] != "none":
+                a += m["accPre"] + ";"
+            for name, key in (("accX", "accX"), ("accY", "accY"), ("accZ", "accZ")):
+                if m[key] != "none":
+                    a += f"{name} = {m[key]};"
+            a += "}{"
+            if m["angAccPre"] != "none":
+                a += m["angAccPre"] + ";"
+            for name, key in (("angAccX", "angAccX"), ("angAccY", "angAccY"), ("angAccZ", "angAccZ")):
+                if m[key] != "none":
+                    a += f"{name} = {m[key]};"
+            acc += a + "}break; }"
+        return vel, pos, acc
 
     def SetFamilyFixed(self, fam):
         self.family_flags[int(fam)] |= abi.FAMILY_FIXED

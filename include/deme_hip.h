@@ -53,6 +53,7 @@ extern "C" {
 #define DEME_FAMILY_FIXED 1
 /* copy of a clump that another rank owns and integrates (slab decomposition): never integrated here */
 #define DEME_FAMILY_GHOST 2
+#define DEME_FAMILY_PRESCRIBED 4 /* the family has a compiled motion prescription (deme_compile_prescriptions) */
 
 /* status codes */
 #define DEME_OK 0
@@ -226,6 +227,14 @@ int deme_download_sphere_geometry(deme_ctx* ctx, double* X, double* Y, double* Z
  * wildcardNames: nWildcards names of per-contact float history variables. */
 int deme_compile_force_model(deme_ctx* ctx, const char* src, size_t len, const char* const* wildcardNames,
                              uint32_t nWildcards, const char* prerequisites);
+
+/* Family motion prescriptions (SetFamilyPrescribedLinVel / AngVel / Position / Quaternion, AddFamilyPrescribedAcc /
+ * AngAcc; API.h:720-838).  The three strings are the bodies of the `switch (family)` statements the reference generates in
+ * equipFamilyPrescribedMotions (APIPrivate.cpp:1600-1708) for applyPrescribedVel / applyPrescribedPos /
+ * applyAddedAcceleration (DEMIntegrationKernels.cu:8-98): "case <family>: { ...; break; }" sequences over the names
+ * vX..omgBarZ, X, Y, Z, oriQw..oriQz, accX..angAccZ, t, ownerID and the ...Prescribed flags.  They are compiled for gfx950
+ * with hipRTC; the families concerned must carry DEME_FAMILY_PRESCRIBED in DemeScene.familyFlags.  NULL / "" clears. */
+int deme_compile_prescriptions(deme_ctx* ctx, const char* velCases, const char* posCases, const char* accCases);
 
 /* compile-only check of a fragment (no context, no GPU needed): same generator and hipRTC options,
  * 2 dummy materials; the compiler log is copied into `log`. */

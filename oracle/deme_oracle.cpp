@@ -628,6 +628,15 @@ struct Sim {
     uint32_t stepsSinceCD = 0;
     bool haveList = false;
     bool seeded = false;  // list loaded by orc_sim_seed_contacts: only feeds the next history map
+    // family motion prescriptions in a parametric test form: quantity k of family f = c0 + c1*t + c2*sinf(c3*t) (fp32), the
+    // same expression the GPU tests hand to the run-time compiler as a string.  k: 0-2 v, 3-5 omgBar, 6-8 position,
+    // 9-11 added linear acc, 12-14 added angular acc.  `has` bit k: quantity k is assigned; `flags`: PrescRec::flags bits.
+    struct Presc {
+        bool used = false;
+        uint32_t has = 0, flags = 0;
+        float c[15][4] = {};
+    };
+    std::vector<Presc> presc = std::vector<Presc>(256);
 };
 
 template <typename T>
@@ -1174,6 +1183,26 @@ void integrate(Sim& s) {
         X += (double)s.p.LBFX;
         Y += (double)s.p.LBFY;
         Z += (double)s.p.LBFZ;
+        // prescribed motion: applyPrescribedVel / applyPrescribedPos / applyAddedAcceleration (DEMIntegrationKernels.cu:8-98)
+        uint32_t pf = 0;
+        float ext[6] = {0, 0, 0, 0, 0, 0};
+        const Sim::Presc& pr = s.presc[s.familyID[o]];
+        if (pr.used && (s.famFlags[s.familyID[o]] & DEME_FAMILY_PRESCRIBED)) {
+            const float t = (float)s.p.timeElapsed;
+            auto val = [&](int k) { return pr.c[k][0] + pr.c[k][1] * t + pr.c[k][2] * sinf(pr.c[k][3] * t); };
+            float* tgt[6] = {&s.vX[o], &s.vY[o], &s.vZ[o], &s.omgX[o], &s.omgY[o], &s.omgZ[o]};
+            for (int k = 0; k < 6; k++)
+                if (pr.has & (1u << k))
+                    *tgt[k] = val(k);
+            double* ptg[3] = {&X, &Y, &Z};
+            for (int k = 0; k < 3; k++)
+                if (pr.has & (1u << (6 + k)))
+                    *ptg[k] = val(6 + k);
+            for (int k = 0; k < 6; k++)
+                if (pr.has & (1u << (9 + k)))
+                    ext[k] = val(9 + k);
+            pf = pr.flags;
+        }
         V3f v_upd{0, 0, 0}, w_upd{0, 0, 0};
         if (fixed) {
             s.vX[o] = s.vY[o] = s.vZ[o] = 0.f;
@@ -1181,18 +1210,42 @@ void integrate(Sim& s) {
             old_v = {0, 0, 0};
             old_w = {0, 0, 0};
         } else {
-            v_upd.x = (s.aX[o] + 0.f + s.p.Gx) * h;
-            s.vX[o] += v_upd.x;
-            v_upd.y = (s.aY[o] + 0.f + s.p.Gy) * h;
-            s.vY[o] += v_upd.y;
-            v_upd.z = (s.aZ[o] + 0.f + s.p.Gz) * h;
-            s.vZ[o] += v_upd.z;
-            w_upd.x = (s.alX[o] + 0.f) * h;
-            s.omgX[o] += w_upd.x;
-            w_upd.y = (s.alY[o] + 0.f) * h;
-            s.omgY[o] += w_upd.y;
-            w_upd.z = (s.alZ[o] + 0.f) * h;
-            s.omgZ[o] += w_upd.z;
+            if (!(pf & 1u)) {
+                v_upd.x = (s.aX[o] + ext[0] + s.p.Gx) * h;
+                s.vX[o] += v_upd.x;
+            } else {
+                old_v.x = s.vX[o];
+            }
+            if (!(pf & 2u)) {
+                v_upd.y = (s.aY[o] + ext[1] + s.p.Gy) * h;
+                s.vY[o] += v_upd.y;
+            } else {
+                old_v.y = s.vY[o];
+            }
+            if (!(pf & 4u)) {
+                v_upd.z = (s.aZ[o] + ext[2] + s.p.Gz) * h;
+                s.vZ[o] += v_upd.z;
+            } else {
+                old_v.z = s.vZ[o];
+            }
+            if (!(pf & 8u)) {
+                w_upd.x = (s.alX[o] + ext[3]) * h;
+                s.omgX[o] += w_upd.x;
+            } else {
+                old_w.x = s.omgX[o];
+            }
+            if (!(pf & 16u)) {
+                w_upd.y = (s.alY[o] + ext[4]) * h;
+                s.omgY[o] += w_upd.y;
+            } else {
+                old_w.y = s.omgY[o];
+            }
+            if (!(pf & 32u)) {
+                w_upd.z = (s.alZ[o] + ext[5]) * h;
+                s.omgZ[o] += w_upd.z;
+            } else {
+                old_w.z = s.omgZ[o];
+            }
         }
         V3f v, w;
         switch (s.p.integrator) {
@@ -1210,15 +1263,18 @@ void integrate(Sim& s) {
                 break;
         }
         if (!fixed) {
-            X += (double)v.x * h;
-            Y += (double)v.y * h;
-            Z += (double)v.z * h;
+            if (!(pf & 64u))
+                X += (double)v.x * h;
+            if (!(pf & 128u))
+                Y += (double)v.y * h;
+            if (!(pf & 256u))
+                Z += (double)v.z * h;
         }
         X -= (double)s.p.LBFX;
         Y -= (double)s.p.LBFY;
         Z -= (double)s.p.LBFZ;
         encode_pos(X, Y, Z, s.p.nvXp2, s.p.nvYp2, s.p.voxelSize, s.p.l, s.voxelID[o], s.locX[o], s.locY[o], s.locZ[o]);
-        if (!fixed) {
+        if (!fixed && !(pf & 512u)) {
             // ha = 0.5 * h * omgBar : (double)(0.5*h) narrowed to float, then float*float3
             const float hh = (float)(0.5 * h);
             const V3f ha = hh * w;
@@ -1547,6 +1603,15 @@ void orc_sim_counts(void* h, DemeCounts* c) {
 // Inspectors: DEMSphereQueryKernels.cu:13-54 / DEMOwnerQueryKernels.cu:11-63 with the quantity fragments of
 // AuxClasses.cpp:19-92.  values (may be null) receives the per-element quantity; the return value is the number
 // of elements; *reduced gets max / min / sum (sums accumulated in double, the reference reduces fp32 with CUB).
+// family prescription in the parametric test form (see Sim::Presc); coef = float[15][4]
+void orc_sim_set_prescription(void* h, uint32_t family, uint32_t has, uint32_t flags, const float* coef) {
+    Sim& s = *(Sim*)h;
+    Sim::Presc& p = s.presc[family & 255u];
+    p.used = true;
+    p.has = has;
+    p.flags = flags;
+    memcpy(p.c, coef, sizeof(p.c));
+}
 // restart / re-decomposition: mirror of deme_seed_contacts (include/deme_hip.h)
 int orc_sim_seed_contacts(void* h, const uint32_t* idA, const uint32_t* idB, const uint8_t* type, const float* wildcards, size_t n) {
     Sim& s = *(Sim*)h;

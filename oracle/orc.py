@@ -268,6 +268,10 @@ class OracleSim:
         st, _ = self._state_factory(self.n_owners, arrays)
         self.L.orc_sim_set_state(C.c_void_p(self.h), C.byref(st))
 
+    def set_prescription(self, family, has, flags, coef):
+        c = np.ascontiguousarray(coef, np.float32).reshape(15, 4)
+        self.L.orc_sim_set_prescription(C.c_void_p(self.h), C.c_uint32(family), C.c_uint32(has), C.c_uint32(flags), _p(c))
+
     def seed_contacts(self, idA, idB, ctype, wildcards=None):
         a = np.ascontiguousarray(idA, np.uint32)
         b = np.ascontiguousarray(idB, np.uint32)
