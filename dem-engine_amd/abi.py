@@ -176,6 +176,7 @@ def load_library():
         "deme_upload_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_seed_contacts": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_compile_prescriptions": [_P, C.c_char_p, C.c_char_p, C.c_char_p],
+        "deme_compile_family_rules": [_P, C.c_char_p], "deme_change_family": [_P, C.c_uint32, C.c_uint32],
         "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)], "deme_inspect_values": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_set_record_contacts": [_P, C.c_int],
         "deme_download_contact_records": [_P, _P, _P, _P, _P, C.c_size_t],
@@ -345,6 +346,13 @@ class Context:
         out = np.zeros(int(n), np.float32)
         self._ck(self.lib.deme_inspect_values(self.h, self.INSPECT_CODES[quantity], _ptr(out), out.size), "deme_inspect_values")
         return out
+
+    def compile_family_rules(self, rules):
+        """ChangeFamilyWhen rules: the _familyChangeRules_ text of equipFamilyOnFlyChanges (see include/deme_hip.h)."""
+        self._ck(self.lib.deme_compile_family_rules(self.h, rules.encode()), "deme_compile_family_rules")
+
+    def change_family(self, frm, to):
+        self._ck(self.lib.deme_change_family(self.h, int(frm), int(to)), "deme_change_family")
 
     def compile_prescriptions(self, vel_cases, pos_cases, acc_cases):
         """Family motion prescriptions: the three switch bodies of equipFamilyPrescribedMotions (see include/deme_hip.h)."""

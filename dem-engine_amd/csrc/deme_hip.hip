@@ -86,6 +86,9 @@ struct deme_ctx {
     hipModule_t prescMod = nullptr;
     hipFunction_t prescFn = nullptr;
     DevBuf prescList, prescSlot, prescRec;
+    hipModule_t rulesMod = nullptr;
+    hipFunction_t rulesFn = nullptr;  // on-the-fly family changes
+    bool rulesNeedAcc = false;
     uint32_t nPresc = 0;
     uint8_t hostFamFlags[DEME_NUM_FAMILIES] = {0};
     bool prescDirty = true;  // owner -> family assignment changed: rebuild the list  // the list was loaded by deme_seed_contacts: it only feeds the next history map
@@ -592,15 +595,21 @@ int rebuild_presc_list(deme_ctx* c) {
     c->nPresc = 0;
     if (!c->prescFn)
         return DEME_OK;
-    std::vector<OwnerRec> h(c->nOwners);
-    HIPCK(hipMemcpyAsync(h.data(), c->owners.p, (size_t)c->nOwners * sizeof(OwnerRec), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
     std::vector<uint32_t> list, slot(c->nOwners, 0u);
-    for (uint32_t o = 0; o < c->nOwners; o++)
-        if (c->hostFamFlags[h[o].family & 255u] & DEME_FAMILY_PRESCRIBED) {
-            slot[o] = (uint32_t)list.size();
-            list.push_back(o);
-        }
+    if (c->rulesFn) {  // families change on the device: every owner may become prescribed, so every owner gets a record
+        list.resize(c->nOwners);
+        for (uint32_t o = 0; o < c->nOwners; o++)
+            list[o] = slot[o] = o;
+    } else {
+        std::vector<OwnerRec> h(c->nOwners);
+        HIPCK(hipMemcpyAsync(h.data(), c->owners.p, (size_t)c->nOwners * sizeof(OwnerRec), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        for (uint32_t o = 0; o < c->nOwners; o++)
+            if (c->hostFamFlags[h[o].family & 255u] & DEME_FAMILY_PRESCRIBED) {
+                slot[o] = (uint32_t)list.size();
+                list.push_back(o);
+            }
+    }
     c->nPresc = (uint32_t)list.size();
     if (int rc = ensure(c, c->prescList, std::max<size_t>(list.size(), 1) * 4))
         return rc;
@@ -1073,7 +1082,21 @@ int deme_step(deme_ctx* c, uint32_t nsteps) {
         }
         if (int rc = launch_forces(c))
             return rc;
-        if (int rc = launch_integrate(c, true))
+        bool fused = true;
+        if (c->rulesFn) {  // routineChecks(): applyFamilyChanges between forces and integration (dT.cpp:2437-2443)
+            const AccRec* accp = nullptr;
+            if (c->rulesNeedAcc) {
+                launch_full_reduction(c);
+                accp = c->acc.as<AccRec>();
+                fused = false;
+            }
+            OwnerRec* ow = c->owners.as<OwnerRec>();
+            uint32_t n = c->nOwners;
+            float t = (float)c->timeElapsed;
+            void* args[] = {&c->dp, &ow, &accp, &n, &t};
+            HIPCK(hipModuleLaunchKernel(c->rulesFn, grid_for(n), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+        }
+        if (int rc = launch_integrate(c, fused))
             return rc;
         c->stepsSinceCD++;
         c->nSteps++;
@@ -1344,6 +1367,59 @@ int deme_compile_prescriptions(deme_ctx* c, const char* velCases, const char* po
     }
     HIPCK(hipModuleLoadData(&c->prescMod, it->second.data()));
     HIPCK(hipModuleGetFunction(&c->prescFn, c->prescMod, "deme_prescribe"));
+    return DEME_OK;
+}
+
+int deme_compile_family_rules(deme_ctx* c, const char* rules) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (c->rulesMod) {
+        (void)hipModuleUnload(c->rulesMod);
+        c->rulesMod = nullptr;
+        c->rulesFn = nullptr;
+    }
+    c->prescDirty = true;
+    const std::string r = rules ? rules : "";
+    if (r.find_first_not_of(" \t\n") == std::string::npos)
+        return DEME_OK;
+    // whole-word scan for the contact acceleration, as the reference scans force models for their ingredients
+    auto mentions = [&](const std::string& w) {
+        for (size_t pos = r.find(w); pos != std::string::npos; pos = r.find(w, pos + 1)) {
+            const bool l = pos == 0 || !(isalnum((unsigned char)r[pos - 1]) || r[pos - 1] == '_');
+            const size_t e = pos + w.size();
+            const bool rr = e >= r.size() || !(isalnum((unsigned char)r[e]) || r[e] == '_');
+            if (l && rr)
+                return true;
+        }
+        return false;
+    };
+    c->rulesNeedAcc = mentions("acc") || mentions("accX") || mentions("accY") || mentions("accZ");
+    std::string gen;
+    deme_jit::generate_family_rules_source(r, gen);
+    const size_t key = std::hash<std::string>{}(gen);
+    auto it = c->jitCache.find(key);
+    if (it == c->jitCache.end()) {
+        std::vector<char> code;
+        std::string log;
+        if (deme_jit::compile(gen, code, log))
+            return fail(c, DEME_ERR_COMPILE, "family change rules failed to compile:\n%.900s", log.c_str());
+        it = c->jitCache.emplace(key, std::move(code)).first;
+    }
+    HIPCK(hipModuleLoadData(&c->rulesMod, it->second.data()));
+    HIPCK(hipModuleGetFunction(&c->rulesFn, c->rulesMod, "deme_family_changes"));
+    return DEME_OK;
+}
+
+int deme_change_family(deme_ctx* c, uint32_t from, uint32_t to) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (from > 255 || to > 255)
+        return fail(c, DEME_ERR_INVALID, "family numbers must not be larger than 255");
+    if (c->nOwners)
+        hipLaunchKernelGGL(k_change_family, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->owners.as<OwnerRec>(),
+                           (uint32_t)c->nOwners, from, to);
+    c->prescDirty = true;
     return DEME_OK;
 }
 

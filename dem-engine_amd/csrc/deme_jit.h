@@ -262,6 +262,60 @@ extern "C" __global__ __launch_bounds__(256) void deme_prescribe(const deme_dev:
     out = o.str();
 }
 
+// On-the-fly family changes (DEMSolver::ChangeFamilyWhen; code generation equipFamilyOnFlyChanges,
+// DEM/APIPrivate.cpp:1576-1598; kernel applyFamilyChanges, kernel/DEMModeratorKernels.cu:10-60).  `rules` is the
+// reference's _familyChangeRules_ text: a sequence of
+//   if (family_code == A) { bool shouldMakeChange = false; <user code> if (shouldMakeChange) {granData->familyID[myOwner] = B;} }
+// written against pos / vel / acc / mass / X..accZ / ts / time.  granData->familyID[myOwner] is an lvalue proxy here.
+inline void generate_family_rules_source(const std::string& rules, std::string& out) {
+    std::ostringstream o;
+    o << "#include \"deme_device.h\"\n" << kVocabulary << R"DEMEFAM(
+namespace deme_dev {
+struct DemeFamRef {
+    deme::family_t* p;
+    __device__ deme::family_t& operator[](size_t) const { return *p; }
+};
+struct DemeGranProxy {
+    DemeFamRef familyID;
+};
+}  // namespace deme_dev
+extern "C" __global__ __launch_bounds__(256) void deme_family_changes(const deme_dev::DevParams p, deme_dev::OwnerRec* owners,
+                                                                      const deme_dev::AccRec* accArr, uint32_t nOwnerBodies,
+                                                                      float timeElapsed) {
+    using namespace deme_dev;
+    const deme::bodyID_t myOwner = blockIdx.x * blockDim.x + threadIdx.x;
+    if (myOwner >= nOwnerBodies)
+        return;
+    const OwnerRec r = load_owner(owners, myOwner);
+    double3 pos;
+    float3 vel, acc;
+    const float mass = p.massProps[r.inertiaOff].x;
+    deme::family_t family_code = (deme::family_t)r.family;
+    deme::family_t deme_new_family = family_code;
+    const d3 P = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);
+    pos = make_double3(P.x + p.LBFX, P.y + p.LBFY, P.z + p.LBFZ);
+    vel = make_float3(r.vx, r.vy, r.vz);
+    acc = make_float3(0.f, 0.f, 0.f);
+    if (accArr)
+        acc = make_float3(accArr[myOwner].ax, accArr[myOwner].ay, accArr[myOwner].az);
+    double X = pos.x, Y = pos.y, Z = pos.z;
+    float vX = vel.x, vY = vel.y, vZ = vel.z;
+    float accX = acc.x, accY = acc.y, accZ = acc.z;
+    float ts = p.h;
+    float time = timeElapsed;
+    DemeGranProxy deme_gran_proxy{{&deme_new_family}};
+    DemeGranProxy* granData = &deme_gran_proxy;
+    (void)mass, (void)X, (void)Y, (void)Z, (void)vX, (void)vY, (void)vZ, (void)accX, (void)accY, (void)accZ, (void)ts, (void)time;
+    {
+)DEMEFAM" << rules << R"DEMEFAM(
+    }
+    if (deme_new_family != family_code)
+        owners[myOwner].family = (uint32_t)deme_new_family;
+}
+)DEMEFAM";
+    out = o.str();
+}
+
 // hipRTC: source -> gfx950 code object.  Needs no GPU (used by the CPU test through deme_jit_probe).
 inline int compile(const std::string& src, std::vector<char>& code, std::string& log) {
     hiprtcProgram prog;

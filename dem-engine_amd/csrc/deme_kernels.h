@@ -1035,6 +1035,12 @@ __global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owner
     }
 }
 
+__global__ __launch_bounds__(256) void k_change_family(OwnerRec* __restrict__ owners, uint32_t n, uint32_t from, uint32_t to) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < n && owners[o].family == from)
+        owners[o].family = to;
+}
+
 // ---- inspectors: DEMSphereQueryKernels.cu:13-54 / DEMOwnerQueryKernels.cu:11-63 with the quantity fragments of
 // AuxClasses.cpp:19-92.  Elements that do not take part get the reduction's identity.
 __global__ __launch_bounds__(256) void k_inspect_sphere(const DevParams p, const OwnerRec* __restrict__ owners,

@@ -377,6 +377,24 @@ class SceneBuilder:
             ctx.compile_force_model(self.force_src, getattr(self, "contact_wildcards", []), self.force_model_prerequisites())
         if getattr(self, "_presc_inputs", None):
             ctx.compile_prescriptions(*self.prescription_cases())
+        if getattr(self, "_family_rules", None):
+            ctx.compile_family_rules(self.family_change_rules())
+
+    def ChangeFamilyWhen(self, id_from, id_to, condition):
+        """condition: C++ statements that `return` a bool, over X, Y, Z, vX, vY, vZ, accX, accY, accZ, pos, vel, acc, mass, ts,
+        time (API.h:1024; DEMModeratorKernels.cu:10-60); checked between force evaluation and integration of every step."""
+        if not hasattr(self, "_family_rules"):
+            self._family_rules = []
+        self._family_rules.append((int(id_from), int(id_to), str(condition)))
+
+    def family_change_rules(self):
+        """_familyChangeRules_ as equipFamilyOnFlyChanges builds it (APIPrivate.cpp:1576-1598)."""
+        out = " "
+        for a, b_, cond in self._family_rules:
+            out += f"if (family_code == {a}) {{ bool shouldMakeChange = false;"
+            out += cond.replace("return", "shouldMakeChange = ")
+            out += f"if (shouldMakeChange) {{granData->familyID[myOwner] = {b_};}}}}"
+        return out
 
     # ---- family motion prescriptions (API.h:720-838; APIPublic.cpp:1013-1330) ---------------------------------
     _PRESC_FIELDS = ("linPosX", "linPosY", "linPosZ", "linVelX", "linVelY", "linVelZ", "oriQ", "rotVelX", "rotVelY", "rotVelZ",

@@ -236,6 +236,14 @@ int deme_compile_force_model(deme_ctx* ctx, const char* src, size_t len, const c
  * with hipRTC; the families concerned must carry DEME_FAMILY_PRESCRIBED in DemeScene.familyFlags.  NULL / "" clears. */
 int deme_compile_prescriptions(deme_ctx* ctx, const char* velCases, const char* posCases, const char* accCases);
 
+/* On-the-fly family changes (DEMSolver::ChangeFamilyWhen, API.h:1024; kernel applyFamilyChanges,
+ * DEMModeratorKernels.cu:10-60; run between the force evaluation and the integration of every step, dT.cpp:2437-2443).
+ * `rules` is the _familyChangeRules_ text equipFamilyOnFlyChanges generates (APIPrivate.cpp:1576-1598).  If it mentions
+ * acc / accX / accY / accZ the owners' contact accelerations are reduced before the rules run.  NULL / "" clears. */
+int deme_compile_family_rules(deme_ctx* ctx, const char* rules);
+/* DEMSolver::ChangeFamily(ID_from, ID_to) (API.h:1028): immediate, all owners of a family */
+int deme_change_family(deme_ctx* ctx, uint32_t from, uint32_t to);
+
 /* compile-only check of a fragment (no context, no GPU needed): same generator and hipRTC options,
  * 2 dummy materials; the compiler log is copied into `log`. */
 int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,

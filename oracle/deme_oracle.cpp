@@ -637,6 +637,13 @@ struct Sim {
         float c[15][4] = {};
     };
     std::vector<Presc> presc = std::vector<Presc>(256);
+    // on-the-fly family changes in a parametric test form: owners of family `from` whose quantity q
+    // (0-2 X,Y,Z; 3-5 vX,vY,vZ; 6-8 accX,accY,accZ; 9 time) is > (op 0) or < (op 1) thr move to family `to`
+    struct FamRule {
+        uint32_t from, to, q, op;
+        double thr;
+    };
+    std::vector<FamRule> famRules;
 };
 
 template <typename T>
@@ -1289,6 +1296,25 @@ void integrate(Sim& s) {
     }
 }
 
+// kernel/DEMModeratorKernels.cu:10-60 (applyFamilyChanges) with the rules in the parametric test form; the rules are
+// applied in order to the family code read at entry (each `if (family_code == A)` tests the original code).
+void apply_family_rules(Sim& s) {
+    if (s.famRules.empty())
+        return;
+    for (uint32_t o = 0; o < s.nOwners; o++) {
+        const uint8_t code = s.familyID[o];
+        double X, Y, Z;
+        decode_pos(s.voxelID[o], s.locX[o], s.locY[o], s.locZ[o], s.p.nvXp2, s.p.nvYp2, s.p.voxelSize, s.p.l, X, Y, Z);
+        X += s.p.LBFX;
+        Y += s.p.LBFY;
+        Z += s.p.LBFZ;
+        const double q[10] = {X, Y, Z, s.vX[o], s.vY[o], s.vZ[o], s.aX[o], s.aY[o], s.aZ[o], (double)(float)s.p.timeElapsed};
+        for (const Sim::FamRule& r : s.famRules)
+            if (code == r.from && (r.op == 0 ? q[r.q] > r.thr : q[r.q] < r.thr))
+                s.familyID[o] = (uint8_t)r.to;
+    }
+}
+
 // Stepping policy of this build (lock-step; SURVEY App. C #10 explains why the
 // reference's own "sync" mode cannot be reproduced step for step): every K steps
 // (K = cdUpdateFreq, K = 0 means every step with zero drift) refresh margins from the
@@ -1306,6 +1332,7 @@ int step(Sim& s, uint32_t n) {
             s.stepsSinceCD = 0;
         }
         calc_forces(s, false);
+        apply_family_rules(s);  // routineChecks(): between forces and integration (dT.cpp:2437-2443)
         integrate(s);
         s.stepsSinceCD++;
         s.nSteps++;
@@ -1603,6 +1630,15 @@ void orc_sim_counts(void* h, DemeCounts* c) {
 // Inspectors: DEMSphereQueryKernels.cu:13-54 / DEMOwnerQueryKernels.cu:11-63 with the quantity fragments of
 // AuxClasses.cpp:19-92.  values (may be null) receives the per-element quantity; the return value is the number
 // of elements; *reduced gets max / min / sum (sums accumulated in double, the reference reduces fp32 with CUB).
+void orc_sim_add_family_rule(void* h, uint32_t from, uint32_t to, uint32_t q, uint32_t op, double thr) {
+    ((Sim*)h)->famRules.push_back({from, to, q, op, thr});
+}
+void orc_sim_change_family(void* h, uint32_t from, uint32_t to) {
+    Sim& s = *(Sim*)h;
+    for (auto& f : s.familyID)
+        if (f == from)
+            f = (uint8_t)to;
+}
 // family prescription in the parametric test form (see Sim::Presc); coef = float[15][4]
 void orc_sim_set_prescription(void* h, uint32_t family, uint32_t has, uint32_t flags, const float* coef) {
     Sim& s = *(Sim*)h;

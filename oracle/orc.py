@@ -268,6 +268,13 @@ class OracleSim:
         st, _ = self._state_factory(self.n_owners, arrays)
         self.L.orc_sim_set_state(C.c_void_p(self.h), C.byref(st))
 
+    def add_family_rule(self, frm, to, quantity, op, threshold):
+        self.L.orc_sim_add_family_rule(C.c_void_p(self.h), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(quantity), C.c_uint32(op),
+                                       C.c_double(threshold))
+
+    def change_family(self, frm, to):
+        self.L.orc_sim_change_family(C.c_void_p(self.h), C.c_uint32(frm), C.c_uint32(to))
+
     def set_prescription(self, family, has, flags, coef):
         c = np.ascontiguousarray(coef, np.float32).reshape(15, 4)
         self.L.orc_sim_set_prescription(C.c_void_p(self.h), C.c_uint32(family), C.c_uint32(has), C.c_uint32(flags), _p(c))

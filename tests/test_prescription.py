@@ -100,3 +100,65 @@ def test_gpu_prescriptions_match_oracle(pkg, orc):
     ctx.step(5)
     g2 = ctx.download_state()
     assert g2["vZ"][n] != gs["vZ"][n]  # the piston now accelerates under gravity / contacts like any free body
+
+
+def _rule_scene(pkg):
+    """clumps that rise above z = 0.0345 m are frozen (family 5 is fixed); clumps that fall faster than 0.6 m/s are tagged
+    family 6, which gets an extra upward acceleration"""
+    b = pkg.model.packed_bed(900, seed=33, cd_freq=0, spacing_mult=2.4, init_vz=-0.3, aspect=(1.0, 1.0, 0.5))
+    b.ChangeFamilyWhen(0, 5, "return Z > 0.0345;")
+    b.ChangeFamilyWhen(0, 6, "return vZ < -0.6;")
+    b.SetFamilyFixed(5)
+    b.AddFamilyPrescribedAcc(6, "none", "none", "40.0f")
+    p, sc = b.Initialize()
+    return b, p, sc
+
+
+def _oracle_rules(sim):
+    sim.add_family_rule(0, 5, 2, 0, 0.0345)  # quantity 2 = Z, op 0 = ">"
+    sim.add_family_rule(0, 6, 5, 1, -0.6)    # quantity 5 = vZ, op 1 = "<"
+    c = np.zeros((15, 4), np.float32)
+    c[11] = (40.0, 0, 0, 0)
+    sim.set_prescription(6, has=1 << 11, flags=0, coef=c)
+
+
+def test_family_rules_codegen_and_oracle(pkg, orc):
+    b, p, sc = _rule_scene(pkg)
+    assert b.family_change_rules() == (" if (family_code == 0) { bool shouldMakeChange = false;shouldMakeChange =  Z > 0.0345;"
+                                       "if (shouldMakeChange) {granData->familyID[myOwner] = 5;}}if (family_code == 0) "
+                                       "{ bool shouldMakeChange = false;shouldMakeChange =  vZ < -0.6;if (shouldMakeChange) "
+                                       "{granData->familyID[myOwner] = 6;}}")
+    sim = orc.make_sim(pkg, p, sc)
+    _oracle_rules(sim)
+    sim.step(150)
+    st = sim.download_state()
+    n = int(sc.nOwnerClumps)
+    fam = st["familyID"][:n]
+    assert (fam == 5).sum() > 3 and (fam == 6).sum() > 3
+    assert np.all(st["vZ"][:n][fam == 5] == 0)  # frozen where they were caught
+
+
+@pytest.mark.gpu
+def test_gpu_family_changes_match_oracle(pkg, orc):
+    b, p, sc = _rule_scene(pkg)
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    b.compile_into(ctx)
+    sim = orc.make_sim(pkg, p, sc)
+    _oracle_rules(sim)
+    ctx.step(150), sim.step(150)
+    gs, os_ = ctx.download_state(), sim.download_state()
+    n = int(sc.nOwnerClumps)
+    assert np.array_equal(gs["familyID"], os_["familyID"])
+    assert (gs["familyID"][:n] == 5).sum() > 3 and (gs["familyID"][:n] == 6).sum() > 3
+    X = pkg.model.decode_positions(gs["voxelID"], gs["locX"], gs["locY"], gs["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    Y = pkg.model.decode_positions(os_["voxelID"], os_["locX"], os_["locY"], os_["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    assert np.abs(X - Y).max() < 2e-7
+    assert np.all(gs["vZ"][:n][gs["familyID"][:n] == 5] == 0)
+    ctx.change_family(6, 0), sim.change_family(6, 0)
+    assert np.array_equal(ctx.download_state()["familyID"], sim.download_state()["familyID"])
+    # a rule that reads the contact acceleration makes the step reduce a/alpha before the rules run
+    ctx.compile_family_rules(" if (family_code == 0) { bool shouldMakeChange = false;shouldMakeChange =  accZ > 1e9;"
+                             "if (shouldMakeChange) {granData->familyID[myOwner] = 7;}}")
+    ctx.step(3)
+    assert not (ctx.download_state()["familyID"] == 7).any()
