@@ -356,6 +356,58 @@ class DEMSolver {
     void SetErrorOutVelocity(float v) { m_err_vel = v; }
     void SetIntegrator(TIME_INTEGRATOR i) { m_integrator = i; }
     void SetFamilyFixed(unsigned int f) { m_family_flags[f & 255] |= DEME_FAMILY_FIXED; }
+
+    // ---- family motion prescriptions and on-the-fly family changes (API.h:720-838, 1024-1028; APIPublic.cpp:1013-1330)
+    void SetFamilyPrescribedLinVel(unsigned int ID, const std::string& velX, const std::string& velY, const std::string& velZ,
+                                   bool dictate = true, const std::string& pre = "none") {
+        Presc& q = new_presc(ID);
+        q.flag[0] = q.flag[1] = q.flag[2] = q.flag[3] = q.flag[4] = q.flag[5] = dictate;  // lin vel prescription also fixes rotation
+        q.s["linVelX"] = velX, q.s["linVelY"] = velY, q.s["linVelZ"] = velZ, q.s["linVelPre"] = pre;
+        if (velX != "none") q.flag[0] = true;
+        if (velY != "none") q.flag[1] = true;
+        if (velZ != "none") q.flag[2] = true;
+    }
+    void SetFamilyPrescribedAngVel(unsigned int ID, const std::string& velX, const std::string& velY, const std::string& velZ,
+                                   bool dictate = true, const std::string& pre = "none") {
+        Presc& q = new_presc(ID);
+        q.flag[0] = q.flag[1] = q.flag[2] = q.flag[3] = q.flag[4] = q.flag[5] = dictate;
+        q.s["rotVelX"] = velX, q.s["rotVelY"] = velY, q.s["rotVelZ"] = velZ, q.s["rotVelPre"] = pre;
+        if (velX != "none") q.flag[3] = true;
+        if (velY != "none") q.flag[4] = true;
+        if (velZ != "none") q.flag[5] = true;
+    }
+    void SetFamilyPrescribedPosition(unsigned int ID, const std::string& X, const std::string& Y, const std::string& Z,
+                                     bool dictate = true, const std::string& pre = "none") {
+        Presc& q = new_presc(ID);
+        q.flag[6] = q.flag[7] = q.flag[8] = q.flag[9] = dictate;
+        q.s["linPosX"] = X, q.s["linPosY"] = Y, q.s["linPosZ"] = Z, q.s["linPosPre"] = pre;
+        if (X != "none") q.flag[6] = true;
+        if (Y != "none") q.flag[7] = true;
+        if (Z != "none") q.flag[8] = true;
+    }
+    void SetFamilyPrescribedQuaternion(unsigned int ID, const std::string& q_formula, bool dictate = true) {
+        Presc& q = new_presc(ID);
+        q.flag[6] = q.flag[7] = q.flag[8] = q.flag[9] = dictate;
+        q.s["oriQ"] = q_formula;
+        if (q_formula != "none") q.flag[9] = true;
+    }
+    void AddFamilyPrescribedAcc(unsigned int ID, const std::string& X, const std::string& Y, const std::string& Z,
+                                const std::string& pre = "none") {
+        Presc& q = new_presc(ID);
+        q.s["accX"] = X, q.s["accY"] = Y, q.s["accZ"] = Z, q.s["accPre"] = pre;
+    }
+    void AddFamilyPrescribedAngAcc(unsigned int ID, const std::string& X, const std::string& Y, const std::string& Z,
+                                   const std::string& pre = "none") {
+        Presc& q = new_presc(ID);
+        q.s["angAccX"] = X, q.s["angAccY"] = Y, q.s["angAccZ"] = Z, q.s["angAccPre"] = pre;
+    }
+    void ChangeFamilyWhen(unsigned int ID_from, unsigned int ID_to, const std::string& condition) {
+        m_family_rules.push_back({ID_from, ID_to, condition});
+    }
+    void ChangeFamily(unsigned int ID_from, unsigned int ID_to) {
+        check(deme_change_family(m_ctx, ID_from, ID_to));
+        m_state_fresh = false;
+    }
     void DisableContactBetweenFamilies(unsigned int a, unsigned int b) {
         if (a > b)
             std::swap(a, b);
@@ -585,6 +637,91 @@ class DEMSolver {
     std::vector<float> m_st_v[3];
 
 
+    struct Presc {
+        unsigned int family = 0;
+        std::map<std::string, std::string> s;  // field name -> expression ("none": absent), names of familyPrescription_t
+        bool flag[10] = {false, false, false, false, false, false, false, false, false, false};
+    };
+    struct FamilyRule {
+        unsigned int from, to;
+        std::string cond;
+    };
+    std::vector<Presc> m_presc_inputs;
+    std::vector<FamilyRule> m_family_rules;
+    Presc& new_presc(unsigned int ID) {
+        if (ID > 255)
+            throw std::runtime_error("You applied prescribed motion to family " + std::to_string(ID) +
+                                     ", but family number should not be larger than 255.");
+        m_presc_inputs.emplace_back();
+        m_presc_inputs.back().family = ID;
+        m_family_flags[ID] |= DEME_FAMILY_PRESCRIBED;
+        return m_presc_inputs.back();
+    }
+    static std::string replace_all(std::string s, const std::string& a, const std::string& b) {
+        for (size_t p = s.find(a); p != std::string::npos; p = s.find(a, p + b.size()))
+            s.replace(p, a.size(), b);
+        return s;
+    }
+    // merge per family (APIPrivate.cpp:843-937) and emit the switch bodies of equipFamilyPrescribedMotions (:1600-1708)
+    void compile_prescriptions_and_rules() {
+        if (!m_presc_inputs.empty()) {
+            std::map<unsigned, Presc> merged;
+            for (auto& in : m_presc_inputs) {
+                Presc& m = merged[in.family];
+                m.family = in.family;
+                for (auto& kv : in.s)
+                    if (kv.second != "none")
+                        m.s[kv.first] = kv.second;
+                for (int k = 0; k < 10; k++)
+                    m.flag[k] = m.flag[k] || in.flag[k];
+            }
+            std::string vel = " ", pos = " ", acc = " ";
+            auto get = [](const Presc& m, const char* k) {
+                auto it = m.s.find(k);
+                return it == m.s.end() ? std::string("none") : it->second;
+            };
+            for (auto& kv : merged) {
+                const Presc& m = kv.second;
+                const std::string head = "case " + std::to_string(m.family) + ": {";
+                auto block = [&](const char* pre, std::initializer_list<std::pair<const char*, const char*>> items) {
+                    std::string o = "{";
+                    if (get(m, pre) != "none")
+                        o += get(m, pre) + ";";
+                    for (auto& it : items)
+                        if (get(m, it.second) != "none")
+                            o += std::string(it.first) + " = " + get(m, it.second) + ";";
+                    return o + "}";
+                };
+                vel += head + block("linVelPre", {{"vX", "linVelX"}, {"vY", "linVelY"}, {"vZ", "linVelZ"}}) +
+                       block("rotVelPre", {{"omgBarX", "rotVelX"}, {"omgBarY", "rotVelY"}, {"omgBarZ", "rotVelZ"}});
+                const char* vn[6] = {"LinVelXPrescribed", "LinVelYPrescribed", "LinVelZPrescribed", "RotVelXPrescribed",
+                                     "RotVelYPrescribed", "RotVelZPrescribed"};
+                for (int k = 0; k < 6; k++)
+                    vel += std::string(vn[k]) + " = " + std::to_string(m.flag[k]) + ";";
+                vel += "break; }";
+                pos += head + block("linPosPre", {{"X", "linPosX"}, {"Y", "linPosY"}, {"Z", "linPosZ"}});
+                if (get(m, "oriQ") != "none")
+                    pos += "{" + replace_all(get(m, "oriQ"), "return", "float4 DEME_Presc_OriQ = ") +
+                           ";oriQw = DEME_Presc_OriQ.w; oriQx = DEME_Presc_OriQ.x; oriQy = DEME_Presc_OriQ.y; oriQz = "
+                           "DEME_Presc_OriQ.z;}";
+                const char* pn[4] = {"LinXPrescribed", "LinYPrescribed", "LinZPrescribed", "RotPrescribed"};
+                for (int k = 0; k < 4; k++)
+                    pos += std::string(pn[k]) + " = " + std::to_string(m.flag[6 + k]) + ";";
+                pos += "break; }";
+                acc += head + block("accPre", {{"accX", "accX"}, {"accY", "accY"}, {"accZ", "accZ"}}) +
+                       block("angAccPre", {{"angAccX", "angAccX"}, {"angAccY", "angAccY"}, {"angAccZ", "angAccZ"}}) + "break; }";
+            }
+            check(deme_compile_prescriptions(m_ctx, vel.c_str(), pos.c_str(), acc.c_str()));
+        }
+        if (!m_family_rules.empty()) {  // equipFamilyOnFlyChanges, APIPrivate.cpp:1576-1598
+            std::string rules = " ";
+            for (auto& r : m_family_rules)
+                rules += "if (family_code == " + std::to_string(r.from) + ") { bool shouldMakeChange = false;" +
+                         replace_all(r.cond, "return", "shouldMakeChange = ") +
+                         "if (shouldMakeChange) {granData->familyID[myOwner] = " + std::to_string(r.to) + ";}}";
+            check(deme_compile_family_rules(m_ctx, rules.c_str()));
+        }
+    }
     unsigned int m_out_content = QUAT | ABSV;                                      // API.h:1418
     unsigned int m_cnt_out_content = OWNER | GEO_ID | FORCE | CNT_POINT | CNT_WILDCARD;  // API.h:1422-1424
     struct Keep {  // scene arrays the writers need after Initialize
@@ -737,6 +874,20 @@ class DEMSolver {
     void check(int rc) {
         if (rc)
             throw std::runtime_error(deme_last_error(m_ctx));
+    }
+    // owners are numbered: clumps (batch load order), analytical objects (+ the bounding box last), meshes
+    size_t tracker_first_owner(int kind, size_t index) const {
+        if (m_n_owners == 0)
+            throw std::runtime_error("trackers can be used after Initialize()");
+        size_t first = 0;
+        if (kind == 0) {
+            for (size_t i = 0; i < index; i++)
+                first += m_batches[i]->nClumps;
+            return first;
+        }
+        if (kind == 1)
+            return m_n_clumps + index;
+        return m_n_owners - m_meshes.size() + index;
     }
     // tracker setters: read-modify-write of the affected SoA columns (null columns keep their device values)
     void set_owner(size_t o, const float3* pos, const float3* vel, const float3* angvel, const float4* q) {
@@ -1075,6 +1226,7 @@ class DEMSolver {
         }
         m_n_clumps = nC, m_n_owners = nO;
         m_state_fresh = false;
+        compile_prescriptions_and_rules();
         m_keep.sphOwner = sphOwner, m_keep.sphComp = sphComp, m_keep.inert = inert, m_keep.objOwner = objOwner, m_keep.triOwner = triOwner;
         m_keep.Radii = Radii, m_keep.rx = rx, m_keep.ry = ry, m_keep.rz = rz;
         for (size_t i = 0; i < m_templates.size(); i++) {
@@ -1148,8 +1300,10 @@ class DEMInspector {
 /// getters read the current device state, setters write it back (DEMTracker, AuxClasses.h:93-420).
 class DEMTracker {
   public:
-    DEMTracker(DEMSolver* sys, size_t first_owner, size_t n) : m_sys(sys), m_first(first_owner), m_n(n) {}
-    bodyID_t GetOwnerID(size_t offset = 0) const { return (bodyID_t)(m_first + in_range(offset)); }
+    /// kind: 0 clump batch, 1 analytical object, 2 mesh; index: load order.  Owner ids are resolved when used, so a tracker
+    /// may be created before Initialize() as in the reference's demos.
+    DEMTracker(DEMSolver* sys, int kind, size_t index, size_t n) : m_sys(sys), m_kind(kind), m_index(index), m_n(n) {}
+    bodyID_t GetOwnerID(size_t offset = 0) const { return (bodyID_t)(m_sys->tracker_first_owner(m_kind, m_index) + in_range(offset)); }
     size_t GetNumOwners() const { return m_n; }
     float3 Pos(size_t offset = 0) { return m_sys->GetOwnerPosition(GetOwnerID(offset)); }
     float3 Vel(size_t offset = 0) { return m_sys->GetOwnerVelocity(GetOwnerID(offset)); }
@@ -1173,7 +1327,8 @@ class DEMTracker {
 
   private:
     DEMSolver* m_sys;
-    size_t m_first, m_n;
+    int m_kind;
+    size_t m_index, m_n;
     size_t in_range(size_t offset) const {
         if (offset >= m_n)
             throw std::runtime_error("tracker offset is out of range");
@@ -1190,24 +1345,21 @@ inline std::shared_ptr<DEMInspector> DEMSolver::CreateInspector(const std::strin
     return std::make_shared<DEMInspector>(this, quantity);
 }
 inline std::shared_ptr<DEMTracker> DEMSolver::Track(const std::shared_ptr<DEMClumpBatch>& batch) {
-    size_t first = 0;
-    for (auto& b : m_batches) {
-        if (b == batch)
-            return std::make_shared<DEMTracker>(this, first, b->nClumps);
-        first += b->nClumps;
-    }
+    for (size_t i = 0; i < m_batches.size(); i++)
+        if (m_batches[i] == batch)
+            return std::make_shared<DEMTracker>(this, 0, i, batch->nClumps);
     throw std::runtime_error("Track: this batch was not loaded into this solver");
 }
 inline std::shared_ptr<DEMTracker> DEMSolver::Track(const std::shared_ptr<DEMExternObj>& obj) {
     for (size_t e = 0; e < m_ext.size(); e++)
         if (m_ext[e] == obj)
-            return std::make_shared<DEMTracker>(this, m_n_clumps + e, 1);
+            return std::make_shared<DEMTracker>(this, 1, e, 1);
     throw std::runtime_error("Track: this object was not loaded into this solver");
 }
 inline std::shared_ptr<DEMTracker> DEMSolver::Track(const std::shared_ptr<DEMMeshConnected>& mesh) {
     for (size_t m = 0; m < m_meshes.size(); m++)
         if (m_meshes[m] == mesh)
-            return std::make_shared<DEMTracker>(this, m_n_owners - m_meshes.size() + m, 1);
+            return std::make_shared<DEMTracker>(this, 2, m, 1);
     throw std::runtime_error("Track: this mesh was not loaded into this solver");
 }
 

@@ -42,6 +42,15 @@ int main(int argc, char** argv) {
     auto batch = DEMSim.AddClumps(tmpl, xyz);
     batch->SetVel(make_float3(0.f, 0.f, -0.5f));
 
+    // a lid: an analytical plane facing down that descends at a prescribed, slowly growing speed (cf. the compressing
+    // plates of DEMdemo_Repose / DEMdemo_Sieve)
+    auto lid = DEMSim.AddExternalObject();
+    lid->AddPlane(make_float3(0.f, 0.f, 0.f), make_float3(0.f, 0.f, -1.f), mat);
+    lid->SetInitPos(make_float3(0.125f, 0.125f, 0.30f));
+    lid->SetFamily(20);
+    DEMSim.SetFamilyPrescribedLinVel(20, "0", "0", "-(0.05f + 2.0f*t)");
+    auto lid_tracker = DEMSim.Track(lid);
+
     DEMSim.UseFrictionalHertzianModel();
     DEMSim.SetInitTimeStep(5e-6);
     DEMSim.SetGravitationalAcceleration(make_float3(0, 0, -9.81f));
@@ -65,6 +74,7 @@ int main(int argc, char** argv) {
         std::printf("t=%.5f contacts=%zu vmax=%.4f zmean=%.5f\n", DEMSim.GetSimTime(), DEMSim.GetNumContacts(),
                     DEMSim.GetMaxOwnerSpeed(), zsum / (double)DEMSim.GetNumClumps());
     }
+    std::printf("LID z=%.6f vz=%.6f\n", lid_tracker->Pos().z, lid_tracker->Vel().z);
     std::printf("INSPECT max_z=%.6f mass=%.6e ke=%.6e tracked0_z=%.6f\n", max_z_finder->GetValue(), total_mass_finder->GetValue(),
                 ke_finder->GetValue(), tracker->Pos(0).z);
     if (argc > 3) {  // output + restart round trip (cf. DEMdemo_Repose.cpp's checkpoint use of WriteClumpFile / ReadClump*FromCsv)

@@ -45,3 +45,8 @@ def test_demo_runs_and_settles(tmp_path):
     vals = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in ins.split()[1:]}
     assert abs(vals["mass"] - 1000 * 2.6e3 * 5.5886717 * 0.005 ** 3) < 1e-6 * vals["mass"]
     assert vals["max_z"] > z[-1] and vals["max_z"] < 0.4 and vals["ke"] >= 0.0 and 0.0 < vals["tracked0_z"] < 0.4
+    # the prescribed lid (family 20, "-(0.05f + 2.0f*t)"): z(t) = 0.30 - 0.05 t - t^2, v(T) as of the last step
+    lid = [l for l in out.stdout.splitlines() if l.startswith("LID")][0]
+    lz, lv = float(lid.split("z=")[1].split()[0]), float(lid.split("vz=")[1])
+    T = 3000 * 5e-6
+    assert abs(lz - (0.30 - 0.05 * T - T * T)) < 2e-6 and abs(lv + (0.05 + 2.0 * (T - 5e-6))) < 1e-6
