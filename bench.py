@@ -30,9 +30,9 @@ README_CLUMP_STEPS_PER_S = 1e6 * 1e6 / 3600.0  # reference README.md:48, two RTX
 HALO = 0.03  # ghost layer thickness [m]: two lattice spacings (clump reach 7.3 mm)
 
 
-def build_bed(pkg, n_clumps, seed, cd_freq, x_mult=1, order="lattice"):
+def build_bed(pkg, n_clumps, seed, cd_freq, x_mult=1, order="lattice", bin_multiple=4.0):
     b = pkg.model.packed_bed(n_clumps * x_mult, seed=seed, cd_freq=cd_freq, aspect=(1.0 * x_mult, 1.0, 0.05),
-                             spacing_mult=3.0, jitter=0.05, bin_multiple=4.0, init_vz=-1.0, order=order)
+                             spacing_mult=3.0, jitter=0.05, bin_multiple=bin_multiple, init_vz=-1.0, order=order)
     b.SetExpandSafetyMultiplier(1.2)
     b.SetExpandSafetyAdder(0.02)
     return b
@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--order", default="lattice", choices=["lattice", "morton", "random"],
                     help="order in which the caller hands the clumps over (experiment)")
+    ap.add_argument("--bin-multiple", type=float, default=4.0,
+                    help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -204,7 +206,7 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     pkg = entry.load_package()
-    b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order)
+    b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order, bin_multiple=args.bin_multiple)
     p, sc = b.Initialize()
     halo, part = None, None
     if world > 1:

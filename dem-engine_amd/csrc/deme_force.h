@@ -75,6 +75,31 @@ __device__ inline f3 pdiv3(f3 a, float s) {
 #endif
 }
 
+// B-side contribution record: 24 B as float4 + float2 in two arrays, or (DEME_CONB32) one 32-byte record so that the
+// integrator's gather touches one line per contact instead of two
+#ifndef DEME_CONB32
+#define DEME_CONB32 0
+#endif
+__device__ inline void conb_store(float4* b4, float2* b2, size_t i, float4 c4, float2 c2) {
+#if DEME_CONB32
+    b4[2 * i] = c4;
+    b4[2 * i + 1] = make_float4(c2.x, c2.y, 0.f, 0.f);
+#else
+    b4[i] = c4;
+    b2[i] = c2;
+#endif
+}
+__device__ inline void conb_load(const float4* b4, const float2* b2, size_t i, float4& c4, float2& c2) {
+#if DEME_CONB32
+    c4 = b4[2 * i];
+    const float4 t = b4[2 * i + 1];
+    c2 = make_float2(t.x, t.y);
+#else
+    c4 = b4[i];
+    c2 = b2[i];
+#endif
+}
+
 struct HertzIn {
     double overlapDepth;
     f3 B2A;
@@ -349,6 +374,7 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
         wcp = reinterpret_cast<float4*>(a.wc) + myContactID;
         hist = *wcp;  // delta_tan_x, delta_tan_y, delta_tan_z, delta_time (std::set order, Models.h:363-378)
     }
+    const float4 hist0 = hist;
     if (ContactType != 0u) {
         f3 force = mk3(0, 0, 0), torque_only_force = mk3(0, 0, 0);
         // rotation by the conjugate quaternion: its nine coefficients are, bit for bit, the transposed forward ones
@@ -418,13 +444,11 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
         outA2 = c2;
         const f3 nF = mk3(-force.x, -force.y, -force.z);
         side_contribution(nF, -1.f * tot, in.BOwnerMass, mk3(mpB.y, mpB.z, mpB.w), RBinv, in.locCPB, c4, c2);
-        a.conB4[myContactID] = c4;
-        a.conB2[myContactID] = c2;
+        conb_store(a.conB4, a.conB2, myContactID, c4, c2);
     } else {
         outA4 = make_float4(0, 0, 0, 0);
         outA2 = make_float2(0, 0);
-        a.conB4[myContactID] = make_float4(0, 0, 0, 0);
-        a.conB2[myContactID] = make_float2(0, 0);
+        conb_store(a.conB4, a.conB2, myContactID, make_float4(0, 0, 0, 0), make_float2(0, 0));
         hist = make_float4(0, 0, 0, 0);  // _forceModelContactWildcardDestroy_
         if (MODEL == 2)
             for (uint32_t w = 0; w < p.nW; w++)
@@ -438,12 +462,25 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
             }
         }
     }
-    if (MODEL == 0)
-        *wcp = hist;  // _forceModelContactWildcardWrite_
+#ifndef DEME_SKIP_SAME_HIST
+#define DEME_SKIP_SAME_HIST 0
+#endif
+    if (MODEL == 0) {  // _forceModelContactWildcardWrite_
+#if DEME_SKIP_SAME_HIST
+        // list entries inside the margin but not touching keep an all-zero history: nothing to write back
+        if (!(hist.x == hist0.x && hist.y == hist0.y && hist.z == hist0.z && hist.w == hist0.w))
+            *wcp = hist;
+#else
+        (void)hist0;
+        *wcp = hist;
+#endif
+    }
 }
 
 // an owner's A run [s, e) is reduced in-workgroup iff it lies inside one block of DEME_FORCE_BLOCK contacts
+#ifndef DEME_FORCE_BLOCK
 #define DEME_FORCE_BLOCK 256
+#endif
 #ifndef DEME_FV
 #define DEME_FV 1
 #endif

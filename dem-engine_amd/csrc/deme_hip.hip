@@ -278,7 +278,7 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
             rc |= ensure(c, c->rec[k], cap * 12);
     rc |= ensure(c, c->conA4, cap * 16);
     rc |= ensure(c, c->conA2, cap * 8);
-    rc |= ensure(c, c->conB4, cap * 16);
+    rc |= ensure(c, c->conB4, cap * (DEME_CONB32 ? 32 : 16));
     rc |= ensure(c, c->conB2, cap * 8);
     rc |= ensure(c, c->ownerA, cap * 4);
     for (int k = 0; k < 2; k++) {
@@ -375,7 +375,7 @@ int do_detect(deme_ctx* c) {
             sortedIdx = 1;
             hipLaunchKernelGGL(k_bin_stats, dim3(std::min<unsigned>(grid_for(P), 1024u)), dim3(256), 0, c->stream, c->incKeys[1].as<uint32_t>(), P,
                                c->ctr.as<DetectCounters>());
-            hipLaunchKernelGGL(k_sweep, dim3((grid_for(P, SW_T) + 3) / 4), dim3(SW_T), 0, c->stream, c->dp,
+            hipLaunchKernelGGL(k_sweep, dim3((grid_for(P, SW_T) + SW_WPB - 1) / SW_WPB), dim3(SW_T), 0, c->stream, c->dp,
                                c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
                                c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
                                c->ctr.as<DetectCounters>());
@@ -567,7 +567,7 @@ int launch_forces(deme_ctx* c) {
     }
     {
         ScopedTimer tm(c, "calc_forces");
-        const dim3 g(grid_for(a.nContacts)), b(256);
+        const dim3 g(grid_for(a.nContacts, DEME_FORCE_BLOCK)), b(DEME_FORCE_BLOCK);
         const bool hasSM = c->nTri > 0;
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
             if (hasSM)  // mesh variant first: the hot variant folds its A-side records into the in-block sums
@@ -581,8 +581,10 @@ int launch_forces(deme_ctx* c) {
         else {  // user model: two entry points of the same code object (hot variant, mesh variant)
             void* args0[] = {&c->dp, &a};
             if (hasSM)
-                HIPCK(hipModuleLaunchKernel(c->customFn[1], grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args0, nullptr));
-            HIPCK(hipModuleLaunchKernel(c->customFn[0], grid_for(a.nContacts), 1, 1, 256, 1, 1, 0, c->stream, args0, nullptr));
+                HIPCK(hipModuleLaunchKernel(c->customFn[1], grid_for(a.nContacts, DEME_FORCE_BLOCK), 1, 1, DEME_FORCE_BLOCK, 1, 1, 0,
+                                            c->stream, args0, nullptr));
+            HIPCK(hipModuleLaunchKernel(c->customFn[0], grid_for(a.nContacts, DEME_FORCE_BLOCK), 1, 1, DEME_FORCE_BLOCK, 1, 1, 0, c->stream,
+                                        args0, nullptr));
         }
     }
     c->conValid = true;
