@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--order", default="lattice", choices=["lattice", "morton", "random"],
                     help="order in which the caller hands the clumps over (experiment)")
+    ap.add_argument("--mesh-triangles", type=int, default=0,
+                    help="BASELINE configs[3] flavour: put a wavy, fixed plate of about this many triangles under the bed")
     ap.add_argument("--bin-multiple", type=float, default=4.0,
                     help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,6 +209,12 @@ def main():
 
     pkg = entry.load_package()
     b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order, bin_multiple=args.bin_multiple)
+    if args.mesh_triangles:
+        lo, hi = b.user_box_min, b.user_box_max
+        n_side = max(2, int(round((args.mesh_triangles / 2) ** 0.5)))
+        v, f = pkg.model.plate_mesh(n_side, n_side, float(hi[0] - lo[0]) * 0.98, float(hi[1] - lo[1]) * 0.98, z=0.0, wavy=0.002)
+        m = b.AddMeshObject(v, f, 0)
+        m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 0.021))  # just under the lowest spheres of the lattice
     p, sc = b.Initialize()
     halo, part = None, None
     if world > 1:
@@ -289,7 +297,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: 1M three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling",
                    "clumps_total": total_clumps, "owners_this_rank": int(sc.nOwners), "spheres_this_rank": int(sc.nSpheres),
                    "contacts_this_rank": int(c.nContacts), "bin_sphere_touches": int(c.nBinSphereTouches),
-                   "cd_every": args.cd_freq, "presettle_steps": args.presettle,
+                   "triangles": int(sc.nTri), "cd_every": args.cd_freq, "presettle_steps": args.presettle,
                    "force_model": "Hertzian (history, 4 wildcards)", "integrator": "extended Taylor", "h": p.h,
                    "parallelism": par,
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},

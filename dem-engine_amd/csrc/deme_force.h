@@ -36,6 +36,8 @@ struct ForceArgs {
     float4* conB4;
     float2* conB2;
     float4* aSum;            // two float4 per owner
+    const uint32_t* smList;  // indices of the sphere-mesh contacts (built per detection): the mesh variant's work list
+    uint32_t nSM;
     const uint32_t* aStart;  // nOwners+1: first contact of each owner's A run
     float* recForce;       // optional per-contact records (3 floats each), may be null
     float* recTorque;
@@ -502,7 +504,12 @@ __host__ __device__ inline bool a_run_in_one_block(uint32_t s, uint32_t e) {
 // into the same in-order sum.
 template <int MODEL, int CLS>
 __device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a) {
-    const uint32_t c = blockIdx.x * DEME_FORCE_BLOCK + threadIdx.x;
+    uint32_t c = blockIdx.x * DEME_FORCE_BLOCK + threadIdx.x;
+    if (CLS == 1) {  // mesh variant: one thread per sphere-mesh contact, through the per-detection index list
+        if (c >= a.nSM)
+            return;
+        c = a.smList[c];
+    }
     const bool valid = c < a.nContacts;
     uint4 ci = make_uint4(0, 0, 0, 0);
     bool mine = false;

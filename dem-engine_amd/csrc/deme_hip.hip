@@ -85,7 +85,7 @@ struct deme_ctx {
     // family motion prescriptions: run-time compiled kernel + the owners it applies to
     hipModule_t prescMod = nullptr;
     hipFunction_t prescFn = nullptr;
-    DevBuf prescList, prescSlot, prescRec;
+    DevBuf prescList, prescSlot, prescRec, smFlag, smList;
     hipModule_t rulesMod = nullptr;
     hipFunction_t rulesFn = nullptr;  // on-the-fly family changes
     bool rulesNeedAcc = false;
@@ -286,6 +286,10 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
         rc |= ensure(c, c->bIdx[k], cap * 4);
     }
     rc |= ensure(c, c->info, cap * 16);
+    if (c->nTri) {
+        rc |= ensure(c, c->smFlag, cap);
+        rc |= ensure(c, c->smList, cap * 4);
+    }
     if (rc)
         return rc;
     c->cntCap = cap;
@@ -462,7 +466,19 @@ int do_detect(deme_ctx* c) {
         if (nC) {
             hipLaunchKernelGGL(k_contact_owners, dim3(grid_for(nC)), dim3(256), 0, c->stream, c->dp, (uint32_t)nC,
                                c->keysSorted[next].as<uint64_t>(), c->spheres.as<SphereRec>(), c->ownerA.as<uint32_t>(),
-                               c->ownerB[0].as<uint32_t>(), c->bIdx[0].as<uint32_t>(), c->info.as<uint4>());
+                               c->ownerB[0].as<uint32_t>(), c->bIdx[0].as<uint32_t>(), c->info.as<uint4>(),
+                               c->nTri ? c->smFlag.as<uint8_t>() : (uint8_t*)nullptr);
+            if (c->nTri) {  // work list of the mesh-variant force kernel; its length lands in RangeCounters::nSM
+                unsigned int* cnt = &c->rangeCtr.as<RangeCounters>()->nSM;
+                size_t need2 = 0;
+                HIPCK(rocprim::select(nullptr, need2, rocprim::counting_iterator<uint32_t>(0), c->smFlag.as<uint8_t>(),
+                                      c->smList.as<uint32_t>(), cnt, (size_t)nC, c->stream));
+                if (int rc = ensure(c, c->scanTmp, need2))
+                    return rc;
+                need2 = c->scanTmp.bytes;
+                HIPCK(rocprim::select(c->scanTmp.p, need2, rocprim::counting_iterator<uint32_t>(0), c->smFlag.as<uint8_t>(),
+                                      c->smList.as<uint32_t>(), cnt, (size_t)nC, c->stream));
+            }
             unsigned obits = 1;
             while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
                 obits++;
@@ -559,6 +575,8 @@ int launch_forces(deme_ctx* c) {
     a.conB4 = c->conB4.as<float4>(), a.conB2 = c->conB2.as<float2>();
     a.aSum = c->aSum.as<float4>();
     a.aStart = c->aStart.as<uint32_t>();
+    a.smList = c->smList.as<uint32_t>();
+    a.nSM = c->nSM;
     a.nContacts = (uint32_t)c->nContacts;
     a.timeElapsed = (float)c->timeElapsed;
     if (c->record) {
@@ -568,20 +586,21 @@ int launch_forces(deme_ctx* c) {
     {
         ScopedTimer tm(c, "calc_forces");
         const dim3 g(grid_for(a.nContacts, DEME_FORCE_BLOCK)), b(DEME_FORCE_BLOCK);
-        const bool hasSM = c->nTri > 0;
+        const bool hasSM = c->nTri > 0 && c->nSM > 0;
+        const dim3 gm(grid_for(std::max<uint32_t>(c->nSM, 1u), DEME_FORCE_BLOCK));
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
             if (hasSM)  // mesh variant first: the hot variant folds its A-side records into the in-block sums
-                hipLaunchKernelGGL((k_calc_forces<0, 1>), g, b, 0, c->stream, c->dp, a);
+                hipLaunchKernelGGL((k_calc_forces<0, 1>), gm, b, 0, c->stream, c->dp, a);
             hipLaunchKernelGGL((k_calc_forces<0, 0>), g, b, 0, c->stream, c->dp, a);
         } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN_FRICTIONLESS) {
             if (hasSM)
-                hipLaunchKernelGGL((k_calc_forces<1, 1>), g, b, 0, c->stream, c->dp, a);
+                hipLaunchKernelGGL((k_calc_forces<1, 1>), gm, b, 0, c->stream, c->dp, a);
             hipLaunchKernelGGL((k_calc_forces<1, 0>), g, b, 0, c->stream, c->dp, a);
         }
         else {  // user model: two entry points of the same code object (hot variant, mesh variant)
             void* args0[] = {&c->dp, &a};
             if (hasSM)
-                HIPCK(hipModuleLaunchKernel(c->customFn[1], grid_for(a.nContacts, DEME_FORCE_BLOCK), 1, 1, DEME_FORCE_BLOCK, 1, 1, 0,
+                HIPCK(hipModuleLaunchKernel(c->customFn[1], gm.x, 1, 1, DEME_FORCE_BLOCK, 1, 1, 0,
                                             c->stream, args0, nullptr));
             HIPCK(hipModuleLaunchKernel(c->customFn[0], grid_for(a.nContacts, DEME_FORCE_BLOCK), 1, 1, DEME_FORCE_BLOCK, 1, 1, 0, c->stream,
                                         args0, nullptr));
@@ -702,7 +721,7 @@ void deme_ctx_destroy(deme_ctx* c) {
     drain_timers(c);
     for (auto e : c->eventPool)
         hipEventDestroy(e);
-    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -883,10 +902,10 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     }
     if (int rc = grow_incidence_arena(c, std::max<size_t>(8 * nS, 4096)))
         return rc;
+    c->nTri = s->nTri;  // before the contact arena: its mesh work-list buffers exist only when triangles do
     if (int rc = grow_contact_arena(c, std::max<size_t>(6 * nS, 4096)))
         return rc;
     // triangles
-    c->nTri = s->nTri;
     if (s->nTri) {
         if (!s->ownerMesh || !s->triNode1 || !s->triNode2 || !s->triNode3)
             return fail(c, DEME_ERR_INVALID, "nTri > 0 but triangle arrays are missing");

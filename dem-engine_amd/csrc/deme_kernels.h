@@ -757,7 +757,8 @@ __global__ __launch_bounds__(256) void k_reduce_heavy(const GatherArgs g, const 
 __global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint32_t nC, const uint64_t* __restrict__ keys,
                                                         const SphereRec* __restrict__ spheres,
                                                         uint32_t* __restrict__ ownerA, uint32_t* __restrict__ ownerB,
-                                                        uint32_t* __restrict__ idx, uint4* __restrict__ info) {
+                                                        uint32_t* __restrict__ idx, uint4* __restrict__ info,
+                                                        uint8_t* __restrict__ smFlag) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nC)
         return;
@@ -778,6 +779,8 @@ __global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint3
     ownerB[c] = ob;
     idx[c] = c;
     info[c] = make_uint4(sa.owner | (cls << 30), ob, (uint32_t)sa.comp | ((uint32_t)sa.mat << 16), w);
+    if (smFlag)
+        smFlag[c] = (cls == DEME_KEY_CLASS_SM) ? 1 : 0;
 }
 
 __device__ inline uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t v) {

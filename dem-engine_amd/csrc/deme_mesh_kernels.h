@@ -99,6 +99,24 @@ __global__ __launch_bounds__(256) void k_tri_fill(const DevParams p, uint32_t nT
             }
 }
 
+#define TRI_WBUF 256u
+// all lanes of one wavefront: append wbuf[0..n) to the global key list (LDS operations of one wavefront complete in order)
+__device__ inline void tri_flush(const uint64_t* wbuf, uint32_t n, uint32_t lane, uint64_t* __restrict__ outKeys, uint64_t cap,
+                                 DetectCounters* ctr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned long long base = 0;
+    if (lane == 0)
+        base = atomicAdd(&ctr->nContactsRaw, (unsigned long long)n);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < n; i += 64u)
+        if (base + i < cap)
+            outKeys[base + i] = wbuf[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // one thread per (bin, triangle) incidence: every sphere registered in that bin (binary search over the
 // bin-sorted sphere incidence list) is tested against both sandwich triangles
 __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t TP, const uint32_t* __restrict__ triKeys,
@@ -107,6 +125,9 @@ __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t T
                                                    const uint32_t* __restrict__ sphIds, const GeoRec* __restrict__ geo,
                                                    const OwnerRec* __restrict__ owners, uint64_t* __restrict__ outKeys,
                                                    uint64_t cap, DetectCounters* ctr) {
+    __shared__ uint64_t wbufAll[4][TRI_WBUF];
+    uint64_t* wbuf = wbufAll[threadIdx.x >> 6];
+    uint32_t nBuf = 0;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const bool valid = e < TP;
@@ -169,20 +190,21 @@ __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t T
                 }
             }
         }
+        // hits are collected in a wavefront-private LDS buffer and appended to the global list with ONE reservation per
+        // flush: a reservation per loop iteration made this kernel atomic-bound (same-address atomics ~12 ns each)
         const unsigned long long m = __ballot(hit);
         if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            unsigned long long base = 0;
-            if ((int)lane == leader)
-                base = atomicAdd(&ctr->nContactsRaw, (unsigned long long)__popcll(m));
-            base = __shfl(base, leader);
-            if (hit) {
-                const unsigned long long slot = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-                if (slot < cap)
-                    outKeys[slot] = key;
-            }
+            if (hit)
+                wbuf[nBuf + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+            nBuf += (uint32_t)__popcll(m);  // wave-uniform
+        }
+        if (nBuf > TRI_WBUF - 64u) {
+            tri_flush(wbuf, nBuf, lane, outKeys, cap, ctr);
+            nBuf = 0;
         }
     }
+    if (nBuf)
+        tri_flush(wbuf, nBuf, lane, outKeys, cap, ctr);
 }
 
 __global__ __launch_bounds__(256) void k_pack_tris(uint32_t nTri, TriRec* tris, const float* n1, const float* n2, const float* n3) {
