@@ -120,8 +120,18 @@ def pmc_calibration(torch):
 class Halo:
     """Per-step ghost exchange with the face neighbours (RCCL P2P through torch.distributed)."""
 
-    def __init__(self, pkg, ctx, part, rank, world, torch, dist, via_host=False):
+    def __init__(self, pkg, ctx, part, rank, world, torch, dist, via_host=False, overlap=True):
         self.ctx, self.rank, self.world, self.torch, self.dist = ctx, rank, world, torch, dist
+        # overlap: ghost traffic on the context's halo stream while the compute stream evaluates the owner runs that read
+        # no ghost (deme_step_overlap_begin / _end); otherwise everything is ordered on the compute stream
+        self.overlap = overlap and not via_host
+        self.halo_stream = None
+        if self.overlap:
+            try:
+                self.halo_stream = torch.cuda.ExternalStream(ctx.halo_stream())
+            except Exception as e:  # an older torch without ExternalStream: fall back to the ordered exchange
+                print(f"[bench] halo overlap disabled: {e}", file=sys.stderr)
+                self.overlap = False
         self.via_host = via_host  # plumbing test on a box with fewer GPUs than ranks: gloo, staged through host memory
         dev = torch.device("cuda", torch.cuda.current_device())
         keys = ("send_left", "send_right", "recv_left", "recv_right")
@@ -130,6 +140,27 @@ class Halo:
         self.buf = {k: torch.empty(max(1, len(part[k])) * gb, dtype=torch.uint8, device=dev) for k in keys}
         self.n = {k: len(part[k]) for k in keys}
         self.bytes_per_step = gb * (self.n["send_left"] + self.n["send_right"])
+
+    def step(self):
+        """one time step including the ghost exchange"""
+        if not self.overlap:
+            self.exchange()
+            self.ctx.step(1)
+            return
+        c, d = self.ctx, self.dist
+        c.step_overlap_begin()
+        sides = [(s, nb) for s, nb in (("left", self.rank - 1), ("right", self.rank + 1)) if 0 <= nb < self.world]
+        ops = []
+        for side, nb in sides:
+            c.halo_pack_async(self.ids["send_" + side].data_ptr(), self.n["send_" + side], self.buf["send_" + side].data_ptr())
+            ops.append(d.P2POp(d.isend, self.buf["send_" + side], nb))
+            ops.append(d.P2POp(d.irecv, self.buf["recv_" + side], nb))
+        with self.torch.cuda.stream(self.halo_stream):  # RCCL orders the transfers against the halo stream
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+        for side, nb in sides:
+            c.halo_unpack_async(self.ids["recv_" + side].data_ptr(), self.n["recv_" + side], self.buf["recv_" + side].data_ptr())
+        c.step_overlap_end()
 
     def exchange(self):
         c, d = self.ctx, self.dist
@@ -180,6 +211,7 @@ def main():
                     help="BASELINE configs[3] flavour: put a wavy, fixed plate of about this many triangles under the bed")
     ap.add_argument("--bin-multiple", type=float, default=4.0,
                     help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: order the ghost exchange on the compute stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -234,15 +266,14 @@ def main():
     ctx.set_params(p)
     ctx.upload_scene(sc)
     if world > 1:
-        halo = Halo(pkg, ctx, part, rank, world, torch, dist, via_host=via_host)
+        halo = Halo(pkg, ctx, part, rank, world, torch, dist, via_host=via_host, overlap=not args.no_overlap)
 
     def run(n):
         if halo is None:
             ctx.step(n)
         else:
             for _ in range(n):
-                halo.exchange()
-                ctx.step(1)
+                halo.step()
 
     def barrier():
         ctx.sync()
@@ -289,6 +320,7 @@ def main():
     achieved = fbytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
     par = f"{world} x-slab(s)"
     if halo:
+        par += (", overlapped with the interior force evaluation on a second stream" if halo.overlap else "")
         par += f", ghost exchange every step over {'gloo via host memory (PLUMBING TEST, not a measurement)' if via_host else 'RCCL'} ({halo.bytes_per_step} B sent per step by rank 0)"
     out = {
         "metric": "clump*steps/s", "value": value, "unit": "clump*steps/s", "n_gpus": world, "steps": args.steps,

@@ -176,6 +176,9 @@ def load_library():
         "deme_upload_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_seed_contacts": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_compile_prescriptions": [_P, C.c_char_p, C.c_char_p, C.c_char_p],
+        "deme_halo_stream": [_P, C.POINTER(_P)], "deme_halo_pack_async": [_P, _P, C.c_uint32, _P],
+        "deme_halo_unpack_async": [_P, _P, C.c_uint32, _P], "deme_halo_sync": [_P],
+        "deme_step_overlap_begin": [_P, C.POINTER(C.c_int)], "deme_step_overlap_end": [_P],
         "deme_compile_family_rules": [_P, C.c_char_p], "deme_change_family": [_P, C.c_uint32, C.c_uint32],
         "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)], "deme_inspect_values": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_set_record_contacts": [_P, C.c_int],
@@ -346,6 +349,29 @@ class Context:
         out = np.zeros(int(n), np.float32)
         self._ck(self.lib.deme_inspect_values(self.h, self.INSPECT_CODES[quantity], _ptr(out), out.size), "deme_inspect_values")
         return out
+
+    # ---- halo exchange overlapped with the interior force evaluation (see include/deme_hip.h)
+    def halo_stream(self):
+        st = _P()
+        self._ck(self.lib.deme_halo_stream(self.h, C.byref(st)), "deme_halo_stream")
+        return st.value
+
+    def halo_pack_async(self, d_ids, n, d_buf):
+        self._ck(self.lib.deme_halo_pack_async(self.h, _P(d_ids), int(n), _P(d_buf)), "deme_halo_pack_async")
+
+    def halo_unpack_async(self, d_ids, n, d_buf):
+        self._ck(self.lib.deme_halo_unpack_async(self.h, _P(d_ids), int(n), _P(d_buf)), "deme_halo_unpack_async")
+
+    def halo_sync(self):
+        self._ck(self.lib.deme_halo_sync(self.h), "deme_halo_sync")
+
+    def step_overlap_begin(self):
+        due = C.c_int(0)
+        self._ck(self.lib.deme_step_overlap_begin(self.h, C.byref(due)), "deme_step_overlap_begin")
+        return bool(due.value)
+
+    def step_overlap_end(self):
+        self._ck(self.lib.deme_step_overlap_end(self.h), "deme_step_overlap_end")
 
     def compile_family_rules(self, rules):
         """ChangeFamilyWhen rules: the _familyChangeRules_ text of equipFamilyOnFlyChanges (see include/deme_hip.h)."""

@@ -36,6 +36,12 @@ struct ForceArgs {
     float4* conB4;
     float2* conB2;
     float4* aSum;            // two float4 per owner
+    // halo overlap (slab decomposition): cDefer[c] = 1 for the contacts of an owner run that touches a ghost owner; they
+    // are evaluated in pass 1, after the ghost records of this step have arrived; blockMode[b] bit p: block b has pass-p
+    // work.  Both null: no split (single GPU, or an un-split step).
+    const uint8_t* cDefer;
+    const uint32_t* blockMode;
+    uint32_t pass;
     const uint32_t* smList;  // indices of the sphere-mesh contacts (built per detection): the mesh variant's work list
     uint32_t nSM;
     const uint32_t* aStart;  // nOwners+1: first contact of each owner's A run
@@ -504,6 +510,8 @@ __host__ __device__ inline bool a_run_in_one_block(uint32_t s, uint32_t e) {
 // into the same in-order sum.
 template <int MODEL, int CLS>
 __device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a) {
+    if (CLS == 0 && a.blockMode && !(a.blockMode[blockIdx.x] & (1u << a.pass)))
+        return;  // nothing of this pass in the block (workgroup-uniform)
     uint32_t c = blockIdx.x * DEME_FORCE_BLOCK + threadIdx.x;
     if (CLS == 1) {  // mesh variant: one thread per sphere-mesh contact, through the per-detection index list
         if (c >= a.nSM)
@@ -516,9 +524,12 @@ __device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a)
     float4 c4 = make_float4(0, 0, 0, 0);
     float2 c2 = make_float2(0, 0);
     uint32_t s = 0, e = 0;
+    bool inPass = valid;
     if (valid) {
         ci = a.info[c];
-        mine = (CLS == 1) == ((ci.x >> 30) == DEME_KEY_CLASS_SM);
+        if (CLS == 0 && a.cDefer)
+            inPass = a.cDefer[c] == a.pass;
+        mine = inPass && ((CLS == 1) == ((ci.x >> 30) == DEME_KEY_CLASS_SM));
 #if DEME_FV >= 1
         if (CLS == 0) {  // issued before the force evaluation so that their latency is hidden behind it
             s = a.aStart[ci.x & 0x3FFFFFFFu];
@@ -537,7 +548,7 @@ __device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a)
     }
     __shared__ float4 s4[DEME_FORCE_BLOCK];
     __shared__ float2 s2[DEME_FORCE_BLOCK];
-    if (valid && !mine) {  // sphere-mesh contact: evaluated by the mesh variant
+    if (inPass && !mine) {  // sphere-mesh contact: evaluated by the mesh variant
         c4 = a.conA4[c];
         c2 = a.conA2[c];
     }
@@ -552,8 +563,8 @@ __device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a)
 #else
     __syncthreads();
 #endif
-    if (!valid)
-        return;
+    if (!inPass)
+        return;  // beyond the list, or a contact of the other pass (whole owner runs belong to one pass)
     const uint32_t AOwner = ci.x & 0x3FFFFFFFu;
 #if DEME_FV == 0
     s = a.aStart[AOwner], e = a.aStart[AOwner + 1];

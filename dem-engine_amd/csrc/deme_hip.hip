@@ -85,7 +85,11 @@ struct deme_ctx {
     // family motion prescriptions: run-time compiled kernel + the owners it applies to
     hipModule_t prescMod = nullptr;
     hipFunction_t prescFn = nullptr;
-    DevBuf prescList, prescSlot, prescRec, smFlag, smList;
+    DevBuf prescList, prescSlot, prescRec, smFlag, smList, cDefer, blockMode;
+    bool hasGhosts = false;  // a family carries DEME_FAMILY_GHOST: force passes can be split for the halo overlap
+    hipStream_t haloStream = nullptr;
+    hipEvent_t evStepDone = nullptr, evHaloDone = nullptr;
+    bool overlapDetect = false;  // the step opened by deme_step_overlap_begin needs a detection first
     hipModule_t rulesMod = nullptr;
     hipFunction_t rulesFn = nullptr;  // on-the-fly family changes
     bool rulesNeedAcc = false;
@@ -286,6 +290,10 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
         rc |= ensure(c, c->bIdx[k], cap * 4);
     }
     rc |= ensure(c, c->info, cap * 16);
+    if (c->hasGhosts) {
+        rc |= ensure(c, c->cDefer, cap);
+        rc |= ensure(c, c->blockMode, (cap / DEME_FORCE_BLOCK + 2) * 4);
+    }
     if (c->nTri) {
         rc |= ensure(c, c->smFlag, cap);
         rc |= ensure(c, c->smList, cap * 4);
@@ -493,11 +501,17 @@ int do_detect(deme_ctx* c) {
                                             c->bIdx[0].as<uint32_t>(), c->bIdx[1].as<uint32_t>(), (size_t)nC, 0, obits,
                                             c->stream));
         }
+        if (c->hasGhosts) {  // (the arena may have been sized before the scene's family flags were known)
+            if (ensure(c, c->cDefer, c->cntCap) || ensure(c, c->blockMode, (c->cntCap / DEME_FORCE_BLOCK + 2) * 4))
+                return c->lastStatus;
+            HIPCK(hipMemsetAsync(c->blockMode.p, 0, c->blockMode.bytes, c->stream));
+        }
         hipLaunchKernelGGL(k_owner_ranges, dim3(grid_for((size_t)c->nOwners + 1)), dim3(256), 0, c->stream, c->dp,
                            (uint32_t)nC, c->ownerA.as<uint32_t>(), c->ownerB[1].as<uint32_t>(), c->owners.as<OwnerRec>(),
                            c->aStart.as<uint32_t>(), c->bStart.as<uint32_t>(), c->heavy.as<uint8_t>(),
                            c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(), (uint32_t)(c->heavyList.bytes / 4),
-                           c->rangeCtr.as<RangeCounters>());
+                           c->rangeCtr.as<RangeCounters>(), c->info.as<uint4>(),
+                           c->hasGhosts ? c->cDefer.as<uint8_t>() : (uint8_t*)nullptr, c->blockMode.as<uint32_t>());
         RangeCounters hr{};
         HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
@@ -558,7 +572,8 @@ void launch_reduce_heavy(deme_ctx* c, bool skipFixed) {
                        skipFixed ? c->fixedFlag.as<uint8_t>() : (const uint8_t*)nullptr, c->acc.as<AccRec>());
 }
 
-int launch_forces(deme_ctx* c) {
+// pass: -1 everything in one launch; 0 / 1 the two halves of a split step (contacts that read no ghost owner / the rest)
+int launch_forces(deme_ctx* c, int pass = -1) {
     if (c->nContacts == 0) {
         c->conValid = true;
         return DEME_OK;
@@ -577,6 +592,11 @@ int launch_forces(deme_ctx* c) {
     a.aStart = c->aStart.as<uint32_t>();
     a.smList = c->smList.as<uint32_t>();
     a.nSM = c->nSM;
+    if (pass >= 0 && c->hasGhosts && c->cDefer.p) {
+        a.cDefer = c->cDefer.as<uint8_t>();
+        a.blockMode = c->blockMode.as<uint32_t>();
+        a.pass = (uint32_t)pass;
+    }
     a.nContacts = (uint32_t)c->nContacts;
     a.timeElapsed = (float)c->timeElapsed;
     if (c->record) {
@@ -721,7 +741,13 @@ void deme_ctx_destroy(deme_ctx* c) {
     drain_timers(c);
     for (auto e : c->eventPool)
         hipEventDestroy(e);
-    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    if (c->haloStream) {
+        hipStreamSynchronize(c->haloStream);
+        hipEventDestroy(c->evStepDone);
+        hipEventDestroy(c->evHaloDone);
+        hipStreamDestroy(c->haloStream);
+    }
+    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -879,6 +905,9 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     memset(c->hostFamFlags, 0, sizeof(c->hostFamFlags));
     if (s->familyFlags)
         memcpy(c->hostFamFlags, s->familyFlags, DEME_NUM_FAMILIES);
+    c->hasGhosts = false;
+    for (int f = 0; f < DEME_NUM_FAMILIES; f++)
+        c->hasGhosts = c->hasGhosts || (c->hostFamFlags[f] & DEME_FAMILY_GHOST);
     c->prescDirty = true;
     bool trivial = true;
     if (s->familyMasks)
@@ -1087,6 +1116,8 @@ int deme_integrate(deme_ctx* c) {
     return DEME_OK;
 }
 
+static int step_tail(deme_ctx* c);
+
 int deme_step(deme_ctx* c, uint32_t nsteps) {
     if (int rc = check_ready(c))
         return rc;
@@ -1103,6 +1134,15 @@ int deme_step(deme_ctx* c, uint32_t nsteps) {
         }
         if (int rc = launch_forces(c))
             return rc;
+        if (int rc = step_tail(c))
+            return rc;
+    }
+    return DEME_OK;
+}
+
+// rules + integration + bookkeeping of one step (after the force evaluation)
+static int step_tail(deme_ctx* c) {
+    {
         bool fused = true;
         if (c->rulesFn) {  // routineChecks(): applyFamilyChanges between forces and integration (dT.cpp:2437-2443)
             const AccRec* accp = nullptr;
@@ -1123,7 +1163,93 @@ int deme_step(deme_ctx* c, uint32_t nsteps) {
         c->nSteps++;
         c->timeElapsed += (double)c->hp.h;
     }
+    if (c->evStepDone)
+        HIPCK(hipEventRecord(c->evStepDone, c->stream));
     return DEME_OK;
+}
+
+static bool detection_due(deme_ctx* c) {
+    const uint32_t K = c->hp.cdUpdateFreq;
+    return !c->haveList || c->seeded || K == 0 || c->stepsSinceCD >= K;
+}
+
+static int ensure_halo_stream(deme_ctx* c) {
+    if (c->haloStream)
+        return DEME_OK;
+    HIPCK(hipStreamCreateWithFlags(&c->haloStream, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&c->evStepDone, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&c->evHaloDone, hipEventDisableTiming));
+    HIPCK(hipEventRecord(c->evStepDone, c->stream));
+    return DEME_OK;
+}
+
+int deme_halo_stream(deme_ctx* c, void** stream) {
+    if (!c || !stream)
+        return DEME_ERR_INVALID;
+    if (int rc = ensure_halo_stream(c))
+        return rc;
+    *stream = (void*)c->haloStream;
+    return DEME_OK;
+}
+
+int deme_halo_pack_async(deme_ctx* c, const uint32_t* d_ids, uint32_t n, void* d_buf) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (int rc = ensure_halo_stream(c))
+        return rc;
+    HIPCK(hipStreamWaitEvent(c->haloStream, c->evStepDone, 0));  // the owners' state of the step just integrated
+    if (n)
+        hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(n)), dim3(256), 0, c->haloStream, n, d_ids, c->owners.as<OwnerRec>(),
+                           (GhostRec*)d_buf);
+    return DEME_OK;
+}
+
+int deme_halo_unpack_async(deme_ctx* c, const uint32_t* d_ids, uint32_t n, const void* d_buf) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (int rc = ensure_halo_stream(c))
+        return rc;
+    if (n)
+        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->haloStream, n, d_ids, c->owners.as<OwnerRec>(),
+                           (const GhostRec*)d_buf);
+    HIPCK(hipEventRecord(c->evHaloDone, c->haloStream));
+    return DEME_OK;
+}
+
+int deme_halo_sync(deme_ctx* c) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    if (c->haloStream)
+        HIPCK(hipStreamSynchronize(c->haloStream));
+    return DEME_OK;
+}
+
+int deme_step_overlap_begin(deme_ctx* c, int* detectionDue) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (int rc = ensure_halo_stream(c))
+        return rc;
+    c->overlapDetect = detection_due(c) || !c->hasGhosts;
+    if (detectionDue)
+        *detectionDue = c->overlapDetect ? 1 : 0;
+    if (c->overlapDetect)
+        return DEME_OK;  // a detection reads the ghosts' new positions: nothing can start before they are in place
+    return launch_forces(c, 0);
+}
+
+int deme_step_overlap_end(deme_ctx* c) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (int rc = ensure_halo_stream(c))
+        return rc;
+    HIPCK(hipStreamWaitEvent(c->stream, c->evHaloDone, 0));
+    if (c->overlapDetect) {
+        c->overlapDetect = false;
+        return deme_step(c, 1);
+    }
+    if (int rc = launch_forces(c, 1))
+        return rc;
+    return step_tail(c);
 }
 
 int deme_get_counts(deme_ctx* c, DemeCounts* out) {

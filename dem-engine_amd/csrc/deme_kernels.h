@@ -809,7 +809,9 @@ __global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_
                                                       const OwnerRec* __restrict__ owners, uint32_t* __restrict__ aStart,
                                                       uint32_t* __restrict__ bStart, uint8_t* __restrict__ heavy,
                                                       uint8_t* __restrict__ fixedFlag, uint32_t* __restrict__ heavyList,
-                                                      uint32_t heavyCap, RangeCounters* rc) {
+                                                      uint32_t heavyCap, RangeCounters* rc,
+                                                      const uint4* __restrict__ info, uint8_t* __restrict__ cDefer,
+                                                      uint32_t* __restrict__ blockMode) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o > p.nOwners)
         return;
@@ -824,6 +826,16 @@ __global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_
     bStart[o] = b0;
     const bool isFixed = (p.familyFlags[owners[o].family] & 3u) != 0;  // fixed or ghost: a/alpha never integrated here
     fixedFlag[o] = isFixed ? 1 : 0;
+    if (cDefer) {  // halo overlap: an owner run that reads any ghost owner is evaluated after the ghost records arrive
+        bool d = (p.familyFlags[owners[o].family] & 2u) != 0;
+        for (uint32_t c = a0; c < a1 && !d; c++)
+            d = (p.familyFlags[owners[info[c].y].family] & 2u) != 0;  // info.y: B's owner (k_contact_owners)
+        for (uint32_t c = a0; c < a1; c++) {
+            cDefer[c] = d ? 1 : 0;
+            if (c == a0 || (c % DEME_FORCE_BLOCK) == 0)
+                atomicOr(&blockMode[c / DEME_FORCE_BLOCK], d ? 2u : 1u);
+        }
+    }
     const bool hv = (a1 - a0) + (b1 - b0) > DEME_HEAVY_THRESHOLD;
     heavy[o] = hv ? 1 : 0;
     if (hv) {
@@ -1136,7 +1148,10 @@ __global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n, const uint32_t*
         return;
     const GhostRec g = buf[i];
     OwnerRec* r = owners + ids[i];
-    r->voxelID = g.voxelID, r->locX = g.locX, r->locY = g.locY, r->locZ = g.locZ, r->family = g.family;
+    // the ghost copy keeps its LOCAL family (the ghost family: never integrated here, left out of inspections, and what
+    // marks an owner run as halo-dependent); the owner rank's family travels in the record but is not applied -- family-
+    // specific contact masks are therefore not honoured across a cut
+    r->voxelID = g.voxelID, r->locX = g.locX, r->locY = g.locY, r->locZ = g.locZ;
     r->qw = g.qw, r->qx = g.qx, r->qy = g.qy, r->qz = g.qz;
     r->vx = g.vx, r->vy = g.vy, r->vz = g.vz, r->wx = g.wx, r->wy = g.wy, r->wz = g.wz;
 }

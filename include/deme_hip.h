@@ -276,6 +276,23 @@ int deme_set_timing(deme_ctx* ctx, int enable);
 int deme_halo_pack(deme_ctx* ctx, const uint32_t* d_ownerIDs, uint32_t n, void* d_buf);
 int deme_halo_unpack(deme_ctx* ctx, const uint32_t* d_ownerIDs, uint32_t n, const void* d_buf);
 
+/* Halo exchange overlapped with the interior force evaluation (north_star; no reference equivalent).  The context owns a
+ * second stream for the ghost traffic.  Per step:
+ *   deme_step_overlap_begin   forces of the owner runs that read no ghost owner (compute stream); *detectionDue = 1 when
+ *                             this step starts with a contact detection, which needs the ghosts first: nothing is launched
+ *   deme_halo_pack_async      pack on the halo stream, ordered after the previous step's integration
+ *   (the caller's send / recv of the packed records, enqueued on deme_halo_stream)
+ *   deme_halo_unpack_async    unpack on the halo stream
+ *   deme_step_overlap_end     compute stream waits for the unpack; remaining forces, integration
+ *                             (or, when a detection was due, the whole un-split step)
+ * The two force passes together evaluate every contact exactly once, in the same arithmetic as deme_step. */
+int deme_halo_stream(deme_ctx* ctx, void** hipStream);
+int deme_halo_pack_async(deme_ctx* ctx, const uint32_t* d_ownerIDs, uint32_t n, void* d_buf);
+int deme_halo_unpack_async(deme_ctx* ctx, const uint32_t* d_ownerIDs, uint32_t n, const void* d_buf);
+int deme_halo_sync(deme_ctx* ctx);
+int deme_step_overlap_begin(deme_ctx* ctx, int* detectionDue);
+int deme_step_overlap_end(deme_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,6 +151,58 @@ def test_two_slabs_on_gpu_match_single_domain(pkg):
     assert np.abs(X - X1).max() < 2e-7
 
 
+@pytest.mark.gpu
+def test_overlapped_halo_steps_equal_plain_steps(pkg):
+    """the split force passes + halo stream (deme_step_overlap_begin / _end) give bit-identical states to the plain
+    pack -> unpack -> deme_step(1) loop, with detection every K steps (K = 7: detection and split steps alternate)"""
+    import ctypes as C
+    b, p, sc, x = build_global(pkg, n=3000, seed=6, cd_freq=7)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
+    hip = C.CDLL("libamdhip64.so")
+
+    def dev(host=None, nbytes=0):
+        ptr = C.c_void_p()
+        nbytes = host.nbytes if host is not None else nbytes
+        assert hip.hipMalloc(C.byref(ptr), C.c_size_t(max(nbytes, 16))) == 0
+        if host is not None and host.nbytes:
+            assert hip.hipMemcpy(ptr, C.c_void_p(host.ctypes.data), C.c_size_t(host.nbytes), 1) == 0
+        return ptr.value
+
+    def make(pp, s):
+        ctx = pkg.Context(0)
+        ctx.set_params(pp), ctx.upload_scene(s)
+        return ctx
+
+    ids = [{k: dev(np.ascontiguousarray(pt[k].astype(np.uint32))) for k in ("send_left", "send_right", "recv_left", "recv_right")}
+           for pt in parts]
+    n01, n10 = len(parts[0]["send_right"]), len(parts[1]["send_left"])
+    buf01, buf10 = dev(nbytes=n01 * pkg.abi.GHOST_BYTES), dev(nbytes=n10 * pkg.abi.GHOST_BYTES)
+    steps = 60
+    plain = [make(p, pt["scene"]) for pt in parts]
+    for _ in range(steps):
+        plain[0].halo_pack(ids[0]["send_right"], n01, buf01), plain[1].halo_pack(ids[1]["send_left"], n10, buf10)
+        plain[0].sync(), plain[1].sync()
+        plain[1].halo_unpack(ids[1]["recv_left"], n01, buf01), plain[0].halo_unpack(ids[0]["recv_right"], n10, buf10)
+        plain[0].step(1), plain[1].step(1)
+    over = [make(p, pt["scene"]) for pt in parts]
+    n_split = 0
+    for _ in range(steps):
+        due = [c.step_overlap_begin() for c in over]  # interior forces start here on the compute streams
+        over[0].halo_sync(), over[1].halo_sync()  # the other context's unpack of the previous step has read my send buffer
+        n_split += int(not due[0])
+        over[0].halo_pack_async(ids[0]["send_right"], n01, buf01), over[1].halo_pack_async(ids[1]["send_left"], n10, buf10)
+        over[0].halo_sync(), over[1].halo_sync()  # stands in for the send / recv between the two ranks
+        over[1].halo_unpack_async(ids[1]["recv_left"], n01, buf01), over[0].halo_unpack_async(ids[0]["recv_right"], n10, buf10)
+        over[0].step_overlap_end(), over[1].step_overlap_end()
+    assert 40 < n_split < steps  # most steps were split, the detection steps were not
+    for a, b_ in zip(plain, over):
+        sa, sb = a.download_state(), b_.download_state()
+        for k in GKEYS:
+            assert np.array_equal(sa[k], sb[k]), k
+        assert int(a.counts().nContacts) == int(b_.counts().nContacts) > 100
+        assert np.array_equal(a.wildcard(3), b_.wildcard(3))
+
+
 def _decode_x(pkg, p):
     def f(arrays):
         X = pkg.model.decode_positions(arrays["voxelID"], arrays["locX"], arrays["locY"], arrays["locZ"], p.nvXp2, p.nvYp2,
