@@ -1,0 +1,100 @@
+"""BASELINE configs[1] at FULL size (1e6 three-sphere clumps) on the GPU: the contact list against the oracle bit for bit,
+plus size-independent properties (sortedness / uniqueness, idempotent detection, Newton's third law over the whole list,
+every listed pair really within reach, every sampled sphere's neighbourhood complete)."""
+import numpy as np
+import pytest
+
+N = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def big(pkg):
+    import bench
+    b = bench.build_bed(pkg, N, 2024, 0)
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    p.cdUpdateFreq = 40
+    ctx.set_params(p)
+    ctx.step(22000)  # the dropped lattice lands and closes up: a few million contacts
+    p.cdUpdateFreq = 0
+    ctx.set_params(p)
+    return b, p, sc, ctx
+
+
+@pytest.mark.gpu
+def test_full_size_contact_list_matches_oracle(pkg, orc, big):
+    import os
+    b, p, sc, ctx = big
+    orc.set_num_threads(min(64, os.cpu_count() or 1))
+    try:
+        st = ctx.download_state()
+        sim = orc.make_sim(pkg, p, sc)
+        sim.upload_state({k: st[k] for k in st if not k.startswith(("a", "alpha"))})
+        ctx.compute_margins(0), sim.compute_margins(0)
+        ctx.detect(), sim.detect()
+        a, bb, t, _ = ctx.contacts()
+        oa, ob, ot, _ = sim.contacts()
+        assert len(a) == len(oa) > 1_000_000
+        assert np.array_equal(a, oa) and np.array_equal(bb, ob) and np.array_equal(t, ot)
+        gi, oi = ctx.bin_incidence(), sim.bin_incidence()
+        assert np.array_equal(gi[0], oi[0]) and np.array_equal(gi[1], oi[1])  # (bin, sphere) incidences, bin-sorted
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+@pytest.mark.gpu
+def test_full_size_properties(pkg, big):
+    b, p, sc, ctx = big
+    ctx.compute_margins(0), ctx.detect(), ctx.migrate()
+    a, bb, t, m = ctx.contacts()
+    n = len(a)
+    # canonical order: by sphere A, then class (SS, SM, SA), then B; no duplicates
+    cls = np.where(t == 1, 0, np.where(t == 2, 1, 2)).astype(np.uint64)
+    key = (a.astype(np.uint64) << np.uint64(33)) | (cls << np.uint64(31)) | bb.astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])
+    ss = t == 1
+    assert np.all(a[ss] < bb[ss])
+    own = b.arrays["ownerClumpBody"]
+    assert np.all(own[a[ss]] != own[bb[ss]])  # never two spheres of one clump
+    # idempotence: detecting again on the same state reproduces the list and maps every contact onto itself
+    ctx.detect()
+    a2, b2, t2, m2 = ctx.contacts()
+    assert np.array_equal(a, a2) and np.array_equal(bb, b2) and np.array_equal(t, t2)
+    assert np.array_equal(m2, np.arange(n, dtype=np.uint32))
+    ctx.migrate()
+    # every listed sphere-sphere pair is within reach (centre distance <= r_A + r_B + both margins) ...
+    gx, gy, gz, R = ctx.sphere_geometry()  # world positions and margin-inflated radii as the sweep sees them
+    X = np.stack([gx, gy, gz], 1)
+    R = R.astype(np.float64)
+    d = np.linalg.norm(X[a[ss]] - X[bb[ss]], axis=1)
+    assert np.all(d <= R[a[ss]] + R[bb[ss]] + 1e-12)
+    # ... and the list is complete around a sample of spheres (k-d tree over all 3e6 sphere centres)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(X)
+    rng = np.random.default_rng(0)
+    sample = rng.choice(len(X), 4000, replace=False)
+    rmax = float(R.max())
+    start = np.searchsorted(a, np.arange(len(X) + 1))
+    listed = set(zip(a[ss].tolist(), bb[ss].tolist()))
+    missing = 0
+    for s in sample:
+        for j in tree.query_ball_point(X[s], R[s] + rmax):
+            if j == s or own[j] == own[s]:
+                continue
+            if np.linalg.norm(X[s] - X[j]) < R[s] + R[j] - 1e-9:  # clearly overlapping (inflated radii)
+                lo, hi = (s, j) if s < j else (j, s)
+                missing += (lo, hi) not in listed
+    assert missing == 0
+    # Newton's third law over the whole list: per-contact records, then the owners' accelerations
+    ctx.set_record_contacts(True)
+    ctx.calc_forces()
+    F, T, _, _ = ctx.contact_records()
+    st = ctx.download_state()
+    nC = int(sc.nOwnerClumps)
+    mass = b.arrays["MassProperties"][b.arrays["inertiaPropOffsets"]].astype(np.float64)
+    acc = np.stack([st["aX"], st["aY"], st["aZ"]], 1).astype(np.float64)
+    total = (mass[:, None] * acc).sum(0)  # clumps + walls: every force appears twice with opposite signs
+    scale = np.abs(F).sum()
+    assert np.abs(total).max() < 1e-5 * scale
+    ctx.set_record_contacts(False)
