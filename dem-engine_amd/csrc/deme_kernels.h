@@ -201,11 +201,22 @@ struct SweepLDS {
     double x[SW_W], y[SW_W], z[SW_W];
     float r[SW_W];
     uint32_t owner[SW_W], sph[SW_W], bin[SW_W], fam[SW_W];
+    uint32_t queue[SW_T / 64][128];  // per wavefront: pairs that passed the distance test, waiting for the exact test
     uint64_t out[SW_OUT];
     unsigned long long gBase;
     uint32_t nOut;
     uint32_t start, endIdx, giant;
 };
+
+// The cheap half of pair_test: different owners and centres closer than the sum of the inflated radii.
+__device__ inline bool pair_near(double ax, double ay, double az, float ar, uint32_t ao, double bx, double by, double bz, float br,
+                                 uint32_t bo) {
+    if (ao == bo)
+        return false;
+    const double rA = (double)ar, rB = (double)br;
+    const double d2 = (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
+    return !(d2 > (rA + rB) * (rA + rB));
+}
 
 __device__ inline bool pair_test(const DevParams& p, double ax, double ay, double az, float ar, uint32_t ao,
                                  uint32_t af, double bx, double by, double bz, float br, uint32_t bo, uint32_t bf,
@@ -257,6 +268,25 @@ __device__ inline void sweep_emit(SweepLDS& L, bool hit, uint64_t key, uint32_t 
 
 __device__ inline uint64_t ss_key(uint32_t a, uint32_t b) {
     return (a < b) ? make_key(DEME_KEY_CLASS_SS, a, b) : make_key(DEME_KEY_CLASS_SS, b, a);
+}
+
+// all lanes of one wavefront: exact test of the first `cnt` queued pairs (entry i | entry q << 16) and emission of the hits
+__device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const uint32_t* wq, uint32_t cnt, uint32_t lane,
+                                     uint64_t* outKeys, uint64_t cap, DetectCounters* ctr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of one wavefront complete in order: only the
+    __builtin_amdgcn_wave_barrier();                         // compiler has to be kept from reordering
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool hit = false;
+    uint64_t key = 0;
+    if (lane < cnt) {
+        const uint32_t e = wq[lane];
+        const uint32_t i = e & 0xFFFFu, q = e >> 16;
+        hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], L.x[q], L.y[q], L.z[q], L.r[q], L.owner[q], L.fam[q],
+                        L.bin[q]);
+        if (hit)
+            key = ss_key(L.sph[i], L.sph[q]);
+    }
+    sweep_emit(L, hit, key, lane, outKeys, cap, ctr);
 }
 
 // block-wide flush of the LDS output buffer (call from uniform control flow)
@@ -349,6 +379,8 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
         L.bin[SW_T + t] = b1;
         __syncthreads();
         // ---- balanced cyclic pairing, entries q = t and q = t + SW_T
+        uint32_t* wq = L.queue[t >> 6];
+        uint32_t qn = 0;  // entries in my wavefront's queue (wave-uniform)
         for (uint32_t q = t; q < SW_W; q += SW_T) {
             const bool valid = q < n_rng;
             uint32_t s = 0, n = 1, k = 0, myBin = DEME_NULL_BINID_DEV;
@@ -381,23 +413,47 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             uint32_t mo = 0, mf = 0, ms = 0;
             if (valid)
                 mx = L.x[q], my = L.y[q], mz = L.z[q], mr = L.r[q], mo = L.owner[q], mf = L.fam[q], ms = L.sph[q];
+            // Two phases (only ~3 % of the pairs of a bin pass the distance test, but with 64 lanes almost every loop
+            // iteration had at least one survivor and paid for the exact test -- sqrt, divisions, contact-point bin): the
+            // loop only runs the distance test and queues the survivors per wavefront; the exact test then runs on full
+            // wavefronts of survivors.
             for (uint32_t m = 1;; m++) {
                 const bool act = m <= trips;
                 if (!__any(act))
                     break;
-                bool hit = false;
-                uint64_t key = 0;
+                bool near = false;
+                uint32_t packed = 0;
                 if (act) {
                     uint32_t qq = k + ((m <= half) ? m : n / 2);
                     if (qq >= n)
                         qq -= n;
                     const uint32_t i = s + qq;
-                    hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf, myBin);
-                    if (hit)
-                        key = ss_key(L.sph[i], ms);
+                    near = pair_near(L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], mx, my, mz, mr, mo);
+                    packed = i | (q << 16);
                 }
-                sweep_emit(L, hit, key, lane, outKeys, cap, ctr);
+                const unsigned long long nm = __ballot(near);
+                if (nm) {
+                    if (near)
+                        wq[qn + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = packed;
+                    qn += (uint32_t)__popcll(nm);  // wave-uniform
+                    if (qn >= 64u) {
+                        sweep_confirm(p, L, wq, 64u, lane, outKeys, cap, ctr);
+                        const uint32_t rest = qn - 64u;
+                        uint32_t carry = 0;
+                        if (lane < rest)
+                            carry = wq[64u + lane];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < rest)
+                            wq[lane] = carry;
+                        qn = rest;
+                    }
+                }
             }
+        }
+        if (qn) {
+            sweep_confirm(p, L, wq, qn, lane, outKeys, cap, ctr);
+            qn = 0;
         }
         // ---- giant bin: SW_T x SW_T tiles, A tile in LDS, each thread holds one B entry
         if (giantStart < SW_W) {
