@@ -521,27 +521,56 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
 // DEMCubContactDetection.cu:195-230; the population check feeds errOutBinSphNum).
 __global__ __launch_bounds__(256) void k_bin_stats(const uint32_t* __restrict__ keys, uint32_t P, DetectCounters* ctr) {
     __shared__ uint32_t sHeads[4], sPop[4];
+    __shared__ unsigned long long wmask[4];
     uint32_t heads = 0, pop = 0;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x) {
-        const uint32_t b = keys[j];
-        if ((j == 0) || (keys[j - 1] != b)) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    // 256 consecutive entries per iteration: coalesced loads only; a bin's population is the distance to the next head,
+    // found through the wavefronts' head masks; only a bin that runs past the block looks further (gallop + bisection)
+    for (uint32_t base = blockIdx.x * 256u; base < P; base += gridDim.x * 256u) {
+        const uint32_t j = base + t;
+        const bool valid = j < P;
+        const uint32_t b = valid ? keys[j] : 0xFFFFFFFFu;
+        const bool isHead = valid && (j == 0 || keys[j - 1] != b);
+        const unsigned long long m = __ballot(isHead);
+        if (lane == 0)
+            wmask[w] = m;
+        __syncthreads();
+        if (isHead) {
             heads++;
-            uint32_t lo = j + 1, hi = P;  // first index with key > b; gallop first: bins are short
-            uint32_t step = 32;
-            while (lo + step < hi && keys[lo + step - 1] == b) {
-                lo += step;
-                step <<= 1;
+            int next = -1;
+            const unsigned long long mine = (lane < 63u) ? (wmask[w] >> (lane + 1u)) : 0ull;
+            if (mine)
+                next = (int)(t + 1u) + (__ffsll((long long)mine) - 1);
+            else
+                for (uint32_t w2 = w + 1; w2 < 4u && next < 0; w2++)
+                    if (wmask[w2])
+                        next = (int)(64u * w2) + (__ffsll((long long)wmask[w2]) - 1);
+            uint32_t len;
+            if (next >= 0) {
+                len = (uint32_t)next - t;
+            } else {
+                const uint32_t end = min(base + 256u, P);
+                uint32_t lo = end, hi = P;  // first index >= end with key > b
+                if (lo < hi && keys[lo] == b) {
+                    uint32_t step = 32;
+                    while (lo + step < hi && keys[lo + step - 1] == b) {
+                        lo += step;
+                        step <<= 1;
+                    }
+                    hi = min(hi, lo + step);
+                    while (lo < hi) {
+                        const uint32_t mid = lo + ((hi - lo) >> 1);
+                        if (keys[mid] <= b)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                }
+                len = lo - j;
             }
-            hi = min(hi, lo + step);
-            while (lo < hi) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (keys[mid] <= b)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            pop = max(pop, lo - j);
+            pop = max(pop, len);
         }
+        __syncthreads();
     }
     for (int off = 32; off > 0; off >>= 1) {
         heads += (uint32_t)__shfl_xor((int)heads, off);
