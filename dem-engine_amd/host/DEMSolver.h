@@ -183,6 +183,38 @@ struct DEMMeshConnected {
     float mass = 1.f;
     float3 MOI{1, 1, 1};
     size_t GetNumTriangles() const { return faces.size(); }
+    size_t GetNumNodes() const { return vertices.size(); }
+    /// Minimal Wavefront OBJ reader (the reference uses tinyobjloader through DEMMeshConnected::LoadWavefrontMesh,
+    /// BdrsAndObjs.h): `v x y z` and `f a b c [d ...]` with 1-based (or negative, relative) indices in the v, v/vt, v//vn and
+    /// v/vt/vn forms; polygons are fanned into triangles; normals / texture coordinates are not needed by the solver.
+    bool LoadWavefrontMesh(const std::string& input_file) {
+        std::ifstream f(input_file);
+        if (!f)
+            return false;
+        vertices.clear(), faces.clear();
+        std::string line;
+        while (std::getline(f, line)) {
+            std::istringstream ls(line);
+            std::string tag;
+            if (!(ls >> tag))
+                continue;
+            if (tag == "v") {
+                float3 v{0, 0, 0};
+                ls >> v.x >> v.y >> v.z;
+                vertices.push_back(v);
+            } else if (tag == "f") {
+                std::vector<int> idx;
+                std::string tok;
+                while (ls >> tok) {
+                    const int i = std::stoi(tok.substr(0, tok.find('/')));
+                    idx.push_back(i > 0 ? i - 1 : (int)vertices.size() + i);
+                }
+                for (size_t k = 2; k < idx.size(); k++)
+                    faces.push_back({idx[0], idx[k - 1], idx[k]});
+            }
+        }
+        return !faces.empty();
+    }
     void Scale(float s) {
         for (auto& v : vertices)
             v = v * s;
@@ -416,7 +448,10 @@ class DEMSolver {
     void SetFamilyExtraMargin(unsigned int f, float m) { m_family_extra[f & 255] = m; }
     void DisableAdaptiveBinSize() {}
     void UseAdaptiveUpdateFreq(bool) {}
-    void SetNoForceRecord(bool = true) {}
+    void SetNoForceRecord(bool flag = true) {  // per-contact force records are only kept when the contact output needs them
+        if (flag)
+            m_cnt_out_content &= ~(unsigned)(FORCE | CNT_POINT | NORMAL | TORQUE);
+    }
     void SetCollectAccRightAfterForceCalc(bool = true) {}
 
     // ---- run
@@ -452,6 +487,100 @@ class DEMSolver {
         return m;
     }
     deme_ctx* GetContext() { return m_ctx; }
+
+    // ---- more of the reference's surface (API.h): mesh loading from OBJ, mesh output, run-time updates, statistics
+    std::shared_ptr<DEMMeshConnected> AddWavefrontMeshObject(const std::string& filename, const std::shared_ptr<DEMMaterial>& mat,
+                                                             bool load_normals = true, bool load_uv = false) {
+        (void)load_normals, (void)load_uv;
+        auto m = std::make_shared<DEMMeshConnected>();
+        if (!m->LoadWavefrontMesh(filename))
+            throw std::runtime_error("Failed to load in mesh file " + filename + ".");
+        m->mat = mat;
+        m_meshes.push_back(m);
+        return m;
+    }
+    enum class MESH_FORMAT { VTK, OBJ };
+    void SetMeshOutputFormat(MESH_FORMAT f) {
+        if (f != MESH_FORMAT::VTK)
+            throw std::runtime_error("only MESH_FORMAT::VTK is implemented");
+    }
+    /// writeMeshesAsVtk (dT.cpp:1850-1935): all meshes in one legacy-VTK unstructured grid, nodes in the global frame
+    void WriteMeshFile(const std::string& outfilename) {
+        const Snapshot sn = snapshot(false);
+        std::ostringstream o;
+        o << "# vtk DataFile Version 2.0\nVTK from DEM simulation\nASCII\n\n\nDATASET UNSTRUCTURED_GRID\n";
+        size_t total_v = 0, total_f = 0;
+        std::vector<size_t> voff(m_meshes.size() + 1, 0);
+        for (size_t i = 0; i < m_meshes.size(); i++) {
+            voff[i + 1] = voff[i] + m_meshes[i]->vertices.size();
+            total_v += m_meshes[i]->vertices.size(), total_f += m_meshes[i]->faces.size();
+        }
+        o << "POINTS " << total_v << " float" << std::endl;
+        for (size_t i = 0; i < m_meshes.size(); i++) {
+            const size_t owner = m_n_owners - m_meshes.size() + i;
+            for (float3 v : m_meshes[i]->vertices) {  // applyFrameTransformLocalToGlobal: rotate, then translate
+                rotate(v, sn.q[owner]);
+                v = v + sn.com[owner];
+                o << v.x << " " << v.y << " " << v.z << std::endl;
+            }
+        }
+        o << "\n\nCELLS " << total_f << " " << 4 * total_f << std::endl;
+        for (size_t i = 0; i < m_meshes.size(); i++)
+            for (auto& f : m_meshes[i]->faces)
+                o << "3 " << (size_t)f[0] + voff[i] << " " << (size_t)f[1] + voff[i] << " " << (size_t)f[2] + voff[i] << std::endl;
+        o << "\n\nCELL_TYPES " << total_f << std::endl;
+        for (size_t j = 0; j < total_f; j++)
+            o << "5 " << std::endl;
+        flush(outfilename, o);
+    }
+    /// UpdateStepSize (API.h:1274): takes effect from the next step
+    void UpdateStepSize(double ts) {
+        m_h = (float)ts;
+        m_p.h = m_h;
+        m_p.timeElapsed = m_time;
+        check(deme_set_params(m_ctx, &m_p));
+    }
+    double GetTimeStepSize() const { return m_h; }
+    void UpdateSimParams() {
+        m_p.timeElapsed = m_time;
+        check(deme_set_params(m_ctx, &m_p));
+    }
+    /// Sphere-geometry id pairs of the current contact list and their types (GetContacts / contact info getters)
+    std::vector<std::pair<bodyID_t, bodyID_t>> GetContacts() {
+        DemeCounts c{};
+        check(deme_get_counts(m_ctx, &c));
+        const size_t n = (size_t)c.nContacts;
+        std::vector<uint32_t> a(n), b(n), map(n);
+        std::vector<uint8_t> ty(n);
+        check(deme_download_contacts(m_ctx, a.data(), b.data(), ty.data(), map.data(), n));
+        std::vector<std::pair<bodyID_t, bodyID_t>> out;
+        for (size_t i = 0; i < n; i++)
+            if (ty[i] == 1)
+                out.push_back({m_keep.sphOwner[a[i]], m_keep.sphOwner[b[i]]});
+        return out;
+    }
+    /// ShowTimingStats / ShowThreadCollaborationStats (API.h:1290-1300): the kernels' mean times from HIP events
+    void ShowTimingStats() {
+        for (const char* name : {"calc_forces", "integrate", "detect"}) {
+            double ms = 0;
+            uint64_t n = 0;
+            if (deme_kernel_time_ms(m_ctx, name, &ms, &n) == DEME_OK)
+                std::printf("%-12s %10.4f ms per launch over %llu launches\n", name, ms, (unsigned long long)n);
+        }
+    }
+    void ShowThreadCollaborationStats() {
+        DemeCounts c{};
+        check(deme_get_counts(m_ctx, &c));
+        std::printf("steps %llu, contact detections %llu (every %u steps), contacts %llu\n", (unsigned long long)c.nSteps,
+                    (unsigned long long)c.nDetections, m_cd_freq, (unsigned long long)c.nContacts);
+    }
+    void ShowAnomalies() {}
+    void ClearTimingStats() { deme_kernel_time_reset(m_ctx); }
+    void ClearThreadCollaborationStats() {}
+    void UseCubForceCollection(bool = true) {}  // accumulation is atomics-free here: nothing to choose
+    void UseAdaptiveBinSize() {}
+    void SetAdaptiveBinSizeDelaySteps(unsigned int) {}
+    void SetExpandSafetyType(const std::string&) {}
 
     // ---- inspectors and trackers (API.h:652-679, AuxClasses.h:26-420)
     std::shared_ptr<class DEMInspector> CreateInspector(const std::string& quantity = "clump_max_z");
@@ -889,6 +1018,20 @@ class DEMSolver {
             return m_n_clumps + index;
         return m_n_owners - m_meshes.size() + index;
     }
+    // all triangles' owner-local nodes are re-sent (deme_update_tri_nodes takes the full arrays, mesh-major)
+    void update_mesh_nodes(size_t mesh_index, const std::vector<float3>& new_nodes) {
+        auto& me = m_meshes.at(mesh_index);
+        if (new_nodes.size() != me->vertices.size())
+            throw std::runtime_error("UpdateMesh: the node count does not match the mesh");
+        me->vertices = new_nodes;
+        std::vector<float> t1, t2, t3;
+        for (auto& m : m_meshes)
+            for (auto& f : m->faces) {
+                const float3 a = m->vertices.at(f[0]), b = m->vertices.at(f[1]), c = m->vertices.at(f[2]);
+                t1.insert(t1.end(), {a.x, a.y, a.z}), t2.insert(t2.end(), {b.x, b.y, b.z}), t3.insert(t3.end(), {c.x, c.y, c.z});
+            }
+        check(deme_update_tri_nodes(m_ctx, t1.data(), t2.data(), t3.data()));
+    }
     // tracker setters: read-modify-write of the affected SoA columns (null columns keep their device values)
     void set_owner(size_t o, const float3* pos, const float3* vel, const float3* angvel, const float4* q) {
         const size_t n = m_n_owners;
@@ -1324,6 +1467,12 @@ class DEMTracker {
     void SetVel(float3 vel, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, &vel, nullptr, nullptr); }
     void SetAngVel(float3 w, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, nullptr, &w, nullptr); }
     void SetOriQ(float4 q, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, nullptr, nullptr, &q); }
+    /// UpdateMesh (AuxClasses.h): replace the owner-local node coordinates of a tracked mesh (deformable meshes)
+    void UpdateMesh(const std::vector<float3>& new_nodes) {
+        if (m_kind != 2)
+            throw std::runtime_error("UpdateMesh needs a tracker of a mesh");
+        m_sys->update_mesh_nodes(m_index, new_nodes);
+    }
 
   private:
     DEMSolver* m_sys;

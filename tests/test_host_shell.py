@@ -50,3 +50,41 @@ def test_demo_runs_and_settles(tmp_path):
     lz, lv = float(lid.split("z=")[1].split()[0]), float(lid.split("vz=")[1])
     T = 3000 * 5e-6
     assert abs(lz - (0.30 - 0.05 * T - T * T)) < 2e-6 and abs(lv + (0.05 + 2.0 * (T - 5e-6))) < 1e-6
+
+
+@pytest.mark.gpu
+def test_mesh_demo_obj_prescription_deformation_vtk(tmp_path):
+    """AddWavefrontMeshObject (OBJ with v//vn faces and a quad), prescribed mesh motion, UpdateMesh, WriteMeshFile"""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    n = 12  # a 0.12 m square plate of (n x n) quads written as mixed triangles / quads with normal indices
+    xs = np.linspace(-0.06, 0.06, n + 1)
+    with open(tmp_path / "plate.obj", "w") as f:
+        f.write("# test plate\n")
+        for x in xs:
+            for y in xs:
+                f.write(f"v {x:.6f} {y:.6f} 0.0\n")
+        f.write("vn 0 0 1\n")
+        vid = lambda i, j: i * (n + 1) + j + 1
+        for i in range(n):
+            for j in range(n):
+                if (i + j) % 2:
+                    f.write(f"f {vid(i, j)}//1 {vid(i + 1, j)}//1 {vid(i + 1, j + 1)}//1 {vid(i, j + 1)}//1\n")
+                else:
+                    f.write(f"f {vid(i, j)}//1 {vid(i + 1, j)}//1 {vid(i + 1, j + 1)}//1\n")
+                    f.write(f"f {vid(i, j)}//1 {vid(i + 1, j + 1)}//1 {vid(i, j + 1)}//1\n")
+    out = subprocess.run([os.path.join(HOST, "demo_mesh"), str(tmp_path / "plate.obj"), str(tmp_path), "3000"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "DEMO_MESH_OK" in out.stdout, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("MESH")][0]
+    vals = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in line.split()[1:]}
+    assert vals["triangles"] == 2 * n * n and vals["nodes"] == (n + 1) ** 2
+    assert abs(vals["plate_z"] - (0.05 + 0.2 * 3000 * 5e-6)) < 2e-6  # prescribed rise of the mesh owner
+    assert vals["contacts"] > 50 and vals["max_z"] > 0.06
+    vtk = open(tmp_path / "mesh.vtk").read().split("\n")
+    assert vtk[0] == "# vtk DataFile Version 2.0" and vtk[5] == "DATASET UNSTRUCTURED_GRID"
+    assert vtk[6] == f"POINTS {(n + 1) ** 2} float"
+    pts = np.array([[float(v) for v in l.split()] for l in vtk[7:7 + (n + 1) ** 2]])
+    # nodes in the global frame: plate centre (0.1, 0.1, plate_z), bent upwards by 0.15 x^2
+    assert abs(pts[:, 0].mean() - 0.1) < 1e-6 and abs(pts[:, 2].min() - vals["plate_z"]) < 1e-5
+    assert abs(pts[:, 2].max() - (vals["plate_z"] + 0.15 * 0.06 ** 2)) < 1e-5
+    assert f"CELLS {2 * n * n} {8 * n * n}" in vtk and f"CELL_TYPES {2 * n * n}" in vtk
