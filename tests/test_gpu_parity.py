@@ -259,3 +259,30 @@ def test_error_paths(pkg):
     ctx.upload_scene(sc)
     with pytest.raises(pkg.abi.DemeError, match="velocity"):
         ctx.step(1)
+
+
+@pytest.mark.gpu
+def test_cylindrical_boundaries(pkg, orc):
+    """analytical cylinders (checkSphereEntityOverlap type 2, DEMHelperKernels.cuh:489-520): a drum wall (normal inward)
+    around the bed and a post (normal outward) through it; contact sets bit-exact, trajectories within tolerance"""
+    b = pkg.model.packed_bed(1500, seed=19, cd_freq=0, spacing_mult=2.5, init_vz=-0.3, aspect=(1.0, 1.0, 0.6))
+    lo, hi = b.user_box_min, b.user_box_max
+    cx, cy = float(lo[0] + hi[0]) / 2, float(lo[1] + hi[1]) / 2
+    drum = b.AddExternalObject()
+    drum.AddCylinder((cx, cy, 0.0), (0, 0, 1), 0.42 * float(hi[0] - lo[0]), 0, normal_inward=True)
+    post = b.AddExternalObject()
+    post.AddCylinder((cx, cy, 0.0), (0, 0, 1), 0.012, 0, normal_inward=False)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.step(150), sim.step(150)
+    a, bb, t, *_ = assert_same_contacts(ctx, sim)
+    assert (t == 13).sum() > 20  # SPHERE_CYL_CONTACT entries from both cylinders
+    anal_owner = b.arrays["objOwner"][bb[t == 13]]
+    assert len(np.unique(anal_owner)) == 2
+    gs, os_ = ctx.download_state(), sim.download_state()
+    X = pkg.model.decode_positions(gs["voxelID"], gs["locX"], gs["locY"], gs["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    Y = pkg.model.decode_positions(os_["voxelID"], os_["locX"], os_["locY"], os_["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    assert np.abs(X - Y).max() < 2e-7
+    # nothing ended up inside the post or outside the drum
+    n = int(sc.nOwnerClumps)
+    r = np.hypot(X[:n, 0] + p.LBFX - cx, X[:n, 1] + p.LBFY - cy)
+    assert r.min() > 0.012 - 0.002 and r.max() < 0.42 * float(hi[0] - lo[0]) + 0.002
