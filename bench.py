@@ -38,6 +38,47 @@ def build_bed(pkg, n_clumps, seed, cd_freq, x_mult=1, order="lattice", bin_multi
     return b
 
 
+# BASELINE configs[4] flavour (--config5): polydisperse single spheres, radii from 8 templates in [r, 3r], a user force
+# fragment (frictionless Hertz + pairwise cohesion + a contact-age wildcard) compiled at run time through hipRTC; written
+# against the reference's ingredient names like DEMUserScripts/ForceModelWithCohesion.cu
+COHESIVE_FRAGMENT = r"""
+if (overlapDepth > 0) {
+    float E_cnt;
+    matProxy2ContactParam<float>(E_cnt, E[bodyAMatType], nu[bodyAMatType], E[bodyBMatType], nu[bodyBMatType]);
+    const float CoR_cnt = CoR[bodyAMatType][bodyBMatType];
+    float3 rotVelCPA = cross(ARotVel, locCPA), rotVelCPB = cross(BRotVel, locCPB);
+    applyOriQToVector3<float, deme::oriQ_t>(rotVelCPA.x, rotVelCPA.y, rotVelCPA.z, AOriQ.w, AOriQ.x, AOriQ.y, AOriQ.z);
+    applyOriQToVector3<float, deme::oriQ_t>(rotVelCPB.x, rotVelCPB.y, rotVelCPB.z, BOriQ.w, BOriQ.x, BOriQ.y, BOriQ.z);
+    const float3 velB2A = (ALinVel + rotVelCPA) - (BLinVel + rotVelCPB);
+    const float projection = dot(velB2A, B2A);
+    const float mass_eff = (AOwnerMass * BOwnerMass) / (AOwnerMass + BOwnerMass);
+    const float sqrt_Rd = sqrt(overlapDepth * (ARadius * BRadius) / (ARadius + BRadius));
+    const float Sn = 2. * E_cnt * sqrt_Rd;
+    const float loge = (CoR_cnt < DEME_TINY_FLOAT) ? log(DEME_TINY_FLOAT) : log(CoR_cnt);
+    const float beta = loge / sqrt(loge * loge + deme::PI_SQUARED);
+    const float k_n = deme::TWO_OVER_THREE * Sn;
+    const float gamma_n = deme::TWO_TIMES_SQRT_FIVE_OVER_SIX * beta * sqrt(Sn * mass_eff);
+    force += (k_n * overlapDepth + gamma_n * projection) * B2A;
+    force += -Cohesion[bodyAMatType][bodyBMatType] * B2A;
+    contact_age += ts;
+}
+"""
+
+
+def build_config5(pkg, n, seed, cd_freq):
+    r = 0.003
+    radii = [r * (1.0 + 2.0 * i / 7.0) for i in range(8)]
+    b = pkg.model.packed_bed(n, seed=seed, cd_freq=cd_freq, scale=3.0 * r, aspect=(1.0, 1.0, 0.05), spacing_mult=2.05, jitter=0.02,
+                             bin_multiple=4.0, init_vz=-1.0, three_sphere=False, radii_poly=radii)
+    b.materials[0]["Cohesion"] = 0.002
+    b.SetMustPairwiseMatProp(["Cohesion"])
+    b.DefineContactForceModel(COHESIVE_FRAGMENT)
+    b.SetPerContactWildcards(["contact_age"])
+    b.SetExpandSafetyMultiplier(1.2)
+    b.SetExpandSafetyAdder(0.02)
+    return b
+
+
 def force_kernel_bytes(n_owners, n_spheres, n_contacts, n_w):
     """Algorithmic HBM bytes of ONE contact-force launch (SURVEY 8d / DESIGN.md 3.2):
     N_c*(9 + 8*n_w) + N_o*57 + N_s*7  (contact ids+type, wildcards read+write, owner and sphere state
@@ -209,6 +250,8 @@ def main():
                     help="order in which the caller hands the clumps over (experiment)")
     ap.add_argument("--mesh-triangles", type=int, default=0,
                     help="BASELINE configs[3] flavour: put a wavy, fixed plate of about this many triangles under the bed")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE configs[4] flavour: polydisperse spheres + a user cohesion model compiled at run time")
     ap.add_argument("--bin-multiple", type=float, default=4.0,
                     help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: order the ghost exchange on the compute stream")
@@ -240,7 +283,10 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     pkg = entry.load_package()
-    b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order, bin_multiple=args.bin_multiple)
+    if args.config5:
+        b = build_config5(pkg, args.clumps * world, args.seed, args.cd_freq)
+    else:
+        b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order, bin_multiple=args.bin_multiple)
     if args.mesh_triangles:
         lo, hi = b.user_box_min, b.user_box_max
         n_side = max(2, int(round((args.mesh_triangles / 2) ** 0.5)))
@@ -265,6 +311,7 @@ def main():
         ctx.set_stream(side.cuda_stream)
     ctx.set_params(p)
     ctx.upload_scene(sc)
+    b.compile_into(ctx)  # user force model / prescriptions, if the scene has any
     if world > 1:
         halo = Halo(pkg, ctx, part, rank, world, torch, dist, via_host=via_host, overlap=not args.no_overlap)
 
@@ -326,14 +373,18 @@ def main():
         "metric": "clump*steps/s", "value": value, "unit": "clump*steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 1M three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling",
+        "config": {"workload": ("BASELINE configs[4] flavour: polydisperse spheres (8 templates, r..3r) with a run-time compiled "
+                                "cohesion model" if args.config5 else
+                                "BASELINE configs[1]: 1M three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling")
+                               + (f" + {int(sc.nTri)}-triangle plate (configs[3] flavour)" if int(sc.nTri) else ""),
                    "clumps_total": total_clumps, "owners_this_rank": int(sc.nOwners), "spheres_this_rank": int(sc.nSpheres),
                    "contacts_this_rank": int(c.nContacts), "bin_sphere_touches": int(c.nBinSphereTouches),
                    "triangles": int(sc.nTri), "cd_every": args.cd_freq, "presettle_steps": args.presettle,
-                   "force_model": "Hertzian (history, 4 wildcards)", "integrator": "extended Taylor", "h": p.h,
+                   "force_model": ("user fragment via hipRTC: frictionless Hertz + cohesion, 1 wildcard" if args.config5
+                                   else "Hertzian (history, 4 wildcards)"), "integrator": "extended Taylor", "h": p.h,
                    "parallelism": par,
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
-        "roofline": {"kernel": "k_calc_forces<0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "deme_custom_forces_ss (hipRTC)" if args.config5 else "k_calc_forces<0, 0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n)},
         "kernels_ms": {"calc_forces": f_ms, "integrate": i_ms, "detect_update": d_ms, "detect_updates": int(d_n)},
