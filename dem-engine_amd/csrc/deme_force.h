@@ -83,29 +83,14 @@ __device__ inline f3 pdiv3(f3 a, float s) {
 #endif
 }
 
-// B-side contribution record: 24 B as float4 + float2 in two arrays, or (DEME_CONB32) one 32-byte record so that the
-// integrator's gather touches one line per contact instead of two
-#ifndef DEME_CONB32
-#define DEME_CONB32 0
-#endif
+// B-side contribution record: 24 B as float4 + float2 in two arrays (a single 32-byte record was measured: no gain)
 __device__ inline void conb_store(float4* b4, float2* b2, size_t i, float4 c4, float2 c2) {
-#if DEME_CONB32
-    b4[2 * i] = c4;
-    b4[2 * i + 1] = make_float4(c2.x, c2.y, 0.f, 0.f);
-#else
     b4[i] = c4;
     b2[i] = c2;
-#endif
 }
 __device__ inline void conb_load(const float4* b4, const float2* b2, size_t i, float4& c4, float2& c2) {
-#if DEME_CONB32
-    c4 = b4[2 * i];
-    const float4 t = b4[2 * i + 1];
-    c2 = make_float2(t.x, t.y);
-#else
     c4 = b4[i];
     c2 = b2[i];
-#endif
 }
 
 struct HertzIn {
@@ -382,7 +367,6 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
         wcp = reinterpret_cast<float4*>(a.wc) + myContactID;
         hist = *wcp;  // delta_tan_x, delta_tan_y, delta_tan_z, delta_time (std::set order, Models.h:363-378)
     }
-    const float4 hist0 = hist;
     if (ContactType != 0u) {
         f3 force = mk3(0, 0, 0), torque_only_force = mk3(0, 0, 0);
         // rotation by the conjugate quaternion: its nine coefficients are, bit for bit, the transposed forward ones
@@ -470,35 +454,16 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
             }
         }
     }
-#ifndef DEME_SKIP_SAME_HIST
-#define DEME_SKIP_SAME_HIST 0
-#endif
-    if (MODEL == 0) {  // _forceModelContactWildcardWrite_
-#if DEME_SKIP_SAME_HIST
-        // list entries inside the margin but not touching keep an all-zero history: nothing to write back
-        if (!(hist.x == hist0.x && hist.y == hist0.y && hist.z == hist0.z && hist.w == hist0.w))
-            *wcp = hist;
-#else
-        (void)hist0;
-        *wcp = hist;
-#endif
-    }
+    if (MODEL == 0)
+        *wcp = hist;  // _forceModelContactWildcardWrite_ (skipping unchanged all-zero histories was measured: slower)
 }
 
 // an owner's A run [s, e) is reduced in-workgroup iff it lies inside one block of DEME_FORCE_BLOCK contacts
 #ifndef DEME_FORCE_BLOCK
 #define DEME_FORCE_BLOCK 256
 #endif
-#ifndef DEME_FV
-#define DEME_FV 1
-#endif
-#if DEME_FV == 2
-#define DEME_ARUN_SPAN 64  // wavefront-level reduction: no workgroup barrier
-#else
-#define DEME_ARUN_SPAN DEME_FORCE_BLOCK
-#endif
 __host__ __device__ inline bool a_run_in_one_block(uint32_t s, uint32_t e) {
-    return s < e && (s / DEME_ARUN_SPAN) == ((e - 1) / DEME_ARUN_SPAN);
+    return s < e && (s / DEME_FORCE_BLOCK) == ((e - 1) / DEME_FORCE_BLOCK);
 }
 
 // Workgroup = DEME_FORCE_BLOCK consecutive contacts.  The list is sorted by A's owner, so an owner's A-side
@@ -530,12 +495,10 @@ __device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a)
         if (CLS == 0 && a.cDefer)
             inPass = a.cDefer[c] == a.pass;
         mine = inPass && ((CLS == 1) == ((ci.x >> 30) == DEME_KEY_CLASS_SM));
-#if DEME_FV >= 1
         if (CLS == 0) {  // issued before the force evaluation so that their latency is hidden behind it
             s = a.aStart[ci.x & 0x3FFFFFFFu];
             e = a.aStart[(ci.x & 0x3FFFFFFFu) + 1];
         }
-#endif
         if (mine)
             calc_forces_body<MODEL, CLS>(p, a, c, ci, c4, c2);
     }
@@ -554,21 +517,10 @@ __device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a)
     }
     s4[threadIdx.x] = c4;
     s2[threadIdx.x] = c2;
-#if DEME_FV == 2
-    // producer and consumer lanes belong to the same wavefront: LDS operations of one wavefront complete in
-    // order, so only the compiler has to be kept from reordering
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
     __syncthreads();
-#endif
     if (!inPass)
         return;  // beyond the list, or a contact of the other pass (whole owner runs belong to one pass)
     const uint32_t AOwner = ci.x & 0x3FFFFFFFu;
-#if DEME_FV == 0
-    s = a.aStart[AOwner], e = a.aStart[AOwner + 1];
-#endif
     if (a_run_in_one_block(s, e)) {
         if (c == s) {
             float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;

@@ -282,7 +282,7 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
             rc |= ensure(c, c->rec[k], cap * 12);
     rc |= ensure(c, c->conA4, cap * 16);
     rc |= ensure(c, c->conA2, cap * 8);
-    rc |= ensure(c, c->conB4, cap * (DEME_CONB32 ? 32 : 16));
+    rc |= ensure(c, c->conB4, cap * 16);
     rc |= ensure(c, c->conB2, cap * 8);
     rc |= ensure(c, c->ownerA, cap * 4);
     for (int k = 0; k < 2; k++) {
