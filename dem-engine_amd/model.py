@@ -268,6 +268,19 @@ class SceneBuilder:
         self.batches.append(b)
         return b
 
+    def SortClumpsSpatially(self, cell=None):
+        """Reorder the clumps of every batch along a Z-order curve (cells of edge `cell`, default 4 x the largest
+        component radius).  No reference equivalent: owner ids follow the load order, and the engine's gathers (B owner in
+        the force kernel, B-side contributions in the integrator) run ~28 % slower when neighbours in space are far apart
+        in memory (measured: bench.py --order random vs lattice / Morton order).  Call before Initialize(); ids change."""
+        rmax = max((float(t.radii.max()) + float(np.abs(t.relpos).max()) for t in self.templates), default=1.0)
+        cell = float(cell) if cell else 4.0 * rmax
+        for b in self.batches:
+            order = np.argsort(morton_codes(b.xyz, cell), kind="stable")
+            b.xyz, b.vel, b.angvel, b.oriq, b.family = b.xyz[order], b.vel[order], b.angvel[order], b.oriq[order], b.family[order]
+            b.templates = [b.templates[i] for i in order]
+        return self
+
     def AddExternalObject(self):
         o = ExternObj()
         self.ext_objs.append(o)

@@ -113,3 +113,18 @@ def test_hcp_sampler_spacing(pkg):
     d = np.linalg.norm(pts[None, :60] - pts[:60, None], axis=2)
     d[d == 0] = 1
     assert d.min() == pytest.approx(0.015, rel=1e-4)
+
+
+def test_spatial_sort_keeps_the_scene_and_localises_neighbours(pkg):
+    b = pkg.model.packed_bed(4000, seed=3, order="random")
+    xyz0 = b.batches[0].xyz.copy()
+    q0 = b.batches[0].oriq.copy()
+    b.SortClumpsSpatially()
+    xyz1 = b.batches[0].xyz
+    # the same clumps (positions and orientations travel together), in a different order
+    i0, i1 = np.lexsort(xyz0.T), np.lexsort(xyz1.T)
+    assert np.array_equal(xyz0[i0], xyz1[i1]) and np.array_equal(q0[i0], b.batches[0].oriq[i1])
+    # consecutive clumps are now close in space (random order: ~1/3 of the box apart)
+    d0 = np.linalg.norm(np.diff(xyz0, axis=0), axis=1).mean()
+    d1 = np.linalg.norm(np.diff(xyz1, axis=0), axis=1).mean()
+    assert d1 < 0.25 * d0
