@@ -176,6 +176,8 @@ def load_library():
         "deme_upload_contact_wildcard": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_seed_contacts": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_compile_prescriptions": [_P, C.c_char_p, C.c_char_p, C.c_char_p],
+        "deme_upload_wildcard_array": [_P, C.c_uint32, C.c_uint32, _P, C.c_size_t],
+        "deme_download_wildcard_array": [_P, C.c_uint32, C.c_uint32, _P, C.c_size_t],
         "deme_halo_stream": [_P, C.POINTER(_P)], "deme_halo_pack_async": [_P, _P, C.c_uint32, _P],
         "deme_halo_unpack_async": [_P, _P, C.c_uint32, _P], "deme_halo_sync": [_P],
         "deme_step_overlap_begin": [_P, C.POINTER(C.c_int)], "deme_step_overlap_end": [_P],
@@ -185,6 +187,8 @@ def load_library():
         "deme_download_contact_records": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_download_sphere_geometry": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_compile_force_model": [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p],
+        "deme_compile_force_model_ex": [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p),
+                                        C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p],
         "deme_kernel_time_ms": [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
         "deme_kernel_time_reset": [_P], "deme_set_timing": [_P, C.c_int],
         "deme_halo_pack": [_P, _P, C.c_uint32, _P], "deme_halo_unpack": [_P, _P, C.c_uint32, _P],
@@ -413,11 +417,27 @@ class Context:
                  "deme_download_sphere_geometry")
         return X, Y, Z, R
 
-    def compile_force_model(self, src, wildcard_names=(), prerequisites=""):
-        names = (C.c_char_p * max(1, len(wildcard_names)))(*[s.encode() for s in wildcard_names])
+    def compile_force_model(self, src, wildcard_names=(), prerequisites="", owner_wildcards=(), geo_wildcards=()):
+        def arr(names):
+            return (C.c_char_p * max(1, len(names)))(*[s.encode() for s in names])
         b = src.encode()
-        self._ck(self.lib.deme_compile_force_model(self.h, b, len(b), names, len(wildcard_names),
-                                                   prerequisites.encode()), "deme_compile_force_model")
+        self._ck(self.lib.deme_compile_force_model_ex(self.h, b, len(b), arr(wildcard_names), len(wildcard_names),
+                                                      arr(owner_wildcards), len(owner_wildcards), arr(geo_wildcards),
+                                                      len(geo_wildcards), prerequisites.encode()), "deme_compile_force_model_ex")
+
+    WC_KINDS = {"owner": 0, "sphere": 1, "triangle": 2, "analytical": 3}
+
+    def set_wildcard_array(self, kind, index, values):
+        """owner / geometry wildcard array `index` of the user force model (kind: owner, sphere, triangle, analytical)"""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        self._ck(self.lib.deme_upload_wildcard_array(self.h, self.WC_KINDS[kind], int(index), _ptr(v), v.size),
+                 "deme_upload_wildcard_array")
+
+    def wildcard_array(self, kind, index, n):
+        out = np.zeros(int(n), np.float32)
+        self._ck(self.lib.deme_download_wildcard_array(self.h, self.WC_KINDS[kind], int(index), _ptr(out), out.size),
+                 "deme_download_wildcard_array")
+        return out
 
     def set_timing(self, enable=True):
         self._ck(self.lib.deme_set_timing(self.h, int(bool(enable))), "deme_set_timing")

@@ -51,6 +51,12 @@ struct ForceArgs {
     float* recCPB;
     uint32_t nContacts;
     float timeElapsed;
+    // user-model wildcards beyond the per-contact ones (Models.h:319-360): per-owner arrays, and per-geometry arrays for
+    // spheres / triangles / analytical components; null when not declared
+    float* ownerWc[8];
+    float* geoWcSph[8];
+    float* geoWcTri[8];
+    float* geoWcAnal[8];
 };
 
 // Physics-only arithmetic (force model, per-side contributions).  Contact / bin DECISIONS never go through these.
@@ -224,14 +230,17 @@ struct UserModelIO {
     float3 ALinVel, BLinVel, ARotVel, BRotVel, AOwnerMOI, BOwnerMOI;
     uint32_t AOwner, BOwner, AGeo, BGeo, myContactID;
     float* wc;  // this contact's wildcard slots
+    float* const* ownerWc;  // owner wildcards: arrays indexed by owner id (aliases, as in the reference)
+    float* const* geoWcA;   // geometry wildcards of A's kind (always spheres)
+    float* const* geoWcB;   // geometry wildcards of B's kind (spheres, triangles or analytical components)
 };
 __device__ void deme_user_model(UserModelIO& io);
 #endif
 
 // One thread per contact.  MODEL: 0 full Hertzian (4 wildcards), 1 frictionless (none), 2 user model (JIT).
 // CLS selects the geometry branches that are compiled in: 0 = sphere-sphere and sphere-analytical (the hot
-// variant), 1 = sphere-mesh only.  Both scan the whole list and threads of the other classes exit at once; the
-// mesh variant is only launched when triangles are loaded.  Keeping the fp64 triangle code out of the hot
+// variant, over the whole list), 1 = sphere-mesh only (over the per-detection list of sphere-mesh contacts, launched
+// first and only when triangles are loaded).  Keeping the fp64 triangle code out of the hot
 // variant saves ~40 VGPRs (3 -> 4 waves per SIMD; measured 174 -> 148 us at 4.2 M contacts).  Measured and
 // rejected: a third variant for analytical contacts (no occupancy gain, one more pass), per-class index lists
 // (their same-address atomics cost 1.7 ms per detection), register caps of 96 / 80 VGPRs (spills: 231 / 385 us).
@@ -412,6 +421,9 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
                 io.AGeo = key_a(key), io.BGeo = key_b(key);
             }
             io.wc = a.wc + (size_t)myContactID * p.nW;
+            io.ownerWc = a.ownerWc;
+            io.geoWcA = a.geoWcSph;
+            io.geoWcB = (cls == DEME_KEY_CLASS_SS) ? a.geoWcSph : (cls == DEME_KEY_CLASS_SM) ? a.geoWcTri : a.geoWcAnal;
             deme_user_model(io);
             force = mk3(io.force.x, io.force.y, io.force.z);
             torque_only_force = mk3(io.torque_only_force.x, io.torque_only_force.y, io.torque_only_force.z);

@@ -86,6 +86,8 @@ struct deme_ctx {
     hipModule_t prescMod = nullptr;
     hipFunction_t prescFn = nullptr;
     DevBuf prescList, prescSlot, prescRec, smFlag, smList, cDefer, blockMode;
+    DevBuf userWc[4][8];  // [kind: owners, spheres, triangles, analytical][index]
+    uint32_t nOwnerWc = 0, nGeoWc = 0;
     bool hasGhosts = false;  // a family carries DEME_FAMILY_GHOST: force passes can be split for the halo overlap
     hipStream_t haloStream = nullptr;
     hipEvent_t evStepDone = nullptr, evHaloDone = nullptr;
@@ -592,6 +594,12 @@ int launch_forces(deme_ctx* c, int pass = -1) {
     a.aStart = c->aStart.as<uint32_t>();
     a.smList = c->smList.as<uint32_t>();
     a.nSM = c->nSM;
+    for (int k = 0; k < 8; k++) {
+        a.ownerWc[k] = c->userWc[0][k].as<float>();
+        a.geoWcSph[k] = c->userWc[1][k].as<float>();
+        a.geoWcTri[k] = c->userWc[2][k].as<float>();
+        a.geoWcAnal[k] = c->userWc[3][k].as<float>();
+    }
     if (pass >= 0 && c->hasGhosts && c->cDefer.p) {
         a.cDefer = c->cDefer.as<uint8_t>();
         a.blockMode = c->blockMode.as<uint32_t>();
@@ -756,6 +764,10 @@ void deme_ctx_destroy(deme_ctx* c) {
     for (DevBuf* b : all)
         if (b->p)
             hipFree(b->p);
+    for (auto& kind : c->userWc)
+        for (auto& b : kind)
+            if (b.p)
+                hipFree(b.p);
     if (c->ownStream && c->stream)
         hipStreamDestroy(c->stream);
     delete c;
@@ -1451,8 +1463,13 @@ int deme_download_sphere_geometry(deme_ctx* c, double* X, double* Y, double* Z, 
     return DEME_OK;
 }
 
-int deme_compile_force_model(deme_ctx* c, const char* src, size_t len, const char* const* wildcardNames, uint32_t nWildcards,
-                             const char* prerequisites) {
+static size_t wc_array_len(deme_ctx* c, uint32_t kind) {
+    return kind == 0 ? c->nOwners : kind == 1 ? c->nSpheres : kind == 2 ? c->nTri : c->nAnal;
+}
+
+int deme_compile_force_model_ex(deme_ctx* c, const char* src, size_t len, const char* const* wildcardNames, uint32_t nWildcards,
+                                const char* const* ownerNames, uint32_t nOwnerWc, const char* const* geoNames, uint32_t nGeoWc,
+                                const char* prerequisites) {
     if (!c || !src)
         return DEME_ERR_INVALID;
     if (!c->haveScene)
@@ -1460,11 +1477,17 @@ int deme_compile_force_model(deme_ctx* c, const char* src, size_t len, const cha
     if (nWildcards != c->hp.nContactWildcards)
         return fail(c, DEME_ERR_INVALID, "%u wildcard names given but DemeParams.nContactWildcards is %u", nWildcards,
                     c->hp.nContactWildcards);
-    std::vector<std::string> names;
+    if (nOwnerWc > 8 || nGeoWc > 8)
+        return fail(c, DEME_ERR_INVALID, "at most 8 owner and 8 geometry wildcards are supported");
+    std::vector<std::string> names, onames, gnames;
     for (uint32_t i = 0; i < nWildcards; i++)
         names.emplace_back(wildcardNames[i] ? wildcardNames[i] : "");
+    for (uint32_t i = 0; i < nOwnerWc; i++)
+        onames.emplace_back(ownerNames[i] ? ownerNames[i] : "");
+    for (uint32_t i = 0; i < nGeoWc; i++)
+        gnames.emplace_back(geoNames[i] ? geoNames[i] : "");
     std::string gen, err;
-    if (deme_jit::generate_source(std::string(src, len), names, prerequisites ? prerequisites : "", c->mt, gen, err))
+    if (deme_jit::generate_source(std::string(src, len), names, prerequisites ? prerequisites : "", c->mt, gen, err, onames, gnames))
         return fail(c, DEME_ERR_COMPILE, "%s", err.c_str());
     const size_t key = std::hash<std::string>{}(gen);
     auto it = c->jitCache.find(key);
@@ -1476,6 +1499,18 @@ int deme_compile_force_model(deme_ctx* c, const char* src, size_t len, const cha
         it = c->jitCache.emplace(key, std::move(code)).first;
     }
     HIPCK(hipStreamSynchronize(c->stream));
+    // wildcard arrays: existing ones keep their values, new ones start at zero
+    for (uint32_t kind = 0; kind < 4; kind++) {
+        const uint32_t want = kind == 0 ? nOwnerWc : nGeoWc;
+        const size_t n = wc_array_len(c, kind);
+        for (uint32_t k = 0; k < want; k++)
+            if (!c->userWc[kind][k].p && n) {
+                if (int rc = ensure(c, c->userWc[kind][k], n * 4))
+                    return rc;
+                HIPCK(hipMemsetAsync(c->userWc[kind][k].p, 0, n * 4, c->stream));
+            }
+    }
+    c->nOwnerWc = nOwnerWc, c->nGeoWc = nGeoWc;
     if (c->customMod) {
         (void)hipModuleUnload(c->customMod);
         c->customMod = nullptr;
@@ -1484,7 +1519,40 @@ int deme_compile_force_model(deme_ctx* c, const char* src, size_t len, const cha
     HIPCK(hipModuleLoadData(&c->customMod, it->second.data()));
     HIPCK(hipModuleGetFunction(&c->customFn[0], c->customMod, "deme_custom_forces_ss"));
     HIPCK(hipModuleGetFunction(&c->customFn[1], c->customMod, "deme_custom_forces_sm"));
+    return DEME_OK;
+}
 
+int deme_compile_force_model(deme_ctx* c, const char* src, size_t len, const char* const* wildcardNames, uint32_t nWildcards,
+                             const char* prerequisites) {
+    return deme_compile_force_model_ex(c, src, len, wildcardNames, nWildcards, nullptr, 0, nullptr, 0, prerequisites);
+}
+
+int deme_upload_wildcard_array(deme_ctx* c, uint32_t kind, uint32_t index, const float* in, size_t n) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (kind > 3 || index >= 8 || !in)
+        return fail(c, DEME_ERR_INVALID, "wildcard array: kind %u index %u", kind, index);
+    if (n != wc_array_len(c, kind))
+        return fail(c, DEME_ERR_INVALID, "wildcard array of kind %u holds %zu values, %zu given", kind, wc_array_len(c, kind), n);
+    if (int rc = ensure(c, c->userWc[kind][index], std::max<size_t>(n, 1) * 4))
+        return rc;
+    if (n)
+        HIPCK(hipMemcpyAsync(c->userWc[kind][index].p, in, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_download_wildcard_array(deme_ctx* c, uint32_t kind, uint32_t index, float* out, size_t cap) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (kind > 3 || index >= 8 || !out || !c->userWc[kind][index].p)
+        return fail(c, DEME_ERR_INVALID, "wildcard array: kind %u index %u does not exist", kind, index);
+    const size_t n = wc_array_len(c, kind);
+    if (cap < n)
+        return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    if (n)
+        HIPCK(hipMemcpyAsync(out, c->userWc[kind][index].p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
     return DEME_OK;
 }
 

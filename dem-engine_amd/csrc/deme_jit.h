@@ -136,7 +136,18 @@ inline bool valid_identifier(const std::string& n) {
 }
 
 inline int generate_source(const std::string& user, const std::vector<std::string>& wildcards, const std::string& prereq,
-                           const MaterialTables& mt, std::string& out, std::string& err) {
+                           const MaterialTables& mt, std::string& out, std::string& err,
+                           const std::vector<std::string>& ownerWildcards = {}, const std::vector<std::string>& geoWildcards = {}) {
+    for (const auto* set : {&ownerWildcards, &geoWildcards})
+        for (const auto& n : *set)
+            if (!valid_identifier(n) || reserved_name(n)) {
+                err = "wildcard name '" + n + "' is not a usable identifier (it clashes with a force-model ingredient)";
+                return 1;
+            }
+    if (ownerWildcards.size() > 8 || geoWildcards.size() > 8) {
+        err = "at most 8 owner and 8 geometry wildcards are supported";
+        return 1;
+    }
     for (size_t i = 0; i < wildcards.size(); i++) {
         if (!valid_identifier(wildcards[i]) || reserved_name(wildcards[i])) {
             err = "contact wildcard name '" + wildcards[i] + "' is not a usable identifier (it clashes with a force-model ingredient)";
@@ -175,6 +186,15 @@ inline int generate_source(const std::string& user, const std::vector<std::strin
          "    (void)BOwner; (void)AGeo; (void)BGeo; (void)myContactID;\n";
     for (size_t i = 0; i < wildcards.size(); i++)  // _forceModelContactWildcardAcq_
         o << "    float " << wildcards[i] << " = io.wc[" << i << "];\n";
+    // owner wildcards are aliases of the per-owner arrays, geometry wildcards come as name_A / name_B (equip_owner_wildcards,
+    // equip_geo_wildcards, Models.h:319-360): updating them -- atomically if need be -- is the fragment's business
+    for (size_t i = 0; i < ownerWildcards.size(); i++)
+        o << "    float* " << ownerWildcards[i] << " = io.ownerWc[" << i << "]; float* " << ownerWildcards[i] << "_A = io.ownerWc[" << i
+          << "]; float* " << ownerWildcards[i] << "_B = io.ownerWc[" << i << "]; (void)" << ownerWildcards[i] << "; (void)"
+          << ownerWildcards[i] << "_A; (void)" << ownerWildcards[i] << "_B;\n";
+    for (size_t i = 0; i < geoWildcards.size(); i++)
+        o << "    float* " << geoWildcards[i] << "_A = io.geoWcA[" << i << "]; float* " << geoWildcards[i] << "_B = io.geoWcB[" << i
+          << "]; (void)" << geoWildcards[i] << "_A; (void)" << geoWildcards[i] << "_B;\n";
     o << "    // ---- _DEMForceModel_ (user statement block, spliced literally)\n    {\n" << user << "\n    }\n";
     for (size_t i = 0; i < wildcards.size(); i++)  // _forceModelContactWildcardWrite_
         o << "    io.wc[" << i << "] = " << wildcards[i] << ";\n";

@@ -352,6 +352,14 @@ class SceneBuilder:
     def ReadContactForceModel(self, path):
         return self.DefineContactForceModel(open(path).read())
 
+    def SetPerOwnerWildcards(self, names):
+        """per-owner float arrays a fragment sees as `name`, `name_A`, `name_B` (Models.h:319-342); sorted like the set."""
+        self.owner_wildcards = sorted(set(names))
+
+    def SetPerGeometryWildcards(self, names):
+        """per-sphere / -triangle / -analytical arrays a fragment sees as `name_A[AGeo]`, `name_B[BGeo]` (Models.h:345-360)."""
+        self.geo_wildcards = sorted(set(names))
+
     def SetPerContactWildcards(self, names):
         """std::set<std::string> in the reference (Models.h:363): indices follow sorted order."""
         self.contact_wildcards = sorted(set(names))
@@ -387,7 +395,8 @@ class SceneBuilder:
     def compile_into(self, ctx):
         """Call after ctx.upload_scene(): builds the user model and the family prescriptions into the context."""
         if self.force_model == abi.FORCE_CUSTOM:
-            ctx.compile_force_model(self.force_src, getattr(self, "contact_wildcards", []), self.force_model_prerequisites())
+            ctx.compile_force_model(self.force_src, getattr(self, "contact_wildcards", []), self.force_model_prerequisites(),
+                                    getattr(self, "owner_wildcards", []), getattr(self, "geo_wildcards", []))
         if getattr(self, "_presc_inputs", None):
             ctx.compile_prescriptions(*self.prescription_cases())
         if getattr(self, "_family_rules", None):

@@ -244,6 +244,18 @@ int deme_compile_family_rules(deme_ctx* ctx, const char* rules);
 /* DEMSolver::ChangeFamily(ID_from, ID_to) (API.h:1028): immediate, all owners of a family */
 int deme_change_family(deme_ctx* ctx, uint32_t from, uint32_t to);
 
+/* Owner and geometry wildcards of user force models (DEMForceModel::SetPerOwnerWildcards / SetPerGeometryWildcards,
+ * AuxClasses.h:422-485; Models.h:319-360).  Owner wildcards are per-owner float arrays the fragment sees as `name`,
+ * `name_A`, `name_B` (aliases, indexed by AOwner / BOwner); geometry wildcards are per-sphere / per-triangle /
+ * per-analytical-component arrays seen as `name_A[AGeo]`, `name_B[BGeo]`.  Arrays start at zero; at most 8 of each.
+ * deme_compile_force_model_ex declares them (after deme_upload_scene), the upload / download calls move one array:
+ * kind 0 owners, 1 spheres, 2 triangles, 3 analytical components. */
+int deme_compile_force_model_ex(deme_ctx* ctx, const char* src, size_t len, const char* const* contactWildcards, uint32_t nContactWc,
+                                const char* const* ownerWildcards, uint32_t nOwnerWc, const char* const* geoWildcards,
+                                uint32_t nGeoWc, const char* prerequisites);
+int deme_upload_wildcard_array(deme_ctx* ctx, uint32_t kind, uint32_t index, const float* in, size_t n);
+int deme_download_wildcard_array(deme_ctx* ctx, uint32_t kind, uint32_t index, float* out, size_t cap);
+
 /* compile-only check of a fragment (no context, no GPU needed): same generator and hipRTC options,
  * 2 dummy materials; the compiler log is copied into `log`. */
 int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,

@@ -111,3 +111,70 @@ def test_custom_model_requires_compilation(pkg):
         ctx.step(1)
     with pytest.raises(pkg.abi.DemeError, match="compile"):
         ctx.compile_force_model("force = nonsense;", [], "")
+
+
+ELECTRO = FRICTIONLESS + """
+}
+// screened Coulomb-like pair force between charged spheres (geometry wildcard `charge`, one value per sphere) acting on every
+// list entry, touching or not; and a per-owner counter of touching contacts (owner wildcard `n_touch`, updated atomically)
+{
+    const float qq = charge_A[AGeo] * charge_B[BGeo];
+    force += (float)(2.5e-3 * qq) * B2A;
+    if (overlapDepth > 0) {
+        atomicAdd(n_touch + AOwner, 1.0f);
+        atomicAdd(n_touch_B + BOwner, 1.0f);
+    }
+}
+"""
+
+
+@pytest.mark.gpu
+def test_owner_and_geometry_wildcards(pkg):
+    """SetPerOwnerWildcards / SetPerGeometryWildcards (Models.h:319-360): owner arrays as `name`, `name_A`, `name_B`
+    aliases, geometry arrays as `name_A[AGeo]`, `name_B[BGeo]` with B's array chosen by the contact kind"""
+    b = pkg.model.packed_bed(2000, seed=31, cd_freq=0, spacing_mult=2.5, init_vz=-0.4, force_model=1)
+    b.AddBCPlane((0.0, 0.0, 0.0174), (0, 0, 1), 0)  # a floor right under the lattice: sphere-analytical contacts at once
+    b.DefineContactForceModel(ELECTRO)
+    b.SetPerContactWildcards([])
+    b.SetPerOwnerWildcards(["n_touch"])
+    b.SetPerGeometryWildcards(["charge"])
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    b.compile_into(ctx)
+    nS, nA, nO = int(sc.nSpheres), int(sc.nAnal), int(sc.nOwners)
+    rng = np.random.default_rng(3)
+    q_sph = rng.choice([-1.0, 1.0, 2.0], nS).astype(np.float32)
+    q_wall = np.full(nA, 3.0, np.float32)
+    ctx.set_wildcard_array("sphere", 0, q_sph)
+    ctx.set_wildcard_array("analytical", 0, q_wall)
+    # reference run without the extra terms: the plain frictionless fragment, stepped until the bed sits on the floor;
+    # its state is then given to the context under test so that both evaluate the same configuration
+    b0 = pkg.model.packed_bed(2000, seed=31, cd_freq=0, spacing_mult=2.5, init_vz=-0.4, force_model=1)
+    b0.AddBCPlane((0.0, 0.0, 0.0174), (0, 0, 1), 0)
+    b0.DefineContactForceModel(PLAIN)
+    b0.SetPerContactWildcards([])
+    p0, sc0 = b0.Initialize()
+    c0 = pkg.Context(0)
+    c0.set_params(p0), c0.upload_scene(sc0)
+    b0.compile_into(c0)
+    c0.step(300)
+    st = c0.download_state()
+    ctx.upload_state({k: st[k] for k in st if not k.startswith(("a", "alpha"))})
+    c0.set_record_contacts(True)
+    c0.compute_margins(0), c0.detect(), c0.calc_forces()
+    F1 = c0.contact_records()[0]
+    ctx.set_record_contacts(True)
+    ctx.compute_margins(0), ctx.detect(), ctx.calc_forces()
+    F2 = ctx.contact_records()[0]
+    a, bb, t, _ = ctx.contacts()
+    assert np.array_equal(c0.contacts()[0], a)
+    qq = q_sph[a] * np.where(t == 1, q_sph[np.minimum(bb, nS - 1)], q_wall[np.minimum(bb, nA - 1)])
+    extra = np.linalg.norm(F2 - F1, axis=1)
+    assert (t != 1).sum() > 20 and np.allclose(extra, 2.5e-3 * np.abs(qq), rtol=2e-3, atol=2e-6)
+    touching = np.linalg.norm(F1, axis=1) > 0
+    own = b.arrays["ownerClumpBody"]
+    ownB = np.where(t == 1, own[np.minimum(bb, nS - 1)], b.arrays["objOwner"][np.minimum(bb, nA - 1)])
+    expect = np.bincount(own[a][touching], minlength=nO) + np.bincount(ownB[touching], minlength=nO)
+    assert np.array_equal(ctx.wildcard_array("owner", 0, nO), expect.astype(np.float32))  # additions of 1.0f are exact
+    assert expect.max() > 5
