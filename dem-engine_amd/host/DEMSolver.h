@@ -253,6 +253,9 @@ class DEMForceModel {
     void DefineCustomModelPrerequisites(const std::string& util) { prerequisites = util; }
     void SetMustPairwiseMatProp(const std::set<std::string>& props) { pairwise_props.insert(props.begin(), props.end()); }
     void SetPerContactWildcards(const std::set<std::string>& wc) { contact_wildcards = wc; }
+    void SetPerOwnerWildcards(const std::set<std::string>& wc) { owner_wildcards = wc; }
+    void SetPerGeometryWildcards(const std::set<std::string>& wc) { geo_wildcards = wc; }
+    std::set<std::string> owner_wildcards, geo_wildcards;
 };
 
 class DEMSolver {
@@ -1364,8 +1367,14 @@ class DEMSolver {
             for (auto& n : m_force_model->contact_wildcards)
                 names.push_back(n.c_str());
             const std::string prereq = pre.str();
-            check(deme_compile_force_model(m_ctx, m_force_model->code.c_str(), m_force_model->code.size(), names.data(),
-                                           (uint32_t)names.size(), prereq.c_str()));
+            std::vector<const char*> onames, gnames;
+            for (auto& n : m_force_model->owner_wildcards)
+                onames.push_back(n.c_str());
+            for (auto& n : m_force_model->geo_wildcards)
+                gnames.push_back(n.c_str());
+            check(deme_compile_force_model_ex(m_ctx, m_force_model->code.c_str(), m_force_model->code.size(), names.data(),
+                                              (uint32_t)names.size(), onames.data(), (uint32_t)onames.size(), gnames.data(),
+                                              (uint32_t)gnames.size(), prereq.c_str()));
         }
         m_n_clumps = nC, m_n_owners = nO;
         m_state_fresh = false;
