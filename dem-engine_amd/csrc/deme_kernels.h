@@ -723,7 +723,9 @@ __device__ inline void gather_owner(const GatherArgs& g, uint32_t o, float4& a, 
 // the same order as gather_owner (A run ascending, then B list ascending) -- bit-identical results, but no
 // lane walks a chain of dependent global loads any more.  `want` is false for lanes that do not need a sum
 // (beyond the end, fixed, ghost, heavy); all lanes of the workgroup must call.
+#ifndef DEME_GATHER_TILE
 #define DEME_GATHER_TILE 1024
+#endif
 struct GatherLds {
     float4 c4[DEME_GATHER_TILE];
     float2 c2[DEME_GATHER_TILE];
