@@ -440,7 +440,8 @@ class Context:
         return out
 
     def set_timing(self, enable=True):
-        self._ck(self.lib.deme_set_timing(self.h, int(bool(enable))), "deme_set_timing")
+        """True / 1: time every launch; n > 1: every n-th launch of each timed kernel; False / 0: off"""
+        self._ck(self.lib.deme_set_timing(self.h, int(enable)), "deme_set_timing")
 
     def kernel_time_reset(self):
         self._ck(self.lib.deme_kernel_time_reset(self.h), "deme_kernel_time_reset")

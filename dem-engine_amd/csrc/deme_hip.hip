@@ -41,6 +41,7 @@ struct TimerSlot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double total_ms = 0;
     uint64_t launches = 0;
+    uint64_t seen = 0;  // launches since the last reset, timed or not
 };
 
 }  // namespace
@@ -103,7 +104,7 @@ struct deme_ctx {
     uint32_t stepsSinceCD = 0;
     uint32_t lastStatus = 0;
     double timeElapsed = 0;
-    bool timing = false;
+    int timing = 0;  // 0 off; n > 0: every n-th launch of each timed kernel is bracketed with HIP events
     std::map<std::string, TimerSlot> timers;
     std::vector<hipEvent_t> eventPool;
 };
@@ -176,10 +177,14 @@ struct ScopedTimer {
     deme_ctx* c;
     TimerSlot* slot = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(deme_ctx* ctx, const char* name) : c(ctx) {
+    ScopedTimer(deme_ctx* ctx, const char* name, bool always = false) : c(ctx) {
         if (!c->timing)
             return;
         slot = &c->timers[name];
+        if (!always && (slot->seen++ % (uint64_t)c->timing) != 0) {  // sampled: an event pair costs ~3 us of dispatch gap per launch
+            slot = nullptr;
+            return;
+        }
         if (slot->pending.size() >= 8192) {  // bounded bookkeeping
             slot = nullptr;
             return;
@@ -337,7 +342,7 @@ int do_margins(deme_ctx* c, uint32_t drift) {
 
 // contactDetection() equivalent
 int do_detect(deme_ctx* c) {
-    ScopedTimer tm(c, "detect");
+    ScopedTimer tm(c, "detect", true);  // once per K steps: always timed
     const uint32_t nS = c->nSpheres;
     DetectCounters hc{};
     // margins kernel may have left status bits in ctr: fetch them before zeroing
@@ -1663,7 +1668,7 @@ int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t n
 int deme_set_timing(deme_ctx* c, int enable) {
     if (!c)
         return DEME_ERR_INVALID;
-    c->timing = enable != 0;
+    c->timing = enable > 0 ? enable : 0;
     return DEME_OK;
 }
 int deme_kernel_time_reset(deme_ctx* c) {
@@ -1674,6 +1679,7 @@ int deme_kernel_time_reset(deme_ctx* c) {
     for (auto& kv : c->timers) {
         kv.second.total_ms = 0;
         kv.second.launches = 0;
+        kv.second.seen = 0;
     }
     return DEME_OK;
 }

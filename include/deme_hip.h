@@ -279,6 +279,8 @@ int deme_inspect_values(deme_ctx* ctx, uint32_t quantity, float* out, size_t cap
  * names: "calc_forces", "integrate", "detect"; returns avg ms per launch since last reset */
 int deme_kernel_time_ms(deme_ctx* ctx, const char* name, double* avg_ms, uint64_t* launches);
 int deme_kernel_time_reset(deme_ctx* ctx);
+/* enable = 0: off; n > 0: every n-th launch of each timed kernel is bracketed with events (an event pair costs ~3 us of
+ * dispatch gap, 4.7 % of a 0.29 ms step when every launch is timed) */
 int deme_set_timing(deme_ctx* ctx, int enable);
 
 /* multi-GPU slab decomposition helpers (no reference equivalent).
