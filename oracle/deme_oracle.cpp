@@ -1132,13 +1132,15 @@ void calc_forces(Sim& s, bool record) {
             s.wc[3][c] = h.delta_time;
         }
     }
-    // accumulation, list order (the reference uses float atomics: order-nondeterministic)
-    for (size_t c = 0; c < nC; c++) {
-        if (!live[c])
-            continue;
-        const V3f force{F[c * 3], F[c * 3 + 1], F[c * 3 + 2]};
-        const V3f tq{T[c * 3], T[c * 3 + 1], T[c * 3 + 2]};
-        for (int side = 0; side < 2; side++) {
+    // accumulation (the reference uses float atomics: order-nondeterministic).  Fixed order of this build: for every owner
+    // first the contacts in which it is the A side, in list order, then those in which it is the B side, in list order --
+    // the order of the HIP path's atomics-free gather, so that a / alpha can be compared bit for bit.
+    for (int side = 0; side < 2; side++) {
+        for (size_t c = 0; c < nC; c++) {
+            if (!live[c])
+                continue;
+            const V3f force{F[c * 3], F[c * 3 + 1], F[c * 3 + 2]};
+            const V3f tq{T[c * 3], T[c * 3 + 1], T[c * 3 + 2]};
             const uint32_t o = side ? ownB[c] : ownA[c];
             const float m = (side && s.cType[c] > 10) ? s.objMass[s.cB[c]] : s.mass[s.inertiaOff[o]];
             const V3f moi{s.moiX[s.inertiaOff[o]], s.moiY[s.inertiaOff[o]], s.moiZ[s.inertiaOff[o]]};
