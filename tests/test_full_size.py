@@ -39,6 +39,16 @@ def test_full_size_contact_list_matches_oracle(pkg, orc, big):
         assert np.array_equal(a, oa) and np.array_equal(bb, ob) and np.array_equal(t, ot)
         gi, oi = ctx.bin_incidence(), sim.bin_incidence()
         assert np.array_equal(gi[0], oi[0]) and np.array_equal(gi[1], oi[1])  # (bin, sphere) incidences, bin-sorted
+        # ... and ten full time steps from here (every-step detection) leave 1e6 clumps in bit-identical states
+        ctx.migrate(), sim.migrate()
+        for w in range(4):
+            ctx.set_wildcard(w, sim.wildcard(w))  # the oracle starts without history: give both the same (empty) one
+        ctx.step(10), sim.step(10)
+        g2, o2 = ctx.download_state(), sim.download_state()
+        for k in ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY",
+                  "omgBarZ"):
+            assert np.array_equal(g2[k], o2[k]), k
+        assert int(ctx.counts().nContacts) == int(sim.counts().nContacts)
     finally:
         orc.set_num_threads(min(8, os.cpu_count() or 1))
 
