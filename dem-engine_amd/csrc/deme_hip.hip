@@ -754,6 +754,9 @@ void deme_ctx_destroy(deme_ctx* c) {
     drain_timers(c);
     for (auto e : c->eventPool)
         hipEventDestroy(e);
+    for (hipModule_t m : {c->customMod, c->prescMod, c->rulesMod})
+        if (m)
+            (void)hipModuleUnload(m);
     if (c->haloStream) {
         hipStreamSynchronize(c->haloStream);
         hipEventDestroy(c->evStepDone);
