@@ -619,7 +619,8 @@ int launch_forces(deme_ctx* c, int pass = -1) {
     {
         ScopedTimer tm(c, "calc_forces");
         const dim3 g(grid_for(a.nContacts, DEME_FORCE_BLOCK)), b(DEME_FORCE_BLOCK);
-        const bool hasSM = c->nTri > 0 && c->nSM > 0;
+        // sphere-mesh contacts read no ghost owner (meshes are replicated, not ghosted): all of them go with pass 0
+        const bool hasSM = c->nTri > 0 && c->nSM > 0 && pass != 1;
         const dim3 gm(grid_for(std::max<uint32_t>(c->nSM, 1u), DEME_FORCE_BLOCK));
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
             if (hasSM)  // mesh variant first: the hot variant folds its A-side records into the in-block sums

@@ -39,13 +39,22 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
     arrays, counts, n_own, global_ids (own clumps' global owner ids), send/recv id lists (local owner ids)."""
     n_clumps = int(counts["nOwnerClumps"])
     n_owners = int(counts["nOwners"])
-    assert int(counts.get("nTri", 0)) == 0, "meshes are not decomposed in this round"
+    # Meshes are replicated on every rank like the analytical owners.  That is exact when a mesh's motion does not depend on
+    # the contact forces it receives (fixed, or every velocity component dictated by a prescription): each rank applies
+    # the mesh's force to its own clumps, and the mesh's own a/alpha -- which would need an all-reduce -- are never used.
+    if int(counts.get("nTri", 0)):
+        flags = np.asarray(arrays["familyFlags"])
+        mesh_owners = np.unique(np.asarray(arrays["ownerMesh"]))
+        free = [int(o) for o in mesh_owners if not (flags[arrays["familyID"][o]] & (abi.FAMILY_FIXED | abi.FAMILY_PRESCRIBED))]
+        if free:
+            raise ValueError(f"mesh owner(s) {free} move under contact forces: only fixed or prescribed meshes can be replicated "
+                             "across slabs (a free mesh would need an all-reduce of its accelerations every step)")
     x = np.asarray(clump_x, np.float64)[:n_clumps]
     edges = slab_edges(x, n_ranks)
     rank_of = np.clip(np.searchsorted(edges, x, side="right") - 1, 0, n_ranks - 1)
     sph_owner_g = arrays["ownerClumpBody"]
     first_sphere = np.searchsorted(sph_owner_g, np.arange(n_owners + 1))  # spheres are clump-major
-    extra_owners = np.arange(n_clumps, n_owners)  # analytical owners, kept on every rank
+    extra_owners = np.arange(n_clumps, n_owners)  # analytical and mesh owners, kept on every rank
     out = []
     for r in range(n_ranks):
         own = np.nonzero(rank_of == r)[0]
@@ -66,6 +75,8 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
             a[k] = arrays[k][sph_idx].copy()
         a["ownerClumpBody"] = new_id[arrays["ownerClumpBody"][sph_idx]].astype(np.uint32)
         a["objOwner"] = new_id[arrays["objOwner"]].astype(np.uint32)
+        if int(counts.get("nTri", 0)):
+            a["ownerMesh"] = new_id[arrays["ownerMesh"]].astype(np.uint32)
         flags = arrays["familyFlags"].copy()
         flags[GHOST_FAMILY] |= FAMILY_GHOST_FLAG
         masks = arrays["familyMasks"].copy()

@@ -273,3 +273,108 @@ def test_redecomposition_on_gpu(pkg):
     X, V, X0, V0, moved, seeds = _run_with_redecomposition(pkg, make, b, p, sc, x, 400, 20)
     assert moved > 5
     assert np.abs(X - X0).max() < 1e-9 and np.abs(V - V0).max() < 1e-5
+
+
+def _bed_on_moving_plate(pkg, n=1600, seed=4, cd_freq=0):
+    """a bed over a wavy triangle plate that rises with a prescribed velocity (family 10): the mesh is replicated on both slabs"""
+    b = pkg.model.packed_bed(n, seed=seed, cd_freq=cd_freq, spacing_mult=2.5, init_vz=-0.4, aspect=(2.0, 1.0, 0.5))
+    b.SetExpandSafetyAdder(0.5)
+    lo, hi = b.user_box_min, b.user_box_max
+    v, f = pkg.model.plate_mesh(24, 12, float(hi[0] - lo[0]) * 0.95, float(hi[1] - lo[1]) * 0.95, z=0.0, wavy=0.002)
+    m = b.AddMeshObject(v, f, 0)
+    m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 0.0165))
+    m.SetFamily(10)
+    b.SetFamilyPrescribedLinVel(10, "0", "0", "0.3f")
+    p, sc = b.Initialize()
+    x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+    return b, p, sc, x
+
+
+def _plate_prescription(sim):
+    c = np.zeros((15, 4), np.float32)
+    c[2] = (0.3, 0, 0, 0)
+    sim.set_prescription(10, has=0b111, flags=0b111111, coef=c)
+
+
+def test_two_slabs_with_a_replicated_prescribed_mesh_oracle(pkg, orc):
+    b, p, sc, x = _bed_on_moving_plate(pkg)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
+    assert all(int(pt["counts"]["nTri"]) == int(sc.nTri) for pt in parts)
+
+    def mk(pp, s):
+        sim = orc.make_sim(pkg, pp, s)
+        _plate_prescription(sim)
+        return sim
+
+    steps = 120
+    sims = run_slabs(pkg, mk, parts, p, steps, host_exchange(pkg, parts))
+    X, V = gather_positions(pkg, parts, sims, p, sc.nOwnerClumps)
+    one = mk(p, sc)
+    one.step(steps)
+    st = one.download_state()
+    n = sc.nOwnerClumps
+    X1 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
+    assert (one.contacts()[2] == 2).sum() > 30  # sphere-mesh contacts exist
+    assert np.abs(X - X1).max() < 2e-7
+    # a free mesh cannot be replicated
+    b2, p2, sc2, x2 = _bed_on_moving_plate(pkg)
+    b2.family_flags[10] = 0
+    b2.arrays["familyFlags"][10] = 0
+    with pytest.raises(ValueError):
+        pkg.decomp.decompose(b2.arrays, b2.counts, x2, 2, halo=0.035)
+
+
+@pytest.mark.gpu
+def test_two_slabs_with_mesh_on_gpu_plain_and_overlapped(pkg):
+    import ctypes as C
+    b, p, sc, x = _bed_on_moving_plate(pkg, n=3000, seed=6, cd_freq=5)  # detection every 5 steps: 4 of 5 steps are split
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
+    hip = C.CDLL("libamdhip64.so")
+
+    def dev(host=None, nbytes=0):
+        ptr = C.c_void_p()
+        nbytes = host.nbytes if host is not None else nbytes
+        assert hip.hipMalloc(C.byref(ptr), C.c_size_t(max(nbytes, 16))) == 0
+        if host is not None and host.nbytes:
+            assert hip.hipMemcpy(ptr, C.c_void_p(host.ctypes.data), C.c_size_t(host.nbytes), 1) == 0
+        return ptr.value
+
+    def make(pp, s):
+        ctx = pkg.Context(0)
+        ctx.set_params(pp), ctx.upload_scene(s)
+        b.compile_into(ctx)  # the plate's prescription
+        return ctx
+
+    ids = [{k: dev(np.ascontiguousarray(pt[k].astype(np.uint32))) for k in ("send_left", "send_right", "recv_left", "recv_right")}
+           for pt in parts]
+    n01, n10 = len(parts[0]["send_right"]), len(parts[1]["send_left"])
+    buf01, buf10 = dev(nbytes=n01 * pkg.abi.GHOST_BYTES), dev(nbytes=n10 * pkg.abi.GHOST_BYTES)
+    steps = 120
+    plain = [make(p, pt["scene"]) for pt in parts]
+    for _ in range(steps):
+        plain[0].halo_pack(ids[0]["send_right"], n01, buf01), plain[1].halo_pack(ids[1]["send_left"], n10, buf10)
+        plain[0].sync(), plain[1].sync()
+        plain[1].halo_unpack(ids[1]["recv_left"], n01, buf01), plain[0].halo_unpack(ids[0]["recv_right"], n10, buf10)
+        plain[0].step(1), plain[1].step(1)
+    over = [make(p, pt["scene"]) for pt in parts]
+    n_split = 0
+    for _ in range(steps):
+        n_split += sum(int(not c.step_overlap_begin()) for c in over)
+        over[0].halo_sync(), over[1].halo_sync()
+        over[0].halo_pack_async(ids[0]["send_right"], n01, buf01), over[1].halo_pack_async(ids[1]["send_left"], n10, buf10)
+        over[0].halo_sync(), over[1].halo_sync()
+        over[1].halo_unpack_async(ids[1]["recv_left"], n01, buf01), over[0].halo_unpack_async(ids[0]["recv_right"], n10, buf10)
+        over[0].step_overlap_end(), over[1].step_overlap_end()
+    one = make(p, sc)
+    one.step(steps)
+    st = one.download_state()
+    n = sc.nOwnerClumps
+    X1 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
+    assert (one.contacts()[2] == 2).sum() > 30
+    X, _ = gather_positions(pkg, parts, plain, p, n)
+    assert np.abs(X - X1).max() < 2e-7
+    assert n_split > steps
+    for a, c in zip(plain, over):
+        sa, sb = a.download_state(), c.download_state()
+        for k in GKEYS:
+            assert np.array_equal(sa[k], sb[k]), k
