@@ -536,6 +536,71 @@ class DEMSolver {
             o << "5 " << std::endl;
         flush(outfilename, o);
     }
+    /// UpdateClumps (API.h:1267): clumps added with AddClumps after Initialize() join the running simulation; old owners keep
+    /// their state and the contact list keeps its history (new clumps are appended, so sphere ids are stable)
+    void UpdateClumps() {
+        const size_t oldClumps = m_n_clumps, oldOwners = m_n_owners;
+        // state of the old owners
+        std::vector<uint64_t> vid(oldOwners);
+        std::vector<uint16_t> lx(oldOwners), ly(oldOwners), lz(oldOwners);
+        std::vector<float> f[10];
+        for (auto& v : f)
+            v.resize(oldOwners);
+        std::vector<uint8_t> fam(oldOwners);
+        DemeOwnerState st{};
+        st.voxelID = vid.data(), st.locX = lx.data(), st.locY = ly.data(), st.locZ = lz.data();
+        st.oriQw = f[0].data(), st.oriQx = f[1].data(), st.oriQy = f[2].data(), st.oriQz = f[3].data();
+        st.vX = f[4].data(), st.vY = f[5].data(), st.vZ = f[6].data();
+        st.omgBarX = f[7].data(), st.omgBarY = f[8].data(), st.omgBarZ = f[9].data();
+        st.familyID = fam.data();
+        check(deme_download_owner_state(m_ctx, &st));
+        // contact list + wildcards
+        DemeCounts c{};
+        check(deme_get_counts(m_ctx, &c));
+        const size_t nc = (size_t)c.nContacts;
+        const uint32_t nW = m_p.nContactWildcards;
+        std::vector<uint32_t> a(nc), b(nc), map(nc);
+        std::vector<uint8_t> ty(nc);
+        check(deme_download_contacts(m_ctx, a.data(), b.data(), ty.data(), map.data(), nc));
+        std::vector<float> W(nc * nW), col(nc);
+        for (uint32_t w = 0; w < nW; w++) {
+            check(deme_download_contact_wildcard(m_ctx, w, col.data(), nc));
+            for (size_t i = 0; i < nc; i++)
+                W[i * nW + w] = col[i];
+        }
+        const double t = m_time;
+        initialize_impl();  // rebuilds and uploads the scene with all batches
+        if (m_n_clumps < oldClumps || m_n_owners - m_n_clumps != oldOwners - oldClumps)
+            throw std::runtime_error("UpdateClumps can only append clumps");
+        // put the old owners' state back: old clumps keep their slots, the other owners moved behind the new clumps
+        const size_t n = m_n_owners;
+        std::vector<uint64_t> vid2(n);
+        std::vector<uint16_t> lx2(n), ly2(n), lz2(n);
+        std::vector<float> g[10];
+        for (auto& v : g)
+            v.resize(n);
+        std::vector<uint8_t> fam2(n);
+        DemeOwnerState s2{};
+        s2.voxelID = vid2.data(), s2.locX = lx2.data(), s2.locY = ly2.data(), s2.locZ = lz2.data();
+        s2.oriQw = g[0].data(), s2.oriQx = g[1].data(), s2.oriQy = g[2].data(), s2.oriQz = g[3].data();
+        s2.vX = g[4].data(), s2.vY = g[5].data(), s2.vZ = g[6].data();
+        s2.omgBarX = g[7].data(), s2.omgBarY = g[8].data(), s2.omgBarZ = g[9].data();
+        s2.familyID = fam2.data();
+        check(deme_download_owner_state(m_ctx, &s2));
+        for (size_t o = 0; o < oldOwners; o++) {
+            const size_t dst = o < oldClumps ? o : m_n_clumps + (o - oldClumps);
+            vid2[dst] = vid[o], lx2[dst] = lx[o], ly2[dst] = ly[o], lz2[dst] = lz[o], fam2[dst] = fam[o];
+            for (int k = 0; k < 10; k++)
+                g[k][dst] = f[k][o];
+        }
+        check(deme_upload_owner_state(m_ctx, &s2));
+        m_time = t;
+        m_p.timeElapsed = t;
+        check(deme_set_params(m_ctx, &m_p));
+        if (nc)
+            check(deme_seed_contacts(m_ctx, a.data(), b.data(), ty.data(), nW ? W.data() : nullptr, nc));
+        m_state_fresh = false;
+    }
     /// UpdateStepSize (API.h:1274): takes effect from the next step
     void UpdateStepSize(double ts) {
         m_h = (float)ts;

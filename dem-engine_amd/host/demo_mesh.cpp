@@ -57,13 +57,20 @@ int main(int argc, char** argv) {
     for (auto& v : nodes)
         v.z += 0.15f * v.x * v.x;
     plate_tracker->UpdateMesh(nodes);
+    // pour a few more spheres onto the running simulation (AddClumps + UpdateClumps, as the reference's filling loops do)
+    std::vector<float3> more;
+    for (int i = 0; i < 25; i++)
+        more.push_back(make_float3(0.06f + (i % 5) * 0.02f, 0.06f + (i / 5) * 0.02f, 0.14f));
+    auto batch2 = DEMSim.AddClumps(ball, more);
+    batch2->SetVel(make_float3(0.f, 0.f, -1.0f));
+    DEMSim.UpdateClumps();
     DEMSim.DoDynamicsThenSync((steps - steps / 2) * 5e-6);
 
     DEMSim.WriteMeshFile(std::string(argv[2]) + "/mesh.vtk");
     DEMSim.SetOutputContent(ABSV | FAMILY);
     DEMSim.WriteSphereFile(std::string(argv[2]) + "/spheres.csv");
-    std::printf("MESH triangles=%zu nodes=%zu plate_z=%.6f contacts=%zu max_z=%.5f\n", plate->GetNumTriangles(), plate->GetNumNodes(),
-                plate_tracker->Pos().z, DEMSim.GetNumContacts(), max_z->GetValue());
+    std::printf("MESH triangles=%zu nodes=%zu plate_z=%.6f contacts=%zu max_z=%.5f clumps=%zu\n", plate->GetNumTriangles(),
+                plate->GetNumNodes(), plate_tracker->Pos().z, DEMSim.GetNumContacts(), max_z->GetValue(), DEMSim.GetNumClumps());
     DEMSim.ShowThreadCollaborationStats();
     DEMSim.ShowTimingStats();
     std::printf("DEMO_MESH_OK\n");

@@ -402,6 +402,35 @@ class SceneBuilder:
         if getattr(self, "_family_rules", None):
             ctx.compile_family_rules(self.family_change_rules())
 
+    def UpdateClumps(self, ctx, time_elapsed):
+        """DEMSolver::UpdateClumps (API.h:1267): clumps added with AddClumps after Initialize() join the running simulation.
+        Old owners keep their state, the contact list keeps its history (sphere ids are stable because new clumps are
+        appended; analytical-component and triangle ids do not change).  `time_elapsed`: the simulation time to continue
+        from (DemeParams.timeElapsed).  Returns the new (params, scene)."""
+        old_counts = dict(self.counts)
+        st = ctx.download_state()
+        cnt = ctx.contacts()
+        nW = int(self.params.nContactWildcards)
+        W = np.stack([ctx.wildcard(w) for w in range(nW)], 1) if nW else np.zeros((len(cnt[0]), 0), np.float32)
+        p, sc = self.Initialize()
+        n_old_c, n_old_o = int(old_counts["nOwnerClumps"]), int(old_counts["nOwners"])
+        n_new_c = int(self.counts["nOwnerClumps"])
+        if n_new_c < n_old_c or int(self.counts["nOwners"]) - n_new_c != n_old_o - n_old_c:
+            raise ValueError("UpdateClumps can only append clumps")
+        idx_new = np.r_[np.arange(n_old_c), n_new_c + np.arange(n_old_o - n_old_c)]
+        for k in ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY",
+                  "omgBarZ", "familyID"):
+            self.arrays[k][idx_new] = st[k]
+        sc = abi.make_scene_struct(self.arrays, self.counts)
+        p.timeElapsed = float(time_elapsed)
+        self.params = p
+        ctx.set_params(p)
+        ctx.upload_scene(sc)
+        self.compile_into(ctx)
+        if len(cnt[0]):
+            ctx.seed_contacts(cnt[0], cnt[1], cnt[2], W)
+        return p, sc
+
     def ChangeFamilyWhen(self, id_from, id_to, condition):
         """condition: C++ statements that `return` a bool, over X, Y, Z, vX, vY, vZ, accX, accY, accZ, pos, vel, acc, mass, ts,
         time (API.h:1024; DEMModeratorKernels.cu:10-60); checked between force evaluation and integration of every step."""

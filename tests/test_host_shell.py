@@ -80,6 +80,7 @@ def test_mesh_demo_obj_prescription_deformation_vtk(tmp_path):
     assert vals["triangles"] == 2 * n * n and vals["nodes"] == (n + 1) ** 2
     assert abs(vals["plate_z"] - (0.05 + 0.2 * 3000 * 5e-6)) < 2e-6  # prescribed rise of the mesh owner
     assert vals["contacts"] > 50 and vals["max_z"] > 0.06
+    assert vals["clumps"] == 4 * 12 * 12 + 25  # UpdateClumps appended the second batch to the running simulation
     vtk = open(tmp_path / "mesh.vtk").read().split("\n")
     assert vtk[0] == "# vtk DataFile Version 2.0" and vtk[5] == "DATASET UNSTRUCTURED_GRID"
     assert vtk[6] == f"POINTS {(n + 1) ** 2} float"

@@ -164,3 +164,45 @@ def test_restart_from_files_on_gpu(pkg, tmp_path):
     # the clump file stores fp32 positions (the reference's format): ~3e-8 m of rounding at restart
     assert np.abs(Xa - Xb).max() < 2e-6
     assert abs(int(ctx.counts().nContacts) - int(ctx2.counts().nContacts)) <= 3
+
+
+@pytest.mark.gpu
+def test_update_clumps_appends_to_a_running_simulation(pkg, orc):
+    """UpdateClumps (API.h:1267): a second batch poured onto a running bed.  The old clumps carry on exactly as in a run
+    without the addition until the newcomers reach them; the combined scene then matches the oracle given the same state."""
+    def bed():
+        return pkg.model.packed_bed(1200, seed=41, cd_freq=0, spacing_mult=2.4, init_vz=-0.5, aspect=(1.0, 1.0, 0.6))
+    b = bed()
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    ctx.step(150)
+    ref = pkg.Context(0)
+    ref.set_params(p), ref.upload_scene(sc)
+    ref.step(150)
+    n_old = int(sc.nOwnerClumps)
+    # a layer of new clumps well above the bed, falling
+    top = float(b.batches[0].xyz[:, 2].max())
+    xy = b.batches[0].xyz[:300, :2]
+    new = np.c_[xy, np.full(len(xy), top + 0.03, np.float32)].astype(np.float32)
+    batch = b.AddClumps(b.templates[0], new)
+    batch.SetVel(np.tile(np.array([0, 0, -1.0], np.float32), (len(new), 1)))
+    p2, sc2 = b.UpdateClumps(ctx, time_elapsed=150 * p.h)
+    assert int(sc2.nOwnerClumps) == n_old + 300 and int(ctx.counts().nContacts) == int(ref.counts().nContacts)
+    ctx.step(100), ref.step(100)  # the newcomers are still in the air: the old clumps must not notice them
+    a, r = ctx.download_state(), ref.download_state()
+    for k in ("voxelID", "locX", "locY", "locZ", "vX", "vY", "vZ", "oriQw", "omgBarZ"):
+        assert np.array_equal(a[k][:n_old], r[k][:n_old]), k
+    assert np.array_equal(ctx.wildcard(3)[: len(ref.wildcard(3))].sum() > 0, True)
+    # from here on: oracle with the same combined state
+    sim = orc.make_sim(pkg, p2, sc2)
+    sim.upload_state({k: a[k] for k in a if not k.startswith(("a", "alpha"))})
+    cnt = ctx.contacts()
+    sim.seed_contacts(cnt[0], cnt[1], cnt[2], np.stack([ctx.wildcard(w) for w in range(4)], 1))
+    ctx.step(3000), sim.step(3000)
+    g, o = ctx.download_state(), sim.download_state()
+    assert int(ctx.counts().nContacts) == int(sim.counts().nContacts)
+    for k in ("voxelID", "locX", "locZ", "vZ", "oriQw"):
+        assert np.array_equal(g[k], o[k]), k
+    newcomers_touch = (np.isin(ctx.contacts()[0] // 3, np.arange(n_old, n_old + 300))).sum()
+    assert newcomers_touch > 20  # the poured layer has landed on the bed
