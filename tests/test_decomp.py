@@ -378,3 +378,12 @@ def test_two_slabs_with_mesh_on_gpu_plain_and_overlapped(pkg):
         sa, sb = a.download_state(), c.download_state()
         for k in GKEYS:
             assert np.array_equal(sa[k], sb[k]), k
+
+
+@pytest.mark.gpu
+def test_overlapped_exchange_through_torch_streams():
+    """bench.py's stream / event choreography with torch ExternalStreams around the contexts' halo streams (torch copies stand
+    in for RCCL isend / irecv): bit-identical to the ordered exchange"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_overlap_torch_worker.py")], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "OVERLAP_TORCH_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
