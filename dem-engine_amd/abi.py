@@ -182,6 +182,8 @@ def load_library():
         "deme_halo_unpack_async": [_P, _P, C.c_uint32, _P], "deme_halo_sync": [_P],
         "deme_step_overlap_begin": [_P, C.POINTER(C.c_int)], "deme_step_overlap_end": [_P],
         "deme_compile_family_rules": [_P, C.c_char_p], "deme_change_family": [_P, C.c_uint32, C.c_uint32],
+        "deme_mark_persistent_contacts": [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_int],
+        "deme_num_persistent_contacts": [_P, C.POINTER(C.c_size_t)],
         "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)], "deme_inspect_values": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_set_record_contacts": [_P, C.c_int],
         "deme_download_contact_records": [_P, _P, _P, _P, _P, C.c_size_t],
@@ -383,6 +385,18 @@ class Context:
 
     def change_family(self, frm, to):
         self._ck(self.lib.deme_change_family(self.h, int(frm), int(to)), "deme_change_family")
+
+    PERSIST_ALL, PERSIST_EITHER, PERSIST_BOTH, PERSIST_PAIR = 0, 1, 2, 3
+
+    def mark_persistent_contacts(self, mode=0, n1=0, n2=0, mark=True):
+        """MarkPersistentContact / MarkFamilyPersistentContact{Either,Both,} and their Remove* inverses (DEM/API.h:874-905)."""
+        self._ck(self.lib.deme_mark_persistent_contacts(self.h, int(mode), int(n1), int(n2), int(bool(mark))),
+                 "deme_mark_persistent_contacts")
+
+    def num_persistent_contacts(self):
+        n = C.c_size_t(0)
+        self._ck(self.lib.deme_num_persistent_contacts(self.h, C.byref(n)), "deme_num_persistent_contacts")
+        return int(n.value)
 
     def compile_prescriptions(self, vel_cases, pos_cases, acc_cases):
         """Family motion prescriptions: the three switch bodies of equipFamilyPrescribedMotions (see include/deme_hip.h)."""

@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
+#include <iterator>
 
 #include "../../include/deme_hip.h"
 #include "deme_device.h"
@@ -65,6 +66,9 @@ struct deme_ctx {
     DevBuf conA4, conA2, conB4, conB2, aSum, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
+    // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
+    DevBuf persistKeys;
+    std::vector<uint64_t> hPersist;
     // triangles (mesh path)
     uint32_t nTri = 0;
     DevBuf tris, triWorld, triLo, triHi, triCounts, triOffsets, triKeys[2], triVals[2];
@@ -460,7 +464,17 @@ int do_detect(deme_ctx* c) {
             return fail(c, DEME_ERR_BIN_TOO_FULL,
                         "a bin contains %u sphere components, exceeding the allowance %u (SetMaxSphereInBin)", c->maxInBin,
                         c->dp.errOutBinSphNum);
-        const uint64_t nC = hc.nContactsRaw;
+        uint64_t nC = hc.nContactsRaw;
+        const size_t nPersist = c->hPersist.size();
+        if (nPersist) {  // marked contacts join the list whether or not the sweep found them (DEMCubContactDetection.cu:605-802)
+            if (nC + nPersist > c->cntCap) {
+                if (int rc = grow_contact_arena(c, (size_t)nC + nPersist + nC / 4 + 1024))
+                    return rc;
+                continue;
+            }
+            HIPCK(hipMemcpyAsync(c->keysRaw.as<uint64_t>() + nC, c->persistKeys.p, nPersist * 8, hipMemcpyDeviceToDevice, c->stream));
+            nC += nPersist;
+        }
         const int next = c->keysCur ^ 1;
         if (nC) {
             size_t need = 0;
@@ -471,6 +485,22 @@ int do_detect(deme_ctx* c) {
             need = c->sortTmp.bytes;
             HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, need, c->keysRaw.as<uint64_t>(),
                                            c->keysSorted[next].as<uint64_t>(), (size_t)nC, 0, 64, c->stream));
+            if (nPersist) {  // a marked contact the sweep found as well appears once (markDuplicateContacts)
+                unsigned long long* cnt = &c->ctr.as<DetectCounters>()->nContactsRaw;
+                size_t need2 = 0;
+                HIPCK(rocprim::unique(nullptr, need2, c->keysSorted[next].as<uint64_t>(), c->keysRaw.as<uint64_t>(), cnt, (size_t)nC,
+                                      rocprim::equal_to<uint64_t>(), c->stream));
+                if (int rc = ensure(c, c->scanTmp, need2))
+                    return rc;
+                need2 = c->scanTmp.bytes;
+                HIPCK(rocprim::unique(c->scanTmp.p, need2, c->keysSorted[next].as<uint64_t>(), c->keysRaw.as<uint64_t>(), cnt,
+                                      (size_t)nC, rocprim::equal_to<uint64_t>(), c->stream));
+                unsigned long long nU = 0;
+                HIPCK(hipMemcpyAsync(&nU, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCK(hipStreamSynchronize(c->stream));
+                nC = nU;
+                HIPCK(hipMemcpyAsync(c->keysSorted[next].p, c->keysRaw.p, (size_t)nC * 8, hipMemcpyDeviceToDevice, c->stream));
+            }
             const uint64_t nPrev = c->haveList ? c->nContacts : 0;
             hipLaunchKernelGGL(k_history, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC,
                                c->keysSorted[next].as<uint64_t>(), (uint32_t)nPrev,
@@ -764,7 +794,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
-    DevBuf* all[] = {&c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1632,6 +1662,53 @@ int deme_compile_family_rules(deme_ctx* c, const char* rules) {
     }
     HIPCK(hipModuleLoadData(&c->rulesMod, it->second.data()));
     HIPCK(hipModuleGetFunction(&c->rulesFn, c->rulesMod, "deme_family_changes"));
+    return DEME_OK;
+}
+
+int deme_mark_persistent_contacts(deme_ctx* c, int mode, uint32_t N1, uint32_t N2, int mark) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (mode < 0 || mode > 3)
+        return fail(c, DEME_ERR_INVALID, "deme_mark_persistent_contacts: mode %d is not one of 0 (all), 1 (either), 2 (both), 3 (pair)", mode);
+    if (c->hp.nContactWildcards == 0)  // DEM/APIPrivate.cpp:38-43
+        return fail(c, DEME_ERR_INVALID,
+                    "persistent contacts cannot be marked with a history-less force model (persistency is part of the history); add a placeholder wildcard");
+    const size_t nC = c->haveList ? c->nContacts : 0;
+    std::vector<uint64_t> hit;
+    if (nC) {
+        if (int rc = ensure(c, c->stage, nC))
+            return rc;
+        hipLaunchKernelGGL(k_persist_flags, dim3(grid_for(nC)), dim3(256), 0, c->stream, c->dp, (uint32_t)nC,
+                           c->keysSorted[c->keysCur].as<uint64_t>(), c->spheres.as<SphereRec>(), c->owners.as<OwnerRec>(), mode, N1, N2,
+                           c->stage.as<uint8_t>());
+        std::vector<uint8_t> flag(nC);
+        std::vector<uint64_t> keys(nC);
+        HIPCK(hipMemcpyAsync(flag.data(), c->stage.p, nC, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipMemcpyAsync(keys.data(), c->keysSorted[c->keysCur].p, nC * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < nC; i++)
+            if (flag[i])
+                hit.push_back(keys[i]);  // ascending already
+    }
+    std::vector<uint64_t> out;
+    if (mark)
+        std::set_union(c->hPersist.begin(), c->hPersist.end(), hit.begin(), hit.end(), std::back_inserter(out));
+    else
+        std::set_difference(c->hPersist.begin(), c->hPersist.end(), hit.begin(), hit.end(), std::back_inserter(out));
+    c->hPersist.swap(out);
+    if (!c->hPersist.empty()) {
+        if (int rc = ensure(c, c->persistKeys, c->hPersist.size() * 8))
+            return rc;
+        HIPCK(hipMemcpyAsync(c->persistKeys.p, c->hPersist.data(), c->hPersist.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+    }
+    return DEME_OK;
+}
+
+int deme_num_persistent_contacts(deme_ctx* c, size_t* n) {
+    if (!c || !n)
+        return DEME_ERR_INVALID;
+    *n = c->hPersist.size();
     return DEME_OK;
 }
 

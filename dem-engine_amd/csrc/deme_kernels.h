@@ -870,6 +870,30 @@ __global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint3
         smFlag[c] = (cls == DEME_KEY_CLASS_SM) ? 1 : 0;
 }
 
+// Persistent-contact qualification of every contact of the current list (DEM/APIPrivate.cpp:33-117, done there in a host
+// loop): mode 0 all, 1 either owner's family == N1, 2 both == N1, 3 the pair (N1, N2) in either order.
+__global__ __launch_bounds__(256) void k_persist_flags(const DevParams p, uint32_t nC, const uint64_t* __restrict__ keys,
+                                                       const SphereRec* __restrict__ spheres,
+                                                       const OwnerRec* __restrict__ owners, int mode, uint32_t N1, uint32_t N2,
+                                                       uint8_t* __restrict__ flag) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nC)
+        return;
+    const uint64_t k = keys[c];
+    const uint32_t oa = load_sphere(spheres, key_a(k)).owner, cls = key_class(k);
+    uint32_t ob;
+    if (cls == DEME_KEY_CLASS_SS)
+        ob = load_sphere(spheres, key_b(k)).owner;
+    else if (cls == DEME_KEY_CLASS_SA)
+        ob = p.anal[key_b(k)].owner;
+    else
+        ob = reinterpret_cast<const uint32_t*>(p.tris)[12 * (size_t)key_b(k) + 9];
+    const uint32_t fA = owners[oa].family, fB = owners[ob].family;
+    const bool q = mode == 0 || (mode == 1 && (fA == N1 || fB == N1)) || (mode == 2 && fA == N1 && fB == N1) ||
+                   (mode == 3 && ((fA == N1 && fB == N2) || (fA == N2 && fB == N1)));
+    flag[c] = q ? 1 : 0;
+}
+
 __device__ inline uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t v) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {

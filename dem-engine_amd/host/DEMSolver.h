@@ -443,6 +443,16 @@ class DEMSolver {
         check(deme_change_family(m_ctx, ID_from, ID_to));
         m_state_fresh = false;
     }
+    // Persistent contacts (DEM/API.h:874-905): contacts of the current list that qualify stay in the list at every later
+    // contact detection.  Like the reference these are post-Initialize calls.
+    void MarkFamilyPersistentContactEither(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 1, N, 0, 1)); }
+    void MarkFamilyPersistentContactBoth(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 2, N, 0, 1)); }
+    void MarkFamilyPersistentContact(unsigned int N1, unsigned int N2) { check(deme_mark_persistent_contacts(m_ctx, 3, N1, N2, 1)); }
+    void MarkPersistentContact() { check(deme_mark_persistent_contacts(m_ctx, 0, 0, 0, 1)); }
+    void RemoveFamilyPersistentContactEither(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 1, N, 0, 0)); }
+    void RemoveFamilyPersistentContactBoth(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 2, N, 0, 0)); }
+    void RemoveFamilyPersistentContact(unsigned int N1, unsigned int N2) { check(deme_mark_persistent_contacts(m_ctx, 3, N1, N2, 0)); }
+    void RemovePersistentContact() { check(deme_mark_persistent_contacts(m_ctx, 0, 0, 0, 0)); }
     void DisableContactBetweenFamilies(unsigned int a, unsigned int b) {
         if (a > b)
             std::swap(a, b);

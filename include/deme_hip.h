@@ -244,6 +244,15 @@ int deme_compile_family_rules(deme_ctx* ctx, const char* rules);
 /* DEMSolver::ChangeFamily(ID_from, ID_to) (API.h:1028): immediate, all owners of a family */
 int deme_change_family(deme_ctx* ctx, uint32_t from, uint32_t to);
 
+/* Persistent contacts (reference: DEM/API.h:874-905 MarkFamilyPersistentContactEither/Both, MarkFamilyPersistentContact,
+ * MarkPersistentContact and their Remove* inverses; DEM/APIPrivate.cpp:33-117; algorithms/DEMCubContactDetection.cu:605-802).
+ * Qualifies contacts of the CURRENT list: mode 0 every contact, 1 either owner's family == N1, 2 both == N1, 3 the family
+ * pair (N1, N2) in either order.  mark != 0: they stay in the contact list at every later detection whether or not the
+ * sweep finds them (the force kernel still treats a separated pair as NOT_A_CONTACT); mark == 0: the qualification is
+ * removed.  Refused for a history-less force model, like the reference.  Host-synchronous. */
+int deme_mark_persistent_contacts(deme_ctx* ctx, int mode, uint32_t N1, uint32_t N2, int mark);
+int deme_num_persistent_contacts(deme_ctx* ctx, size_t* n);
+
 /* Owner and geometry wildcards of user force models (DEMForceModel::SetPerOwnerWildcards / SetPerGeometryWildcards,
  * AuxClasses.h:422-485; Models.h:319-360).  Owner wildcards are per-owner float arrays the fragment sees as `name`,
  * `name_A`, `name_B` (aliases, indexed by AOwner / BOwner); geometry wildcards are per-sphere / per-triangle /

@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <iterator>
 #include <vector>
 
 #include "../include/deme_hip.h"
@@ -583,6 +584,11 @@ inline T3f tri_incenter(T3f p1, T3f p2, T3f p3) {
 // ===========================================================================
 // Simulation object mirroring the C-ABI context, one stage per entry point.
 // ===========================================================================
+struct Key {
+    uint32_t a, b;
+    uint8_t t;
+};
+
 struct Sim {
     DemeParams p{};
     uint32_t nOwners = 0, nOwnerClumps = 0, nSpheres = 0, nAnal = 0, nMat = 0, nComp = 0, nMassProps = 0;
@@ -644,6 +650,10 @@ struct Sim {
         double thr;
     };
     std::vector<FamRule> famRules;
+    // persistent contacts (DEM/APIPrivate.cpp:33-117 marks them in the previous list; algorithms/DEMCubContactDetection.cu:
+    // 605-802 adds every marked contact the detection did not find back into the new list): kept here as the sorted set of
+    // marked (A, class, B) keys, which is what the flag array travelling with the list amounts to
+    std::vector<Key> persist;
 };
 
 template <typename T>
@@ -693,10 +703,6 @@ void compute_margins(Sim& s, uint32_t drift) {
     }
 }
 
-struct Key {
-    uint32_t a, b;
-    uint8_t t;
-};
 inline int type_class(uint8_t t) {  // within one sphere A: sphere-sphere, sphere-mesh, sphere-analytical
     return t == DEME_SPHERE_SPHERE_CONTACT ? 0 : (t == DEME_SPHERE_MESH_CONTACT ? 1 : 2);
 }
@@ -930,7 +936,11 @@ int detect(Sim& s) {
     }
     for (auto& v : perThread)
         keys.insert(keys.end(), v.begin(), v.end());
+    keys.insert(keys.end(), s.persist.begin(), s.persist.end());
     std::sort(keys.begin(), keys.end(), key_less);
+    if (!s.persist.empty())  // a marked contact the sweep found as well appears once (markDuplicateContacts)
+        keys.erase(std::unique(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.a == y.a && x.b == y.b && x.t == y.t; }),
+                   keys.end());
 
     // history map: "same (A, B, type) in the previous list", DEMHistoryMappingKernels.cu:17-61
     s.pA.swap(s.cA);
@@ -1635,6 +1645,29 @@ void orc_sim_counts(void* h, DemeCounts* c) {
 void orc_sim_add_family_rule(void* h, uint32_t from, uint32_t to, uint32_t q, uint32_t op, double thr) {
     ((Sim*)h)->famRules.push_back({from, to, q, op, thr});
 }
+// DEM/APIPrivate.cpp:33-117: mode 0 every contact of the current list, 1 either owner family == N1, 2 both == N1,
+// 3 the pair (N1, N2) in either order; mark != 0 marks, 0 removes the qualification
+void orc_sim_mark_persistent(void* h, int mode, uint32_t N1, uint32_t N2, int mark) {
+    Sim& s = *(Sim*)h;
+    std::vector<Key> hit;
+    for (size_t i = 0; i < s.cA.size(); i++) {
+        const uint32_t oA = s.ownerOfSphere[s.cA[i]];
+        const uint32_t oB = s.cType[i] == DEME_SPHERE_SPHERE_CONTACT ? s.ownerOfSphere[s.cB[i]]
+                            : (s.cType[i] == DEME_SPHERE_MESH_CONTACT ? s.ownerMesh[s.cB[i]] : s.objOwner[s.cB[i]]);
+        const uint32_t fA = s.familyID[oA], fB = s.familyID[oB];
+        const bool q = mode == 0 || (mode == 1 && (fA == N1 || fB == N1)) || (mode == 2 && fA == N1 && fB == N1) ||
+                       (mode == 3 && ((fA == N1 && fB == N2) || (fA == N2 && fB == N1)));
+        if (q)
+            hit.push_back({s.cA[i], s.cB[i], s.cType[i]});  // the list is in key_less order already
+    }
+    std::vector<Key> out;
+    if (mark)
+        std::set_union(s.persist.begin(), s.persist.end(), hit.begin(), hit.end(), std::back_inserter(out), key_less);
+    else
+        std::set_difference(s.persist.begin(), s.persist.end(), hit.begin(), hit.end(), std::back_inserter(out), key_less);
+    s.persist.swap(out);
+}
+size_t orc_sim_num_persistent(void* h) { return ((Sim*)h)->persist.size(); }
 void orc_sim_change_family(void* h, uint32_t from, uint32_t to) {
     Sim& s = *(Sim*)h;
     for (auto& f : s.familyID)

@@ -275,6 +275,13 @@ class OracleSim:
     def change_family(self, frm, to):
         self.L.orc_sim_change_family(C.c_void_p(self.h), C.c_uint32(frm), C.c_uint32(to))
 
+    def mark_persistent_contacts(self, mode=0, n1=0, n2=0, mark=True):
+        self.L.orc_sim_mark_persistent(C.c_void_p(self.h), C.c_int(mode), C.c_uint32(n1), C.c_uint32(n2), C.c_int(int(bool(mark))))
+
+    def num_persistent_contacts(self):
+        self.L.orc_sim_num_persistent.restype = C.c_size_t
+        return int(self.L.orc_sim_num_persistent(C.c_void_p(self.h)))
+
     def set_prescription(self, family, has, flags, coef):
         c = np.ascontiguousarray(coef, np.float32).reshape(15, 4)
         self.L.orc_sim_set_prescription(C.c_void_p(self.h), C.c_uint32(family), C.c_uint32(has), C.c_uint32(flags), _p(c))

@@ -292,3 +292,63 @@ def test_cylindrical_boundaries(pkg, orc):
     n = int(sc.nOwnerClumps)
     r = np.hypot(X[:n, 0] + p.LBFX - cx, X[:n, 1] + p.LBFY - cy)
     assert r.min() > 0.012 - 0.002 and r.max() < 0.42 * float(hi[0] - lo[0]) + 0.002
+
+
+def persistent_scene(pkg):
+    b = pkg.model.packed_bed(1000, seed=21, cd_freq=0, spacing_mult=2.6, init_vz=-0.8)
+    fam = (np.arange(len(b.batches[0].xyz)) % 2).astype(np.uint8)
+    b.batches[0].SetFamily(fam)
+    return b
+
+
+def test_persistent_contacts(pkg, orc):
+    """MarkFamilyPersistentContactEither / MarkPersistentContact / Remove* (DEM/API.h:874-905): marked contacts of the current
+    list stay in every later list whether or not the sweep finds them; lists, history and state stay bit-identical to the
+    oracle, the physics is that of an unmarked twin, and removing the marks returns the twin's list."""
+    ctx, sim, p, sc = pair(pkg, orc, persistent_scene(pkg))
+    twin = orc.make_sim(pkg, p, sc)
+    ctx.step(60), sim.step(60), twin.step(60)
+    a0, b0, t0, *_ = assert_same_contacts(ctx, sim)
+    assert len(a0) > 200
+    ctx.mark_persistent_contacts(ctx.PERSIST_EITHER, 1), sim.mark_persistent_contacts(1, 1)
+    nP = ctx.num_persistent_contacts()
+    assert nP == sim.num_persistent_contacts() and 0 < nP < len(a0)
+    marked = set(zip(a0.tolist(), b0.tolist(), t0.tolist()))
+    grew = False
+    for chunk in range(6):
+        ctx.step(40), sim.step(40), twin.step(40)
+        a, b, t, *_ = assert_same_contacts(ctx, sim)
+        now = set(zip(a.tolist(), b.tolist(), t.tolist()))
+        ta, tb, tt, _ = twin.contacts()
+        plain = set(zip(ta.tolist(), tb.tolist(), tt.tolist()))
+        assert plain <= now and len(now - plain) == len(now) - len(plain)
+        assert (now - plain) <= marked  # what the sweep did not find is there only because it was marked
+        grew = grew or len(now) > len(plain)
+        gs, os_, ts = ctx.download_state(), sim.download_state(), twin.download_state()
+        for k in STATE_KEYS:
+            assert np.array_equal(gs[k], os_[k]) and np.array_equal(gs[k], ts[k]), (chunk, k)
+        for w in range(4):
+            assert np.array_equal(ctx.wildcard(w), sim.wildcard(w)), (chunk, w)
+    assert grew, "no marked contact ever separated: the scenario does not exercise persistence"
+    # every contact marked on top (mode 0), then all marks removed: the next list is the plain detection again
+    ctx.mark_persistent_contacts(), sim.mark_persistent_contacts()
+    assert ctx.num_persistent_contacts() == sim.num_persistent_contacts() >= nP
+    ctx.step(20), sim.step(20), twin.step(20)
+    assert_same_contacts(ctx, sim)
+    ctx.mark_persistent_contacts(mark=False), sim.mark_persistent_contacts(mark=False)
+    assert ctx.num_persistent_contacts() == sim.num_persistent_contacts() == 0
+    ctx.step(1), sim.step(1), twin.step(1)
+    a, b, t, *_ = assert_same_contacts(ctx, sim)
+    ta, tb, tt, _ = twin.contacts()
+    assert np.array_equal(a, ta) and np.array_equal(b, tb) and np.array_equal(t, tt)
+
+
+def test_persistent_contacts_need_history(pkg):
+    b = persistent_scene(pkg)
+    b.UseFrictionlessHertzianModel()
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    ctx.step(5)
+    with pytest.raises(pkg.abi.DemeError, match="history-less"):
+        ctx.mark_persistent_contacts()
