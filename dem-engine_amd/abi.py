@@ -184,7 +184,10 @@ def load_library():
         "deme_compile_family_rules": [_P, C.c_char_p], "deme_change_family": [_P, C.c_uint32, C.c_uint32],
         "deme_mark_persistent_contacts": [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_int],
         "deme_num_persistent_contacts": [_P, C.POINTER(C.c_size_t)],
-        "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)], "deme_inspect_values": [_P, C.c_uint32, _P, C.c_size_t],
+        "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)],
+        "deme_compile_region": [_P, C.c_char_p, C.POINTER(C.c_int)],
+        "deme_inspect_region": [_P, C.c_uint32, C.c_int, C.POINTER(C.c_float)],
+        "deme_upload_volumes": [_P, _P, C.c_size_t], "deme_inspect_values": [_P, C.c_uint32, _P, C.c_size_t],
         "deme_set_record_contacts": [_P, C.c_int],
         "deme_download_contact_records": [_P, _P, _P, _P, _P, C.c_size_t],
         "deme_download_sphere_geometry": [_P, _P, _P, _P, _P, C.c_size_t],
@@ -340,15 +343,25 @@ class Context:
 
     # DEMInspector quantity names (AuxClasses.cpp:94-170)
     INSPECT_CODES = {"clump_max_z": 0, "clump_min_z": 1, "clump_max_absv": 2, "clump_mass": 3, "max_absv": 4,
-                     "clump_kinetic_energy": 5, "absv": 6}
+                     "clump_kinetic_energy": 5, "absv": 6, "clump_volume": 7}
 
-    def inspect(self, quantity):
-        """DEMInspector::GetValue of a named quantity (reduced on the device)."""
+    def compile_region(self, code):
+        """CreateInspector(quantity, region): compiles the region string once, returns the handle inspect(region=) takes."""
+        rid = C.c_int(-1)
+        self._ck(self.lib.deme_compile_region(self.h, code.encode(), C.byref(rid)), "deme_compile_region")
+        return int(rid.value)
+
+    def inspect(self, quantity, region=-1):
+        """DEMInspector::GetValue of a named quantity (reduced on the device), optionally limited to a compiled region."""
         if quantity not in self.INSPECT_CODES:
             raise DemeError(f"{quantity} is not a known query type.")
         out = C.c_float(0)
-        self._ck(self.lib.deme_inspect(self.h, self.INSPECT_CODES[quantity], C.byref(out)), "deme_inspect")
+        self._ck(self.lib.deme_inspect_region(self.h, self.INSPECT_CODES[quantity], int(region), C.byref(out)), "deme_inspect_region")
         return float(out.value)
+
+    def upload_volumes(self, volumes):
+        v = np.ascontiguousarray(volumes, np.float32)
+        self._ck(self.lib.deme_upload_volumes(self.h, _ptr(v), v.size), "deme_upload_volumes")
 
     def inspect_values(self, quantity, n):
         """DEMInspector::GetValues: the unreduced per-sphere / per-owner array (n elements)."""

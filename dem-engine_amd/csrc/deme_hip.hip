@@ -98,6 +98,11 @@ struct deme_ctx {
     hipEvent_t evStepDone = nullptr, evHaloDone = nullptr;
     bool overlapDetect = false;  // the step opened by deme_step_overlap_begin needs a detection first
     hipModule_t rulesMod = nullptr;
+    // inspector region filters: one module per compiled region (id = index)
+    std::vector<hipModule_t> regionMod;
+    std::vector<hipFunction_t> regionFn;
+    DevBuf volumes;  // per mass-property entry: declared clump volume ("clump_volume" inspector)
+    bool haveVolumes = false;
     hipFunction_t rulesFn = nullptr;  // on-the-fly family changes
     bool rulesNeedAcc = false;
     uint32_t nPresc = 0;
@@ -788,13 +793,16 @@ void deme_ctx_destroy(deme_ctx* c) {
     for (hipModule_t m : {c->customMod, c->prescMod, c->rulesMod})
         if (m)
             (void)hipModuleUnload(m);
+    for (hipModule_t m : c->regionMod)
+        if (m)
+            (void)hipModuleUnload(m);
     if (c->haloStream) {
         hipStreamSynchronize(c->haloStream);
         hipEventDestroy(c->evStepDone);
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
-    DevBuf* all[] = {&c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1771,10 +1779,15 @@ struct FMax {
 struct FMin {
     __host__ __device__ float operator()(float a, float b) const { return a < b ? a : b; }
 };
-// fills c->stage with the per-element quantity; returns the element count through n
-int inspect_fill(deme_ctx* c, uint32_t q, float identity, size_t& n) {
-    if (q > DEME_INSPECT_ABSV)
+// fills c->stage with the per-element quantity; returns the element count through n.  region >= 0: elements outside the
+// compiled region (deme_compile_region) get `identity`
+int inspect_fill(deme_ctx* c, uint32_t q, float identity, size_t& n, int region = -1) {
+    if (q > DEME_INSPECT_CLUMP_VOLUME)
         return fail(c, DEME_ERR_INVALID, "unknown inspection quantity %u", q);
+    if (region >= (int)c->regionFn.size())
+        return fail(c, DEME_ERR_INVALID, "unknown inspection region %d", region);
+    if (q == DEME_INSPECT_CLUMP_VOLUME && !c->haveVolumes)
+        return fail(c, DEME_ERR_INVALID, "clump_volume needs the templates' volumes (deme_upload_volumes)");
     const bool perSphere = q <= DEME_INSPECT_CLUMP_MAX_ABSV;
     n = perSphere ? c->nSpheres : c->nOwners;
     if (int rc = ensure(c, c->stage, std::max<size_t>(n, 1) * 4 + 16))
@@ -1786,12 +1799,21 @@ int inspect_fill(deme_ctx* c, uint32_t q, float identity, size_t& n) {
                            c->spheres.as<SphereRec>(), q, identity, c->stage.as<float>());
     else
         hipLaunchKernelGGL(k_inspect_owner, dim3(grid_for(n)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
-                           (uint32_t)c->nOwnerClumps, q, identity, c->stage.as<float>());
+                           (uint32_t)c->nOwnerClumps, q, identity, c->volumes.as<float>(), c->stage.as<float>());
+    if (region >= 0) {
+        DevParams dp = c->dp;
+        const OwnerRec* owners = c->owners.as<OwnerRec>();
+        const SphereRec* spheres = c->spheres.as<SphereRec>();
+        uint32_t nn = (uint32_t)n, ps = perSphere ? 1u : 0u;
+        float* values = c->stage.as<float>();
+        void* args[] = {&dp, &owners, &spheres, &nn, &ps, &identity, &values};
+        HIPCK(hipModuleLaunchKernel(c->regionFn[region], grid_for(n), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+    }
     return DEME_OK;
 }
 }  // namespace
 
-int deme_inspect(deme_ctx* c, uint32_t q, float* out) {
+int deme_inspect_region(deme_ctx* c, uint32_t q, int region, float* out) {
     if (int rc = check_ready(c))
         return rc;
     if (!out || q == DEME_INSPECT_ABSV)
@@ -1800,7 +1822,7 @@ int deme_inspect(deme_ctx* c, uint32_t q, float* out) {
     const bool isMin = q == DEME_INSPECT_CLUMP_MIN_Z;
     const float identity = isMax ? -3.402823466e38f : isMin ? 3.402823466e38f : 0.f;
     size_t n = 0;
-    if (int rc = inspect_fill(c, q, identity, n))
+    if (int rc = inspect_fill(c, q, identity, n, region))
         return rc;
     float* in = c->stage.as<float>();
     float* res = in + n;  // one spare slot behind the values
@@ -1824,6 +1846,59 @@ int deme_inspect(deme_ctx* c, uint32_t q, float* out) {
     }
     HIPCK(hipMemcpyAsync(out, res, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
+    return DEME_OK;
+}
+
+int deme_inspect(deme_ctx* c, uint32_t q, float* out) { return deme_inspect_region(c, q, -1, out); }
+
+int deme_compile_region(deme_ctx* c, const char* code, int* regionId) {
+    if (!c || !regionId)
+        return DEME_ERR_INVALID;
+    const std::string r = code ? code : "";
+    auto word = [&](const std::string& w) {
+        for (size_t pos = r.find(w); pos != std::string::npos; pos = r.find(w, pos + 1)) {
+            const bool l = pos == 0 || !(isalnum((unsigned char)r[pos - 1]) || r[pos - 1] == '_');
+            const size_t e = pos + w.size();
+            const bool rr = e >= r.size() || !(isalnum((unsigned char)r[e]) || r[e] == '_');
+            if (l && rr)
+                return true;
+        }
+        return false;
+    };
+    if (!(word("X") || word("Y") || word("Z")) || !word("return"))  // DEM/AuxClasses.cpp:209-219
+        return fail(c, DEME_ERR_INVALID,
+                    "an inspection region must return a bool that is a result of logical operations involving X, Y and Z");
+    std::string gen;
+    deme_jit::generate_region_source(r, gen);
+    const size_t key = std::hash<std::string>{}(gen);
+    auto it = c->jitCache.find(key);
+    if (it == c->jitCache.end()) {
+        std::vector<char> bin;
+        std::string log;
+        if (deme_jit::compile(gen, bin, log))
+            return fail(c, DEME_ERR_COMPILE, "inspection region failed to compile:\n%.900s", log.c_str());
+        it = c->jitCache.emplace(key, std::move(bin)).first;
+    }
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    HIPCK(hipModuleLoadData(&mod, it->second.data()));
+    HIPCK(hipModuleGetFunction(&fn, mod, "deme_region_filter"));
+    c->regionMod.push_back(mod);
+    c->regionFn.push_back(fn);
+    *regionId = (int)c->regionFn.size() - 1;
+    return DEME_OK;
+}
+
+int deme_upload_volumes(deme_ctx* c, const float* volumes, size_t n) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (!volumes || n != c->nMassProps)
+        return fail(c, DEME_ERR_INVALID, "deme_upload_volumes: expected %u values (one per mass-property entry)", c->nMassProps);
+    if (int rc = ensure(c, c->volumes, std::max<size_t>(n, 1) * 4))
+        return rc;
+    HIPCK(hipMemcpyAsync(c->volumes.p, volumes, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    c->haveVolumes = true;
     return DEME_OK;
 }
 

@@ -336,6 +336,46 @@ extern "C" __global__ __launch_bounds__(256) void deme_family_changes(const deme
     out = o.str();
 }
 
+// Inspector region filter (DEM/AuxClasses.cpp:205-223 `_inRegionPolicy_` in DEMSphereQueryKernels.cu:41-47 /
+// DEMOwnerQueryKernels.cu:47-53): the user's statement block returns a bool from float X, Y, Z (sphere centre or owner CoM,
+// domain offset included).  It runs as the body of a lambda, so its own `return` statements work unedited; an element
+// outside the region gets the reduction's identity.
+inline void generate_region_source(const std::string& code, std::string& out) {
+    std::ostringstream o;
+    o << "#include \"deme_device.h\"\n" << kVocabulary << R"DEMEREG(
+extern "C" __global__ __launch_bounds__(256) void deme_region_filter(const deme_dev::DevParams p, const deme_dev::OwnerRec* owners,
+                                                                     const deme_dev::SphereRec* spheres, uint32_t n,
+                                                                     uint32_t perSphere, float identity, float* values) {
+    using namespace deme_dev;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    uint32_t myOwner = i;
+    double rx = 0., ry = 0., rz = 0.;
+    if (perSphere) {
+        const SphereRec sr = spheres[i];
+        myOwner = sr.owner;
+        const OwnerRec q = load_owner(owners, myOwner);
+        const float4 c = p.comp[sr.comp];
+        const f3 rel = rot_apply(rot_coeffs(q.qw, q.qx, q.qy, q.qz), mk3(c.x, c.y, c.z));
+        rx = (double)rel.x, ry = (double)rel.y, rz = (double)rel.z;
+    }
+    const OwnerRec r = load_owner(owners, myOwner);
+    const d3 P = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);
+    const float X = perSphere ? (float)(P.x + rx + (double)p.LBFX) : (float)(P.x + (double)p.LBFX);
+    const float Y = perSphere ? (float)(P.y + ry + (double)p.LBFY) : (float)(P.y + (double)p.LBFY);
+    const float Z = perSphere ? (float)(P.z + rz + (double)p.LBFZ) : (float)(P.z + (double)p.LBFZ);
+    (void)X, (void)Y, (void)Z;
+    const bool isInRegion = [&]() -> bool {
+)DEMEREG" << code << R"DEMEREG(
+    }();
+    if (!isInRegion)
+        values[i] = identity;
+}
+)DEMEREG";
+    out = o.str();
+}
+
 // hipRTC: source -> gfx950 code object.  Needs no GPU (used by the CPU test through deme_jit_probe).
 inline int compile(const std::string& src, std::vector<char>& code, std::string& log) {
     hiprtcProgram prog;

@@ -1207,12 +1207,13 @@ __global__ __launch_bounds__(256) void k_inspect_sphere(const DevParams p, const
 }
 
 __global__ __launch_bounds__(256) void k_inspect_owner(const DevParams p, const OwnerRec* __restrict__ owners, uint32_t nClumps,
-                                                      uint32_t quantity, float identity, float* __restrict__ out) {
+                                                      uint32_t quantity, float identity, const float* __restrict__ volumes,
+                                                      float* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.nOwners)
         return;
     const OwnerRec o = load_owner(owners, i);
-    const bool clumpOnly = quantity == 3u || quantity == 5u;  // OWNER_T_CLUMP quantities
+    const bool clumpOnly = quantity == 3u || quantity == 5u || quantity == 7u;  // OWNER_T_CLUMP quantities
     if ((p.familyFlags[o.family] & 2u) || (clumpOnly && i >= nClumps)) {
         out[i] = identity;
         return;
@@ -1221,6 +1222,8 @@ __global__ __launch_bounds__(256) void k_inspect_owner(const DevParams p, const 
     float q;
     if (quantity == 3u) {
         q = mp.x;
+    } else if (quantity == 7u) {  // INSP_CODE_CLUMP_APPROX_VOL: the template's volume as the user declared it
+        q = volumes[o.inertiaOff];
     } else if (quantity == 5u) {
         double vx = o.vx, vy = o.vy, vz = o.vz;
         double ke = 0.5 * mp.x * (vx * vx + vy * vy + vz * vz);

@@ -72,12 +72,14 @@ struct DEMMaterial {
 struct DEMClumpTemplate {
     float mass = 0;
     float3 MOI{0, 0, 0};
+    float volume = 0;  // SetVolume: read by the "clump_volume" inspector only
     std::vector<float> radii;
     std::vector<float3> relPos;
     std::vector<std::shared_ptr<DEMMaterial>> materials;
     unsigned int nComp = 0, mark = 0;
     std::string m_name;  // AssignName (Structs.h:697); default "%04d" of the load order (APIPublic.cpp:1751-1755)
     void AssignName(const std::string& n) { m_name = n; }
+    void SetVolume(float v) { volume = v; }
     // x,y,z,r rows, '#' comments (data/clumps/*.csv in the reference)
     void ReadComponentFromFile(const std::string& file) {
         std::ifstream in(file);
@@ -99,6 +101,7 @@ struct DEMClumpTemplate {
     }
     void Scale(float s) {  // Structs.h: lengths*s, mass*s^3, MOI*s^5
         mass *= s * s * s;
+        volume *= s * s * s;
         const float s5 = s * s * s * s * s;
         MOI = {MOI.x * s5, MOI.y * s5, MOI.z * s5};
         for (auto& r : radii)
@@ -662,6 +665,8 @@ class DEMSolver {
 
     // ---- inspectors and trackers (API.h:652-679, AuxClasses.h:26-420)
     std::shared_ptr<class DEMInspector> CreateInspector(const std::string& quantity = "clump_max_z");
+    /// region: statements returning a bool from X, Y, Z, e.g. "return (X * X + Y * Y <= 0.25 * 0.25) && (Z <= -0.3);"
+    std::shared_ptr<class DEMInspector> CreateInspector(const std::string& quantity, const std::string& region);
     std::shared_ptr<class DEMTracker> Track(const std::shared_ptr<DEMClumpBatch>& batch);
     std::shared_ptr<class DEMTracker> Track(const std::shared_ptr<DEMExternObj>& obj);
     std::shared_ptr<class DEMTracker> Track(const std::shared_ptr<DEMMeshConnected>& mesh);
@@ -1223,7 +1228,7 @@ class DEMSolver {
         // templates by component count (stable), marks renumbered
         std::vector<std::shared_ptr<DEMClumpTemplate>> ts = m_templates;
         std::stable_sort(ts.begin(), ts.end(), [](const auto& a, const auto& b) { return a->nComp < b->nComp; });
-        std::vector<float> Radii, rx, ry, rz, mass, moix, moiy, moiz;
+        std::vector<float> Radii, rx, ry, rz, mass, moix, moiy, moiz, volumes;
         std::vector<unsigned> prefix(ts.size());
         float smallest = 1e30f;
         for (size_t i = 0; i < ts.size(); i++) {
@@ -1235,6 +1240,7 @@ class DEMSolver {
                 smallest = std::min(smallest, ts[i]->radii[k]);
             }
             mass.push_back(ts[i]->mass), moix.push_back(ts[i]->MOI.x), moiy.push_back(ts[i]->MOI.y), moiz.push_back(ts[i]->MOI.z);
+            volumes.push_back(ts[i]->volume);
         }
         if (Radii.size() > 65535)
             throw std::runtime_error("more than 65535 clump components");
@@ -1409,6 +1415,9 @@ class DEMSolver {
         s.triMaterialOffset = triMat.data();
         check(deme_set_params(m_ctx, &p));
         check(deme_upload_scene(m_ctx, &s));
+        volumes.resize(mass.size(), 0.f);  // analytical / mesh owners: unused, like the reference (dT.cpp:607-618)
+        if (std::any_of(volumes.begin(), volumes.end(), [](float v) { return v != 0.f; }))
+            check(deme_upload_volumes(m_ctx, volumes.data(), volumes.size()));
         if (m_force_model->type == FORCE_MODEL::CUSTOM) {
             // _materialDefs_ for properties beyond the five built-in ones (APIPrivate.cpp:1877-2026)
             std::set<std::string> extra;
@@ -1491,25 +1500,30 @@ class DEMSolver {
 
 
 /// A named reduction over the spheres / owners, evaluated on the device (deme_inspect).  Quantities: clump_max_z,
-/// clump_min_z, clump_max_absv, clump_mass, max_absv, clump_kinetic_energy, absv (AuxClasses.cpp:94-170).
+/// clump_min_z, clump_max_absv, clump_mass, clump_volume, max_absv, clump_kinetic_energy, absv (AuxClasses.cpp:94-170);
+/// optionally limited to a region given as code (AuxClasses.cpp:205-223), compiled at the first GetValue like the
+/// reference's lazy Initialize.
 class DEMInspector {
   public:
-    DEMInspector(DEMSolver* sys, const std::string& quantity) : m_sys(sys) {
+    DEMInspector(DEMSolver* sys, const std::string& quantity, const std::string& region = "") : m_sys(sys), m_region_code(region) {
         static const std::map<std::string, uint32_t> codes = {{"clump_max_z", DEME_INSPECT_CLUMP_MAX_Z},
                                                               {"clump_min_z", DEME_INSPECT_CLUMP_MIN_Z},
                                                               {"clump_max_absv", DEME_INSPECT_CLUMP_MAX_ABSV},
                                                               {"clump_mass", DEME_INSPECT_CLUMP_MASS},
                                                               {"max_absv", DEME_INSPECT_MAX_ABSV},
                                                               {"clump_kinetic_energy", DEME_INSPECT_CLUMP_KINETIC_ENERGY},
-                                                              {"absv", DEME_INSPECT_ABSV}};
+                                                              {"absv", DEME_INSPECT_ABSV},
+                                                              {"clump_volume", DEME_INSPECT_CLUMP_VOLUME}};
         auto it = codes.find(quantity);
         if (it == codes.end())
             throw std::runtime_error(quantity + " is not a known query type.");
         m_code = it->second;
     }
     float GetValue() {
+        if (m_region < 0 && m_region_code.find_first_not_of(" \t\n") != std::string::npos)
+            m_sys->check(deme_compile_region(m_sys->m_ctx, m_region_code.c_str(), &m_region));
         float v = 0;
-        m_sys->check(deme_inspect(m_sys->m_ctx, m_code, &v));
+        m_sys->check(deme_inspect_region(m_sys->m_ctx, m_code, m_region, &v));
         return v;
     }
     std::vector<float> GetValues() {
@@ -1521,6 +1535,8 @@ class DEMInspector {
   private:
     DEMSolver* m_sys;
     uint32_t m_code = 0;
+    std::string m_region_code;
+    int m_region = -1;
 };
 
 /// Access to the state of the owners of one loaded object (a batch of clumps, an analytical object, a mesh):
@@ -1576,6 +1592,9 @@ class DEMTracker {
 
 inline std::shared_ptr<DEMInspector> DEMSolver::CreateInspector(const std::string& quantity) {
     return std::make_shared<DEMInspector>(this, quantity);
+}
+inline std::shared_ptr<DEMInspector> DEMSolver::CreateInspector(const std::string& quantity, const std::string& region) {
+    return std::make_shared<DEMInspector>(this, quantity, region);
 }
 inline std::shared_ptr<DEMTracker> DEMSolver::Track(const std::shared_ptr<DEMClumpBatch>& batch) {
     for (size_t i = 0; i < m_batches.size(); i++)

@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     const float3 MOI = make_float3(2.928f, 2.6029f, 3.9908f) * 2.6e3f;
     auto tmpl = DEMSim.LoadClumpType(mass, MOI, std::vector<float>{0.8f, 0.8f, 0.8f},
                                      std::vector<float3>{{0.5f, 0.341729f, 0.f}, {0.f, -0.658271f, 0.f}, {-0.5f, 0.341729f, 0.f}}, mat);
+    tmpl->SetVolume(3.f * 4.f / 3.f * 3.14159265f * 0.8f * 0.8f * 0.8f);  // declared (overlaps ignored), scaled with the template
     tmpl->Scale(r);
 
     std::mt19937 rng(12345);  // seeded: the reference demos use std::random_device
@@ -114,6 +115,23 @@ int main(int argc, char** argv) {
             dmax = std::max({dmax, (double)std::fabs(a.x - b.x), (double)std::fabs(a.y - b.y), (double)std::fabs(a.z - b.z)});
         }
         std::printf("RESTART contacts=%zu/%zu max_pos_diff=%.3e\n", DEMSim.GetNumContacts(), Again.GetNumContacts(), dmax);
+    }
+    {   // region-limited inspectors (CreateInspector(quantity, region)) and the declared-volume quantity
+        auto lower = DEMSim.CreateInspector("clump_mass", "return Z < 0.05;");
+        auto upper = DEMSim.CreateInspector("clump_mass", "return Z >= 0.05;");
+        auto column = DEMSim.CreateInspector("clump_max_z", "return (X - 0.1f) * (X - 0.1f) + (Y - 0.1f) * (Y - 0.1f) <= 0.03f * 0.03f;");
+        auto volume = DEMSim.CreateInspector("clump_volume");
+        std::printf("REGION lower=%.6e upper=%.6e total=%.6e column_max_z=%.6f bed_max_z=%.6f volume=%.6e\n", lower->GetValue(),
+                    upper->GetValue(), total_mass_finder->GetValue(), column->GetValue(), max_z_finder->GetValue(), volume->GetValue());
+    }
+    {   // persistent contacts (cf. DEMdemo_SingleSphereCollide.cpp:165): every current contact stays in the list from now on
+        const size_t marked = DEMSim.GetNumContacts();
+        DEMSim.MarkPersistentContact();
+        DEMSim.DoDynamicsThenSync(300 * 5e-6);
+        const size_t kept = DEMSim.GetNumContacts();
+        DEMSim.RemovePersistentContact();
+        DEMSim.DoDynamicsThenSync(20 * 5e-6);
+        std::printf("PERSIST marked=%zu later=%zu unmarked=%zu\n", marked, kept, DEMSim.GetNumContacts());
     }
     std::printf("DEMO_OK clumps=%zu\n", DEMSim.GetNumClumps());
     return 0;

@@ -66,16 +66,22 @@ class ClumpTemplate:
         self.relpos = np.asarray(relpos, np.float32).reshape(-1, 3)
         self.materials = list(materials)
         self.mark = None
+        self.volume = 0.0  # SetVolume (DEMClumpTemplate::volume, read by the "clump_volume" inspector)
         self.name = None  # AssignName (Structs.h:697); default "%04d" of the load order (APIPublic.cpp:1751-1755)
 
     def AssignName(self, name):
         self.name = str(name)
         return self
 
+    def SetVolume(self, v):
+        self.volume = float(v)
+        return self
+
     def Scale(self, s):
         """DEMClumpTemplate::Scale (DEM/Structs.h): lengths*s, mass*s^3, MOI*s^5."""
         s = float(s)
         self.mass *= s ** 3
+        self.volume *= s ** 3
         self.moi = tuple(m * s ** 5 for m in self.moi)
         self.radii = (self.radii * np.float32(s)).astype(np.float32)
         self.relpos = (self.relpos * np.float32(s)).astype(np.float32)
@@ -401,6 +407,16 @@ class SceneBuilder:
             ctx.compile_prescriptions(*self.prescription_cases())
         if getattr(self, "_family_rules", None):
             ctx.compile_family_rules(self.family_change_rules())
+        vols = self.volumes()
+        if vols.any():
+            ctx.upload_volumes(vols)
+
+    def volumes(self):
+        """declared volume per mass-property entry (clump templates first; other owner kinds 0)"""
+        v = np.zeros(int(self.counts["nMassProps"]), np.float32)
+        tv = np.asarray(getattr(self, "template_volumes", []), np.float32)
+        v[:len(tv)] = tv
+        return v
 
     def UpdateClumps(self, ctx, time_elapsed):
         """DEMSolver::UpdateClumps (API.h:1267): clumps added with AddClumps after Initialize() join the running simulation.
@@ -719,6 +735,7 @@ class SceneBuilder:
             o += n
         n_tmpl = len(tmpl_sorted)
         mass = [t.mass for t in tmpl_sorted]
+        self.template_volumes = [t.volume for t in tmpl_sorted]  # analytical / mesh owners: 0, like the reference (dT.cpp:607-618)
         moi = [t.moi for t in tmpl_sorted]
         obj = {k: [] for k in ("type", "owner", "normal", "mat", "px", "py", "pz", "rx", "ry", "rz", "s1", "s2", "s3",
                                "mass")}

@@ -280,9 +280,19 @@ int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t n
 #define DEME_INSPECT_MAX_ABSV 4             /* "max_absv": max owner speed, all owner kinds */
 #define DEME_INSPECT_CLUMP_KINETIC_ENERGY 5 /* "clump_kinetic_energy" */
 #define DEME_INSPECT_ABSV 6                 /* "absv": per-owner values only (deme_inspect_values) */
+#define DEME_INSPECT_CLUMP_VOLUME 7         /* "clump_volume": sum of the declared template volumes (deme_upload_volumes) */
 int deme_inspect(deme_ctx* ctx, uint32_t quantity, float* out);
 /* unreduced values (DEMInspector::GetValues): one per sphere (quantities 0-2) or per owner (3-6) */
 int deme_inspect_values(deme_ctx* ctx, uint32_t quantity, float* out, size_t cap);
+/* Region-limited inspection (reference: DEMSolver::CreateInspector(quantity, region) DEM/API.h:675, AuxClasses.cpp:205-223).
+ * `code` is the reference's region string: a C++ statement block that returns a bool from float X, Y, Z (sphere centre for
+ * the per-sphere quantities, owner CoM otherwise), e.g. "return (X * X + Y * Y <= 0.25 * 0.25) && (Z <= -0.3);".  It is
+ * compiled once at run time; elements outside the region do not take part in the reduction (an empty region yields the
+ * reduction's identity: -FLT_MAX / FLT_MAX / 0).  deme_inspect(q) == deme_inspect_region(q, -1). */
+int deme_compile_region(deme_ctx* ctx, const char* code, int* regionId);
+int deme_inspect_region(deme_ctx* ctx, uint32_t quantity, int regionId, float* out);
+/* Declared clump volumes, one per mass-property entry (reference: DEMClumpTemplate::volume, APIPrivate.cpp:730, 1849-1858). */
+int deme_upload_volumes(deme_ctx* ctx, const float* volumes, size_t n);
 
 /* timing of the kernels this library launched (HIP events on the context stream);
  * names: "calc_forces", "integrate", "detect"; returns avg ms per launch since last reset */

@@ -654,6 +654,7 @@ struct Sim {
     // 605-802 adds every marked contact the detection did not find back into the new list): kept here as the sorted set of
     // marked (A, class, B) keys, which is what the flag array travelling with the list amounts to
     std::vector<Key> persist;
+    std::vector<float> volume;  // per mass-property entry ("clump_volume" inspector)
 };
 
 template <typename T>
@@ -1713,7 +1714,9 @@ int orc_sim_seed_contacts(void* h, const uint32_t* idA, const uint32_t* idB, con
     s.seeded = true;
     return DEME_OK;
 }
-size_t orc_sim_inspect(void* h, uint32_t q, float* reduced, float* values) {
+// region (test form of the reference's region string, AuxClasses.cpp:205-223): axis-aligned box lo <= (X, Y, Z) <= hi on
+// the float coordinates the query kernels form (DEMSphereQueryKernels.cu:41-47, DEMOwnerQueryKernels.cu:47-53); null = all
+size_t orc_sim_inspect_region(void* h, uint32_t q, const float* lo, const float* hi, float* reduced, float* values) {
     Sim& s = *(Sim*)h;
     const bool perSphere = q <= DEME_INSPECT_CLUMP_MAX_ABSV;
     const size_t n = perSphere ? s.nSpheres : s.nOwners;
@@ -1725,7 +1728,7 @@ size_t orc_sim_inspect(void* h, uint32_t q, float* reduced, float* values) {
     for (size_t i = 0; i < n; i++) {
         const uint32_t o = perSphere ? s.ownerOfSphere[i] : (uint32_t)i;
         float v;
-        const bool clumpOnly = q == DEME_INSPECT_CLUMP_MASS || q == DEME_INSPECT_CLUMP_KINETIC_ENERGY;
+        const bool clumpOnly = q == DEME_INSPECT_CLUMP_MASS || q == DEME_INSPECT_CLUMP_KINETIC_ENERGY || q == DEME_INSPECT_CLUMP_VOLUME;
         if ((s.famFlags[s.familyID[o]] & DEME_FAMILY_GHOST) || (clumpOnly && o >= s.nOwnerClumps)) {
             v = identity;
         } else if (perSphere) {
@@ -1748,6 +1751,8 @@ size_t orc_sim_inspect(void* h, uint32_t q, float* reduced, float* values) {
             const uint16_t io = s.inertiaOff[o];
             if (q == DEME_INSPECT_CLUMP_MASS) {
                 v = s.mass[io];
+            } else if (q == DEME_INSPECT_CLUMP_VOLUME) {
+                v = io < s.volume.size() ? s.volume[io] : 0.f;
             } else if (q == DEME_INSPECT_CLUMP_KINETIC_ENERGY) {
                 double vx = s.vX[o], vy = s.vY[o], vz = s.vZ[o];
                 double ke = 0.5 * s.mass[io] * (vx * vx + vy * vy + vz * vz);
@@ -1759,6 +1764,20 @@ size_t orc_sim_inspect(void* h, uint32_t q, float* reduced, float* values) {
                 v = (float)sqrt(vx * vx + vy * vy + vz * vz);
             }
         }
+        if (lo && hi) {
+            double oX, oY, oZ, rx = 0., ry = 0., rz = 0.;
+            decode_pos(s.voxelID[o], s.locX[o], s.locY[o], s.locZ[o], s.p.nvXp2, s.p.nvYp2, s.p.voxelSize, s.p.l, oX, oY, oZ);
+            if (perSphere) {
+                const uint16_t c = s.compOff[i];
+                const V3f rel = rotate_f(rot_coeffs(s.oriQw[o], s.oriQx[o], s.oriQy[o], s.oriQz[o]), {s.relX[c], s.relY[c], s.relZ[c]});
+                rx = (double)rel.x, ry = (double)rel.y, rz = (double)rel.z;
+            }
+            const float X = perSphere ? (float)(oX + rx + (double)s.p.LBFX) : (float)(oX + (double)s.p.LBFX);
+            const float Y = perSphere ? (float)(oY + ry + (double)s.p.LBFY) : (float)(oY + (double)s.p.LBFY);
+            const float Z = perSphere ? (float)(oZ + rz + (double)s.p.LBFZ) : (float)(oZ + (double)s.p.LBFZ);
+            if (!(X >= lo[0] && X <= hi[0] && Y >= lo[1] && Y <= hi[1] && Z >= lo[2] && Z <= hi[2]))
+                v = identity;
+        }
         if (values)
             values[i] = v;
         sum += v;
@@ -1769,6 +1788,10 @@ size_t orc_sim_inspect(void* h, uint32_t q, float* reduced, float* values) {
         *reduced = (isMax || isMin) ? best : (float)sum;
     return n;
 }
+size_t orc_sim_inspect(void* h, uint32_t q, float* reduced, float* values) {
+    return orc_sim_inspect_region(h, q, nullptr, nullptr, reduced, values);
+}
+void orc_sim_set_volumes(void* h, const float* v, size_t n) { ((Sim*)h)->volume.assign(v, v + n); }
 void orc_sim_get_state(void* h, DemeOwnerState* st) {
     Sim* s = (Sim*)h;
     auto cp = [](auto& v, auto* dst) {

@@ -51,7 +51,7 @@ def lib():
 
 
 INSPECT_CODES = {"clump_max_z": 0, "clump_min_z": 1, "clump_max_absv": 2, "clump_mass": 3, "max_absv": 4,
-                 "clump_kinetic_energy": 5, "absv": 6}
+                 "clump_kinetic_energy": 5, "absv": 6, "clump_volume": 7}
 
 
 def ref_available():
@@ -295,14 +295,23 @@ class OracleSim:
         rc = self.L.orc_sim_seed_contacts(C.c_void_p(self.h), _p(a), _p(b), _p(t), _p(w), C.c_size_t(len(a)))
         assert rc == 0, "duplicate contact pair in the seed list"
 
-    def inspect(self, quantity, values=False):
+    def inspect(self, quantity, values=False, box=None):
+        """box: ((xlo, ylo, zlo), (xhi, yhi, zhi)) region in the test form of the reference's region string"""
         q = INSPECT_CODES[quantity] if isinstance(quantity, str) else int(quantity)
         n = self.n_spheres if q <= 2 else self.n_owners
         red = C.c_float(0)
         vals = np.zeros(n, np.float32) if values else None
-        self.L.orc_sim_inspect.restype = C.c_size_t
-        self.L.orc_sim_inspect(C.c_void_p(self.h), C.c_uint32(q), C.byref(red), None if vals is None else _p(vals))
+        lo = hi = None
+        if box is not None:
+            lo, hi = (np.ascontiguousarray(b, np.float32) for b in box)
+        self.L.orc_sim_inspect_region.restype = C.c_size_t
+        self.L.orc_sim_inspect_region(C.c_void_p(self.h), C.c_uint32(q), None if lo is None else _p(lo), None if hi is None else _p(hi),
+                                      C.byref(red), None if vals is None else _p(vals))
         return vals if values else float(red.value)
+
+    def set_volumes(self, volumes):
+        v = np.ascontiguousarray(volumes, np.float32)
+        self.L.orc_sim_set_volumes(C.c_void_p(self.h), _p(v), C.c_size_t(v.size))
 
     def bin_incidence(self):
         n = int(self.counts().nBinSphereTouches)

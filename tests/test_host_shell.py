@@ -45,6 +45,17 @@ def test_demo_runs_and_settles(tmp_path):
     vals = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in ins.split()[1:]}
     assert abs(vals["mass"] - 1000 * 2.6e3 * 5.5886717 * 0.005 ** 3) < 1e-6 * vals["mass"]
     assert vals["max_z"] > z[-1] and vals["max_z"] < 0.4 and vals["ke"] >= 0.0 and 0.0 < vals["tracked0_z"] < 0.4
+    # region-limited inspectors: the two half spaces partition the bed's mass; a vertical column tops out below the bed's top;
+    # the declared template volume is summed per clump
+    reg = [l for l in out.stdout.splitlines() if l.startswith("REGION")][0]
+    rv = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in reg.split()[1:]}
+    assert rv["lower"] > 0 and rv["upper"] > 0 and abs(rv["lower"] + rv["upper"] - rv["total"]) < 1e-5 * rv["total"]
+    assert 0.0 < rv["column_max_z"] <= rv["bed_max_z"]
+    assert abs(rv["volume"] - 1000 * 4 * np.pi * 0.8 ** 3 * 0.005 ** 3) < 1e-5 * rv["volume"]
+    # persistent contacts: everything marked stays listed; unmarking returns to the plain detection
+    per = [l for l in out.stdout.splitlines() if l.startswith("PERSIST")][0]
+    pv = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in per.split()[1:]}
+    assert pv["later"] >= pv["marked"] > 10 and pv["unmarked"] <= pv["later"]
     # the prescribed lid (family 20, "-(0.05f + 2.0f*t)"): z(t) = 0.30 - 0.05 t - t^2, v(T) as of the last step
     lid = [l for l in out.stdout.splitlines() if l.startswith("LID")][0]
     lz, lv = float(lid.split("z=")[1].split()[0]), float(lid.split("vz=")[1])

@@ -6,8 +6,11 @@ import pytest
 QUANTITIES = ("clump_max_z", "clump_min_z", "clump_max_absv", "clump_mass", "max_absv", "clump_kinetic_energy")
 
 
-def _bed(pkg, n=1200):
+def _bed(pkg, n=1200, volumes=False):
     b = pkg.model.packed_bed(n, seed=21, cd_freq=0, spacing_mult=2.4, init_vz=-0.5, aspect=(1.0, 1.0, 0.6))
+    if volumes:  # SetVolume is a template declaration (pre-Initialize), like the reference's
+        for t in b.templates:
+            t.SetVolume(4.0 / 3.0 * np.pi * float((t.radii.astype(np.float64) ** 3).sum()))
     p, sc = b.Initialize()
     return b, p, sc
 
@@ -60,3 +63,75 @@ def test_gpu_inspectors_match_oracle(pkg, orc):
         assert np.array_equal(ctx.inspect_values(name, n), sim.inspect(name, values=True)), name
     with pytest.raises(pkg.abi.DemeError):
         ctx.inspect("no_such_quantity")
+
+
+def _f(x):
+    """float literal that reads back as exactly this fp32 value"""
+    return f"{float(np.float32(x)):.9g}f"
+
+
+def _box_code(lo, hi):
+    terms = [f"({a} >= {_f(l)}) && ({a} <= {_f(h)})" for a, l, h in zip("XYZ", lo, hi)]
+    return "bool inside = " + " && ".join(terms) + ";\nreturn inside;"
+
+
+def test_oracle_region_and_volume(pkg, orc):
+    b, p, sc = _bed(pkg, 400)
+    sim = orc.make_sim(pkg, p, sc)
+    n = int(sc.nOwnerClumps)
+    st = sim.download_state()
+    X = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    X = (X + np.array([p.LBFX, p.LBFY, p.LBFZ])).astype(np.float32)[:n]
+    lo, hi = np.percentile(X, 25, axis=0).astype(np.float32), np.percentile(X, 80, axis=0).astype(np.float32)
+    inside = ((X >= lo) & (X <= hi)).all(1)
+    m = b.arrays["MassProperties"][b.arrays["inertiaPropOffsets"][:n]].astype(np.float64)
+    assert 0 < inside.sum() < n
+    assert abs(sim.inspect("clump_mass", box=(lo, hi)) - m[inside].sum()) < 1e-6 * m.sum()
+    vols = np.arange(1, int(sc.nMassProps) + 1, dtype=np.float32) * 1e-7
+    sim.set_volumes(vols)
+    v = vols[b.arrays["inertiaPropOffsets"][:n]].astype(np.float64)
+    assert abs(sim.inspect("clump_volume") - v.sum()) < 1e-6 * v.sum()
+    assert abs(sim.inspect("clump_volume", box=(lo, hi)) - v[inside].sum()) < 1e-6 * v.sum()
+    far = (np.full(3, 1e3, np.float32), np.full(3, 2e3, np.float32))
+    assert sim.inspect("clump_mass", box=far) == 0.0 and sim.inspect("clump_max_z", box=far) < -3e38
+
+
+@pytest.mark.gpu
+def test_gpu_region_inspectors_match_oracle(pkg, orc):
+    """CreateInspector(quantity, region): the region string is compiled at run time; per-element membership is the same fp32
+    comparison as the oracle's box, so max / min agree exactly and the sums to fp32 summation order."""
+    b, p, sc = _bed(pkg, volumes=True)
+    assert b.volumes().any()
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    b.compile_into(ctx)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.set_volumes(b.volumes())
+    ctx.step(150)
+    st = ctx.download_state()
+    sim.upload_state({k: v for k, v in st.items() if k in
+                      ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY",
+                       "omgBarZ")})
+    n = int(sc.nOwnerClumps)
+    X = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    X = (X + np.array([p.LBFX, p.LBFY, p.LBFZ]))[:n]
+    lo, hi = np.percentile(X, 20, axis=0).astype(np.float32), np.percentile(X, 75, axis=0).astype(np.float32)
+    rid = ctx.compile_region(_box_code(lo, hi))
+    assert rid == 0 and ctx.compile_region("return Z > " + _f(hi[2]) + ";") == 1
+    whole = {}
+    for name in QUANTITIES + ("clump_volume",):
+        g, o, whole[name] = ctx.inspect(name, region=rid), sim.inspect(name, box=(lo, hi)), ctx.inspect(name)
+        if name in ("clump_mass", "clump_kinetic_energy", "clump_volume"):
+            assert abs(g - o) <= 2e-5 * abs(o) and 0 < g < whole[name], name
+        else:
+            assert g == o, name
+    assert ctx.inspect("clump_max_z", region=rid) < whole["clump_max_z"]
+    top = ctx.inspect("clump_mass", region=1)
+    big = (np.full(3, -1e3, np.float32), np.array([1e3, 1e3, hi[2]], np.float32))
+    assert abs(top + sim.inspect("clump_mass", box=big) - whole["clump_mass"]) <= 4e-5 * whole["clump_mass"]
+    with pytest.raises(pkg.abi.DemeError, match="X, Y and Z"):
+        ctx.compile_region("return true;")
+    with pytest.raises(pkg.abi.DemeError, match="compile"):
+        ctx.compile_region("return X > nonsense_symbol;")
+    with pytest.raises(pkg.abi.DemeError, match="region"):
+        ctx.inspect("clump_mass", region=7)
