@@ -254,6 +254,9 @@ def main():
                     help="BASELINE configs[4] flavour: polydisperse spheres + a user cohesion model compiled at run time")
     ap.add_argument("--bin-multiple", type=float, default=4.0,
                     help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
+    ap.add_argument("--adaptive", default="off", choices=["off", "bin", "freq", "both"],
+                    help="let the engine tune the bin size / the update frequency on device timers during the pre-settling and "
+                         "warm-up (the reference's default mode); frozen before the timed region.  Default: off (fixed K and bin size)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: order the ghost exchange on the compute stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -312,6 +315,9 @@ def main():
     ctx.set_params(p)
     ctx.upload_scene(sc)
     b.compile_into(ctx)  # user force model / prescriptions, if the scene has any
+    if args.adaptive != "off":
+        ctx.set_adaptive(bin_size=args.adaptive in ("bin", "both"), update_freq=args.adaptive in ("freq", "both"),
+                         bin_observe=5, max_update_freq=200, freq_observe=3)
     if world > 1:
         halo = Halo(pkg, ctx, part, rank, world, torch, dist, via_host=via_host, overlap=not args.no_overlap)
 
@@ -344,6 +350,13 @@ def main():
         last_nc = nc
     args.presettle = done
     run(args.warmup)
+    adaptive_state = None
+    if args.adaptive != "off":  # what the controllers settled on; frozen for the timed region
+        adaptive_state = ctx.adaptive_state()
+        ctx.set_adaptive()
+        args.cd_freq = adaptive_state[1]
+        if rank == 0 and args.verbose:
+            print(f"[adaptive] bin size {adaptive_state[0]:.6g} K {adaptive_state[1]} changes {adaptive_state[2:]}", file=sys.stderr)
     # every 8th launch of the force / integration kernels is bracketed with HIP events (the detection always is: its timer
     # only ticks once per K steps); timing every launch costs 4.7 % of the step in dispatch gaps
     ctx.set_timing(0 if os.environ.get("DEME_BENCH_NO_KERNEL_TIMING") else 8)
@@ -385,6 +398,9 @@ def main():
                    "force_model": ("user fragment via hipRTC: frictionless Hertz + cohesion, 1 wildcard" if args.config5
                                    else "Hertzian (history, 4 wildcards)"), "integrator": "extended Taylor", "h": p.h,
                    "parallelism": par,
+                   "adaptive": (None if adaptive_state is None else
+                                {"mode": args.adaptive, "bin_size": adaptive_state[0], "cd_every": adaptive_state[1],
+                                 "bin_size_changes": adaptive_state[2], "update_freq_changes": adaptive_state[3]}),
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
         "roofline": {"kernel": "deme_custom_forces_ss (hipRTC)" if args.config5 else "k_calc_forces<0, 0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

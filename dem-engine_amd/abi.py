@@ -95,6 +95,13 @@ class DemeCounts(C.Structure):
                 ("maxSpheresInBin", C.c_uint32), ("lastStatus", C.c_uint32)]
 
 
+class DemeAdaptive(C.Structure):
+    """include/deme_hip.h DemeAdaptive; the defaults are the reference's (DEM/Structs.h:204-216)"""
+    _fields_ = [("autoBinSize", C.c_uint32), ("binObserveSteps", C.c_uint32), ("binMaxRate", C.c_float), ("binAcc", C.c_float),
+                ("binUpperSafety", C.c_float), ("binLowerSafety", C.c_float), ("autoUpdateFreq", C.c_uint32),
+                ("maxUpdateFreq", C.c_uint32), ("freqObserveDetections", C.c_uint32)]
+
+
 def make_scene_struct(arrays, counts):
     """arrays: dict name -> numpy array (kept alive by the caller); counts: dict of n* fields."""
     sc = DemeScene()
@@ -182,6 +189,8 @@ def load_library():
         "deme_halo_unpack_async": [_P, _P, C.c_uint32, _P], "deme_halo_sync": [_P],
         "deme_step_overlap_begin": [_P, C.POINTER(C.c_int)], "deme_step_overlap_end": [_P],
         "deme_compile_family_rules": [_P, C.c_char_p], "deme_change_family": [_P, C.c_uint32, C.c_uint32],
+        "deme_set_adaptive": [_P, C.POINTER(DemeAdaptive)],
+        "deme_get_adaptive_state": [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "deme_mark_persistent_contacts": [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_int],
         "deme_num_persistent_contacts": [_P, C.POINTER(C.c_size_t)],
         "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)],
@@ -398,6 +407,19 @@ class Context:
 
     def change_family(self, frm, to):
         self._ck(self.lib.deme_change_family(self.h, int(frm), int(to)), "deme_change_family")
+
+    def set_adaptive(self, bin_size=False, update_freq=False, bin_observe=25, bin_max_rate=0.05, bin_acc=0.1, bin_upper_safety=0.25,
+                     bin_lower_safety=0.3, max_update_freq=2500, freq_observe=4):
+        """UseAdaptiveBinSize / UseAdaptiveUpdateFreq and their tuning knobs (DEM/API.h:253-309), on device timers."""
+        a = DemeAdaptive(int(bool(bin_size)), int(bin_observe), float(bin_max_rate), float(bin_acc), float(bin_upper_safety),
+                         float(bin_lower_safety), int(bool(update_freq)), int(max_update_freq), int(freq_observe))
+        self._ck(self.lib.deme_set_adaptive(self.h, C.byref(a)), "deme_set_adaptive")
+
+    def adaptive_state(self):
+        """(bin size, cdUpdateFreq, number of bin-size changes, number of update-frequency changes)"""
+        b, k, nb, nk = C.c_double(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._ck(self.lib.deme_get_adaptive_state(self.h, C.byref(b), C.byref(k), C.byref(nb), C.byref(nk)), "deme_get_adaptive_state")
+        return float(b.value), int(k.value), int(nb.value), int(nk.value)
 
     PERSIST_ALL, PERSIST_EITHER, PERSIST_BOTH, PERSIST_PAIR = 0, 1, 2, 3
 

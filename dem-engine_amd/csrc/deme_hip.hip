@@ -98,6 +98,15 @@ struct deme_ctx {
     hipEvent_t evStepDone = nullptr, evHaloDone = nullptr;
     bool overlapDetect = false;  // the step opened by deme_step_overlap_begin needs a detection first
     hipModule_t rulesMod = nullptr;
+    // adaptive controllers (deme_set_adaptive)
+    DemeAdaptive ad{};
+    hipEvent_t evDet0 = nullptr, evDet1 = nullptr, evWin0 = nullptr, evWin1 = nullptr;
+    double binAccMs = 0, binPrevMs = -1, freqPrevMs = -1;
+    float binRate = 0.f;
+    uint32_t binObs = 0, freqObs = 0, nBinChanges = 0, nFreqChanges = 0;
+    uint64_t winStartStep = 0;
+    int freqDir = 1, binFlip = 1;
+    bool winOpen = false;
     // inspector region filters: one module per compiled region (id = index)
     std::vector<hipModule_t> regionMod;
     std::vector<hipFunction_t> regionFn;
@@ -796,6 +805,9 @@ void deme_ctx_destroy(deme_ctx* c) {
     for (hipModule_t m : c->regionMod)
         if (m)
             (void)hipModuleUnload(m);
+    for (hipEvent_t e : {c->evDet0, c->evDet1, c->evWin0, c->evWin1})
+        if (e)
+            hipEventDestroy(e);
     if (c->haloStream) {
         hipStreamSynchronize(c->haloStream);
         hipEventDestroy(c->evStepDone);
@@ -1176,21 +1188,154 @@ int deme_integrate(deme_ctx* c) {
 }
 
 static int step_tail(deme_ctx* c);
+static bool detection_due(deme_ctx* c);
+
+// ---- adaptive controllers (include/deme_hip.h: DemeAdaptive) ----------------------------------------------------------
+static void apply_bin_size(deme_ctx* c, double s) {
+    DemeParams& h = c->hp;
+    h.binSize = s;
+    // hostCalcBinNum (DEM/HostSideHelpers.hpp) as SceneBuilder._calc_bin_num / DEMSolver::Initialize use it
+    h.nbX = (uint32_t)(h.voxelSize * (double)(1ull << h.nvXp2) / s) + 1;
+    h.nbY = (uint32_t)(h.voxelSize * (double)(1ull << h.nvYp2) / s) + 1;
+    h.nbZ = (uint32_t)(h.voxelSize * (double)(1ull << h.nvZp2) / s) + 1;
+    refresh_dev_params(c);
+}
+
+// the detection just timed took `ms` on the device: DEMKinematicThread::calibrateParams (DEM/kT.cpp:43-98)
+static void adapt_bin_size(deme_ctx* c, double ms) {
+    const DemeAdaptive& a = c->ad;
+    c->binAccMs += ms;
+    if (++c->binObs < std::max(1u, a.binObserveSteps))
+        return;
+    const double cur = c->binAccMs / (double)c->binObs, prev = c->binPrevMs;
+    c->binAccMs = 0, c->binObs = 0, c->binPrevMs = cur;
+    if (prev < 0)
+        return;  // first window: nothing to compare with yet
+    int dir = (c->binRate > 0.f) - (c->binRate < 0.f);
+    if (dir == 0) {  // the reference draws a random direction here; alternate instead (reproducible runs)
+        dir = c->binFlip;
+        c->binFlip = -c->binFlip;
+    }
+    float upd = ((cur < prev) ? dir : -dir) * a.binAcc * a.binMaxRate;
+    if ((double)c->maxInBin > (double)a.binUpperSafety * (double)c->dp.errOutBinSphNum)
+        upd = -1.f * a.binAcc * a.binMaxRate;  // bins too full: the size must start to decrease
+    const double nBins = (double)c->hp.nbX * (double)c->hp.nbY * (double)c->hp.nbZ;
+    if (nBins > (double)a.binLowerSafety * 4294967295.0)
+        upd = 1.f * a.binAcc * a.binMaxRate;  // too many bins for the 32-bit bin id: the size must start to increase
+    c->binRate = std::min(a.binMaxRate, std::max(-a.binMaxRate, c->binRate + upd));
+    double s = c->hp.binSize;
+    if (c->binRate > 0.f)
+        s *= 1.0 + (double)c->binRate;
+    else
+        s /= 1.0 - (double)c->binRate;
+    const double nb = (c->hp.voxelSize * (double)(1ull << c->hp.nvXp2) / s + 1) * (c->hp.voxelSize * (double)(1ull << c->hp.nvYp2) / s + 1) *
+                      (c->hp.voxelSize * (double)(1ull << c->hp.nvZp2) / s + 1);
+    if (nb >= 4294967295.0)
+        return;  // would overflow the bin id: keep the size
+    apply_bin_size(c, s);
+    c->nBinChanges++;
+}
+
+// a window of steps ending at a detection took `ms` per step: hill climb on K = cdUpdateFreq
+static void adapt_update_freq(deme_ctx* c, double msPerStep) {
+    const DemeAdaptive& a = c->ad;
+    const double prev = c->freqPrevMs;
+    c->freqPrevMs = msPerStep;
+    if (prev >= 0 && msPerStep >= prev)
+        c->freqDir = -c->freqDir;  // no improvement: turn round
+    const uint32_t K = std::max(1u, c->hp.cdUpdateFreq), hi = std::max(1u, a.maxUpdateFreq);
+    const uint32_t stepK = std::max(1u, K / 8);
+    const uint32_t nK = c->freqDir > 0 ? std::min(hi, K + stepK) : (K > stepK ? K - stepK : 1u);
+    if (nK != K) {
+        c->hp.cdUpdateFreq = nK;
+        refresh_dev_params(c);
+        c->nFreqChanges++;
+    }
+}
+
+static int ensure_adaptive_events(deme_ctx* c) {
+    if (c->evDet0)
+        return DEME_OK;
+    HIPCK(hipEventCreate(&c->evDet0));
+    HIPCK(hipEventCreate(&c->evDet1));
+    HIPCK(hipEventCreate(&c->evWin0));
+    HIPCK(hipEventCreate(&c->evWin1));
+    return DEME_OK;
+}
+
+// margins + detection + history migration of a step whose list is due, with the controllers' timing around it
+static int detection_phase(deme_ctx* c) {
+    const bool adaptive = c->ad.autoBinSize || c->ad.autoUpdateFreq;
+    if (adaptive) {
+        if (int rc = ensure_adaptive_events(c))
+            return rc;
+        if (c->ad.autoUpdateFreq && c->hp.cdUpdateFreq > 0) {
+            if (c->winOpen && ++c->freqObs >= std::max(1u, c->ad.freqObserveDetections)) {
+                HIPCK(hipEventRecord(c->evWin1, c->stream));
+                HIPCK(hipEventSynchronize(c->evWin1));
+                float ms = 0.f;
+                HIPCK(hipEventElapsedTime(&ms, c->evWin0, c->evWin1));
+                const uint64_t n = c->nSteps - c->winStartStep;
+                if (n)
+                    adapt_update_freq(c, (double)ms / (double)n);
+                c->winOpen = false;
+            }
+            if (!c->winOpen) {  // a window starts at a detection and includes it
+                HIPCK(hipEventRecord(c->evWin0, c->stream));
+                c->winStartStep = c->nSteps, c->freqObs = 0, c->winOpen = true;
+            }
+        }
+        if (c->ad.autoBinSize)
+            HIPCK(hipEventRecord(c->evDet0, c->stream));
+    }
+    if (int rc = do_margins(c, c->hp.cdUpdateFreq))
+        return rc;
+    if (int rc = do_detect(c))
+        return rc;
+    if (adaptive && c->ad.autoBinSize) {
+        HIPCK(hipEventRecord(c->evDet1, c->stream));
+        HIPCK(hipEventSynchronize(c->evDet1));  // (do_detect ended on a synchronisation: nothing is queued behind)
+        float ms = 0.f;
+        HIPCK(hipEventElapsedTime(&ms, c->evDet0, c->evDet1));
+        adapt_bin_size(c, (double)ms);
+    }
+    if (int rc = do_migrate(c))
+        return rc;
+    c->stepsSinceCD = 0;
+    return DEME_OK;
+}
+
+int deme_set_adaptive(deme_ctx* c, const DemeAdaptive* a) {
+    if (!c || !a)
+        return DEME_ERR_INVALID;
+    if (a->autoBinSize && (!(a->binMaxRate >= 0.f) || !(a->binAcc > 0.f)))
+        return fail(c, DEME_ERR_INVALID, "deme_set_adaptive: binMaxRate must be >= 0 and binAcc > 0");
+    c->ad = *a;
+    c->binAccMs = 0, c->binPrevMs = -1, c->freqPrevMs = -1, c->binRate = 0.f, c->binObs = 0, c->freqObs = 0, c->winOpen = false;
+    return DEME_OK;
+}
+
+int deme_get_adaptive_state(deme_ctx* c, double* binSize, uint32_t* cdUpdateFreq, uint32_t* nBinChanges, uint32_t* nFreqChanges) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    if (binSize)
+        *binSize = c->hp.binSize;
+    if (cdUpdateFreq)
+        *cdUpdateFreq = c->hp.cdUpdateFreq;
+    if (nBinChanges)
+        *nBinChanges = c->nBinChanges;
+    if (nFreqChanges)
+        *nFreqChanges = c->nFreqChanges;
+    return DEME_OK;
+}
 
 int deme_step(deme_ctx* c, uint32_t nsteps) {
     if (int rc = check_ready(c))
         return rc;
-    const uint32_t K = c->hp.cdUpdateFreq;
     for (uint32_t i = 0; i < nsteps; i++) {
-        if (!c->haveList || c->seeded || K == 0 || c->stepsSinceCD >= K) {
-            if (int rc = do_margins(c, K))
+        if (detection_due(c))
+            if (int rc = detection_phase(c))
                 return rc;
-            if (int rc = do_detect(c))
-                return rc;
-            if (int rc = do_migrate(c))
-                return rc;
-            c->stepsSinceCD = 0;
-        }
         if (int rc = launch_forces(c))
             return rc;
         if (int rc = step_tail(c))

@@ -280,7 +280,12 @@ __device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const uint
     uint64_t key = 0;
     if (lane < cnt) {
         const uint32_t e = wq[lane];
-        const uint32_t i = e & 0xFFFFu, q = e >> 16;
+        // A is the entry that comes first in the bin's list (= the smaller sphere id: the list is stably sorted), as in the
+        // reference's i < j loop.  The order matters: the contact point is computed from B's side, and a point within
+        // rounding of a bin face must fall on the same side in every bin that tests the pair -- the cyclic pairing meets
+        // the two entries in either order, which (measured: once per ~1e9 pair evaluations) dropped or doubled a contact.
+        const uint32_t e0 = e & 0xFFFFu, e1 = e >> 16;
+        const uint32_t i = min(e0, e1), q = max(e0, e1);
         hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], L.x[q], L.y[q], L.z[q], L.r[q], L.owner[q], L.fam[q],
                         L.bin[q]);
         if (hit)

@@ -244,6 +244,34 @@ int deme_compile_family_rules(deme_ctx* ctx, const char* rules);
 /* DEMSolver::ChangeFamily(ID_from, ID_to) (API.h:1028): immediate, all owners of a family */
 int deme_change_family(deme_ctx* ctx, uint32_t from, uint32_t to);
 
+/* Adaptive controllers (reference: DEMKinematicThread::calibrateParams DEM/kT.cpp:43-98 -- bin-size
+ * hill climb on kT's time per detection; DEMDynamicThread::calibrateParams DEM/dT.cpp:2276-2299 -- drift tuner;
+ * API: UseAdaptiveBinSize, SetAdaptiveBinSizeDelaySteps / MaxRate / Acc / UpperProactivity / LowerProactivity,
+ * UseAdaptiveUpdateFreq, SetCDMaxUpdateFreq, DEM/API.h:253-309).  Here both run on device timers (HIP events around the
+ * detection / around a window of steps), inside deme_step:
+ *  - bin size: every binObserveSteps detections the average device time per detection is compared with the previous
+ *    window's; the change rate accelerates in the current direction on an improvement and turns round otherwise, with the
+ *    reference's rule, clamps and safety overrides (too many spheres in a bin => shrink; too many bins => grow);
+ *  - update frequency: this build has no second thread to drift ahead of, so the quantity tuned is K = cdUpdateFreq itself,
+ *    hill-climbing the measured time per step (detection amortised over K + force pass over the K-inflated list) every
+ *    freqObserveDetections detections, within [1, maxUpdateFreq].
+ * Neither changes the physics: the contact set does not depend on the bin size, and a larger K only adds non-touching
+ * pairs to the list (tests/test_adaptive.py: bit-identical state with the controllers on).  Off by default. */
+typedef struct DemeAdaptive {
+    uint32_t autoBinSize;           /* UseAdaptiveBinSize */
+    uint32_t binObserveSteps;       /* SetAdaptiveBinSizeDelaySteps (reference default 25) */
+    float binMaxRate;               /* SetAdaptiveBinSizeMaxRate (0.05) */
+    float binAcc;                   /* SetAdaptiveBinSizeAcc (0.1) */
+    float binUpperSafety;           /* 0.25: shrink when maxSpheresInBin > this * errOutBinSphNum */
+    float binLowerSafety;           /* 0.3: grow when the bin count > this * 2^32 */
+    uint32_t autoUpdateFreq;        /* UseAdaptiveUpdateFreq */
+    uint32_t maxUpdateFreq;         /* SetCDMaxUpdateFreq */
+    uint32_t freqObserveDetections; /* detections per adjustment of K */
+} DemeAdaptive;
+int deme_set_adaptive(deme_ctx* ctx, const DemeAdaptive* a);
+/* current bin size / cdUpdateFreq and how many adjustments each controller has made */
+int deme_get_adaptive_state(deme_ctx* ctx, double* binSize, uint32_t* cdUpdateFreq, uint32_t* nBinChanges, uint32_t* nFreqChanges);
+
 /* Persistent contacts (reference: DEM/API.h:874-905 MarkFamilyPersistentContactEither/Both, MarkFamilyPersistentContact,
  * MarkPersistentContact and their Remove* inverses; DEM/APIPrivate.cpp:33-117; algorithms/DEMCubContactDetection.cu:605-802).
  * Qualifies contacts of the CURRENT list: mode 0 every contact, 1 either owner's family == N1, 2 both == N1, 3 the family

@@ -108,3 +108,43 @@ def test_full_size_properties(pkg, big):
     scale = np.abs(F).sum()
     assert np.abs(total).max() < 1e-5 * scale
     ctx.set_record_contacts(False)
+
+
+@pytest.mark.gpu
+def test_full_size_update_frequency_and_margins(pkg, big):
+    """The K-step detection policy at full size, from a bed that is still moving (speeds up to ~2 m/s) with its contact
+    history.  A list built every K = 40 steps with a margin that covers 3 m/s of unforeseen approach speed misses no contact:
+    300 steps later 1e6 clumps are BIT-IDENTICAL to the run that detects at every step (the extra listed pairs are
+    non-touching and contribute exact zeros).  With bench.py's knobs (1.2 x own speed + 0.02 m/s, the reference demos'
+    order of magnitude) the policy is the reference's approximation: collisions inside a window change speeds by more than the
+    margin foresees for ~1 % of the clumps, whose positions then differ by ~1e-5 m (a 400th of a sphere radius)."""
+    import copy
+    b, p, sc, ctx = big
+    st = ctx.download_state()
+    ctx.compute_margins(0), ctx.detect(), ctx.migrate()
+    a, bb, t, _ = ctx.contacts()
+    W = np.stack([ctx.wildcard(w) for w in range(4)], 1)
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+
+    def run(K, adder):
+        q = copy.copy(p)
+        q.cdUpdateFreq, q.expSafetyAdder = K, adder
+        c = pkg.Context(0)
+        c.set_params(q), c.upload_scene(sc)
+        c.upload_state({k: st[k] for k in keys})
+        c.seed_contacts(a, bb, t, W)
+        c.step(300)
+        out = c.download_state(), int(c.counts().nDetections), int(c.counts().nContacts)
+        del c
+        return out
+
+    every, d0, n0 = run(0, p.expSafetyAdder)
+    wide, d1, n1 = run(40, 3.0)
+    assert d0 == 300 and d1 == 8 and n1 > n0 > 1_000_000  # the K-step list carries the margin's extra (non-touching) pairs
+    for k in keys:
+        assert np.array_equal(wide[k], every[k]), k
+    tight, d2, n2 = run(40, p.expSafetyAdder)
+    pos = lambda s: pkg.model.decode_positions(s["voxelID"], s["locX"], s["locY"], s["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    d = np.abs(pos(tight) - pos(every)).max(1)
+    assert d2 == 8 and n0 < n2 < n1
+    assert (d > 0).mean() < 0.02 and d.max() < 1e-4, ((d > 0).mean(), d.max())
