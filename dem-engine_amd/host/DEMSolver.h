@@ -462,8 +462,32 @@ class DEMSolver {
         m_family_masks[(1 + b) * b / 2 + a] = 1;  // locateMaskPair, DEMHelperKernels.cuh:57-62
     }
     void SetFamilyExtraMargin(unsigned int f, float m) { m_family_extra[f & 255] = m; }
-    void DisableAdaptiveBinSize() {}
-    void UseAdaptiveUpdateFreq(bool) {}
+    // ---- adaptive controllers (API.h:253-309) on device timers: deme_set_adaptive.  The reference switches both on by
+    // default; here they are opt-in so that runs are reproducible step for step unless asked otherwise.
+    void UseAdaptiveBinSize(bool use = true) { m_adaptive.autoBinSize = use, push_adaptive(); }
+    void DisableAdaptiveBinSize() { UseAdaptiveBinSize(false); }
+    void UseAdaptiveUpdateFreq(bool use = true) { m_adaptive.autoUpdateFreq = use, push_adaptive(); }
+    void DisableAdaptiveUpdateFreq() { UseAdaptiveUpdateFreq(false); }
+    void SetAdaptiveBinSizeDelaySteps(unsigned int n) { m_adaptive.binObserveSteps = n >= 1 ? n : 1, push_adaptive(); }
+    void SetAdaptiveBinSizeMaxRate(float rate) { m_adaptive.binMaxRate = rate > 0 ? rate : 0, push_adaptive(); }
+    void SetAdaptiveBinSizeAcc(float acc) { m_adaptive.binAcc = std::min(1.f, std::max(0.01f, acc)), push_adaptive(); }
+    void SetAdaptiveBinSizeUpperProactivity(float r) {  // API.h:282-284 -> APIPrivate.cpp:1106-1107
+        m_adaptive.binUpperSafety = 0.01f + (1.f - std::min(1.f, std::max(0.f, r))) * 0.98f, push_adaptive();
+    }
+    void SetAdaptiveBinSizeLowerProactivity(float r) {
+        m_adaptive.binLowerSafety = 0.01f + (1.f - std::min(1.f, std::max(0.f, r))) * 0.98f, push_adaptive();
+    }
+    void SetCDMaxUpdateFreq(unsigned int max_freq) { m_adaptive.maxUpdateFreq = max_freq, push_adaptive(); }
+    double GetBinSize() const {
+        double b = 0;
+        deme_get_adaptive_state(m_ctx, &b, nullptr, nullptr, nullptr);
+        return b;
+    }
+    unsigned int GetUpdateFreq() const {
+        uint32_t k = 0;
+        deme_get_adaptive_state(m_ctx, nullptr, &k, nullptr, nullptr);
+        return k;
+    }
     void SetNoForceRecord(bool flag = true) {  // per-contact force records are only kept when the contact output needs them
         if (flag)
             m_cnt_out_content &= ~(unsigned)(FORCE | CNT_POINT | NORMAL | TORQUE);
@@ -471,7 +495,11 @@ class DEMSolver {
     void SetCollectAccRightAfterForceCalc(bool = true) {}
 
     // ---- run
-    void Initialize() { initialize_impl(); }
+    void Initialize() {
+        initialize_impl();
+        m_initialized = true;
+        push_adaptive();
+    }
     void DoDynamics(double t) { step((uint32_t)std::llround(t / (double)m_h)); }
     void DoDynamicsThenSync(double t) {
         DoDynamics(t);
@@ -659,8 +687,6 @@ class DEMSolver {
     void ClearTimingStats() { deme_kernel_time_reset(m_ctx); }
     void ClearThreadCollaborationStats() {}
     void UseCubForceCollection(bool = true) {}  // accumulation is atomics-free here: nothing to choose
-    void UseAdaptiveBinSize() {}
-    void SetAdaptiveBinSizeDelaySteps(unsigned int) {}
     void SetExpandSafetyType(const std::string&) {}
 
     // ---- inspectors and trackers (API.h:652-679, AuxClasses.h:26-420)
@@ -843,6 +869,13 @@ class DEMSolver {
     uint8_t m_family_flags[DEME_NUM_FAMILIES] = {0};
     DemeParams m_p{};
     size_t m_n_clumps = 0, m_n_owners = 0;
+    bool m_initialized = false;
+    // reference defaults of the controllers' knobs (DEM/Structs.h:204-216); both switched off until asked for
+    DemeAdaptive m_adaptive{0u, 25u, 0.05f, 0.1f, 0.25f, 0.3f, 0u, 2500u, 4u};
+    void push_adaptive() {  // the knobs may be turned before or after Initialize
+        if (m_initialized)
+            check(deme_set_adaptive(m_ctx, &m_adaptive));
+    }
     double m_time = 0;
     bool m_state_fresh = false;
     std::vector<float3> m_pos;

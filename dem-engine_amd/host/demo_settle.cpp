@@ -124,6 +124,15 @@ int main(int argc, char** argv) {
         std::printf("REGION lower=%.6e upper=%.6e total=%.6e column_max_z=%.6f bed_max_z=%.6f volume=%.6e\n", lower->GetValue(),
                     upper->GetValue(), total_mass_finder->GetValue(), column->GetValue(), max_z_finder->GetValue(), volume->GetValue());
     }
+    {   // adaptive bin size (reference default mode): the size moves, the simulation carries on
+        const double b0 = DEMSim.GetBinSize();
+        DEMSim.SetAdaptiveBinSizeDelaySteps(2);
+        DEMSim.SetAdaptiveBinSizeMaxRate(0.1f);
+        DEMSim.UseAdaptiveBinSize();
+        DEMSim.DoDynamicsThenSync(400 * 5e-6);
+        std::printf("ADAPTIVE bin0=%.6f bin=%.6f K=%u\n", b0, DEMSim.GetBinSize(), DEMSim.GetUpdateFreq());
+        DEMSim.DisableAdaptiveBinSize();
+    }
     {   // persistent contacts (cf. DEMdemo_SingleSphereCollide.cpp:165): every current contact stays in the list from now on
         const size_t marked = DEMSim.GetNumContacts();
         DEMSim.MarkPersistentContact();
