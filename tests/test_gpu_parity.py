@@ -352,3 +352,54 @@ def test_persistent_contacts_need_history(pkg):
     ctx.step(5)
     with pytest.raises(pkg.abi.DemeError, match="history-less"):
         ctx.mark_persistent_contacts()
+
+
+def test_contact_points_on_bin_faces(pkg, orc):
+    """The contact-point-in-this-bin rule when the contact point sits within rounding of a bin face: equal spheres placed
+    symmetrically about faces of the bin grid (on the position codec's integer lattice, bin size a whole number of lattice
+    units), thousands of them crowded into a few bins so that the sweep meets the two entries of a pair in a different
+    order in different bins.  The pair must be claimed by exactly one bin and that bin must be the oracle's: with the pair's
+    roles taken in meeting order (instead of list order, as the reference's i < j loop does) the two bins could each
+    decide the point belongs to the other -- once per ~1e9 pairs in a settling bed, most pairs here."""
+    rng = np.random.default_rng(77)
+    b = pkg.SceneBuilder()
+    m = b.LoadMaterial({"E": 1e8, "nu": 0.3, "CoR": 0.5, "mu": 0.3, "Crr": 0.0})
+    b.InstructBoxDomainDimension((0.0, 1.0), (0.0, 1.0), (0.0, 1.0))
+    b.InstructBoxDomainBoundingBC("none", m)
+    nv, l, voxel = b._figure_out_nv()
+    M = int(round(0.02 / l))  # lattice units per bin (l ~ 1e-11 m: 2^37 lattice points per metre)
+    b.SetInitBinSize(M * l)
+    r = 0.27 * M * l
+    t = b.LoadSphereType(1e-3, r, m)
+    n_pairs = 3000
+    face_axis = rng.integers(0, 3, n_pairs)
+    C = rng.integers(20 * M, 23 * M, (n_pairs, 3))  # pair centres: a 3 x 3 x 3 block of bins ...
+    C[np.arange(n_pairs), face_axis] = rng.integers(20, 24, n_pairs) * M  # ... with one coordinate ON a bin face
+    u = rng.normal(size=(n_pairs, 3))
+    u = u / np.linalg.norm(u, axis=1, keepdims=True) * rng.uniform(0.55, 0.98, (n_pairs, 1)) * (r / l)
+    u = np.rint(u).astype(np.int64)
+    G = np.empty((2 * n_pairs, 3), np.int64)
+    swap = rng.random(n_pairs) < 0.5  # which of the two gets the smaller sphere id
+    G[0::2] = np.where(swap[:, None], C + u, C - u)
+    G[1::2] = np.where(swap[:, None], C - u, C + u)
+    b.AddClumps(t, (G * l).astype(np.float32))  # placeholder positions; the codec fields are overwritten below
+    b.SetCDUpdateFreq(0)
+    p, sc = b.Initialize()
+    assert abs(p.binSize - M * p.l) < 1e-18 and p.l == l
+    n = 2 * n_pairs
+    vox = G // 65536
+    b.arrays["voxelID"][:n] = (vox[:, 0] + (vox[:, 1] << p.nvXp2) + (vox[:, 2] << (p.nvXp2 + p.nvYp2))).astype(np.uint64)
+    for k, name in enumerate(("locX", "locY", "locZ")):
+        b.arrays[name][:n] = (G[:, k] % 65536).astype(np.uint16)
+    sc = pkg.abi.make_scene_struct(b.arrays, b.counts)
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    sim = orc.make_sim(pkg, p, sc)
+    ctx.compute_margins(0), sim.compute_margins(0)
+    ctx.detect(), sim.detect()
+    a, bb, tt, *_ = assert_same_contacts(ctx, sim)
+    made = set(zip(a.tolist(), bb.tolist()))
+    assert all((2 * i, 2 * i + 1) in made for i in range(n_pairs))  # every constructed pair is listed (once: keys are unique)
+    key = (a.astype(np.uint64) << np.uint64(33)) | bb.astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])
+    assert int(ctx.counts().maxSpheresInBin) > 256  # crowded: both the in-LDS and the tiled (giant bin) paths ran
