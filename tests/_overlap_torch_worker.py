@@ -18,7 +18,9 @@ GKEYS = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", 
 
 def main():
     pkg = g.load_package()
-    b = pkg.model.packed_bed(3000, seed=6, cd_freq=7, spacing_mult=2.5, init_vz=-0.4, aspect=(2.0, 1.0, 0.5))
+    n_clumps = int(os.environ.get("DEME_OVERLAP_TEST_CLUMPS", "3000"))  # (a 400k-clump run of this worker is how the deferral
+    # logic was checked at scale: 1e8 owner-steps, bit-identical)
+    b = pkg.model.packed_bed(n_clumps, seed=6, cd_freq=7, spacing_mult=2.5, init_vz=-0.4, aspect=(2.0, 1.0, 0.5))
     p, sc = b.Initialize()
     x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
     parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
@@ -35,7 +37,7 @@ def main():
 
     ids = [ids_of(pt) for pt in parts]
     n01, n10 = len(parts[0]["send_right"]), len(parts[1]["send_left"])
-    steps = 60
+    steps = int(os.environ.get("DEME_OVERLAP_TEST_STEPS", "60"))
     # ---- ordered exchange (reference)
     plain = [make(pt) for pt in parts]
     s01 = torch.empty(max(1, n01) * gb, dtype=torch.uint8, device=dev)
