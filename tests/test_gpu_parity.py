@@ -265,6 +265,24 @@ def test_error_paths(pkg):
     ctx.upload_scene(sc)
     with pytest.raises(pkg.abi.DemeError, match="velocity"):
         ctx.step(1)
+    # id-width limits of the key / info records are refused before any array is read
+    import ctypes as C
+    ctx2 = pkg.Context(0)
+    ctx2.set_params(p)
+    for field, n, what in (("nSpheres", 1 << 31, "31 bits"), ("nOwners", 1 << 30, "30 bits")):
+        big = pkg.abi.DemeScene()
+        C.memmove(C.byref(big), C.byref(sc), C.sizeof(big))
+        setattr(big, field, n)
+        with pytest.raises(pkg.abi.DemeError, match=what):
+            ctx2.upload_scene(big)
+    q = pkg.abi.DemeParams()
+    C.memmove(C.byref(q), C.byref(p), C.sizeof(q))
+    q.nContactWildcards = 17
+    with pytest.raises(pkg.abi.DemeError, match="wildcards"):
+        ctx2.set_params(q)
+    q.nContactWildcards, q.binSize = 4, 0.0
+    with pytest.raises(pkg.abi.DemeError, match="sizing"):
+        ctx2.set_params(q)
 
 
 @pytest.mark.gpu
