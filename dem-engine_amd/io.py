@@ -259,3 +259,30 @@ def read_clump_template_csv(path):
     ix = [header.index(c) for c in ("x", "y", "z", "r")]
     a = np.asarray([[np.float32(r[i]) for i in ix] for r in rows], np.float32)
     return a[:, :3].copy(), a[:, 3].copy()
+
+
+def read_obj(path):
+    """AddWavefrontMeshObject's input (API.h:638-645; the reference reads it through tinyobjloader): `v x y z` vertices and
+    `f` faces whose corners are `i`, `i/t`, `i//n` or `i/t/n` (1-based, negative = relative to the end); polygons are
+    fanned into triangles.  Returns (vertices float32 (n, 3), faces int64 (m, 3)); normals / texture coordinates / groups are
+    ignored, like the reference ignores them for contact purposes."""
+    verts, faces = [], []
+    with open(path) as f:
+        for line in f:
+            parts = line.split()
+            if not parts or parts[0].startswith("#"):
+                continue
+            if parts[0] == "v":
+                verts.append([float(x) for x in parts[1:4]])
+            elif parts[0] == "f":
+                idx = []
+                for c in parts[1:]:
+                    i = int(c.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    v = np.asarray(verts, np.float32).reshape(-1, 3)
+    fa = np.asarray(faces, np.int64).reshape(-1, 3)
+    if len(fa) and (fa.min() < 0 or fa.max() >= len(v)):
+        raise ValueError(f"{path}: face index out of range")
+    return v, fa

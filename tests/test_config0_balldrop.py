@@ -3,6 +3,7 @@
 spherical projectile mesh dropped into the bed (DEMdemo_BallDrop.cpp:53-150; seeded HCP + jitter instead of
 std::random_device / PD sampling).  The CPU test is the plumbing run on the oracle; the GPU test is parity."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -48,8 +49,9 @@ def balldrop(pkg, n_target=10000):
     pick = rng.integers(0, len(tmpls), len(pts))
     batch = b.AddClumps([tmpls[i] for i in pick], pts)
     batch.SetVel(np.tile(np.array([0, 0, -0.2], np.float32), (len(pts), 1)))
-    v, f = icosphere(0.012, 2)
-    proj = b.AddMeshObject(v, f, mat)
+    # the reference's projectile: data/mesh/sphere.obj (a unit icosphere, 162 vertices / 320 facets) scaled to 12 mm
+    v, f = pkg.io.read_obj(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data", "sphere.obj"))
+    proj = b.AddMeshObject(v * np.float32(0.012), f, mat)
     under = (np.abs(pts[:, 0]) < 0.008) & (np.abs(pts[:, 1]) < 0.008)  # the top layer may be partial: look under the projectile
     proj.SetInitPos((0.0, 0.0, float(pts[under, 2].max()) + 0.0015 + 0.012 + 0.0001))  # ~0.1 mm above the spheres below it
     proj.SetMass(2.6e3 * 4.0 / 3.0 * math.pi * 0.012 ** 3)
@@ -95,3 +97,20 @@ def test_config0_gpu_matches_oracle(pkg, orc):
     assert np.abs(X - Y).max() == 0.0  # bit-identical trajectories
     for q in ("clump_max_z", "clump_mass", "max_absv"):
         assert abs(ctx.inspect(q) - sim.inspect(q)) <= 2e-5 * abs(sim.inspect(q))
+
+
+def test_reference_projectile_mesh_file(pkg):
+    """tests/golden/ref_data/sphere.obj is the reference's data/mesh/sphere.obj (a DATA file): `f a//n b//n c//n` corners; the
+    a twice-subdivided icosahedron on the unit sphere, outward-facing facets"""
+    v, f = pkg.io.read_obj(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data", "sphere.obj"))
+    assert v.shape == (162, 3) and f.shape == (320, 3)
+    assert np.allclose(np.linalg.norm(v, axis=1), 1.0, atol=2e-6)
+    # a closed 2-manifold: every edge belongs to exactly two facets, V - E + F = 2; 12 vertices of valence 5, the rest 6
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+    ue, cnt = np.unique(e, axis=0, return_counts=True)
+    assert (cnt == 2).all() and len(v) - len(ue) + len(f) == 2
+    val = np.bincount(ue.reshape(-1), minlength=len(v))
+    assert sorted(np.unique(val).tolist()) == [5, 6] and int((val == 5).sum()) == 12
+    n = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    c = v[f].mean(axis=1)
+    assert (np.einsum("ij,ij->i", n, c) > 0).all()
