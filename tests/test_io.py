@@ -1,8 +1,7 @@
 """Output writers / CSV readers against the reference's own data fixtures and formats.
 
-tests/golden/ref_data/ holds three DATA files of the reference (the third, data/mesh/sphere.obj, is BallDrop's projectile:
-tests/test_config0_balldrop.py); (data/sim_data/example_cnt_pairs.csv -- a contact
-file written by the reference -- and data/clumps/3_clump.csv).  CPU tests use the oracle as the state provider;
+tests/golden/ref_data/ holds three DATA files of the reference: data/sim_data/example_cnt_pairs.csv (a contact file written
+by the reference), data/clumps/3_clump.csv, and data/mesh/sphere.obj (BallDrop's projectile, tests/test_config0_balldrop.py).  CPU tests use the oracle as the state provider;
 the GPU test does a write -> read -> restart round trip through the C-ABI (deme_seed_contacts)."""
 import os
 
