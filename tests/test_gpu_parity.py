@@ -421,3 +421,51 @@ def test_contact_points_on_bin_faces(pkg, orc):
     key = (a.astype(np.uint64) << np.uint64(33)) | bb.astype(np.uint64)
     assert np.all(key[1:] > key[:-1])
     assert int(ctx.counts().maxSpheresInBin) > 256  # crowded: both the in-LDS and the tiled (giant bin) paths ran
+
+
+def raft_scene(pkg):
+    """a bed of 1 mm spheres with a rigid raft of 283 spheres (one clump) set down on its top layer: > 256 contacts on one FREE
+    owner"""
+    import math
+    r = 0.001
+    b = pkg.model.packed_bed(6000, seed=31, cd_freq=0, scale=r, spacing_mult=2.02, jitter=0.0, three_sphere=False,
+                             aspect=(1.0, 1.0, 0.6), init_vz=0.0)
+    xyz = b.batches[0].xyz
+    top = xyz[xyz[:, 2] > xyz[:, 2].max() - 0.2 * r]
+    c = top.mean(0)
+    rel = (top - c).astype(np.float32)
+    n = len(rel)
+    L = float(rel[:, 0].max() - rel[:, 0].min())
+    mass = n * 2.6e3 * 4 / 3 * math.pi * r ** 3
+    t = b.LoadClumpType(mass, (mass * L * L / 12, mass * L * L / 12, mass * L * L / 6), np.full(n, r, np.float32), rel, 0)
+    raft = b.AddClumps(t, [[float(c[0]), float(c[1]), float(c[2]) + 1.9995 * r]])
+    raft.SetVel(np.array([[0.01, 0.0, -0.02]], np.float32))
+    return b, n
+
+
+def test_free_owner_with_hundreds_of_contacts(pkg, orc):
+    """Owners with more than 256 contacts are reduced by a workgroup each (k_reduce_heavy, fixed-shape tree) instead of the
+    per-owner gather; the walls exercise that path in every test but are fixed -- here the heavy owner is a free clump whose
+    motion depends on the sum.  Lists bit-exact; states to fp32 summation-order tolerance (the tree's order differs from the
+    oracle's list order)."""
+    b, n_raft = raft_scene(pkg)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    own = b.arrays["ownerClumpBody"]
+    raft = int(sc.nOwnerClumps) - 1
+    assert n_raft > 256 and int((own == raft).sum()) == n_raft
+    seen_heavy = 0
+    for chunk in range(6):
+        ctx.step(10), sim.step(10)
+        a, bb, t, *_ = assert_same_contacts(ctx, sim)
+        on_raft = int(((own[a] == raft) | ((t == 1) & (own[np.minimum(bb, len(own) - 1)] == raft))).sum())
+        seen_heavy += on_raft > 256
+        gs, os_ = ctx.download_state(), sim.download_state()
+        X, Xo = positions(pkg, gs, p), positions(pkg, os_, p)
+        assert np.abs(X - Xo).max() < 1e-9, chunk
+        for k in ("vX", "vY", "vZ"):
+            assert np.abs(gs[k] - os_[k]).max() < 2e-6, (chunk, k)
+        for k in ("omgBarX", "omgBarY", "omgBarZ"):
+            assert np.abs(gs[k] - os_[k]).max() < 2e-3, (chunk, k)  # (1 mm spheres: 1e-6 m/s at the surface)
+        assert abs(gs["vZ"][raft] - os_["vZ"][raft]) < 1e-7
+    assert seen_heavy >= 2  # the raft really carried > 256 contacts while it was being decelerated
+    assert gs["vZ"][raft] > -0.02 + 0.005
