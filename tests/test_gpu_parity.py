@@ -469,3 +469,37 @@ def test_free_owner_with_hundreds_of_contacts(pkg, orc):
         assert abs(gs["vZ"][raft] - os_["vZ"][raft]) < 1e-7
     assert seen_heavy >= 2  # the raft really carried > 256 contacts while it was being decelerated
     assert gs["vZ"][raft] > -0.02 + 0.005
+
+
+def test_large_size_ratio_incidence_and_contacts(pkg, orc):
+    """a 12 mm sphere among 1 mm spheres (bins of 4 mm): the big sphere is registered in hundreds of bins and meets every
+    small neighbour in several of them; incidences, contact list and 40 steps of motion against the oracle"""
+    import math
+    r, R = 0.001, 0.012
+    b = pkg.model.packed_bed(9000, seed=31, cd_freq=0, scale=r, spacing_mult=2.02, jitter=0.01, three_sphere=False,
+                             aspect=(1.0, 1.0, 1.0), init_vz=0.0)
+    batch = b.batches[0]
+    c = (batch.xyz.min(0) + batch.xyz.max(0)) / 2
+    keep = np.linalg.norm(batch.xyz - c, axis=1) > (R + 0.9 * r)
+    for name in ("xyz", "vel", "angvel", "oriq", "family"):
+        setattr(batch, name, getattr(batch, name)[keep])
+    if isinstance(batch.templates, list):
+        batch.templates = [t for t, k in zip(batch.templates, keep) if k]
+    t = b.LoadSphereType(2.6e3 * 4 / 3 * math.pi * R ** 3, R, 0)
+    big = b.AddClumps(t, [c.tolist()])
+    big.SetVel(np.array([[0.3, 0.1, -0.5]], np.float32))
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.compute_margins(0), sim.compute_margins(0)
+    ctx.detect(), sim.detect()
+    gi, oi = ctx.bin_incidence(), sim.bin_incidence()
+    assert np.array_equal(gi[0], oi[0]) and np.array_equal(gi[1], oi[1])
+    big_sphere = int(sc.nSpheres) - 1
+    assert int((gi[1] == big_sphere).sum()) > 200  # bins the big sphere is registered in
+    assert_same_contacts(ctx, sim)
+    ctx.migrate(), sim.migrate()
+    ctx.step(40), sim.step(40)
+    a, bb, tt, *_ = assert_same_contacts(ctx, sim)
+    assert int(((a == big_sphere) | ((tt == 1) & (bb == big_sphere))).sum()) >= 10  # it has ploughed into its neighbours
+    gs, os_ = ctx.download_state(), sim.download_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(gs[k], os_[k]), k
