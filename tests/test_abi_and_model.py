@@ -32,14 +32,15 @@ def test_struct_layouts_match_header(pkg):
     # sizes computed by a C compiler from the real header
     import subprocess
     import tempfile
-    src = ('#include <stdio.h>\n#include "deme_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(DemeParams),'
-           'sizeof(DemeScene),sizeof(DemeOwnerState),sizeof(DemeCounts));}')
+    src = ('#include <stdio.h>\n#include "deme_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",sizeof(DemeParams),'
+           'sizeof(DemeScene),sizeof(DemeOwnerState),sizeof(DemeCounts),sizeof(DemeAdaptive));}')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o",
                                os.path.join(d, "s")])
         out = subprocess.check_output([os.path.join(d, "s")]).split()
-    got = [C.sizeof(pkg.DemeParams), C.sizeof(pkg.DemeScene), C.sizeof(pkg.DemeOwnerState), C.sizeof(pkg.DemeCounts)]
+    got = [C.sizeof(pkg.DemeParams), C.sizeof(pkg.DemeScene), C.sizeof(pkg.DemeOwnerState), C.sizeof(pkg.DemeCounts),
+           C.sizeof(pkg.abi.DemeAdaptive)]
     assert [int(x) for x in out] == got
 
 
