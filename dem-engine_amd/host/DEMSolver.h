@@ -446,6 +446,72 @@ class DEMSolver {
         check(deme_change_family(m_ctx, ID_from, ID_to));
         m_state_fresh = false;
     }
+    // ---- wildcard values (API.h:852-868, 936-1014).  Owner and geometry wildcards belong to a user force model
+    // (SetPerOwnerWildcards / SetPerGeometryWildcards); contact wildcards to whichever model runs.  Post-Initialize calls.
+    void SetOwnerWildcardValue(bodyID_t ownerID, const std::string& name, const std::vector<float>& vals) {
+        edit_wildcard(0, m_n_owners, m_force_model->owner_wildcards, name, [&](std::vector<float>& a) {
+            for (size_t k = 0; k < vals.size() && ownerID + k < a.size(); k++)
+                a[ownerID + k] = vals[k];
+        });
+    }
+    void SetOwnerWildcardValue(bodyID_t ownerID, const std::string& name, float val, size_t n = 1) {
+        SetOwnerWildcardValue(ownerID, name, std::vector<float>(n, val));
+    }
+    void SetFamilyOwnerWildcardValue(unsigned int N, const std::string& name, const std::vector<float>& vals) {
+        const std::vector<uint8_t> fam = owner_families();
+        edit_wildcard(0, m_n_owners, m_force_model->owner_wildcards, name, [&](std::vector<float>& a) {
+            size_t k = 0;  // one value: every member gets it; several: handed out in owner order
+            for (size_t o = 0; o < a.size(); o++)
+                if (fam[o] == N) {
+                    a[o] = vals[std::min(k, vals.size() - 1)];
+                    k++;
+                }
+        });
+    }
+    void SetFamilyOwnerWildcardValue(unsigned int N, const std::string& name, float val) {
+        SetFamilyOwnerWildcardValue(N, name, std::vector<float>(1, val));
+    }
+    std::vector<float> GetAllOwnerWildcardValue(const std::string& name) {
+        return get_wildcard(0, m_n_owners, m_force_model->owner_wildcards, name);
+    }
+    std::vector<float> GetOwnerWildcardValue(bodyID_t ownerID, const std::string& name, bodyID_t n = 1) {
+        const std::vector<float> a = GetAllOwnerWildcardValue(name);
+        return std::vector<float>(a.begin() + ownerID, a.begin() + std::min<size_t>(a.size(), (size_t)ownerID + n));
+    }
+    std::vector<float> GetFamilyOwnerWildcardValue(unsigned int N, const std::string& name) {
+        const std::vector<float> a = GetAllOwnerWildcardValue(name);
+        const std::vector<uint8_t> fam = owner_families();
+        std::vector<float> out;
+        for (size_t o = 0; o < a.size(); o++)
+            if (fam[o] == N)
+                out.push_back(a[o]);
+        return out;
+    }
+    void SetSphereWildcardValue(bodyID_t geoID, const std::string& name, const std::vector<float>& vals) {
+        set_geo(1, m_keep.sphOwner.size(), geoID, name, vals);
+    }
+    void SetTriWildcardValue(bodyID_t geoID, const std::string& name, const std::vector<float>& vals) {
+        set_geo(2, m_keep.triOwner.size(), geoID, name, vals);
+    }
+    void SetAnalWildcardValue(bodyID_t geoID, const std::string& name, const std::vector<float>& vals) {
+        set_geo(3, m_keep.objOwner.size(), geoID, name, vals);
+    }
+    std::vector<float> GetSphereWildcardValue(bodyID_t geoID, const std::string& name, size_t n) {
+        return get_geo(1, m_keep.sphOwner.size(), geoID, name, n);
+    }
+    std::vector<float> GetTriWildcardValue(bodyID_t geoID, const std::string& name, size_t n) {
+        return get_geo(2, m_keep.triOwner.size(), geoID, name, n);
+    }
+    std::vector<float> GetAnalWildcardValue(bodyID_t geoID, const std::string& name, size_t n) {
+        return get_geo(3, m_keep.objOwner.size(), geoID, name, n);
+    }
+    /// every contact of the current list (DEMSolver::SetContactWildcardValue, API.h:868)
+    void SetContactWildcardValue(const std::string& name, float val) { set_contact_wc(0, 0, 0, name, val); }
+    void SetFamilyContactWildcardValueEither(unsigned int N, const std::string& name, float val) { set_contact_wc(1, N, 0, name, val); }
+    void SetFamilyContactWildcardValueBoth(unsigned int N, const std::string& name, float val) { set_contact_wc(2, N, 0, name, val); }
+    void SetFamilyContactWildcardValue(unsigned int N1, unsigned int N2, const std::string& name, float val) {
+        set_contact_wc(3, N1, N2, name, val);
+    }
     // Persistent contacts (DEM/API.h:874-905): contacts of the current list that qualify stay in the list at every later
     // contact detection.  Like the reference these are post-Initialize calls.
     void MarkFamilyPersistentContactEither(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 1, N, 0, 1)); }
@@ -705,10 +771,17 @@ class DEMSolver {
     void SetOutputContent(unsigned int content) { m_out_content = content; }
     void SetContactOutputContent(unsigned int content) { m_cnt_out_content = content; }
     void WriteSphereFile(const std::string& outfilename) {
-        const Snapshot sn = snapshot(false);
+        Snapshot sn = snapshot(false);
+        if (m_out_content & OWNER_WILDCARD)
+            sn.ownerWc = wildcard_arrays(0, m_n_owners, m_force_model->owner_wildcards);
+        if (m_out_content & GEO_WILDCARD)
+            sn.sphereWc = wildcard_arrays(1, m_keep.sphOwner.size(), m_force_model->geo_wildcards);
         std::ostringstream o;
         o << "X,Y,Z,r";
         owner_header(o);
+        if (m_out_content & GEO_WILDCARD)  // dT.cpp:1297-1301
+            for (auto& n : m_force_model->geo_wildcards)
+                o << "," << n;
         o << "\n";
         for (size_t i = 0; i < m_keep.sphOwner.size(); i++) {
             const uint32_t ow = m_keep.sphOwner[i];
@@ -717,13 +790,17 @@ class DEMSolver {
             rotate(d, sn.q[ow]);
             const float3 pos = sn.com[ow] + d;
             o << pos.x << "," << pos.y << "," << pos.z << "," << m_keep.Radii[cp];
-            owner_columns(o, sn, ow);
+            owner_columns(o, sn, ow);  // (a sphere's owner wildcards are its owner's; the reference indexes them with the sphere id)
+            for (auto& arr : sn.sphereWc)
+                o << "," << arr[i];
             o << "\n";
         }
         flush(outfilename, o);
     }
     void WriteClumpFile(const std::string& outfilename, unsigned int accuracy = 10) {
-        const Snapshot sn = snapshot(false);
+        Snapshot sn = snapshot(false);
+        if (m_out_content & OWNER_WILDCARD)
+            sn.ownerWc = wildcard_arrays(0, m_n_owners, m_force_model->owner_wildcards);
         std::ostringstream o;
         o.precision(accuracy);
         o << "X,Y,Z,Qw,Qx,Qy,Qz,clump_type";
@@ -869,6 +946,66 @@ class DEMSolver {
     uint8_t m_family_flags[DEME_NUM_FAMILIES] = {0};
     DemeParams m_p{};
     size_t m_n_clumps = 0, m_n_owners = 0;
+    static uint32_t wc_slot(const std::set<std::string>& names, const std::string& name, const char* what) {
+        uint32_t j = 0;
+        for (auto it = names.begin(); it != names.end(); ++it, ++j)
+            if (*it == name)
+                return j;
+        throw std::runtime_error("no " + std::string(what) + " wildcard is named " + name);
+    }
+    std::vector<float> get_wildcard(uint32_t kind, size_t n, const std::set<std::string>& names, const std::string& name) {
+        std::vector<float> a(n, 0.f);
+        check(deme_download_wildcard_array(m_ctx, kind, wc_slot(names, name, kind ? "geometry" : "owner"), a.data(), n));
+        return a;
+    }
+    template <typename F>
+    void edit_wildcard(uint32_t kind, size_t n, const std::set<std::string>& names, const std::string& name, F&& edit) {
+        std::vector<float> a = get_wildcard(kind, n, names, name);
+        edit(a);
+        check(deme_upload_wildcard_array(m_ctx, kind, wc_slot(names, name, kind ? "geometry" : "owner"), a.data(), n));
+    }
+    void set_geo(uint32_t kind, size_t n, bodyID_t geoID, const std::string& name, const std::vector<float>& vals) {
+        edit_wildcard(kind, n, m_force_model->geo_wildcards, name, [&](std::vector<float>& a) {
+            for (size_t k = 0; k < vals.size() && geoID + k < a.size(); k++)
+                a[geoID + k] = vals[k];
+        });
+    }
+    std::vector<float> get_geo(uint32_t kind, size_t n_all, bodyID_t geoID, const std::string& name, size_t n) {
+        const std::vector<float> a = get_wildcard(kind, n_all, m_force_model->geo_wildcards, name);
+        return std::vector<float>(a.begin() + geoID, a.begin() + std::min(a.size(), (size_t)geoID + n));
+    }
+    std::vector<uint8_t> owner_families() {
+        std::vector<uint8_t> fam(m_n_owners);
+        DemeOwnerState st{};
+        st.familyID = fam.data();
+        check(deme_download_owner_state(m_ctx, &st));
+        return fam;
+    }
+    // mode 0 all, 1 either owner's family == N1, 2 both, 3 the pair (N1, N2): APIPrivate.cpp's setFamilyContactWildcardValue_impl
+    void set_contact_wc(int mode, unsigned int N1, unsigned int N2, const std::string& name, float val) {
+        const uint32_t w = wc_slot(m_force_model->contact_wildcards, name, "contact");
+        DemeCounts c{};
+        check(deme_get_counts(m_ctx, &c));
+        const size_t nc = (size_t)c.nContacts;
+        if (!nc)
+            return;
+        std::vector<uint32_t> a(nc), b(nc), map(nc);
+        std::vector<uint8_t> ty(nc);
+        check(deme_download_contacts(m_ctx, a.data(), b.data(), ty.data(), map.data(), nc));
+        std::vector<float> col(nc);
+        check(deme_download_contact_wildcard(m_ctx, w, col.data(), nc));
+        const std::vector<uint8_t> fam = owner_families();
+        for (size_t i = 0; i < nc; i++) {
+            const unsigned fA = fam[m_keep.sphOwner[a[i]]];
+            const unsigned fB = fam[ty[i] == DEME_SPHERE_SPHERE_CONTACT ? m_keep.sphOwner[b[i]]
+                                    : (ty[i] == DEME_SPHERE_MESH_CONTACT ? m_keep.triOwner[b[i]] : m_keep.objOwner[b[i]])];
+            const bool q = mode == 0 || (mode == 1 && (fA == N1 || fB == N1)) || (mode == 2 && fA == N1 && fB == N1) ||
+                           (mode == 3 && ((fA == N1 && fB == N2) || (fA == N2 && fB == N1)));
+            if (q)
+                col[i] = val;
+        }
+        check(deme_upload_contact_wildcard(m_ctx, w, col.data(), nc));
+    }
     bool m_initialized = false;
     // reference defaults of the controllers' knobs (DEM/Structs.h:204-216); both switched off until asked for
     DemeAdaptive m_adaptive{0u, 25u, 0.05f, 0.1f, 0.25f, 0.3f, 0u, 2500u, 4u};
@@ -983,6 +1120,7 @@ class DEMSolver {
         std::vector<uint8_t> type;
         std::vector<float> F, T, cpA;
         std::vector<std::vector<float>> wc;
+        std::vector<std::vector<float>> ownerWc, sphereWc;  // user-model owner / sphere wildcards (when the output asks for them)
     };
     static void require_csv(OUTPUT_FORMAT f) {
         if (f != OUTPUT_FORMAT::CSV)
@@ -1005,6 +1143,20 @@ class DEMSolver {
         if (fl & ACC) o << ",a_x,a_y,a_z";
         if (fl & ANG_ACC) o << ",alpha_x,alpha_y,alpha_z";
         if (fl & FAMILY) o << ",family";
+        if (fl & OWNER_WILDCARD)  // dT.cpp:1292-1296: named as the force model names them
+            for (auto& n : m_force_model->owner_wildcards)
+                o << "," << n;
+    }
+    // owner (kind 0) / sphere (kind 1) wildcard arrays of the user force model, in the model's name order
+    std::vector<std::vector<float>> wildcard_arrays(uint32_t kind, size_t n_elem, const std::set<std::string>& names) const {
+        std::vector<std::vector<float>> out;
+        uint32_t j = 0;
+        for (auto it = names.begin(); it != names.end(); ++it, ++j) {
+            out.emplace_back(n_elem, 0.f);
+            if (m_force_model->type == FORCE_MODEL::CUSTOM)
+                const_cast<DEMSolver*>(this)->check(deme_download_wildcard_array(m_ctx, kind, j, out.back().data(), n_elem));
+        }
+        return out;
     }
     void owner_columns(std::ostringstream& o, const Snapshot& sn, size_t i) const {
         const unsigned fl = m_out_content;
@@ -1016,6 +1168,9 @@ class DEMSolver {
         if (fl & ACC) o << "," << sn.a[i].x << "," << sn.a[i].y << "," << sn.a[i].z;
         if (fl & ANG_ACC) o << "," << sn.al[i].x << "," << sn.al[i].y << "," << sn.al[i].z;
         if (fl & FAMILY) o << "," << +sn.fam[i];
+        if (fl & OWNER_WILDCARD)
+            for (auto& arr : sn.ownerWc)
+                o << "," << arr[i];
     }
     static void flush(const std::string& path, const std::ostringstream& o) {
         std::ofstream f(path, std::ios::out);

@@ -111,8 +111,12 @@ def _write_table(path, header, cols, prec, text_cols=()):
             f.write(",".join(row) + "\n")
 
 
-def write_sphere_file(path, p, arrays, counts, state, flags=DEFAULT_OUTPUT_CONTENT, no_output_families=()):
-    """DEMSolver::WriteSphereFile -> writeSpheresAsCsv (dT.cpp:1254-1405): one row per sphere component."""
+def write_sphere_file(path, p, arrays, counts, state, flags=DEFAULT_OUTPUT_CONTENT, no_output_families=(), owner_wildcards=None,
+                      geo_wildcards=None):
+    """DEMSolver::WriteSphereFile -> writeSpheresAsCsv (dT.cpp:1254-1405): one row per sphere component.
+    owner_wildcards / geo_wildcards: {name: per-owner array} / {name: per-sphere array}, written after the family column when
+    the OWNER_WILDCARD / GEO_WILDCARD bits are set (dT.cpp:1292-1301, 1386-1398).  The owner value of a sphere's row is its
+    OWNER's (the reference indexes the owner array with the sphere id there, dT.cpp:1390 -- not reproduced)."""
     owner = np.asarray(arrays["ownerClumpBody"], np.int64)
     keep = ~np.isin(state["familyID"][owner], list(no_output_families))
     owner = owner[keep]
@@ -123,14 +127,21 @@ def write_sphere_file(path, p, arrays, counts, state, flags=DEFAULT_OUTPUT_CONTE
     header = ["X", "Y", "Z", "r"]
     cols = [pos[:, 0], pos[:, 1], pos[:, 2], np.asarray(arrays["Radii"], np.float32)[comp]]
     names, extra = _owner_columns(flags, state, owner, 6)
+    if flags & OUTPUT_CONTENT.OWNER_WILDCARD:
+        for name, arr in (owner_wildcards or {}).items():
+            names.append(name), extra.append(np.asarray(arr, np.float32)[owner])
+    if flags & OUTPUT_CONTENT.GEO_WILDCARD:
+        for name, arr in (geo_wildcards or {}).items():
+            names.append(name), extra.append(np.asarray(arr, np.float32)[keep])
     _write_table(path, header + names, cols + extra, 6)
     return len(owner)
 
 
 def write_clump_file(path, p, arrays, counts, state, template_names, flags=DEFAULT_OUTPUT_CONTENT, accuracy=10,
-                     no_output_families=()):
+                     no_output_families=(), owner_wildcards=None):
     """DEMSolver::WriteClumpFile -> writeClumpsAsCsv (dT.cpp:1491-1618): one row per clump owner; xyz, quaternion
-    and clump_type are always written."""
+    and clump_type are always written; owner wildcards ({name: per-owner array}) follow the family column when the
+    OWNER_WILDCARD bit is set (dT.cpp:1526-1530, 1605-1611)."""
     n = int(counts["nOwnerClumps"])
     owners = np.arange(n)
     owners = owners[~np.isin(state["familyID"][:n], list(no_output_families))]
@@ -140,6 +151,9 @@ def write_clump_file(path, p, arrays, counts, state, template_names, flags=DEFAU
     header = ["X", "Y", "Z", "Qw", "Qx", "Qy", "Qz", "clump_type"]
     cols = [com[:, 0], com[:, 1], com[:, 2], q[:, 0], q[:, 1], q[:, 2], q[:, 3], [template_names[int(m)] for m in marks]]
     names, extra = _owner_columns(flags, state, owners, accuracy)
+    if flags & OUTPUT_CONTENT.OWNER_WILDCARD:
+        for name, arr in (owner_wildcards or {}).items():
+            names.append(name), extra.append(np.asarray(arr, np.float32)[owners])
     _write_table(path, header + names, cols + extra, accuracy, text_cols=(7,))
     return len(owners)
 

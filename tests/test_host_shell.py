@@ -103,3 +103,32 @@ def test_mesh_demo_obj_prescription_deformation_vtk(tmp_path):
     assert abs(pts[:, 0].mean() - 0.1) < 1e-6 and abs(pts[:, 2].min() - vals["plate_z"]) < 1e-5
     assert abs(pts[:, 2].max() - (vals["plate_z"] + 0.15 * 0.06 ** 2)) < 1e-5
     assert f"CELLS {2 * n * n} {8 * n * n}" in vtk and f"CELL_TYPES {2 * n * n}" in vtk
+
+
+@pytest.mark.gpu
+def test_custom_model_demo_wildcards_from_the_script(tmp_path):
+    """demo_custom.cpp: DefineContactForceModel with contact / owner / geometry wildcards, the script-side setters and getters
+    (SetSphereWildcardValue, SetOwnerWildcardValue, SetFamilyOwnerWildcardValue, Get*, SetFamilyContactWildcardValueBoth) and
+    the OWNER_WILDCARD / GEO_WILDCARD / CNT_WILDCARD output columns"""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(HOST, "demo_custom"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DEMO_OK" in out.stdout, out.stdout + out.stderr
+    chk = {l.split()[1]: l.split()[2:] for l in out.stdout.splitlines() if l.startswith("CHECK")}
+    assert chk["charge"] == ["1.0", "-1.0", "1.0", "-1.0"]
+    assert chk["n_touch_before"] == ["1000.0", "100.0", "1000.0", "0.0"]  # owners 2..5: family 2 = even owners, 3 set by id
+    total = float(chk["n_touch_total"][0])
+    n_own = int(chk["n_touch_total"][4])
+    assert n_own == 601 and int(chk["n_touch_total"][2]) == 300  # 600 clumps + the wall owner; family 1 = odd clumps
+    assert total > 300 * 1000 + 100 + 1000  # the counters grew on top of what the script put there
+    sph = np.genfromtxt(tmp_path / "spheres.csv", delimiter=",", names=True)
+    assert sph.dtype.names == ("X", "Y", "Z", "r", "family", "n_touch", "charge")
+    assert np.array_equal(sph["charge"], np.where(np.arange(600) % 2 == 0, 1.0, -1.0))
+    assert 0.9 * total < sph["n_touch"].sum() <= total  # one sphere per clump here; the rest is the wall owner's counter
+    clp = open(tmp_path / "clumps.csv").readline().strip()
+    assert clp == "X,Y,Z,Qw,Qx,Qy,Qz,clump_type,family,n_touch"
+    cnt = np.genfromtxt(tmp_path / "contacts.csv", delimiter=",", names=True, dtype=None, encoding="utf8")
+    assert cnt.dtype.names == ("contact_type", "A", "B", "f_x", "f_y", "f_z", "contact_age")
+    ss = cnt["contact_type"] == "SS"
+    both1 = ss & (cnt["A"] % 2 == 1) & (cnt["B"] % 2 == 1)
+    assert both1.sum() > 0 and (cnt["contact_age"][both1] == -1.0).all()
+    assert (cnt["contact_age"][ss & ~both1] >= 0.0).all()

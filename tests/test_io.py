@@ -72,7 +72,22 @@ def test_writers_headers_and_round_trip(pkg, orc, tmp_path):
     assert np.abs(rows[::3, :3] - X[own[::3]]).max() < 0.012  # a component sits within the clump's extent
     assert np.allclose(rows[:, 3], b.arrays["Radii"][b.arrays["clumpComponentOffset"]], rtol=1e-5)
 
+    # owner / geometry wildcard columns (OWNER_WILDCARD, GEO_WILDCARD) follow the family column, named as the model names them
+    nO, nS = int(b.counts["nOwners"]), int(b.counts["nSpheres"])
+    ow = {"mu_custom": np.linspace(0.1, 0.9, nO, dtype=np.float32), "cohesion": np.arange(nO, dtype=np.float32)}
+    gw = {"wear": np.arange(nS, dtype=np.float32) * 0.5}
+    io.write_sphere_file(sph, p, b.arrays, b.counts, st, flags=allf.FAMILY | allf.OWNER_WILDCARD | allf.GEO_WILDCARD,
+                         owner_wildcards=ow, geo_wildcards=gw)
+    assert open(sph).readline().strip() == "X,Y,Z,r,family,mu_custom,cohesion,wear"
+    rows = np.loadtxt(sph, delimiter=",", skiprows=1)
+    assert np.allclose(rows[:, 5], ow["mu_custom"][own], rtol=1e-5) and np.array_equal(rows[:, 6], ow["cohesion"][own])
+    assert np.array_equal(rows[:, 7], gw["wear"])
+    io.write_sphere_file(sph, p, b.arrays, b.counts, st, flags=allf.FAMILY, owner_wildcards=ow, geo_wildcards=gw)
+    assert open(sph).readline().strip() == "X,Y,Z,r,family"  # bits not set: no columns
+
     clp = tmp_path / "clumps.csv"
+    io.write_clump_file(clp, p, b.arrays, b.counts, st, b.template_names, flags=allf.OWNER_WILDCARD, owner_wildcards=ow)
+    assert open(clp).readline().strip() == "X,Y,Z,Qw,Qx,Qy,Qz,clump_type,mu_custom,cohesion"
     nc = io.write_clump_file(clp, p, b.arrays, b.counts, st, b.template_names, flags=allf.ABSV | allf.VEL | allf.ANG_VEL)
     assert nc == b.counts["nOwnerClumps"]
     assert open(clp).readline().strip() == "X,Y,Z,Qw,Qx,Qy,Qz,clump_type,absv,v_x,v_y,v_z,w_x,w_y,w_z"
