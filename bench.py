@@ -181,6 +181,7 @@ class Halo:
         self.buf = {k: torch.empty(max(1, len(part[k])) * gb, dtype=torch.uint8, device=dev) for k in keys}
         self.n = {k: len(part[k]) for k in keys}
         self.bytes_per_step = gb * (self.n["send_left"] + self.n["send_right"])
+        self._plan = None
 
     def step(self):
         """one time step including the ghost exchange"""
@@ -188,19 +189,25 @@ class Halo:
             self.exchange()
             self.ctx.step(1)
             return
-        c, d = self.ctx, self.dist
+        c = self.ctx
+        if self._plan is None:  # pointers, counts and the P2P op list never change: built once (the loop body is host-bound work)
+            sides = [(s, nb) for s, nb in (("left", self.rank - 1), ("right", self.rank + 1)) if 0 <= nb < self.world]
+            pack = [(self.ids["send_" + s].data_ptr(), self.n["send_" + s], self.buf["send_" + s].data_ptr()) for s, _ in sides]
+            unpack = [(self.ids["recv_" + s].data_ptr(), self.n["recv_" + s], self.buf["recv_" + s].data_ptr()) for s, _ in sides]
+            ops = []
+            for s, nb in sides:
+                ops.append(self.dist.P2POp(self.dist.isend, self.buf["send_" + s], nb))
+                ops.append(self.dist.P2POp(self.dist.irecv, self.buf["recv_" + s], nb))
+            self._plan = (pack, unpack, ops)
+        pack, unpack, ops = self._plan
         c.step_overlap_begin()
-        sides = [(s, nb) for s, nb in (("left", self.rank - 1), ("right", self.rank + 1)) if 0 <= nb < self.world]
-        ops = []
-        for side, nb in sides:
-            c.halo_pack_async(self.ids["send_" + side].data_ptr(), self.n["send_" + side], self.buf["send_" + side].data_ptr())
-            ops.append(d.P2POp(d.isend, self.buf["send_" + side], nb))
-            ops.append(d.P2POp(d.irecv, self.buf["recv_" + side], nb))
+        for a in pack:
+            c.halo_pack_async(*a)
         with self.torch.cuda.stream(self.halo_stream):  # RCCL orders the transfers against the halo stream
-            for w in d.batch_isend_irecv(ops):
+            for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
-        for side, nb in sides:
-            c.halo_unpack_async(self.ids["recv_" + side].data_ptr(), self.n["recv_" + side], self.buf["recv_" + side].data_ptr())
+        for a in unpack:
+            c.halo_unpack_async(*a)
         c.step_overlap_end()
 
     def exchange(self):
