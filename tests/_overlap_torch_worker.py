@@ -55,6 +55,13 @@ def main():
     send = [torch.empty(max(1, n01) * gb, dtype=torch.uint8, device=dev), torch.empty(max(1, n10) * gb, dtype=torch.uint8, device=dev)]
     recv = [torch.empty(max(1, n10) * gb, dtype=torch.uint8, device=dev), torch.empty(max(1, n01) * gb, dtype=torch.uint8, device=dev)]
     packed = [torch.cuda.Event(), torch.cuda.Event()]
+    delivered = torch.cuda.Event()
+    use_rccl = os.environ.get("DEME_OVERLAP_TEST_RCCL") == "1"
+    if use_rccl:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     n_split = 0
     for _ in range(steps):
         n_split += sum(int(not c.step_overlap_begin()) for c in over)
@@ -62,10 +69,22 @@ def main():
         over[1].halo_pack_async(ids[1]["send_left"].data_ptr(), n10, send[1].data_ptr())
         for r in (0, 1):
             packed[r].record(ext[r])  # "send posted": the peer's receive may proceed once my pack has run
-        for r in (0, 1):
-            with torch.cuda.stream(ext[r]):
-                ext[r].wait_event(packed[1 - r])
-                recv[r].copy_(send[1 - r], non_blocking=True)  # what irecv delivers
+        if use_rccl:
+            # both slabs' ghost records through RCCL itself: a world-size-1 communicator delivers a send to self to the receive
+            # posted in the same group, in order -- send[0] -> recv[1], send[1] -> recv[0].  One batch on slab 0's halo stream.
+            with torch.cuda.stream(ext[0]):
+                ext[0].wait_event(packed[1])
+                ops = [dist.P2POp(dist.isend, send[0], 0), dist.P2POp(dist.irecv, recv[1], 0),
+                       dist.P2POp(dist.isend, send[1], 0), dist.P2POp(dist.irecv, recv[0], 0)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                delivered.record(ext[0])
+            ext[1].wait_event(delivered)
+        else:
+            for r in (0, 1):
+                with torch.cuda.stream(ext[r]):
+                    ext[r].wait_event(packed[1 - r])
+                    recv[r].copy_(send[1 - r], non_blocking=True)  # what irecv delivers
         over[0].halo_unpack_async(ids[0]["recv_right"].data_ptr(), n10, recv[0].data_ptr())
         over[1].halo_unpack_async(ids[1]["recv_left"].data_ptr(), n01, recv[1].data_ptr())
         over[0].step_overlap_end(), over[1].step_overlap_end()
@@ -78,7 +97,9 @@ def main():
         for k in GKEYS:
             assert np.array_equal(sa[k], sb[k]), k
         assert int(a.counts().nContacts) == int(c.counts().nContacts) > 100
-    print("OVERLAP_TORCH_OK split steps", n_split)
+    print("OVERLAP_TORCH_OK split steps", n_split, "through RCCL" if use_rccl else "through device copies")
+    if use_rccl:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -387,3 +387,15 @@ def test_overlapped_exchange_through_torch_streams():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_overlap_torch_worker.py")], capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0 and "OVERLAP_TORCH_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_overlapped_exchange_through_rccl_on_one_gpu():
+    """the same two-slab run with the ghost records travelling through RCCL itself (torch.distributed, backend nccl): a
+    world-size-1 communicator matches a send to self with the receive posted in the same group, so slab 0's records reach slab
+    1's buffer and vice versa -- isend / irecv / batch / wait on the context's halo stream (a torch ExternalStream), exactly the
+    calls bench.py makes per step; bit-identical to the ordered exchange"""
+    env = dict(os.environ, DEME_OVERLAP_TEST_RCCL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_overlap_torch_worker.py")], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0 and "OVERLAP_TORCH_OK" in out.stdout and "through RCCL" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
