@@ -1177,9 +1177,14 @@ int deme_calc_forces(deme_ctx* c) {
     return DEME_OK;
 }
 
+static int launch_family_rules(deme_ctx* c, const AccRec* accp);
+
 int deme_integrate(deme_ctx* c) {
     if (int rc = check_ready(c))
         return rc;
+    if (c->rulesFn)  // routineChecks(): family changes sit between the force evaluation and the integration (dT.cpp:2437-2443)
+        if (int rc = launch_family_rules(c, c->acc.as<AccRec>()))  // the staged path always has a/alpha stored
+            return rc;
     if (int rc = launch_integrate(c, false))  // from the stored a/alpha
         return rc;
     c->nSteps++;
@@ -1344,6 +1349,15 @@ int deme_step(deme_ctx* c, uint32_t nsteps) {
     return DEME_OK;
 }
 
+static int launch_family_rules(deme_ctx* c, const AccRec* accp) {
+    OwnerRec* ow = c->owners.as<OwnerRec>();
+    uint32_t n = c->nOwners;
+    float t = (float)c->timeElapsed;
+    void* args[] = {&c->dp, &ow, &accp, &n, &t};
+    HIPCK(hipModuleLaunchKernel(c->rulesFn, grid_for(n), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+    return DEME_OK;
+}
+
 // rules + integration + bookkeeping of one step (after the force evaluation)
 static int step_tail(deme_ctx* c) {
     {
@@ -1355,11 +1369,8 @@ static int step_tail(deme_ctx* c) {
                 accp = c->acc.as<AccRec>();
                 fused = false;
             }
-            OwnerRec* ow = c->owners.as<OwnerRec>();
-            uint32_t n = c->nOwners;
-            float t = (float)c->timeElapsed;
-            void* args[] = {&c->dp, &ow, &accp, &n, &t};
-            HIPCK(hipModuleLaunchKernel(c->rulesFn, grid_for(n), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+            if (int rc = launch_family_rules(c, accp))
+                return rc;
         }
         if (int rc = launch_integrate(c, fused))
             return rc;

@@ -155,6 +155,15 @@ def test_gpu_family_changes_match_oracle(pkg, orc):
     Y = pkg.model.decode_positions(os_["voxelID"], os_["locX"], os_["locY"], os_["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
     assert np.abs(X - Y).max() == 0.0  # bit-identical trajectories
     assert np.all(gs["vZ"][:n][gs["familyID"][:n] == 5] == 0)
+    # the staged calls (margins / detect / migrate / forces / integrate) apply the rules in the same place as deme_step
+    staged = pkg.Context(0)
+    staged.set_params(p), staged.upload_scene(sc)
+    b.compile_into(staged)
+    for _ in range(150):
+        staged.compute_margins(int(p.cdUpdateFreq)), staged.detect(), staged.migrate(), staged.calc_forces(), staged.integrate()
+    ss = staged.download_state()
+    for k in ("familyID", "voxelID", "locX", "locY", "locZ", "vX", "vY", "vZ"):
+        assert np.array_equal(ss[k], gs[k]), k
     ctx.change_family(6, 0), sim.change_family(6, 0)
     assert np.array_equal(ctx.download_state()["familyID"], sim.download_state()["familyID"])
     # a rule that reads the contact acceleration makes the step reduce a/alpha before the rules run
