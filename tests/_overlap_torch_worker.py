@@ -1,8 +1,8 @@
-"""Worker for tests/test_decomp.py::test_overlapped_exchange_through_torch_streams (GPU).  One process, two contexts (two
-slabs) on one GPU; the ghost records travel between them with torch copies enqueued on torch ExternalStreams wrapping
-the contexts' halo streams -- the same stream / event choreography bench.py uses around RCCL's isend / irecv, minus the
-communicator (which needs one GPU per rank).  torch is imported first: importing it after libdeme_hip.so would bring a
-second ROCm runtime into the process."""
+"""Worker for tests/test_decomp.py::test_overlapped_exchange_through_torch_streams / _through_rccl_on_one_gpu (GPU).  One
+process, two contexts (two slabs) on one GPU; the ghost records travel between them on torch ExternalStreams wrapping the
+contexts' halo streams -- the stream / event choreography bench.py uses -- either as device copies or
+(DEME_OVERLAP_TEST_RCCL=1) through RCCL itself: a world-size-1 nccl group delivers a send to self to the receive posted in the
+same batch.  torch is imported first: importing it after libdeme_hip.so would bring a second ROCm runtime into the process."""
 import os
 import sys
 
