@@ -193,6 +193,8 @@ def load_library():
         "deme_get_adaptive_state": [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "deme_mark_persistent_contacts": [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_int],
         "deme_num_persistent_contacts": [_P, C.POINTER(C.c_size_t)],
+        "deme_download_persistent_contacts": [_P, _P, _P, _P, C.c_size_t],
+        "deme_upload_persistent_contacts": [_P, _P, _P, _P, C.c_size_t],
         "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)],
         "deme_compile_region": [_P, C.c_char_p, C.POINTER(C.c_int)],
         "deme_inspect_region": [_P, C.c_uint32, C.c_int, C.POINTER(C.c_float)],
@@ -432,6 +434,17 @@ class Context:
         n = C.c_size_t(0)
         self._ck(self.lib.deme_num_persistent_contacts(self.h, C.byref(n)), "deme_num_persistent_contacts")
         return int(n.value)
+
+    def persistent_contacts(self):
+        """the marked set as (idA, idB, type) arrays"""
+        n = self.num_persistent_contacts()
+        a, b, t = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        self._ck(self.lib.deme_download_persistent_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), n), "deme_download_persistent_contacts")
+        return a, b, t
+
+    def set_persistent_contacts(self, idA, idB, ctype):
+        a, b, t = np.ascontiguousarray(idA, np.uint32), np.ascontiguousarray(idB, np.uint32), np.ascontiguousarray(ctype, np.uint8)
+        self._ck(self.lib.deme_upload_persistent_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), len(a)), "deme_upload_persistent_contacts")
 
     def compile_prescriptions(self, vel_cases, pos_cases, acc_cases):
         """Family motion prescriptions: the three switch bodies of equipFamilyPrescribedMotions (see include/deme_hip.h)."""

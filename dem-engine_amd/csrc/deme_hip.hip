@@ -1869,6 +1869,55 @@ int deme_mark_persistent_contacts(deme_ctx* c, int mode, uint32_t N1, uint32_t N
     return DEME_OK;
 }
 
+int deme_download_persistent_contacts(deme_ctx* c, uint32_t* idA, uint32_t* idB, uint8_t* type, size_t cap) {
+    if (int rc = check_ready(c))
+        return rc;
+    const size_t n = c->hPersist.size();
+    if (cap < n)
+        return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t k = c->hPersist[i];
+        const uint32_t cls = key_class(k);
+        if (idA)
+            idA[i] = key_a(k);
+        if (idB)
+            idB[i] = key_b(k);
+        if (type)
+            type[i] = cls == DEME_KEY_CLASS_SS   ? DEME_SPHERE_SPHERE_CONTACT
+                      : cls == DEME_KEY_CLASS_SM ? DEME_SPHERE_MESH_CONTACT
+                      : (c->hObjType[key_b(k)] == DEME_ANAL_OBJ_TYPE_PLANE ? DEME_SPHERE_PLANE_CONTACT : DEME_SPHERE_CYL_CONTACT);
+    }
+    return DEME_OK;
+}
+
+int deme_upload_persistent_contacts(deme_ctx* c, const uint32_t* idA, const uint32_t* idB, const uint8_t* type, size_t n) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (n && (!idA || !idB || !type))
+        return fail(c, DEME_ERR_INVALID, "deme_upload_persistent_contacts: null input");
+    if (n && c->hp.nContactWildcards == 0)
+        return fail(c, DEME_ERR_INVALID, "persistent contacts cannot be marked with a history-less force model");
+    std::vector<uint64_t> keys(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t cls = (type[i] == 1) ? DEME_KEY_CLASS_SS : (type[i] == 2) ? DEME_KEY_CLASS_SM : DEME_KEY_CLASS_SA;
+        const uint32_t nB = (cls == DEME_KEY_CLASS_SS) ? c->dp.nSpheres : (cls == DEME_KEY_CLASS_SM) ? c->dp.nTri : c->dp.nAnal;
+        if (idA[i] >= c->dp.nSpheres || idB[i] >= nB)
+            return fail(c, DEME_ERR_INVALID, "deme_upload_persistent_contacts: pair %zu (%u, %u, type %u) is out of range", i, idA[i],
+                        idB[i], (unsigned)type[i]);
+        keys[i] = make_key(cls, idA[i], idB[i]);
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    c->hPersist.swap(keys);
+    if (!c->hPersist.empty()) {
+        if (int rc = ensure(c, c->persistKeys, c->hPersist.size() * 8))
+            return rc;
+        HIPCK(hipMemcpyAsync(c->persistKeys.p, c->hPersist.data(), c->hPersist.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+    }
+    return DEME_OK;
+}
+
 int deme_num_persistent_contacts(deme_ctx* c, size_t* n) {
     if (!c || !n)
         return DEME_ERR_INVALID;

@@ -122,33 +122,80 @@ def exchange_host(parts, states):
 
 
 # ---- re-decomposition (migration of clumps and of their contact history between ranks) --------------------------
-def owned_payload(part, state, contacts, wildcards, flip_sign_wildcards=(0, 1, 2)):
-    """What one rank contributes to a re-decomposition: the state of its OWN clumps and its share of the contact
-    history in global ids.  A sphere-sphere pair is reported once, by the rank that owns the clump of the globally
-    smaller sphere id, stored (smaller, larger); where the local numbering had it the other way round the B-to-A
-    vector wildcards (flip_sign_wildcards) change sign.  Sphere-analytical contacts go with sphere A's owner.
-    contacts = (idA, idB, type[, map]) local; wildcards = float[n, nW]."""
-    n_own = part["n_own"]
-    own_state = {k: np.asarray(state[k])[:n_own].copy() for k in GHOST_STATE_KEYS}
-    idA, idB, ctype = (np.asarray(x) for x in contacts[:3])
-    W = np.asarray(wildcards, np.float32).reshape(len(idA), -1)
+def _globalise_pairs(part, idA, idB, ctype):
+    """local (A, B, type) pairs -> global sphere ids, stored (smaller, larger) for sphere-sphere pairs.  Returns
+    (mine, gA, gB, flipped): `mine` marks the pairs this rank reports (it owns the clump of the globally smaller sphere;
+    sphere-analytical / sphere-mesh pairs go with sphere A's owner), `flipped` the pairs whose local order was the other way."""
     local_owner = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
     sg = part["sphere_global"]
     ss = ctype == 1
     gA = sg[idA]
-    gB = np.where(ss, sg[np.where(ss, idB, 0)], idB.astype(np.int64))  # analytical component ids are global already
+    gB = np.where(ss, sg[np.where(ss, idB, 0)], idB.astype(np.int64))  # analytical component / triangle ids are global already
     flipped = ss & (gA > gB)
     lo_local = np.where(flipped, idB, idA)  # local id of the sphere that is sphere A in the global numbering
-    mine = local_owner[np.where(ss, lo_local, idA)] < n_own
-    gA2 = np.where(flipped, gB, gA)[mine]
-    gB2 = np.where(flipped, gA, gB)[mine]
+    mine = local_owner[np.where(ss, lo_local, idA)] < part["n_own"]
+    return mine, np.where(flipped, gB, gA), np.where(flipped, gA, gB), flipped
+
+
+def owned_payload(part, state, contacts, wildcards, flip_sign_wildcards=(0, 1, 2), persistent=None, owner_wildcards=None,
+                  sphere_wildcards=None):
+    """What one rank contributes to a re-decomposition: the state of its OWN clumps and its share of the contact
+    history in global ids.  A sphere-sphere pair is reported once, by the rank that owns the clump of the globally
+    smaller sphere id, stored (smaller, larger); where the local numbering had it the other way round the B-to-A
+    vector wildcards (flip_sign_wildcards) change sign.  Sphere-analytical contacts go with sphere A's owner.
+    contacts = (idA, idB, type[, map]) local; wildcards = float[n, nW].  Optional: persistent = (idA, idB, type) of the marked
+    contacts (Context.persistent_contacts()); owner_wildcards / sphere_wildcards = {name: per-local-owner / per-local-sphere
+    array} of a user force model -- the values of this rank's own clumps travel, replicated owners (walls, meshes) keep
+    whatever each rank holds."""
+    n_own = part["n_own"]
+    own_state = {k: np.asarray(state[k])[:n_own].copy() for k in GHOST_STATE_KEYS}
+    idA, idB, ctype = (np.asarray(x) for x in contacts[:3])
+    W = np.asarray(wildcards, np.float32).reshape(len(idA), -1)
+    mine, gA, gB, flipped = _globalise_pairs(part, idA, idB, ctype)
     Wm = W[mine].copy()
     fm = flipped[mine]
     for k in flip_sign_wildcards:
         if k < Wm.shape[1]:
             Wm[fm, k] = -Wm[fm, k]
-    return {"global_ids": np.asarray(part["global_ids"], np.int64), "state": own_state, "gA": gA2, "gB": gB2, "type": ctype[mine],
-            "wc": Wm}
+    out = {"global_ids": np.asarray(part["global_ids"], np.int64), "state": own_state, "gA": gA[mine], "gB": gB[mine],
+           "type": ctype[mine], "wc": Wm}
+    if persistent is not None:
+        pA, pB, pT = (np.asarray(x) for x in persistent[:3])
+        pm, pgA, pgB, _ = _globalise_pairs(part, pA, pB, pT)
+        out["persistent"] = (pgA[pm], pgB[pm], pT[pm])
+    local_owner = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
+    n_own_sph = int((local_owner < n_own).sum())  # spheres are clump-major and a rank's own clumps come first
+    n_clumps_here = int(part["counts"]["nOwnerClumps"])
+    if owner_wildcards:
+        out["owner_wc"] = {k: np.asarray(v, np.float32)[:n_own].copy() for k, v in owner_wildcards.items()}
+        out["owner_wc_replicated"] = {k: np.asarray(v, np.float32)[n_clumps_here:].copy() for k, v in owner_wildcards.items()}
+    if sphere_wildcards:
+        out["sphere_wc"] = {k: np.asarray(v, np.float32)[:n_own_sph].copy() for k, v in sphere_wildcards.items()}
+        out["sphere_global_own"] = np.asarray(part["sphere_global"], np.int64)[:n_own_sph].copy()
+    return out
+
+
+def _localise_pairs(part, n_sph_global, gA, gB, ty):
+    """global pairs -> this part's local sphere ids: (keep, la, lb, flip) for the pairs with an owned clump on either side"""
+    loc = np.full(n_sph_global, -1, np.int64)
+    loc[part["sphere_global"]] = np.arange(len(part["sphere_global"]))
+    owner_local = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
+    a = loc[gA]
+    ss = ty == 1
+    b = np.where(ss, loc[np.where(ss, gB, 0)], gB)
+    present = (a >= 0) & (b >= 0)
+    own_a = np.zeros(len(a), bool)
+    own_a[present] = owner_local[a[present]] < part["n_own"]
+    own_b = np.zeros(len(a), bool)
+    sel = present & ss
+    own_b[sel] = owner_local[b[sel]] < part["n_own"]
+    keep = present & (own_a | own_b)  # ghost-ghost pairs and contacts of foreign clumps stay with their owners
+    # a sphere-sphere pair is stored with the smaller sphere id first (DEMContactKernels_SphereSphere.cu:199-207):
+    # the local numbering may flip it
+    la, lb = a[keep].copy(), b[keep].copy()
+    flip = (ty[keep] == 1) & (la > lb)
+    la[flip], lb[flip] = lb[flip], la[flip].copy()
+    return keep, la, lb, flip
 
 
 def redecompose(global_arrays, counts, payloads, n_ranks, halo, decode_x, flip_sign_wildcards=(0, 1, 2)):
@@ -156,7 +203,10 @@ def redecompose(global_arrays, counts, payloads, n_ranks, halo, decode_x, flip_s
     decode_x(arrays) -> world x of every clump centre.  Returns (global_arrays_now, new_parts, seeds) where
     seeds[r] = (idA, idB, type, wildcards) in rank r's new local sphere ids, ready for seed_contacts().
     flip_sign_wildcards: wildcards that are vectors from B to A (the Hertzian model's delta_tan_x/y/z, indices 0-2 in
-    its alphabetical order): they change sign when a rank's local numbering stores the pair the other way round."""
+    its alphabetical order): they change sign when a rank's local numbering stores the pair the other way round.
+    When the payloads carry them, new_parts[r] also gets "persistent" = (idA, idB, type) for set_persistent_contacts() and
+    "owner_wc" / "sphere_wc" = {name: array in rank r's new local numbering} for set_wildcard_array() (ghost copies included:
+    the force model reads B's owner through them)."""
     g = dict(global_arrays)
     for k in GHOST_STATE_KEYS:
         g[k] = np.array(global_arrays[k], copy=True)
@@ -169,31 +219,38 @@ def redecompose(global_arrays, counts, payloads, n_ranks, halo, decode_x, flip_s
     ty = np.concatenate([pl["type"] for pl in payloads])
     wc = np.concatenate([pl["wc"] for pl in payloads]) if payloads else np.zeros((0, 0), np.float32)
     n_sph_global = len(global_arrays["ownerClumpBody"])
+    n_clumps_global = int(counts["nOwnerClumps"])
     seeds = []
     for part in parts:
-        loc = np.full(n_sph_global, -1, np.int64)
-        loc[part["sphere_global"]] = np.arange(len(part["sphere_global"]))
-        owner_local = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
-        a = loc[gA]
-        ss = ty == 1
-        b = np.where(ss, loc[np.where(ss, gB, 0)], gB)
-        present = (a >= 0) & (b >= 0)
-        own_a = np.zeros(len(a), bool)
-        own_a[present] = owner_local[a[present]] < part["n_own"]
-        own_b = np.zeros(len(a), bool)
-        sel = present & ss
-        own_b[sel] = owner_local[b[sel]] < part["n_own"]
-        keep = present & (own_a | own_b)  # ghost-ghost pairs and contacts of foreign clumps stay with their owners
-        # a sphere-sphere pair is stored with the smaller sphere id first (DEMContactKernels_SphereSphere.cu:199-207):
-        # the local numbering may flip it
-        la, lb = a[keep].copy(), b[keep].copy()
-        flip = (ty[keep] == 1) & (la > lb)
-        la[flip], lb[flip] = lb[flip], la[flip].copy()
+        keep, la, lb, flip = _localise_pairs(part, n_sph_global, gA, gB, ty)
         w = wc[keep].copy()
         for k in flip_sign_wildcards:
             if k < w.shape[1]:
                 w[flip, k] = -w[flip, k]
         seeds.append((la.astype(np.uint32), lb.astype(np.uint32), ty[keep].astype(np.uint8), w))
+    if payloads and all("persistent" in pl for pl in payloads):
+        pA = np.concatenate([pl["persistent"][0] for pl in payloads])
+        pB = np.concatenate([pl["persistent"][1] for pl in payloads])
+        pT = np.concatenate([pl["persistent"][2] for pl in payloads])
+        for part in parts:
+            keep, la, lb, _ = _localise_pairs(part, n_sph_global, pA, pB, pT)
+            part["persistent"] = (la.astype(np.uint32), lb.astype(np.uint32), pT[keep].astype(np.uint8))
+    if payloads and all("owner_wc" in pl for pl in payloads):
+        for name in payloads[0]["owner_wc"]:
+            glob = np.zeros(n_clumps_global, np.float32)
+            for pl in payloads:
+                glob[pl["global_ids"]] = pl["owner_wc"][name]
+            for r, part in enumerate(parts):
+                n_here = int(part["counts"]["nOwnerClumps"])
+                arr = np.concatenate([glob[part["owner_global"][:n_here]], payloads[r]["owner_wc_replicated"][name]])
+                part.setdefault("owner_wc", {})[name] = arr.astype(np.float32)
+    if payloads and all("sphere_wc" in pl for pl in payloads):
+        for name in payloads[0]["sphere_wc"]:
+            glob = np.zeros(n_sph_global, np.float32)
+            for pl in payloads:
+                glob[pl["sphere_global_own"]] = pl["sphere_wc"][name]
+            for part in parts:
+                part.setdefault("sphere_wc", {})[name] = glob[part["sphere_global"]].astype(np.float32)
     return g, parts, seeds
 
 
@@ -202,6 +259,7 @@ def redecompose_distributed(dist, rank, world, global_arrays, counts, part, stat
     per million clumps, amortised over the thousands of steps between re-decompositions), cut again, and return
     this rank's (global arrays, new part, seed)."""
     payloads = [None] * world
-    dist.all_gather_object(payloads, owned_payload(part, state, contacts, wildcards))
+    dist.all_gather_object(payloads, owned_payload(part, state, contacts, wildcards,
+                                                   **{k: kw.pop(k) for k in ("persistent", "owner_wildcards", "sphere_wildcards") if k in kw}))
     g, parts, seeds = redecompose(global_arrays, counts, payloads, world, halo, decode_x, **kw)
     return g, parts[rank], seeds[rank]

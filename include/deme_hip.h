@@ -280,6 +280,10 @@ int deme_get_adaptive_state(deme_ctx* ctx, double* binSize, uint32_t* cdUpdateFr
  * removed.  Refused for a history-less force model, like the reference.  Host-synchronous. */
 int deme_mark_persistent_contacts(deme_ctx* ctx, int mode, uint32_t N1, uint32_t N2, int mark);
 int deme_num_persistent_contacts(deme_ctx* ctx, size_t* n);
+/* The marked set itself, as (sphere A, geometry B, contact type) triples in list order -- for a restart or a re-decomposition
+ * (dem-engine_amd/decomp.py carries the marks to the ranks that own the pairs afterwards).  Upload replaces the set. */
+int deme_download_persistent_contacts(deme_ctx* ctx, uint32_t* idA, uint32_t* idB, uint8_t* type, size_t cap);
+int deme_upload_persistent_contacts(deme_ctx* ctx, const uint32_t* idA, const uint32_t* idB, const uint8_t* type, size_t n);
 
 /* Owner and geometry wildcards of user force models (DEMForceModel::SetPerOwnerWildcards / SetPerGeometryWildcards,
  * AuxClasses.h:422-485; Models.h:319-360).  Owner wildcards are per-owner float arrays the fragment sees as `name`,

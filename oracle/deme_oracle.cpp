@@ -1669,6 +1669,21 @@ void orc_sim_mark_persistent(void* h, int mode, uint32_t N1, uint32_t N2, int ma
     s.persist.swap(out);
 }
 size_t orc_sim_num_persistent(void* h) { return ((Sim*)h)->persist.size(); }
+void orc_sim_get_persistent(void* h, uint32_t* a, uint32_t* b, uint8_t* t) {
+    Sim& s = *(Sim*)h;
+    for (size_t i = 0; i < s.persist.size(); i++)
+        a[i] = s.persist[i].a, b[i] = s.persist[i].b, t[i] = s.persist[i].t;
+}
+void orc_sim_set_persistent(void* h, const uint32_t* a, const uint32_t* b, const uint8_t* t, size_t n) {
+    Sim& s = *(Sim*)h;
+    s.persist.clear();
+    for (size_t i = 0; i < n; i++)
+        s.persist.push_back({a[i], b[i], t[i]});
+    std::sort(s.persist.begin(), s.persist.end(), key_less);
+    s.persist.erase(std::unique(s.persist.begin(), s.persist.end(),
+                                [](const Key& x, const Key& y) { return x.a == y.a && x.b == y.b && type_class(x.t) == type_class(y.t); }),
+                    s.persist.end());
+}
 void orc_sim_change_family(void* h, uint32_t from, uint32_t to) {
     Sim& s = *(Sim*)h;
     for (auto& f : s.familyID)

@@ -282,6 +282,16 @@ class OracleSim:
         self.L.orc_sim_num_persistent.restype = C.c_size_t
         return int(self.L.orc_sim_num_persistent(C.c_void_p(self.h)))
 
+    def persistent_contacts(self):
+        n = self.num_persistent_contacts()
+        a, b, t = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        self.L.orc_sim_get_persistent(C.c_void_p(self.h), _p(a), _p(b), _p(t))
+        return a, b, t
+
+    def set_persistent_contacts(self, idA, idB, ctype):
+        a, b, t = np.ascontiguousarray(idA, np.uint32), np.ascontiguousarray(idB, np.uint32), np.ascontiguousarray(ctype, np.uint8)
+        self.L.orc_sim_set_persistent(C.c_void_p(self.h), _p(a), _p(b), _p(t), C.c_size_t(len(a)))
+
     def set_prescription(self, family, has, flags, coef):
         c = np.ascontiguousarray(coef, np.float32).reshape(15, 4)
         self.L.orc_sim_set_prescription(C.c_void_p(self.h), C.c_uint32(family), C.c_uint32(has), C.c_uint32(flags), _p(c))

@@ -399,3 +399,56 @@ def test_overlapped_exchange_through_rccl_on_one_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_overlap_torch_worker.py")], capture_output=True, text=True,
                          timeout=900, env=env)
     assert out.returncode == 0 and "OVERLAP_TORCH_OK" in out.stdout and "through RCCL" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_redecomposition_carries_wildcard_arrays_and_persistent_marks(pkg, orc):
+    """owner / sphere wildcards of a user model and the persistent-contact marks move with the clumps: values tagged with the
+    global ids come out under the new local numbering (ghost copies included), and the union of the ranks' marked pairs is the
+    same set of global pairs before and after"""
+    b, p, sc, x = _sheared_bed(pkg, 1200, 9)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
+    sims = run_slabs(pkg, lambda pp, s: orc.make_sim(pkg, pp, s), parts, p, 400, host_exchange(pkg, parts))
+    nW = int(p.nContactWildcards)
+    n_clumps = int(sc.nOwnerClumps)
+
+    def global_pairs(part, trip):
+        a, bb, t = trip
+        sg = part["sphere_global"]
+        ga = sg[a]
+        gb = np.where(t == 1, sg[np.where(t == 1, bb, 0)], bb.astype(np.int64))
+        lo, hi = np.where((t == 1) & (ga > gb), gb, ga), np.where((t == 1) & (ga > gb), ga, gb)
+        own = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
+        touches_own = (own[a] < part["n_own"]) | ((t == 1) & (own[np.where(t == 1, bb, 0)] < part["n_own"]))
+        return set(zip(lo[touches_own].tolist(), hi[touches_own].tolist(), t[touches_own].tolist()))
+
+    payloads, before = [], set()
+    for pt, s in zip(parts, sims):
+        s.mark_persistent_contacts()  # every contact of the current list
+        cnt = s.contacts()
+        W = np.stack([s.wildcard(w) for w in range(nW)], 1)
+        n_o, n_s = int(pt["counts"]["nOwners"]), int(pt["counts"]["nSpheres"])
+        n_c = int(pt["counts"]["nOwnerClumps"])
+        ow = np.r_[pt["owner_global"][:n_c] + 0.5, np.full(n_o - n_c, -7.0)].astype(np.float32)  # tag = global id + 0.5
+        sw = (pt["sphere_global"] + 0.25).astype(np.float32)
+        payloads.append(pkg.decomp.owned_payload(pt, s.download_state(), cnt, W, persistent=s.persistent_contacts(),
+                                                 owner_wildcards={"tag": ow}, sphere_wildcards={"stag": sw}))
+        before |= global_pairs(pt, s.persistent_contacts())
+    assert len(before) > 200
+    g, parts2, seeds = pkg.decomp.redecompose(b.arrays, b.counts, payloads, 2, 0.035, _decode_x(pkg, p))
+    assert sum(len(np.setdiff1d(a["global_ids"], b_["global_ids"])) for a, b_ in zip(parts2, parts)) > 3
+    after = set()
+    for pt, sd in zip(parts2, seeds):
+        n_c = int(pt["counts"]["nOwnerClumps"])
+        assert np.array_equal(pt["owner_wc"]["tag"][:n_c], (pt["owner_global"][:n_c] + 0.5).astype(np.float32))  # own + ghosts
+        assert (pt["owner_wc"]["tag"][n_c:] == -7.0).all()  # replicated owners keep the rank's own values
+        assert np.array_equal(pt["sphere_wc"]["stag"], (pt["sphere_global"] + 0.25).astype(np.float32))
+        s = orc.make_sim(pkg, p, pt["scene"])
+        s.seed_contacts(*sd)
+        s.set_persistent_contacts(*pt["persistent"])
+        assert s.num_persistent_contacts() == len(pt["persistent"][0]) > 50
+        after |= global_pairs(pt, s.persistent_contacts())
+        s.step(3)  # the marks are live: every marked pair is in the list the next detection builds
+        a, bb, t, _ = s.contacts()
+        listed = set(zip(a.tolist(), bb.tolist(), t.tolist()))
+        assert set(zip(*[x.tolist() for x in s.persistent_contacts()])) <= listed
+    assert after == before

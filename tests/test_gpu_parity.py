@@ -331,6 +331,17 @@ def test_persistent_contacts(pkg, orc):
     ctx.mark_persistent_contacts(ctx.PERSIST_EITHER, 1), sim.mark_persistent_contacts(1, 1)
     nP = ctx.num_persistent_contacts()
     assert nP == sim.num_persistent_contacts() and 0 < nP < len(a0)
+    # the marked set can be read back and loaded into another context (restart / re-decomposition)
+    pa, pb, pt = ctx.persistent_contacts()
+    oa, ob, ot = sim.persistent_contacts()
+    assert np.array_equal(pa, oa) and np.array_equal(pb, ob) and np.array_equal(pt, ot) and len(pa) == nP
+    other = pkg.Context(0)
+    other.set_params(p), other.upload_scene(sc)
+    other.set_persistent_contacts(pa[::-1], pb[::-1], pt[::-1])  # any order; duplicates would be dropped
+    assert all(np.array_equal(x, y) for x, y in zip(other.persistent_contacts(), (pa, pb, pt)))
+    with pytest.raises(pkg.abi.DemeError, match="out of range"):
+        other.set_persistent_contacts([int(sc.nSpheres)], [0], [1])
+    del other
     marked = set(zip(a0.tolist(), b0.tolist(), t0.tolist()))
     grew = False
     for chunk in range(6):
