@@ -447,6 +447,73 @@ class SceneBuilder:
             ctx.seed_contacts(cnt[0], cnt[1], cnt[2], W)
         return p, sc
 
+    def ResortClumps(self, ctx, time_elapsed, cell=None):
+        """Restore spatial order in a RUNNING simulation: the clumps of every batch are renumbered along a Z-order curve of
+        their current positions, and state, contact list, contact history and persistent marks follow.  Mixing destroys the
+        locality the initial numbering had, and the engine's gathers slow down with it (bench.py --order random: 28 %).
+        Host-side like UpdateClumps (a few seconds per million clumps): meant to be called every few thousand steps.  Returns
+        (params, scene, new_owner_of_old_owner); owner / geometry wildcards of a user model are the caller's to permute with that
+        array.  No reference equivalent (its owner ids never change)."""
+        st = ctx.download_state()
+        cnt = ctx.contacts()
+        nW = int(self.params.nContactWildcards)
+        W = np.stack([ctx.wildcard(w) for w in range(nW)], 1) if nW else np.zeros((len(cnt[0]), 0), np.float32)
+        pers = ctx.persistent_contacts() if ctx.num_persistent_contacts() else None
+        p_old = self.params
+        n_c, n_o = int(self.counts["nOwnerClumps"]), int(self.counts["nOwners"])
+        old_owner_of_sphere = np.asarray(self.arrays["ownerClumpBody"], np.int64)
+        n_sph_of = np.bincount(old_owner_of_sphere, minlength=n_c)[:n_c]
+        first_old = np.r_[0, np.cumsum(n_sph_of)]
+        X = decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p_old.nvXp2, p_old.nvYp2, p_old.voxelSize, p_old.l)[:n_c]
+        rmax = max((float(t.radii.max()) + float(np.abs(t.relpos).max()) for t in self.templates), default=1.0)
+        cell = float(cell) if cell else 4.0 * rmax
+        old_of_new = np.zeros(n_c, np.int64)
+        o0 = 0
+        for bt in self.batches:  # a batch keeps its id range; its clumps are reordered inside it
+            n = len(bt.xyz)
+            order = np.argsort(morton_codes((X[o0:o0 + n] - X.min(0)).astype(np.float32), cell), kind="stable")
+            old_of_new[o0:o0 + n] = o0 + order
+            bt.xyz, bt.vel, bt.angvel, bt.oriq, bt.family = bt.xyz[order], bt.vel[order], bt.angvel[order], bt.oriq[order], bt.family[order]
+            bt.templates = [bt.templates[i] for i in order]
+            o0 += n
+        new_of_old = np.arange(n_o, dtype=np.int64)
+        new_of_old[old_of_new] = np.arange(n_c)
+        p, sc = self.Initialize()
+        src = np.r_[old_of_new, np.arange(n_c, n_o)]
+        for k in ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY",
+                  "omgBarZ", "familyID"):
+            self.arrays[k][:] = st[k][src]
+        sc = abi.make_scene_struct(self.arrays, self.counts)
+        # sphere ids: spheres are clump-major, a clump's spheres keep their order
+        first_new = np.r_[0, np.cumsum(n_sph_of[old_of_new])]
+        new_sphere = np.zeros(len(old_owner_of_sphere), np.int64)
+        k_in_clump = np.arange(len(old_owner_of_sphere)) - first_old[old_owner_of_sphere]
+        new_sphere[:] = first_new[new_of_old[old_owner_of_sphere]] + k_in_clump
+
+        def remap(a, b, t):
+            a, b, t = np.asarray(a, np.int64), np.asarray(b, np.int64), np.asarray(t)
+            ss = t == 1
+            a2 = new_sphere[a]
+            b2 = np.where(ss, new_sphere[np.where(ss, b, 0)], b)
+            flip = ss & (a2 > b2)  # a sphere-sphere pair is stored smaller id first
+            a3, b3 = np.where(flip, b2, a2), np.where(flip, a2, b2)
+            return a3.astype(np.uint32), b3.astype(np.uint32), flip
+
+        p.timeElapsed = float(time_elapsed)
+        self.params = p
+        ctx.set_params(p)
+        ctx.upload_scene(sc)
+        self.compile_into(ctx)
+        if len(cnt[0]):
+            a, b2, flip = remap(*cnt[:3])
+            W = W.copy()
+            W[flip, :min(3, W.shape[1])] *= -1.0  # B-to-A vector history of the Hertzian model (cf. decomp.redecompose)
+            ctx.seed_contacts(a, b2, cnt[2], W)
+        if pers is not None:
+            a, b2, _ = remap(*pers)
+            ctx.set_persistent_contacts(a, b2, pers[2])
+        return p, sc, new_of_old
+
     def ChangeFamilyWhen(self, id_from, id_to, condition):
         """condition: C++ statements that `return` a bool, over X, Y, Z, vX, vY, vZ, accX, accY, accZ, pos, vel, acc, mass, ts,
         time (API.h:1024; DEMModeratorKernels.cu:10-60); checked between force evaluation and integration of every step."""

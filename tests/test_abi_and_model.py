@@ -129,3 +129,44 @@ def test_spatial_sort_keeps_the_scene_and_localises_neighbours(pkg):
     d0 = np.linalg.norm(np.diff(xyz0, axis=0), axis=1).mean()
     d1 = np.linalg.norm(np.diff(xyz1, axis=0), axis=1).mean()
     assert d1 < 0.25 * d0
+
+
+@pytest.mark.gpu
+def test_resort_clumps_in_a_running_simulation(pkg):
+    """ResortClumps: a bed handed over in random order is renumbered along a Z-order curve mid-run; state, contact history and
+    persistent marks follow, the physics carries on as in a twin that keeps its numbering (to fp32 summation order), and
+    neighbours in space become neighbours in memory"""
+    def make():
+        b = pkg.model.packed_bed(4000, seed=3, cd_freq=5, spacing_mult=2.5, init_vz=-0.4, order="random")
+        b.SetExpandSafetyAdder(1.0)
+        p, sc = b.Initialize()
+        ctx = pkg.Context(0)
+        ctx.set_params(p), ctx.upload_scene(sc)
+        return b, p, sc, ctx
+
+    (b, p, sc, ctx), (b2, p2, sc2, twin) = make(), make()
+    ctx.step(400), twin.step(400)
+    ctx.mark_persistent_contacts(), twin.mark_persistent_contacts()
+    n_marked = ctx.num_persistent_contacts()
+    own_old = np.asarray(b.arrays["ownerClumpBody"], np.int64).copy()
+
+    def spread(builder, c):
+        a, bb, t, _ = c.contacts()
+        own = np.asarray(builder.arrays["ownerClumpBody"], np.int64)
+        ss = t == 1
+        return float(np.abs(own[a[ss]] - own[bb[ss]]).mean()), int(ss.sum())
+
+    before, n_ss = spread(b, ctx)
+    pnew, scnew, new_of_old = b.ResortClumps(ctx, 400 * p.h)
+    assert sorted(new_of_old[:int(sc.nOwnerClumps)].tolist()) == list(range(int(sc.nOwnerClumps)))
+    assert ctx.num_persistent_contacts() == n_marked > 100
+    ctx.step(25), twin.step(25)
+    after, n_ss2 = spread(b, ctx)
+    assert n_ss > 1000 and after < 0.2 * before, (before, after)  # owner-id distance of contacting clumps
+    gs, ts = ctx.download_state(), twin.download_state()
+    n = int(sc.nOwnerClumps)
+    X = pkg.model.decode_positions(gs["voxelID"], gs["locX"], gs["locY"], gs["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    Xt = pkg.model.decode_positions(ts["voxelID"], ts["locX"], ts["locY"], ts["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    assert np.abs(X[new_of_old[:n]] - Xt[:n]).max() < 1e-9
+    assert np.abs(gs["vZ"][new_of_old[:n]] - ts["vZ"][:n]).max() < 1e-5
+    assert int(ctx.counts().nContacts) == int(twin.counts().nContacts)
