@@ -391,6 +391,12 @@ class DEMSolver {
     void SetExpandSafetyMultiplier(float m) { m_safety_multi = m; }
     void SetExpandSafetyAdder(float a) { m_safety_adder = a; }
     void SetMaxVelocity(float v) { m_max_vel = v; }
+    void SetMaxSphereInBin(unsigned int n) { m_max_sph_in_bin = n; }  // errOutBinSphNum (API.h:212)
+    void SetMaxTriangleInBin(unsigned int) {}  // triangles are swept per (bin, triangle) incidence here: no per-bin staging limit
+    void SetErrorOutAvgContacts(float) {}      // the contact arena grows on demand: nothing to cap
+    void SetSortContactPairs(bool) {}          // the list is always in (A, class, B) order
+    void DisableFamilyOutput(unsigned int fam) { m_no_output_families.insert(fam & 255u); }
+    void EnableFamilyOutput(unsigned int fam) { m_no_output_families.erase(fam & 255u); }
     void SetErrorOutVelocity(float v) { m_err_vel = v; }
     void SetIntegrator(TIME_INTEGRATOR i) { m_integrator = i; }
     void SetFamilyFixed(unsigned int f) { m_family_flags[f & 255] |= DEME_FAMILY_FIXED; }
@@ -589,6 +595,47 @@ class DEMSolver {
         refresh_state();
         return {m_st_v[0].at(owner), m_st_v[1].at(owner), m_st_v[2].at(owner)};
     }
+    // DEMSolver::Get/SetOwner* (API.h:515-586): whole-state round trips through the ABI -- scripting calls, not for inner loops
+    float3 GetOwnerAngVel(unsigned int owner) { return owner_column3(owner, 2); }
+    float3 GetOwnerAcc(unsigned int owner) { return owner_column3(owner, 3); }
+    float3 GetOwnerAngAcc(unsigned int owner) { return owner_column3(owner, 4); }
+    float4 GetOwnerOriQ(unsigned int owner) {
+        const Snapshot sn = snapshot(false);
+        return sn.q.at(owner);
+    }
+    unsigned int GetOwnerFamily(unsigned int owner) { return owner_families().at(owner); }
+    float GetOwnerMass(unsigned int owner) const { return m_keep.mass.at(m_keep.inert.at(owner)); }
+    void SetOwnerPosition(unsigned int owner, float3 pos) { set_owner(owner, &pos, nullptr, nullptr, nullptr); }
+    void SetOwnerVelocity(unsigned int owner, float3 vel) { set_owner(owner, nullptr, &vel, nullptr, nullptr); }
+    void SetOwnerAngVel(unsigned int owner, float3 w) { set_owner(owner, nullptr, nullptr, &w, nullptr); }
+    void SetOwnerOriQ(unsigned int owner, float4 q) { set_owner(owner, nullptr, nullptr, nullptr, &q); }
+    void SetOwnerFamily(unsigned int owner, unsigned int fam, size_t n = 1) {
+        std::vector<uint8_t> f = owner_families();
+        for (size_t k = 0; k < n && owner + k < f.size(); k++)
+            f[owner + k] = (uint8_t)fam;
+        DemeOwnerState st{};
+        st.familyID = f.data();
+        check(deme_upload_owner_state(m_ctx, &st));
+        m_state_fresh = false;
+    }
+    /// every clump whose CoM lies in the box becomes family `fam_num`; returns how many did (API.h:699-709)
+    size_t ChangeClumpFamily(unsigned int fam_num, const std::pair<double, double>& X = {-1e30, 1e30},
+                             const std::pair<double, double>& Y = {-1e30, 1e30}, const std::pair<double, double>& Z = {-1e30, 1e30}) {
+        refresh_state();
+        std::vector<uint8_t> f = owner_families();
+        size_t changed = 0;
+        for (size_t i = 0; i < m_n_clumps; i++) {
+            const float3 c = m_pos[i];
+            if (c.x >= X.first && c.x <= X.second && c.y >= Y.first && c.y <= Y.second && c.z >= Z.first && c.z <= Z.second) {
+                f[i] = (uint8_t)fam_num;
+                changed++;
+            }
+        }
+        DemeOwnerState st{};
+        st.familyID = f.data();
+        check(deme_upload_owner_state(m_ctx, &st));
+        return changed;
+    }
     float GetMaxOwnerSpeed() {
         refresh_state();
         float m = 0;
@@ -785,6 +832,8 @@ class DEMSolver {
         o << "\n";
         for (size_t i = 0; i < m_keep.sphOwner.size(); i++) {
             const uint32_t ow = m_keep.sphOwner[i];
+            if (m_no_output_families.count(sn.fam[ow]))
+                continue;
             const uint16_t cp = m_keep.sphComp[i];
             float3 d = {m_keep.rx[cp], m_keep.ry[cp], m_keep.rz[cp]};
             rotate(d, sn.q[ow]);
@@ -807,6 +856,8 @@ class DEMSolver {
         owner_header(o);
         o << "\n";
         for (size_t i = 0; i < m_n_clumps; i++) {
+            if (m_no_output_families.count(sn.fam[i]))
+                continue;
             o << sn.com[i].x << "," << sn.com[i].y << "," << sn.com[i].z;
             o << "," << sn.q[i].w << "," << sn.q[i].x << "," << sn.q[i].y << "," << sn.q[i].z;
             o << "," << m_keep.templateName.at(m_keep.inert[i]);
@@ -1007,6 +1058,13 @@ class DEMSolver {
         check(deme_upload_contact_wildcard(m_ctx, w, col.data(), nc));
     }
     bool m_initialized = false;
+    unsigned int m_max_sph_in_bin = 32768;  // API.h:1483 default
+    std::set<unsigned int> m_no_output_families;  // familiesNoOutput (dT.cpp:1309-1312)
+    float3 owner_column3(unsigned int owner, int which) {
+        const Snapshot sn = snapshot(false);
+        const std::vector<float3>& col = which == 2 ? sn.w : which == 3 ? sn.a : sn.al;
+        return col.at(owner);
+    }
     // reference defaults of the controllers' knobs (DEM/Structs.h:204-216); both switched off until asked for
     DemeAdaptive m_adaptive{0u, 25u, 0.05f, 0.1f, 0.25f, 0.3f, 0u, 2500u, 4u};
     void push_adaptive() {  // the knobs may be turned before or after Initialize
@@ -1109,7 +1167,7 @@ class DEMSolver {
     struct Keep {  // scene arrays the writers need after Initialize
         std::vector<uint32_t> sphOwner, objOwner, triOwner;
         std::vector<uint16_t> sphComp, inert;
-        std::vector<float> Radii, rx, ry, rz;
+        std::vector<float> Radii, rx, ry, rz, mass;
         std::map<unsigned, std::string> templateName;
     } m_keep;
     struct Snapshot {
@@ -1579,7 +1637,7 @@ class DEMSolver {
                                                                                      : DEME_FORCE_CUSTOM;
         p.nContactWildcards = (uint32_t)m_force_model->contact_wildcards.size();
         p.cdUpdateFreq = m_cd_freq;
-        p.errOutBinSphNum = 32768;
+        p.errOutBinSphNum = m_max_sph_in_bin;
         p.errOutVel = m_err_vel;
 
         DemeScene s{};
@@ -1652,7 +1710,7 @@ class DEMSolver {
         m_state_fresh = false;
         compile_prescriptions_and_rules();
         m_keep.sphOwner = sphOwner, m_keep.sphComp = sphComp, m_keep.inert = inert, m_keep.objOwner = objOwner, m_keep.triOwner = triOwner;
-        m_keep.Radii = Radii, m_keep.rx = rx, m_keep.ry = ry, m_keep.rz = rz;
+        m_keep.Radii = Radii, m_keep.rx = rx, m_keep.ry = ry, m_keep.rz = rz, m_keep.mass = mass;
         for (size_t i = 0; i < m_templates.size(); i++) {
             char nm[32];
             snprintf(nm, sizeof nm, "%04d", (int)i);

@@ -86,6 +86,16 @@ int main(int argc, char** argv) {
     DEMSim.WriteClumpFile(dir + "/clumps.csv");
     DEMSim.SetContactOutputContent(OWNER | FORCE | CNT_WILDCARD);
     DEMSim.WriteContactFile(dir + "/contacts.csv");
+    // owner-level getters / setters of the solver object (API.h:515-586, 699-709) and per-family output control
+    DEMSim.SetOwnerVelocity(5, make_float3(0.f, 0.f, 1.f));
+    DEMSim.SetOwnerFamily(7, 9);
+    const size_t moved = DEMSim.ChangeClumpFamily(3, {0.0, 0.066}, {0.0, 1.0}, {0.0, 1.0});  // the three leftmost columns
+    const float3 v5 = DEMSim.GetOwnerVelocity(5);
+    std::printf("CHECK owner v5z %.3f fam7 %u moved %zu mass0 %.6e oriq0w %.3f\n", v5.z, DEMSim.GetOwnerFamily(7), moved,
+                DEMSim.GetOwnerMass(0), DEMSim.GetOwnerOriQ(0).w);
+    DEMSim.DisableFamilyOutput(3);
+    DEMSim.SetOutputContent(FAMILY);
+    DEMSim.WriteSphereFile(dir + "/spheres_no3.csv");
     std::printf("DEMO_OK\n");
     return 0;
 }

@@ -126,6 +126,12 @@ def test_custom_model_demo_wildcards_from_the_script(tmp_path):
     assert 0.9 * total < sph["n_touch"].sum() <= total  # one sphere per clump here; the rest is the wall owner's counter
     clp = open(tmp_path / "clumps.csv").readline().strip()
     assert clp == "X,Y,Z,Qw,Qx,Qy,Qz,clump_type,family,n_touch"
+    # solver-level owner setters / getters, ChangeClumpFamily by region, DisableFamilyOutput
+    ow = chk["owner"]
+    assert float(ow[1]) == 1.0 and int(ow[3]) == 9 and int(ow[5]) == 3 * 10 * 6 and float(ow[9]) == 1.0
+    assert abs(float(ow[7]) - 2.6e3 * 4 / 3 * np.pi * 0.004 ** 3) < 1e-9
+    no3 = np.genfromtxt(tmp_path / "spheres_no3.csv", delimiter=",", names=True)
+    assert len(no3) == 600 - 180 and not (no3["family"] == 3).any() and (no3["family"] == 9).sum() <= 1
     cnt = np.genfromtxt(tmp_path / "contacts.csv", delimiter=",", names=True, dtype=None, encoding="utf8")
     assert cnt.dtype.names == ("contact_type", "A", "B", "f_x", "f_y", "f_z", "contact_age")
     ss = cnt["contact_type"] == "SS"
