@@ -781,6 +781,25 @@ class DEMSolver {
                 out.push_back({m_keep.sphOwner[a[i]], m_keep.sphOwner[b[i]]});
         return out;
     }
+    /// Owner-id pairs of the clump--clump contacts of the list (potential contacts, like the reference's GetClumpContacts,
+    /// API.h:500-528), sorted by A's owner; optionally only pairs whose two families are both in `family_to_include`
+    std::vector<std::pair<bodyID_t, bodyID_t>> GetClumpContacts() { return GetContacts(); }
+    std::vector<std::pair<bodyID_t, bodyID_t>> GetClumpContacts(const std::set<unsigned int>& family_to_include) {
+        const std::vector<uint8_t> fam = owner_families();
+        std::vector<std::pair<bodyID_t, bodyID_t>> out;
+        for (auto& pr : GetContacts())
+            if (family_to_include.count(fam[pr.first]) && family_to_include.count(fam[pr.second]))
+                out.push_back(pr);
+        return out;
+    }
+    std::vector<std::pair<bodyID_t, bodyID_t>> GetClumpContacts(std::vector<std::pair<unsigned int, unsigned int>>& family_pair) {
+        const std::vector<uint8_t> fam = owner_families();
+        std::vector<std::pair<bodyID_t, bodyID_t>> out = GetContacts();
+        family_pair.clear();
+        for (auto& pr : out)
+            family_pair.push_back({fam[pr.first], fam[pr.second]});
+        return out;
+    }
     /// ShowTimingStats / ShowThreadCollaborationStats (API.h:1290-1300): the kernels' mean times from HIP events
     void ShowTimingStats() {
         for (const char* name : {"calc_forces", "integrate", "detect"}) {
