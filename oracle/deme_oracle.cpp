@@ -1184,6 +1184,19 @@ void calc_forces(Sim& s, bool record) {
     }
 }
 
+// DEMCustomizablePolicies/IntegrationVelPassOn{ForwardEuler,CenteredDiff,ExtendedTaylor}.cu: the velocity the position
+// update uses, from the velocity before the step and this step's increment (golden vectors G9)
+inline V3f vel_pass_on(uint32_t integrator, const V3f& old_v, const V3f& v_upd) {
+    switch (integrator) {
+        case DEME_INTEGRATOR_FORWARD_EULER:
+            return old_v;
+        case DEME_INTEGRATOR_CENTERED_DIFFERENCE:
+            return old_v + v_upd;
+        default:  // extended Taylor: `v_update * 0.5` narrows 0.5 to float (CUDAMathHelpers.cuh:674)
+            return old_v + v_upd * 0.5f;
+    }
+}
+
 // kernel/DEMIntegrationKernels.cu:100-236 (integrateVelPos) with the velocity pass-on
 // of DEMCustomizablePolicies/IntegrationVelPassOn{ForwardEuler,CenteredDiff,ExtendedTaylor}.cu.
 // Fixed families (SetFamilyFixed, APIPublic.cpp:980-1011) zero and freeze all six velocity
@@ -1267,21 +1280,7 @@ void integrate(Sim& s) {
                 old_w.z = s.omgZ[o];
             }
         }
-        V3f v, w;
-        switch (s.p.integrator) {
-            case DEME_INTEGRATOR_FORWARD_EULER:
-                v = old_v;
-                w = old_w;
-                break;
-            case DEME_INTEGRATOR_CENTERED_DIFFERENCE:
-                v = old_v + v_upd;
-                w = old_w + w_upd;
-                break;
-            default:  // extended Taylor: `v_update * 0.5` narrows 0.5 to float (CUDAMathHelpers.cuh:674)
-                v = old_v + v_upd * 0.5f;
-                w = old_w + w_upd * 0.5f;
-                break;
-        }
+        const V3f v = vel_pass_on(s.p.integrator, old_v, v_upd), w = vel_pass_on(s.p.integrator, old_w, w_upd);
         if (!fixed) {
             if (!(pf & 64u))
                 X += (double)v.x * h;
@@ -1493,6 +1492,13 @@ void orc_el_force(size_t n, int model, const double* depth, const float* fin, co
 }
 
 // ---- mesh helpers (parity unpinned; checked against analytic cases and fenv rounding) -------------
+void orc_el_vel_pass_on(size_t n, int scheme, const float* old_v, const float* v_update, float* out) {
+    for (size_t i = 0; i < n; i++) {
+        const V3f v = vel_pass_on((uint32_t)scheme, {old_v[3 * i], old_v[3 * i + 1], old_v[3 * i + 2]},
+                                  {v_update[3 * i], v_update[3 * i + 1], v_update[3 * i + 2]});
+        out[3 * i] = v.x, out[3 * i + 1] = v.y, out[3 * i + 2] = v.z;
+    }
+}
 void orc_el_rcp_mul_ru(size_t n, const double* x, const double* y, double* rcp, double* mul) {
     for (size_t i = 0; i < n; i++) {
         rcp[i] = rcp_ru(x[i]);

@@ -131,3 +131,38 @@ def test_g7b_triangle_bbox_bins(orc, golden):
                           [int(x) for x in golden["g7b_nb"]])
     assert (lo == golden["g7b_L"]).all() and (hi == golden["g7b_U"]).all()
     assert (hi > lo).any()
+
+
+def test_g9_integrator_velocity_pass_on(orc, golden):
+    """IntegrationVelPassOn{ForwardEuler,CenteredDiff,ExtendedTaylor}.cu, compiled from the reference when the fixture was
+    made: the velocity the position update uses, bit for bit"""
+    import ctypes as C
+    L = orc.lib()
+    ov, vu = np.ascontiguousarray(golden["g9_old_v"]), np.ascontiguousarray(golden["g9_v_update"])
+    for scheme in (0, 1, 2):
+        out = np.zeros_like(ov)
+        L.orc_el_vel_pass_on(C.c_size_t(len(ov)), C.c_int(scheme), C.c_void_p(ov.ctypes.data), C.c_void_p(vu.ctypes.data),
+                             C.c_void_p(out.ctypes.data))
+        assert np.array_equal(out, golden[f"g9_v_scheme{scheme}"]), scheme
+    assert not np.array_equal(golden["g9_v_scheme1"], golden["g9_v_scheme2"])
+
+
+def test_g3_pair_enumeration_covers_what_the_cyclic_pairing_covers(golden):
+    """recoverCntPair (DEMHelperKernels.cuh) enumerates the n(n-1)/2 pairs of a bin; k_sweep spreads the same pairs by cyclic
+    pairing instead (entry k tests k+1 ... k+floor((n-1)/2) mod n, plus k+n/2 for k < n/2 when n is even): same set, each once"""
+    ind, n, gi, gj = (golden[k] for k in ("g3_ind", "g3_n", "g3_i", "g3_j"))
+    for nn in np.unique(n)[:: max(1, len(np.unique(n)) // 40)]:
+        sel = n == nn
+        ref = set(zip(np.minimum(gi[sel], gj[sel]).tolist(), np.maximum(gi[sel], gj[sel]).tolist()))
+        nn = int(nn)
+        half = (nn - 1) // 2
+        mine = []
+        for k in range(nn):
+            for m in range(1, half + 1):
+                mine.append((k, (k + m) % nn))
+            if nn % 2 == 0 and k < nn // 2:
+                mine.append((k, k + nn // 2))
+        canon = [(min(a, b), max(a, b)) for a, b in mine]
+        assert len(canon) == nn * (nn - 1) // 2 == len(set(canon))
+        full = {(a, b) for a in range(nn) for b in range(a + 1, nn)}
+        assert set(canon) == full and ref <= full
