@@ -366,7 +366,8 @@ def main():
             print(f"[adaptive] bin size {adaptive_state[0]:.6g} K {adaptive_state[1]} changes {adaptive_state[2:]}", file=sys.stderr)
     # every 8th launch of the force / integration kernels is bracketed with HIP events (the detection always is: its timer
     # only ticks once per K steps); timing every launch costs 4.7 % of the step in dispatch gaps
-    ctx.set_timing(0 if os.environ.get("DEME_BENCH_NO_KERNEL_TIMING") else 8)
+    stride = max(1, min(8, args.steps // 10))  # short runs (--steps < 80) time more of their launches so that the mean exists
+    ctx.set_timing(0 if os.environ.get("DEME_BENCH_NO_KERNEL_TIMING") else stride)
     ctx.kernel_time_reset()
     barrier()
     t0 = time.perf_counter()
@@ -412,7 +413,7 @@ def main():
         "roofline": {"kernel": "deme_custom_forces_ss (hipRTC)" if args.config5 else "k_calc_forces<0, 0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),
-                     "launch_sampling": "every 8th launch inside the timed region is bracketed with HIP events"},
+                     "launch_sampling": f"every {stride}{'th' if stride > 3 else ('st', 'nd', 'rd')[stride - 1]} launch inside the timed region is bracketed with HIP events"},
         "kernels_ms": {"calc_forces": f_ms, "integrate": i_ms, "detect_update": d_ms, "detect_updates": int(d_n)},
     }
     out["roofline"].update(pmc_traffic(int(c.nContacts)))
