@@ -341,8 +341,8 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # untimed pre-settling: the lattice (no contacts at t=0) is dropped at 1 m/s and compacts; single-GPU runs
-    # stop early once the contact count has plateaued
+    # untimed pre-settling: the lattice (no contacts at t=0) is dropped at 1 m/s and compacts; the run stops early once the
+    # (job-wide) contact count has plateaued
     done, last_nc = 0, -1
     t_pre = time.perf_counter()
     while done < args.presettle:
@@ -350,9 +350,13 @@ def main():
         run(chunk)
         done += chunk
         nc = int(ctx.counts().nContacts)
+        if world > 1:  # the same stopping rule on the job's total, so that every N times a bed in the same state
+            tot_nc = torch.tensor([float(nc)], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tot_nc, op=dist.ReduceOp.SUM)
+            nc = int(tot_nc.item())
         if rank == 0 and args.verbose:
             print(f"[presettle] step {done} contacts {nc} t {time.perf_counter() - t_pre:.1f}s", file=sys.stderr, flush=True)
-        if world == 1 and done >= 4000 and last_nc > 0 and abs(nc - last_nc) < 0.002 * nc:
+        if done >= 4000 and last_nc > 0 and abs(nc - last_nc) < 0.002 * nc:
             break
         last_nc = nc
     args.presettle = done
