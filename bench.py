@@ -183,6 +183,39 @@ class Halo:
         self.bytes_per_step = gb * (self.n["send_left"] + self.n["send_right"])
         self._plan = None
 
+    def neighbours(self):
+        """[(side, rank)] of the face neighbours in the x-slab chain"""
+        return [(s, nb) for s, nb in (("left", self.rank - 1), ("right", self.rank + 1)) if 0 <= nb < self.world]
+
+    def probe_overlap(self):
+        """One tiny exchange with the face neighbours on the halo stream before anything depends on it.  If torch / RCCL refuse
+        the external stream the call raises on every rank alike; the ranks then agree (all-reduce MIN) to use the ordered
+        exchange on the compute stream instead.  Returns whether the overlapped path stays on."""
+        if not self.overlap:
+            return False
+        t, d = self.torch, self.dist
+        ok = 1
+        try:
+            dev = t.device("cuda", t.cuda.current_device())
+            ops, keep = [], []
+            for _, nb in self.neighbours():
+                a, b = t.full((16,), self.rank, dtype=t.uint8, device=dev), t.full((16,), 255, dtype=t.uint8, device=dev)
+                keep.append((a, b, nb))
+                ops += [d.P2POp(d.isend, a, nb), d.P2POp(d.irecv, b, nb)]
+            with t.cuda.stream(self.halo_stream):
+                for w in d.batch_isend_irecv(ops):
+                    w.wait()
+            self.halo_stream.synchronize()
+            ok = int(all(int(b[0].item()) == nb for _, b, nb in keep))
+        except Exception as e:  # noqa: BLE001 -- whatever the stack refuses, the answer is the ordered path
+            print(f"[bench] rank {self.rank}: halo-stream exchange refused ({type(e).__name__}: {e}); ordered exchange instead",
+                  file=sys.stderr, flush=True)
+            ok = 0
+        flag = t.tensor([ok], dtype=t.int32, device="cuda")
+        d.all_reduce(flag, op=d.ReduceOp.MIN)
+        self.overlap = bool(int(flag.item()))
+        return self.overlap
+
     def step(self):
         """one time step including the ghost exchange"""
         if not self.overlap:
@@ -191,7 +224,7 @@ class Halo:
             return
         c = self.ctx
         if self._plan is None:  # pointers, counts and the P2P op list never change: built once (the loop body is host-bound work)
-            sides = [(s, nb) for s, nb in (("left", self.rank - 1), ("right", self.rank + 1)) if 0 <= nb < self.world]
+            sides = self.neighbours()
             pack = [(self.ids["send_" + s].data_ptr(), self.n["send_" + s], self.buf["send_" + s].data_ptr()) for s, _ in sides]
             unpack = [(self.ids["recv_" + s].data_ptr(), self.n["recv_" + s], self.buf["recv_" + s].data_ptr()) for s, _ in sides]
             ops = []
@@ -213,7 +246,7 @@ class Halo:
     def exchange(self):
         c, d = self.ctx, self.dist
         ops = []
-        sides = [(s, nb) for s, nb in (("left", self.rank - 1), ("right", self.rank + 1)) if 0 <= nb < self.world]
+        sides = self.neighbours()
         for side, nb in sides:
             s, r = "send_" + side, "recv_" + side
             c.halo_pack(self.ids[s].data_ptr(), self.n[s], self.buf[s].data_ptr())
@@ -327,6 +360,8 @@ def main():
                          bin_observe=5, max_update_freq=200, freq_observe=3)
     if world > 1:
         halo = Halo(pkg, ctx, part, rank, world, torch, dist, via_host=via_host, overlap=not args.no_overlap)
+        if not via_host:
+            halo.probe_overlap()
 
     def run(n):
         if halo is None:
