@@ -21,6 +21,10 @@ import time
 
 import numpy as np
 
+# the hosts of this pool only support dmabuf IPC: without this RCCL's cross-process buffers fail with
+# "hipIpcGetMemHandle: invalid argument".  Normally exported already; set before torch / the HIP runtime load.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
