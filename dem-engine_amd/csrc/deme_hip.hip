@@ -491,14 +491,27 @@ int do_detect(deme_ctx* c) {
         }
         const int next = c->keysCur ^ 1;
         if (nC) {
-            size_t need = 0;
-            HIPCK(rocprim::radix_sort_keys(nullptr, need, c->keysRaw.as<uint64_t>(), c->keysSorted[next].as<uint64_t>(),
-                                           (size_t)nC, 0, 64, c->stream));
-            if (int rc = ensure(c, c->sortTmp, need))
+            // key = A << 33 | class << 31 | B with A, B < 2^bits(ids): bits [bitsB, 31) and [33 + bitsA, 64) are zero, so the 64-bit
+            // order is reached by two stable LSD sorts over the occupied ranges only (6 radix passes instead of 8 at 3e6 spheres)
+            auto bits_of = [](uint64_t n) {
+                unsigned b = 1;
+                while (b < 31 && (1ull << b) < n)
+                    b++;
+                return b;
+            };
+            const unsigned bitsA = bits_of(c->dp.nSpheres);
+            const unsigned bitsB = bits_of(std::max<uint64_t>({c->dp.nSpheres, c->dp.nTri, c->dp.nAnal, 1u}));
+            uint64_t* mid = c->conA4.as<uint64_t>();  // 16 B per contact of scratch: the contribution records are dead until the next force pass
+            size_t need = 0, needHi = 0;
+            HIPCK(rocprim::radix_sort_keys(nullptr, need, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 0, bitsB, c->stream));
+            HIPCK(rocprim::radix_sort_keys(nullptr, needHi, mid, c->keysSorted[next].as<uint64_t>(), (size_t)nC, 31, 33 + bitsA,
+                                           c->stream));
+            if (int rc = ensure(c, c->sortTmp, std::max(need, needHi)))
                 return rc;
-            need = c->sortTmp.bytes;
-            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, need, c->keysRaw.as<uint64_t>(),
-                                           c->keysSorted[next].as<uint64_t>(), (size_t)nC, 0, 64, c->stream));
+            need = needHi = c->sortTmp.bytes;
+            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, need, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 0, bitsB, c->stream));
+            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, needHi, mid, c->keysSorted[next].as<uint64_t>(), (size_t)nC, 31, 33 + bitsA,
+                                           c->stream));
             if (nPersist) {  // a marked contact the sweep found as well appears once (markDuplicateContacts)
                 unsigned long long* cnt = &c->ctr.as<DetectCounters>()->nContactsRaw;
                 size_t need2 = 0;
