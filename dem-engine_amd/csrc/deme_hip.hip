@@ -67,7 +67,7 @@ struct deme_ctx {
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
     // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
-    DevBuf persistKeys;
+    DevBuf persistKeys, binStat;
     std::vector<uint64_t> hPersist;
     // triangles (mesh path)
     uint32_t nTri = 0;
@@ -410,8 +410,14 @@ int do_detect(deme_ctx* c) {
                                             c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
                                             c->stream));
             sortedIdx = 1;
-            hipLaunchKernelGGL(k_bin_stats, dim3(std::min<unsigned>(grid_for(P), 1024u)), dim3(256), 0, c->stream, c->incKeys[1].as<uint32_t>(), P,
-                               c->ctr.as<DetectCounters>());
+            {
+                const unsigned nb = std::min<unsigned>(grid_for(P), 8192u);
+                if (int rc = ensure(c, c->binStat, 8192 * sizeof(uint2)))
+                    return rc;
+                hipLaunchKernelGGL(k_bin_stats, dim3(nb), dim3(256), 0, c->stream, c->incKeys[1].as<uint32_t>(), P, c->binStat.as<uint2>());
+                hipLaunchKernelGGL(k_bin_stats_final, dim3(1), dim3(256), 0, c->stream, c->binStat.as<uint2>(), nb,
+                                   c->ctr.as<DetectCounters>());
+            }
             hipLaunchKernelGGL(k_sweep, dim3((grid_for(P, SW_T) + SW_WPB - 1) / SW_WPB), dim3(SW_T), 0, c->stream, c->dp,
                                c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
                                c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
@@ -827,7 +833,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
-    DevBuf* all[] = {&c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],

@@ -524,37 +524,28 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
 
 // Active-bin count and the largest bin population (numSpheresBinTouches statistics of
 // DEMCubContactDetection.cu:195-230; the population check feeds errOutBinSphNum).
-__global__ __launch_bounds__(256) void k_bin_stats(const uint32_t* __restrict__ keys, uint32_t P, DetectCounters* ctr) {
+__global__ __launch_bounds__(256) void k_bin_stats(const uint32_t* __restrict__ keys, uint32_t P, uint2* __restrict__ perBlock) {
     __shared__ uint32_t sHeads[4], sPop[4];
-    __shared__ unsigned long long wmask[4];
     uint32_t heads = 0, pop = 0;
-    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
-    // 256 consecutive entries per iteration: coalesced loads only; a bin's population is the distance to the next head,
-    // found through the wavefronts' head masks; only a bin that runs past the block looks further (gallop + bisection)
-    for (uint32_t base = blockIdx.x * 256u; base < P; base += gridDim.x * 256u) {
-        const uint32_t j = base + t;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nWaves = (gridDim.x * 256u) >> 6;
+    // a wavefront takes 64 consecutive entries per iteration (coalesced, no workgroup barrier: a barrier per 256 entries made
+    // this kernel latency-bound, 89 us for 41 MB); a bin's population is the distance to the next head, found in the wave's
+    // head mask; a bin that runs past the wave's 64 entries looks further with a gallop + bisection over the sorted keys
+    for (uint32_t base = wave * 64u; base < P; base += nWaves * 64u) {
+        const uint32_t j = base + lane;
         const bool valid = j < P;
         const uint32_t b = valid ? keys[j] : 0xFFFFFFFFu;
         const bool isHead = valid && (j == 0 || keys[j - 1] != b);
         const unsigned long long m = __ballot(isHead);
-        if (lane == 0)
-            wmask[w] = m;
-        __syncthreads();
         if (isHead) {
             heads++;
-            int next = -1;
-            const unsigned long long mine = (lane < 63u) ? (wmask[w] >> (lane + 1u)) : 0ull;
-            if (mine)
-                next = (int)(t + 1u) + (__ffsll((long long)mine) - 1);
-            else
-                for (uint32_t w2 = w + 1; w2 < 4u && next < 0; w2++)
-                    if (wmask[w2])
-                        next = (int)(64u * w2) + (__ffsll((long long)wmask[w2]) - 1);
+            const unsigned long long mine = (lane < 63u) ? (m >> (lane + 1u)) : 0ull;
             uint32_t len;
-            if (next >= 0) {
-                len = (uint32_t)next - t;
+            if (mine) {
+                len = (uint32_t)__ffsll((long long)mine);
             } else {
-                const uint32_t end = min(base + 256u, P);
+                const uint32_t end = min(base + 64u, P);
                 uint32_t lo = end, hi = P;  // first index >= end with key > b
                 if (lo < hi && keys[lo] == b) {
                     uint32_t step = 32;
@@ -575,7 +566,28 @@ __global__ __launch_bounds__(256) void k_bin_stats(const uint32_t* __restrict__ 
             }
             pop = max(pop, len);
         }
-        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        heads += (uint32_t)__shfl_xor((int)heads, off);
+        pop = max(pop, (uint32_t)__shfl_xor((int)pop, off));
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        sHeads[threadIdx.x >> 6] = heads;
+        sPop[threadIdx.x >> 6] = pop;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)  // one record per workgroup, reduced by k_bin_stats_final: thousands of same-address atomics would
+        perBlock[blockIdx.x] = make_uint2(sHeads[0] + sHeads[1] + sHeads[2] + sHeads[3],  // serialise at ~12 ns each
+                                          max(max(sPop[0], sPop[1]), max(sPop[2], sPop[3])));
+}
+
+__global__ __launch_bounds__(256) void k_bin_stats_final(const uint2* __restrict__ perBlock, uint32_t nBlocks, DetectCounters* ctr) {
+    __shared__ uint32_t sHeads[4], sPop[4];
+    uint32_t heads = 0, pop = 0;
+    for (uint32_t i = threadIdx.x; i < nBlocks; i += 256u) {
+        const uint2 v = perBlock[i];
+        heads += v.x;
+        pop = max(pop, v.y);
     }
     for (int off = 32; off > 0; off >>= 1) {
         heads += (uint32_t)__shfl_xor((int)heads, off);
@@ -587,12 +599,9 @@ __global__ __launch_bounds__(256) void k_bin_stats(const uint32_t* __restrict__ 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t h = sHeads[0] + sHeads[1] + sHeads[2] + sHeads[3];
+        ctr->nActiveBins = sHeads[0] + sHeads[1] + sHeads[2] + sHeads[3];
         const uint32_t m = max(max(sPop[0], sPop[1]), max(sPop[2], sPop[3]));
-        if (h)
-            atomicAdd(&ctr->nActiveBins, h);
-        if (m > 1)
-            atomicMax(&ctr->maxInBin, m);
+        ctr->maxInBin = m > 1 ? m : 0u;
     }
 }
 
