@@ -800,6 +800,61 @@ class DEMSolver {
             family_pair.push_back({fam[pr.first], fam[pr.second]});
         return out;
     }
+    /// getContactForcesConcerningOwners (algorithms/DEMDynamicMisc.cu:14-100): every contact of the list with an owner in
+    /// `owners` on either side and a non-negligible force; the force as the tracked owner feels it (A's side first), the contact
+    /// point in global coordinates, optionally the contact torque in the owner's local or the global frame.  Needs the
+    /// per-contact records (on unless SetNoForceRecord).  Returns the number of pairs.
+    size_t GetOwnerContactForces(const std::vector<bodyID_t>& owners, std::vector<float3>& points, std::vector<float3>& forces,
+                                 std::vector<float3>* torques = nullptr, bool torque_in_local = false) {
+        const Snapshot sn = snapshot(true);
+        DemeCounts c{};
+        check(deme_get_counts(m_ctx, &c));
+        const size_t nc = sn.idA.size();
+        std::vector<float> cpB(3 * nc);
+        {
+            std::vector<float> f(3 * nc), t(3 * nc), a(3 * nc);
+            check(deme_download_contact_records(m_ctx, f.data(), t.data(), a.data(), cpB.data(), nc));
+        }
+        std::vector<bodyID_t> sorted = owners;
+        std::sort(sorted.begin(), sorted.end());
+        points.clear(), forces.clear();
+        if (torques)
+            torques->clear();
+        for (size_t i = 0; i < nc; i++) {
+            const uint8_t ty = sn.type[i];
+            const bodyID_t oA = m_keep.sphOwner[sn.idA[i]];
+            const bodyID_t oB = ty == 1 ? m_keep.sphOwner[sn.idB[i]] : ty == 2 ? m_keep.triOwner[sn.idB[i]] : m_keep.objOwner[sn.idB[i]];
+            bool isA;
+            if (std::binary_search(sorted.begin(), sorted.end(), oA))
+                isA = true;
+            else if (std::binary_search(sorted.begin(), sorted.end(), oB))
+                isA = false;
+            else
+                continue;
+            float3 force = {sn.F[3 * i], sn.F[3 * i + 1], sn.F[3 * i + 2]}, torque = {sn.T[3 * i], sn.T[3 * i + 1], sn.T[3 * i + 2]};
+            auto len = [](float3 v) { return std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); };
+            if ((torques ? len(force) + len(torque) : len(force)) < DEME_TINY_FLOAT_HOST)
+                continue;
+            float3 pnt = isA ? make_float3(sn.cpA[3 * i], sn.cpA[3 * i + 1], sn.cpA[3 * i + 2]) : make_float3(cpB[3 * i], cpB[3 * i + 1], cpB[3 * i + 2]);
+            const bodyID_t o = isA ? oA : oB;
+            if (!isA) {
+                force = force * -1.f;
+                torque = torque * -1.f;
+            }
+            const float4 q = sn.q[o];
+            if (torques) {  // the torque-only force becomes a torque about the contact point, in the owner's frame
+                rotate(torque, {-q.x, -q.y, -q.z, q.w});
+                torque = {pnt.y * torque.z - pnt.z * torque.y, pnt.z * torque.x - pnt.x * torque.z, pnt.x * torque.y - pnt.y * torque.x};
+                if (!torque_in_local)
+                    rotate(torque, q);
+                torques->push_back(torque);
+            }
+            rotate(pnt, q);
+            points.push_back(pnt + sn.com[o]);
+            forces.push_back(force);
+        }
+        return points.size();
+    }
     /// ShowTimingStats / ShowThreadCollaborationStats (API.h:1290-1300): the kernels' mean times from HIP events
     void ShowTimingStats() {
         for (const char* name : {"calc_forces", "integrate", "detect"}) {
@@ -1832,6 +1887,27 @@ class DEMTracker {
     void SetVel(float3 vel, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, &vel, nullptr, nullptr); }
     void SetAngVel(float3 w, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, nullptr, &w, nullptr); }
     void SetOriQ(float4 q, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, nullptr, nullptr, &q); }
+    /// every contact force on one tracked owner / on all of them (AuxClasses.h:335-410)
+    size_t GetContactForces(std::vector<float3>& points, std::vector<float3>& forces, size_t offset = 0) {
+        return m_sys->GetOwnerContactForces({GetOwnerID(offset)}, points, forces);
+    }
+    size_t GetContactForcesForAll(std::vector<float3>& points, std::vector<float3>& forces) {
+        return m_sys->GetOwnerContactForces(all_owner_ids(), points, forces);
+    }
+    size_t GetContactForcesAndGlobalTorque(std::vector<float3>& points, std::vector<float3>& forces, std::vector<float3>& torques,
+                                           size_t offset = 0) {
+        return m_sys->GetOwnerContactForces({GetOwnerID(offset)}, points, forces, &torques, false);
+    }
+    size_t GetContactForcesAndGlobalTorqueForAll(std::vector<float3>& points, std::vector<float3>& forces, std::vector<float3>& torques) {
+        return m_sys->GetOwnerContactForces(all_owner_ids(), points, forces, &torques, false);
+    }
+    size_t GetContactForcesAndLocalTorque(std::vector<float3>& points, std::vector<float3>& forces, std::vector<float3>& torques,
+                                          size_t offset = 0) {
+        return m_sys->GetOwnerContactForces({GetOwnerID(offset)}, points, forces, &torques, true);
+    }
+    size_t GetContactForcesAndLocalTorqueForAll(std::vector<float3>& points, std::vector<float3>& forces, std::vector<float3>& torques) {
+        return m_sys->GetOwnerContactForces(all_owner_ids(), points, forces, &torques, true);
+    }
     /// UpdateMesh (AuxClasses.h): replace the owner-local node coordinates of a tracked mesh (deformable meshes)
     void UpdateMesh(const std::vector<float3>& new_nodes) {
         if (m_kind != 2)
@@ -1843,6 +1919,12 @@ class DEMTracker {
     DEMSolver* m_sys;
     int m_kind;
     size_t m_index, m_n;
+    std::vector<bodyID_t> all_owner_ids() const {
+        std::vector<bodyID_t> ids(m_n);
+        for (size_t k = 0; k < m_n; k++)
+            ids[k] = GetOwnerID(k);
+        return ids;
+    }
     size_t in_range(size_t offset) const {
         if (offset >= m_n)
             throw std::runtime_error("tracker offset is out of range");

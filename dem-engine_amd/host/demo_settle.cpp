@@ -76,6 +76,22 @@ int main(int argc, char** argv) {
                     DEMSim.GetMaxOwnerSpeed(), zsum / (double)DEMSim.GetNumClumps());
     }
     std::printf("LID z=%.6f vz=%.6f\n", lid_tracker->Pos().z, lid_tracker->Vel().z);
+    {   // per-contact forces of tracked owners (DEMTracker::GetContactForces): their sum on one clump is its mass times its
+        // contact acceleration; find a clump that is in contact right now
+        std::vector<float3> pts, frc, trq;
+        const size_t n_all = tracker->GetContactForcesForAll(pts, frc);
+        size_t pick = 0, n_pick = 0;
+        for (size_t k = 0; k < tracker->GetNumOwners() && n_pick < 2; k++) {
+            pick = k;
+            n_pick = tracker->GetContactForcesAndLocalTorque(pts, frc, trq, k);
+        }
+        float3 sum = make_float3(0.f, 0.f, 0.f);
+        for (auto& f : frc)
+            sum = sum + f;
+        const float3 ma = tracker->ContactAcc(pick) * DEMSim.GetOwnerMass(tracker->GetOwnerID(pick));
+        std::printf("FORCES all=%zu picked=%zu pairs=%zu sum=%.6e,%.6e,%.6e ma=%.6e,%.6e,%.6e p0z=%.5f\n", n_all, pick, n_pick, sum.x, sum.y,
+                    sum.z, ma.x, ma.y, ma.z, pts.empty() ? -1.f : pts[0].z);
+    }
     std::printf("INSPECT max_z=%.6f mass=%.6e ke=%.6e tracked0_z=%.6f\n", max_z_finder->GetValue(), total_mass_finder->GetValue(),
                 ke_finder->GetValue(), tracker->Pos(0).z);
     if (argc > 3) {  // output + restart round trip (cf. DEMdemo_Repose.cpp's checkpoint use of WriteClumpFile / ReadClump*FromCsv)

@@ -45,6 +45,12 @@ def test_demo_runs_and_settles(tmp_path):
     vals = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in ins.split()[1:]}
     assert abs(vals["mass"] - 1000 * 2.6e3 * 5.5886717 * 0.005 ** 3) < 1e-6 * vals["mass"]
     assert vals["max_z"] > z[-1] and vals["max_z"] < 0.4 and vals["ke"] >= 0.0 and 0.0 < vals["tracked0_z"] < 0.4
+    # DEMTracker::GetContactForces*: the pair forces on a clump add up to its mass times its contact acceleration
+    fr = [l for l in out.stdout.splitlines() if l.startswith("FORCES")][0]
+    fv = dict(kv.split("=") for kv in fr.split()[1:])
+    fs, ma = np.array(fv["sum"].split(","), float), np.array(fv["ma"].split(","), float)
+    assert int(fv["all"]) > 100 and int(fv["pairs"]) >= 2 and 0.0 < float(fv["p0z"]) < 0.4
+    assert np.abs(fs - ma).max() <= 2e-5 * max(np.abs(fs).max(), 1e-12), (fs, ma)
     # region-limited inspectors: the two half spaces partition the bed's mass; a vertical column tops out below the bed's top;
     # the declared template volume is summed per clump
     reg = [l for l in out.stdout.splitlines() if l.startswith("REGION")][0]
