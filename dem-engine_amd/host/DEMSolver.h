@@ -605,6 +605,10 @@ class DEMSolver {
     }
     unsigned int GetOwnerFamily(unsigned int owner) { return owner_families().at(owner); }
     float GetOwnerMass(unsigned int owner) const { return m_keep.mass.at(m_keep.inert.at(owner)); }
+    float3 GetOwnerMOI(unsigned int owner) const {
+        const uint16_t k = m_keep.inert.at(owner);
+        return {m_keep.moix.at(k), m_keep.moiy.at(k), m_keep.moiz.at(k)};
+    }
     void SetOwnerPosition(unsigned int owner, float3 pos) { set_owner(owner, &pos, nullptr, nullptr, nullptr); }
     void SetOwnerVelocity(unsigned int owner, float3 vel) { set_owner(owner, nullptr, &vel, nullptr, nullptr); }
     void SetOwnerAngVel(unsigned int owner, float3 w) { set_owner(owner, nullptr, nullptr, &w, nullptr); }
@@ -1241,7 +1245,7 @@ class DEMSolver {
     struct Keep {  // scene arrays the writers need after Initialize
         std::vector<uint32_t> sphOwner, objOwner, triOwner;
         std::vector<uint16_t> sphComp, inert;
-        std::vector<float> Radii, rx, ry, rz, mass;
+        std::vector<float> Radii, rx, ry, rz, mass, moix, moiy, moiz;
         std::map<unsigned, std::string> templateName;
     } m_keep;
     struct Snapshot {
@@ -1785,6 +1789,7 @@ class DEMSolver {
         compile_prescriptions_and_rules();
         m_keep.sphOwner = sphOwner, m_keep.sphComp = sphComp, m_keep.inert = inert, m_keep.objOwner = objOwner, m_keep.triOwner = triOwner;
         m_keep.Radii = Radii, m_keep.rx = rx, m_keep.ry = ry, m_keep.rz = rz, m_keep.mass = mass;
+        m_keep.moix = moix, m_keep.moiy = moiy, m_keep.moiz = moiz;
         for (size_t i = 0; i < m_templates.size(); i++) {
             char nm[32];
             snprintf(nm, sizeof nm, "%04d", (int)i);
@@ -1887,6 +1892,62 @@ class DEMTracker {
     void SetVel(float3 vel, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, &vel, nullptr, nullptr); }
     void SetAngVel(float3 w, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, nullptr, &w, nullptr); }
     void SetOriQ(float4 q, size_t offset = 0) { m_sys->set_owner(GetOwnerID(offset), nullptr, nullptr, nullptr, &q); }
+    // the rest of the getters / setters of AuxClasses.h:117-333 (std::vector<float> twins of the float3 getters included)
+    float3 AngVelGlobal(size_t offset = 0) {
+        float3 w = AngVelLocal(offset);
+        DEMSolver::rotate(w, OriQ(offset));
+        return w;
+    }
+    float3 ContactAngAccGlobal(size_t offset = 0) {
+        float3 a = ContactAngAccLocal(offset);
+        DEMSolver::rotate(a, OriQ(offset));
+        return a;
+    }
+    float Mass(size_t offset = 0) { return m_sys->GetOwnerMass(GetOwnerID(offset)); }
+    float3 MOI(size_t offset = 0) { return m_sys->GetOwnerMOI(GetOwnerID(offset)); }
+    unsigned int GetFamily(size_t offset = 0) { return m_sys->GetOwnerFamily(GetOwnerID(offset)); }
+    void SetFamily(unsigned int fam_num) { m_sys->SetOwnerFamily(GetOwnerID(0), fam_num, m_n); }
+    void SetFamily(unsigned int fam_num, size_t offset) { m_sys->SetOwnerFamily(GetOwnerID(offset), fam_num, 1); }
+    static std::vector<float> vec3(float3 v) { return {v.x, v.y, v.z}; }
+    std::vector<float> GetPos(size_t offset = 0) { return vec3(Pos(offset)); }
+    std::vector<float> GetVel(size_t offset = 0) { return vec3(Vel(offset)); }
+    std::vector<float> GetAngVelLocal(size_t offset = 0) { return vec3(AngVelLocal(offset)); }
+    std::vector<float> GetAngVelGlobal(size_t offset = 0) { return vec3(AngVelGlobal(offset)); }
+    std::vector<float> GetContactAcc(size_t offset = 0) { return vec3(ContactAcc(offset)); }
+    std::vector<float> GetContactAngAccLocal(size_t offset = 0) { return vec3(ContactAngAccLocal(offset)); }
+    std::vector<float> GetContactAngAccGlobal(size_t offset = 0) { return vec3(ContactAngAccGlobal(offset)); }
+    std::vector<float> GetMOI(size_t offset = 0) { return vec3(MOI(offset)); }
+    std::vector<float> GetOriQ(size_t offset = 0) {
+        const float4 q = OriQ(offset);
+        return {q.x, q.y, q.z, q.w};
+    }
+    void SetPos(const std::vector<float3>& pos) {
+        for (size_t k = 0; k < pos.size() && k < m_n; k++)
+            SetPos(pos[k], k);
+    }
+    void SetVel(const std::vector<float3>& vel) {
+        for (size_t k = 0; k < vel.size() && k < m_n; k++)
+            SetVel(vel[k], k);
+    }
+    void SetAngVel(const std::vector<float3>& w) {
+        for (size_t k = 0; k < w.size() && k < m_n; k++)
+            SetAngVel(w[k], k);
+    }
+    void SetOriQ(const std::vector<float4>& q) {
+        for (size_t k = 0; k < q.size() && k < m_n; k++)
+            SetOriQ(q[k], k);
+    }
+    std::vector<float> GetOwnerWildcardValues(const std::string& name) {
+        const std::vector<float> all = m_sys->GetAllOwnerWildcardValue(name);
+        const size_t o0 = GetOwnerID(0);
+        return std::vector<float>(all.begin() + o0, all.begin() + o0 + m_n);
+    }
+    void SetOwnerWildcardValue(const std::string& name, float wc, size_t offset = 0) {
+        m_sys->SetOwnerWildcardValue(GetOwnerID(offset), name, wc, 1);
+    }
+    void SetOwnerWildcardValues(const std::string& name, const std::vector<float>& wc) {
+        m_sys->SetOwnerWildcardValue(GetOwnerID(0), name, wc);
+    }
     /// every contact force on one tracked owner / on all of them (AuxClasses.h:335-410)
     size_t GetContactForces(std::vector<float3>& points, std::vector<float3>& forces, size_t offset = 0) {
         return m_sys->GetOwnerContactForces({GetOwnerID(offset)}, points, forces);

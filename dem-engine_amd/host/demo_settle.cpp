@@ -76,6 +76,11 @@ int main(int argc, char** argv) {
                     DEMSim.GetMaxOwnerSpeed(), zsum / (double)DEMSim.GetNumClumps());
     }
     std::printf("LID z=%.6f vz=%.6f\n", lid_tracker->Pos().z, lid_tracker->Vel().z);
+    {   // the smaller tracker getters: template mass / MOI, family, global-frame angular velocity (|w| is frame-independent)
+        const float3 wl = tracker->AngVelLocal(7), wg = tracker->AngVelGlobal(7), moi = tracker->MOI(7);
+        std::printf("TRACK mass=%.6e moi_z=%.6e fam=%u wl2=%.6e wg2=%.6e lidfam=%u\n", tracker->Mass(7), moi.z, tracker->GetFamily(7),
+                    wl.x * wl.x + wl.y * wl.y + wl.z * wl.z, wg.x * wg.x + wg.y * wg.y + wg.z * wg.z, lid_tracker->GetFamily());
+    }
     {   // per-contact forces of tracked owners (DEMTracker::GetContactForces): their sum on one clump is its mass times its
         // contact acceleration; find a clump that is in contact right now
         std::vector<float3> pts, frc, trq;

@@ -51,6 +51,10 @@ def test_demo_runs_and_settles(tmp_path):
     fs, ma = np.array(fv["sum"].split(","), float), np.array(fv["ma"].split(","), float)
     assert int(fv["all"]) > 100 and int(fv["pairs"]) >= 2 and 0.0 < float(fv["p0z"]) < 0.4
     assert np.abs(fs - ma).max() <= 2e-5 * max(np.abs(fs).max(), 1e-12), (fs, ma)
+    tr = dict(kv.split("=") for kv in [l for l in out.stdout.splitlines() if l.startswith("TRACK")][0].split()[1:])
+    assert abs(float(tr["mass"]) - 2.6e3 * 5.5886717 * 0.005 ** 3) < 1e-6 * float(tr["mass"])
+    assert abs(float(tr["moi_z"]) - 3.9908 * 2.6e3 * 0.005 ** 5) < 1e-5 * float(tr["moi_z"])
+    assert tr["fam"] == "0" and tr["lidfam"] == "20" and abs(float(tr["wl2"]) - float(tr["wg2"])) <= 1e-4 * float(tr["wl2"]) + 1e-12
     # region-limited inspectors: the two half spaces partition the bed's mass; a vertical column tops out below the bed's top;
     # the declared template volume is summed per clump
     reg = [l for l in out.stdout.splitlines() if l.startswith("REGION")][0]
