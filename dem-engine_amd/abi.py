@@ -193,6 +193,7 @@ def load_library():
         "deme_get_adaptive_state": [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "deme_mark_persistent_contacts": [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_int],
         "deme_num_persistent_contacts": [_P, C.POINTER(C.c_size_t)],
+        "deme_add_owner_acc": [_P, C.c_uint32, C.c_uint32, _P, _P],
         "deme_download_persistent_contacts": [_P, _P, _P, _P, C.c_size_t],
         "deme_upload_persistent_contacts": [_P, _P, _P, _P, C.c_size_t],
         "deme_inspect": [_P, C.c_uint32, C.POINTER(C.c_float)],
@@ -434,6 +435,14 @@ class Context:
         n = C.c_size_t(0)
         self._ck(self.lib.deme_num_persistent_contacts(self.h, C.byref(n)), "deme_num_persistent_contacts")
         return int(n.value)
+
+    def add_owner_acc(self, owner, acc=None, ang_acc=None):
+        """DEMTracker::AddAcc / AddAngAcc: n x 3 arrays for owners [owner, owner + n), consumed by the next step only"""
+        a = None if acc is None else np.ascontiguousarray(acc, np.float32).reshape(-1, 3)
+        l = None if ang_acc is None else np.ascontiguousarray(ang_acc, np.float32).reshape(-1, 3)
+        n = len(a) if a is not None else len(l)
+        self._ck(self.lib.deme_add_owner_acc(self.h, int(owner), n, None if a is None else _ptr(a), None if l is None else _ptr(l)),
+                 "deme_add_owner_acc")
 
     def persistent_contacts(self):
         """the marked set as (idA, idB, type) arrays"""

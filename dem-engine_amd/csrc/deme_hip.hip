@@ -68,6 +68,10 @@ struct deme_ctx {
     DevBuf info;
     // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
     DevBuf persistKeys, binStat;
+    // acceleration the script adds for the next step only (deme_add_owner_acc): device records + host mirror
+    DevBuf nextAcc;
+    std::vector<AccRec> hNextAcc;
+    bool nextAccPending = false;
     std::vector<uint64_t> hPersist;
     // triangles (mesh path)
     uint32_t nTri = 0;
@@ -630,6 +634,7 @@ GatherArgs gather_args(deme_ctx* c) {
     g.conA4 = c->conA4.as<float4>(), g.conA2 = c->conA2.as<float2>();
     g.conB4 = c->conB4.as<float4>(), g.conB2 = c->conB2.as<float2>();
     g.aSum = c->aSum.as<float4>();
+    g.nextAcc = c->nextAccPending ? c->nextAcc.as<AccRec>() : nullptr;
     return g;
 }
 
@@ -769,6 +774,11 @@ int launch_integrate(deme_ctx* c, bool fused) {
         hipLaunchKernelGGL(k_integrate<false>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
                            c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c), pa);
     }
+    if (c->nextAccPending) {  // one step only (cleanUpAcc clears the flag when it honours it, DEMPrepForceKernels.cu:14-31)
+        c->nextAccPending = false;
+        std::fill(c->hNextAcc.begin(), c->hNextAcc.end(), AccRec{});
+        HIPCK(hipMemsetAsync(c->nextAcc.p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
+    }
     return DEME_OK;
 }
 
@@ -833,7 +843,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
-    DevBuf* all[] = {&c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1845,6 +1855,32 @@ int deme_compile_family_rules(deme_ctx* c, const char* rules) {
     }
     HIPCK(hipModuleLoadData(&c->rulesMod, it->second.data()));
     HIPCK(hipModuleGetFunction(&c->rulesFn, c->rulesMod, "deme_family_changes"));
+    return DEME_OK;
+}
+
+int deme_add_owner_acc(deme_ctx* c, uint32_t owner, uint32_t n, const float* acc, const float* angAcc) {
+    if (int rc = check_ready(c))
+        return rc;
+    if ((uint64_t)owner + n > c->nOwners || (!acc && !angAcc))
+        return fail(c, DEME_ERR_INVALID, "deme_add_owner_acc: owners [%u, %u) out of range or nothing to set", owner, owner + n);
+    if (c->hNextAcc.size() != c->nOwners) {
+        c->hNextAcc.assign(c->nOwners, AccRec{});
+        if (int rc = ensure(c, c->nextAcc, std::max<size_t>(c->nOwners, 1) * sizeof(AccRec)))
+            return rc;
+        HIPCK(hipMemsetAsync(c->nextAcc.p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        AccRec& r = c->hNextAcc[owner + k];
+        if (acc)
+            r.ax = acc[3 * k], r.ay = acc[3 * k + 1], r.az = acc[3 * k + 2];
+        if (angAcc)
+            r.lx = angAcc[3 * k], r.ly = angAcc[3 * k + 1], r.lz = angAcc[3 * k + 2];
+    }
+    if (n)
+        HIPCK(hipMemcpyAsync(c->nextAcc.as<AccRec>() + owner, c->hNextAcc.data() + owner, (size_t)n * sizeof(AccRec),
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    c->nextAccPending = true;
     return DEME_OK;
 }
 

@@ -669,6 +669,7 @@ struct GatherArgs {
     const float4* conB4;
     const float2* conB2;
     const float4* aSum;      // in-order sum of an A run that lies inside one force-kernel block (deme_force.h)
+    const AccRec* nextAcc;   // null, or per owner: acceleration the script added for this step (deme_add_owner_acc)
 };
 
 // A-side sum of one owner: the force kernel's in-workgroup result when the run lay inside one block, else the
@@ -1009,6 +1010,12 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         al = ap[1];
     }
 
+    if (g.nextAcc) {  // DEMTracker::AddAcc / AddAngAcc: on top of the contact sums (added last: the sums keep their order)
+        const float4* ep = reinterpret_cast<const float4*>(g.nextAcc + o);
+        const float4 ea = ep[0], el = ep[1];
+        a.x += ea.x, a.y += ea.y, a.z += ea.z;
+        al.x += el.x, al.y += el.y, al.z += el.z;
+    }
     const float h = p.h;
     f3 old_v = mk3(r.vx, r.vy, r.vz), old_w = mk3(r.wx, r.wy, r.wz);
     d3 X = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);

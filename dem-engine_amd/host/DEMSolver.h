@@ -1948,6 +1948,17 @@ class DEMTracker {
     void SetOwnerWildcardValues(const std::string& name, const std::vector<float>& wc) {
         m_sys->SetOwnerWildcardValue(GetOwnerID(0), name, wc);
     }
+    /// AddAcc / AddAngAcc (AuxClasses.h:264-274): extra acceleration for the coming step only (co-simulation hand-over)
+    void AddAcc(float3 acc, size_t offset = 0) {
+        const float v[3] = {acc.x, acc.y, acc.z};
+        m_sys->check(deme_add_owner_acc(m_sys->m_ctx, GetOwnerID(offset), 1, v, nullptr));
+    }
+    void AddAcc(const std::vector<float3>& acc) { add_many(acc, true); }
+    void AddAngAcc(float3 angAcc, size_t offset = 0) {
+        const float v[3] = {angAcc.x, angAcc.y, angAcc.z};
+        m_sys->check(deme_add_owner_acc(m_sys->m_ctx, GetOwnerID(offset), 1, nullptr, v));
+    }
+    void AddAngAcc(const std::vector<float3>& angAcc) { add_many(angAcc, false); }
     /// every contact force on one tracked owner / on all of them (AuxClasses.h:335-410)
     size_t GetContactForces(std::vector<float3>& points, std::vector<float3>& forces, size_t offset = 0) {
         return m_sys->GetOwnerContactForces({GetOwnerID(offset)}, points, forces);
@@ -1980,6 +1991,15 @@ class DEMTracker {
     DEMSolver* m_sys;
     int m_kind;
     size_t m_index, m_n;
+    void add_many(const std::vector<float3>& v, bool linear) {
+        if (v.size() != m_n)
+            throw std::runtime_error("AddAcc / AddAngAcc: one value per tracked owner is needed");
+        std::vector<float> flat(3 * m_n);
+        for (size_t k = 0; k < m_n; k++)
+            flat[3 * k] = v[k].x, flat[3 * k + 1] = v[k].y, flat[3 * k + 2] = v[k].z;
+        m_sys->check(deme_add_owner_acc(m_sys->m_ctx, GetOwnerID(0), (uint32_t)m_n, linear ? flat.data() : nullptr,
+                                        linear ? nullptr : flat.data()));
+    }
     std::vector<bodyID_t> all_owner_ids() const {
         std::vector<bodyID_t> ids(m_n);
         for (size_t k = 0; k < m_n; k++)

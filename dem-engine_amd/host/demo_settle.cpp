@@ -76,6 +76,15 @@ int main(int argc, char** argv) {
                     DEMSim.GetMaxOwnerSpeed(), zsum / (double)DEMSim.GetNumClumps());
     }
     std::printf("LID z=%.6f vz=%.6f\n", lid_tracker->Pos().z, lid_tracker->Vel().z);
+    {   // AddAcc: 1000 m/s^2 upwards on the lid for one step = +5e-3 m/s on top of... nothing: the lid's velocity is dictated
+        // by its prescription, so use a clump instead -- clump 11 gains a*h in x over what its twin step would have given
+        const float vx0 = tracker->Vel(11).x;
+        tracker->AddAcc(make_float3(1000.f, 0.f, 0.f), 11);
+        DEMSim.DoDynamicsThenSync(5e-6);
+        const float vx1 = tracker->Vel(11).x;
+        DEMSim.DoDynamicsThenSync(5e-6);
+        std::printf("ADDACC dv1=%.6e dv2=%.6e\n", vx1 - vx0, tracker->Vel(11).x - vx1);
+    }
     {   // the smaller tracker getters: template mass / MOI, family, global-frame angular velocity (|w| is frame-independent)
         const float3 wl = tracker->AngVelLocal(7), wg = tracker->AngVelGlobal(7), moi = tracker->MOI(7);
         std::printf("TRACK mass=%.6e moi_z=%.6e fam=%u wl2=%.6e wg2=%.6e lidfam=%u\n", tracker->Mass(7), moi.z, tracker->GetFamily(7),

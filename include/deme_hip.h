@@ -272,6 +272,14 @@ int deme_set_adaptive(deme_ctx* ctx, const DemeAdaptive* a);
 /* current bin size / cdUpdateFreq and how many adjustments each controller has made */
 int deme_get_adaptive_state(deme_ctx* ctx, double* binSize, uint32_t* cdUpdateFreq, uint32_t* nBinChanges, uint32_t* nFreqChanges);
 
+/* Acceleration added by the script for the NEXT step only (reference: DEMTracker::AddAcc / AddAngAcc, AuxClasses.h:264-274 ->
+ * DEMDynamicThread::addOwnerNextStepAcc / addOwnerNextStepAngAcc, dT.cpp:3160-3174: the values are written into a / alpha and a
+ * flag keeps prepareAccArrays from clearing them once, DEMPrepForceKernels.cu:14-31 -- co-simulation hands forces over this way).
+ * acc / angAcc: n x 3 floats for owners [owner, owner + n), either may be null; like the reference's setVal a second call
+ * for the same owner replaces the first.  The integrator adds them to the contact sums of the coming step (after the sums,
+ * whose order stays fixed) and the records clear themselves.  angAcc is in the owner's local frame like alpha. */
+int deme_add_owner_acc(deme_ctx* ctx, uint32_t owner, uint32_t n, const float* acc, const float* angAcc);
+
 /* Persistent contacts (reference: DEM/API.h:874-905 MarkFamilyPersistentContactEither/Both, MarkFamilyPersistentContact,
  * MarkPersistentContact and their Remove* inverses; DEM/APIPrivate.cpp:33-117; algorithms/DEMCubContactDetection.cu:605-802).
  * Qualifies contacts of the CURRENT list: mode 0 every contact, 1 either owner's family == N1, 2 both == N1, 3 the family

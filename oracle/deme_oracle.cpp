@@ -655,6 +655,8 @@ struct Sim {
     // marked (A, class, B) keys, which is what the flag array travelling with the list amounts to
     std::vector<Key> persist;
     std::vector<float> volume;  // per mass-property entry ("clump_volume" inspector)
+    // DEMTracker::AddAcc / AddAngAcc (dT.cpp:3160-3174): added to a / alpha of the coming step only, after the contact sums
+    std::vector<float> nextAcc;  // 6 per owner, empty when nothing is pending
 };
 
 template <typename T>
@@ -1203,6 +1205,13 @@ inline V3f vel_pass_on(uint32_t integrator, const V3f& old_v, const V3f& v_upd) 
 // components and the pose.
 void integrate(Sim& s) {
     const float h = s.p.h;
+    if (!s.nextAcc.empty()) {
+        for (uint32_t o = 0; o < s.nOwners; o++) {
+            s.aX[o] += s.nextAcc[6 * o], s.aY[o] += s.nextAcc[6 * o + 1], s.aZ[o] += s.nextAcc[6 * o + 2];
+            s.alX[o] += s.nextAcc[6 * o + 3], s.alY[o] += s.nextAcc[6 * o + 4], s.alZ[o] += s.nextAcc[6 * o + 5];
+        }
+        s.nextAcc.clear();
+    }
 #pragma omp parallel for schedule(static)
     for (int64_t oi = 0; oi < (int64_t)s.nOwners; oi++) {
         const uint32_t o = (uint32_t)oi;
@@ -1673,6 +1682,18 @@ void orc_sim_mark_persistent(void* h, int mode, uint32_t N1, uint32_t N2, int ma
     else
         std::set_difference(s.persist.begin(), s.persist.end(), hit.begin(), hit.end(), std::back_inserter(out), key_less);
     s.persist.swap(out);
+}
+void orc_sim_add_owner_acc(void* h, uint32_t owner, uint32_t n, const float* acc, const float* angAcc) {
+    Sim& s = *(Sim*)h;
+    if (s.nextAcc.empty())
+        s.nextAcc.assign(6 * (size_t)s.nOwners, 0.f);
+    for (uint32_t k = 0; k < n; k++)
+        for (int d = 0; d < 3; d++) {
+            if (acc)
+                s.nextAcc[6 * (size_t)(owner + k) + d] = acc[3 * k + d];
+            if (angAcc)
+                s.nextAcc[6 * (size_t)(owner + k) + 3 + d] = angAcc[3 * k + d];
+        }
 }
 size_t orc_sim_num_persistent(void* h) { return ((Sim*)h)->persist.size(); }
 void orc_sim_get_persistent(void* h, uint32_t* a, uint32_t* b, uint8_t* t) {

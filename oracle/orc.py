@@ -282,6 +282,13 @@ class OracleSim:
         self.L.orc_sim_num_persistent.restype = C.c_size_t
         return int(self.L.orc_sim_num_persistent(C.c_void_p(self.h)))
 
+    def add_owner_acc(self, owner, acc=None, ang_acc=None):
+        a = None if acc is None else np.ascontiguousarray(acc, np.float32).reshape(-1, 3)
+        l = None if ang_acc is None else np.ascontiguousarray(ang_acc, np.float32).reshape(-1, 3)
+        n = len(a) if a is not None else len(l)
+        self.L.orc_sim_add_owner_acc(C.c_void_p(self.h), C.c_uint32(owner), C.c_uint32(n), None if a is None else _p(a),
+                                     None if l is None else _p(l))
+
     def persistent_contacts(self):
         n = self.num_persistent_contacts()
         a, b, t = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)

@@ -514,3 +514,32 @@ def test_large_size_ratio_incidence_and_contacts(pkg, orc):
     gs, os_ = ctx.download_state(), sim.download_state()
     for k in STATE_KEYS:
         assert np.array_equal(gs[k], os_[k]), k
+
+
+def test_added_acceleration_for_one_step(pkg, orc):
+    """DEMTracker::AddAcc / AddAngAcc (co-simulation hand-over): accelerations the script adds act on the coming step only, on
+    top of the contact sums; bit-identical to the oracle; a later call for the same owner replaces the earlier one"""
+    b = pkg.model.packed_bed(1000, seed=8, cd_freq=0, spacing_mult=2.5, init_vz=-0.4)
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    twin = orc.make_sim(pkg, p, sc)
+    ctx.step(60), sim.step(60), twin.step(60)
+    rng = np.random.default_rng(0)
+    for k in range(5):
+        acc = rng.uniform(-50, 50, (40, 3)).astype(np.float32)
+        ang = rng.uniform(-500, 500, (40, 3)).astype(np.float32)
+        for s in (ctx, sim):
+            s.add_owner_acc(100, acc * 9.0)        # replaced by the next call
+            s.add_owner_acc(100, acc, ang)
+            s.add_owner_acc(500, None, ang[:3])    # angular part only
+        ctx.step(1), sim.step(1), twin.step(1)
+        gs, os_ = ctx.download_state(), sim.download_state()
+        for key in STATE_KEYS:
+            assert np.array_equal(gs[key], os_[key]), (k, key)
+        ctx.step(3), sim.step(3), twin.step(3)  # nothing pending any more
+    gs, os_, ts = ctx.download_state(), sim.download_state(), twin.download_state()
+    for key in STATE_KEYS:
+        assert np.array_equal(gs[key], os_[key]), key
+    dv = np.abs(gs["vX"] - ts["vX"]) + np.abs(gs["vY"] - ts["vY"]) + np.abs(gs["vZ"] - ts["vZ"])
+    assert (dv[100:140] > 1e-5).all() and (np.abs(gs["omgBarX"][500:503] - ts["omgBarX"][500:503]) > 1e-6).all()
+    with pytest.raises(pkg.abi.DemeError, match="out of range"):
+        ctx.add_owner_acc(int(sc.nOwners) - 1, np.zeros((2, 3), np.float32))

@@ -51,6 +51,9 @@ def test_demo_runs_and_settles(tmp_path):
     fs, ma = np.array(fv["sum"].split(","), float), np.array(fv["ma"].split(","), float)
     assert int(fv["all"]) > 100 and int(fv["pairs"]) >= 2 and 0.0 < float(fv["p0z"]) < 0.4
     assert np.abs(fs - ma).max() <= 2e-5 * max(np.abs(fs).max(), 1e-12), (fs, ma)
+    aa = dict(kv.split("=") for kv in [l for l in out.stdout.splitlines() if l.startswith("ADDACC")][0].split()[1:])
+    assert abs(float(aa["dv1"]) - 1000.0 * 5e-6) < 2e-3 and abs(float(aa["dv2"])) < 2e-3  # one step only (contacts add ~1e-3)
+    assert abs(float(aa["dv1"]) - float(aa["dv2"]) - 5e-3) < 2e-3
     tr = dict(kv.split("=") for kv in [l for l in out.stdout.splitlines() if l.startswith("TRACK")][0].split()[1:])
     assert abs(float(tr["mass"]) - 2.6e3 * 5.5886717 * 0.005 ** 3) < 1e-6 * float(tr["mass"])
     assert abs(float(tr["moi_z"]) - 3.9908 * 2.6e3 * 0.005 ** 5) < 1e-5 * float(tr["moi_z"])
