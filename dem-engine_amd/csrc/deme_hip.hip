@@ -915,6 +915,8 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         return fail(c, DEME_ERR_INVALID, "owner ids must fit 30 bits");
     hipSetDevice(c->device);
     c->nOwners = s->nOwners, c->nOwnerClumps = s->nOwnerClumps, c->nSpheres = s->nSpheres, c->nAnal = s->nAnal;
+    c->nextAccPending = false;  // per-owner records of the previous scene do not carry over
+    c->hNextAcc.clear();
     c->nMat = s->nMat, c->nComp = s->nComp, c->nMassProps = s->nMassProps;
     const size_t nO = s->nOwners, nS = s->nSpheres;
     // owners
