@@ -1066,6 +1066,18 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
             return rc;
         HIPCK(hipStreamSynchronize(c->stream));
     }
+    if (!c->hPersist.empty()) {  // persistent marks survive a re-upload (UpdateClumps appends) as long as their ids still exist
+        const size_t before = c->hPersist.size();
+        c->hPersist.erase(std::remove_if(c->hPersist.begin(), c->hPersist.end(),
+                                         [&](uint64_t k) {
+                                             const uint32_t cls = key_class(k);
+                                             const uint32_t nB = cls == DEME_KEY_CLASS_SS ? s->nSpheres : cls == DEME_KEY_CLASS_SM ? s->nTri : s->nAnal;
+                                             return key_a(k) >= s->nSpheres || key_b(k) >= nB;
+                                         }),
+                          c->hPersist.end());
+        if (c->hPersist.size() != before && !c->hPersist.empty())
+            HIPCK(hipMemcpyAsync(c->persistKeys.p, c->hPersist.data(), c->hPersist.size() * 8, hipMemcpyHostToDevice, c->stream));
+    }
     c->haveScene = true;
     c->haveList = false;
     c->mapFresh = false;
