@@ -418,6 +418,34 @@ class SceneBuilder:
         v[:len(tv)] = tv
         return v
 
+    def _user_wildcards(self, ctx):
+        """the user model's owner / geometry wildcard arrays as {(kind, slot): array}, read before a scene is uploaded again"""
+        if self.force_model != abi.FORCE_CUSTOM:
+            return {}
+        n = {"owner": int(self.counts["nOwners"]), "sphere": int(self.counts["nSpheres"]), "triangle": int(self.counts.get("nTri", 0)),
+             "analytical": int(self.counts["nAnal"])}
+        out = {}
+        for j in range(len(getattr(self, "owner_wildcards", []))):
+            out[("owner", j)] = ctx.wildcard_array("owner", j, n["owner"])
+        for j in range(len(getattr(self, "geo_wildcards", []))):
+            for kind in ("sphere", "triangle", "analytical"):
+                if n[kind]:
+                    out[(kind, j)] = ctx.wildcard_array(kind, j, n[kind])
+        return out
+
+    def _restore_user_wildcards(self, ctx, saved, owner_dst, sphere_dst):
+        """owner_dst / sphere_dst: new index of every old owner / sphere; triangles and analytical components keep theirs"""
+        for (kind, j), old in saved.items():
+            if kind == "owner":
+                new = np.zeros(int(self.counts["nOwners"]), np.float32)
+                new[owner_dst] = old
+            elif kind == "sphere":
+                new = np.zeros(int(self.counts["nSpheres"]), np.float32)
+                new[sphere_dst] = old
+            else:
+                new = old
+            ctx.set_wildcard_array(kind, j, new)
+
     def UpdateClumps(self, ctx, time_elapsed):
         """DEMSolver::UpdateClumps (API.h:1267): clumps added with AddClumps after Initialize() join the running simulation.
         Old owners keep their state, the contact list keeps its history (sphere ids are stable because new clumps are
@@ -425,6 +453,7 @@ class SceneBuilder:
         from (DemeParams.timeElapsed).  Returns the new (params, scene)."""
         old_counts = dict(self.counts)
         st = ctx.download_state()
+        saved_wc = self._user_wildcards(ctx)
         cnt = ctx.contacts()
         nW = int(self.params.nContactWildcards)
         W = np.stack([ctx.wildcard(w) for w in range(nW)], 1) if nW else np.zeros((len(cnt[0]), 0), np.float32)
@@ -443,6 +472,7 @@ class SceneBuilder:
         ctx.set_params(p)
         ctx.upload_scene(sc)
         self.compile_into(ctx)
+        self._restore_user_wildcards(ctx, saved_wc, idx_new, np.arange(int(old_counts["nSpheres"])))  # new spheres are appended
         if len(cnt[0]):
             ctx.seed_contacts(cnt[0], cnt[1], cnt[2], W)
         return p, sc
@@ -452,9 +482,10 @@ class SceneBuilder:
         their current positions, and state, contact list, contact history and persistent marks follow.  Mixing destroys the
         locality the initial numbering had, and the engine's gathers slow down with it (bench.py --order random: 28 %).
         Host-side like UpdateClumps (a few seconds per million clumps): meant to be called every few thousand steps.  Returns
-        (params, scene, new_owner_of_old_owner); owner / geometry wildcards of a user model are the caller's to permute with that
-        array.  No reference equivalent (its owner ids never change)."""
+        (params, scene, new_owner_of_old_owner); a user model's owner / geometry wildcard arrays are permuted along.  No reference
+        equivalent (its owner ids never change)."""
         st = ctx.download_state()
+        saved_wc = self._user_wildcards(ctx)
         cnt = ctx.contacts()
         nW = int(self.params.nContactWildcards)
         W = np.stack([ctx.wildcard(w) for w in range(nW)], 1) if nW else np.zeros((len(cnt[0]), 0), np.float32)
@@ -504,10 +535,12 @@ class SceneBuilder:
         ctx.set_params(p)
         ctx.upload_scene(sc)
         self.compile_into(ctx)
+        self._restore_user_wildcards(ctx, saved_wc, new_of_old, new_sphere)
         if len(cnt[0]):
             a, b2, flip = remap(*cnt[:3])
             W = W.copy()
-            W[flip, :min(3, W.shape[1])] *= -1.0  # B-to-A vector history of the Hertzian model (cf. decomp.redecompose)
+            if self.force_model == abi.FORCE_HERTZIAN:  # its delta_tan_x/y/z point from B to A (cf. decomp.redecompose); a user
+                W[flip, :3] *= -1.0                      # model's directional history is the user's to re-orient
             ctx.seed_contacts(a, b2, cnt[2], W)
         if pers is not None:
             a, b2, _ = remap(*pers)

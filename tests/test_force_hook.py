@@ -178,3 +178,50 @@ def test_owner_and_geometry_wildcards(pkg):
     expect = np.bincount(own[a][touching], minlength=nO) + np.bincount(ownB[touching], minlength=nO)
     assert np.array_equal(ctx.wildcard_array("owner", 0, nO), expect.astype(np.float32))  # additions of 1.0f are exact
     assert expect.max() > 5
+
+
+@pytest.mark.gpu
+def test_user_wildcard_arrays_follow_resort_and_update(pkg):
+    """owner / sphere wildcard arrays of a user model travel with their owners / spheres through ResortClumps (renumbering) and
+    UpdateClumps (appending), analytical ones stay put"""
+    b = pkg.model.packed_bed(1500, seed=31, cd_freq=0, spacing_mult=2.5, init_vz=-0.4, force_model=1, order="random")
+    b.AddBCPlane((0.0, 0.0, 0.0174), (0, 0, 1), 0)
+    b.DefineContactForceModel(ELECTRO)
+    b.SetPerContactWildcards([])
+    b.SetPerOwnerWildcards(["n_touch"])
+    b.SetPerGeometryWildcards(["charge"])
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    b.compile_into(ctx)
+    nS, nA, nO, nC = int(sc.nSpheres), int(sc.nAnal), int(sc.nOwners), int(sc.nOwnerClumps)
+    rng = np.random.default_rng(5)
+    q_sph = rng.uniform(-1, 1, nS).astype(np.float32)
+    q_wall = np.arange(1, nA + 1, dtype=np.float32)
+    ctx.set_wildcard_array("sphere", 0, q_sph)
+    ctx.set_wildcard_array("analytical", 0, q_wall)
+    ctx.step(30)
+    touch_old = ctx.wildcard_array("owner", 0, nO)
+    assert touch_old[:nC].sum() > 100
+    own_old = np.asarray(b.arrays["ownerClumpBody"], np.int64).copy()
+    pnew, scnew, new_of_old = b.ResortClumps(ctx, 30 * p.h)
+    touch_new = ctx.wildcard_array("owner", 0, nO)
+    assert np.array_equal(touch_new[new_of_old], touch_old)
+    q_new = ctx.wildcard_array("sphere", 0, nS)
+    own_new = np.asarray(b.arrays["ownerClumpBody"], np.int64)
+    first_old, first_new = np.searchsorted(own_old, np.arange(nC)), np.searchsorted(own_new, np.arange(nC))
+    for o in rng.integers(0, nC, 200):
+        assert np.array_equal(q_new[first_new[new_of_old[o]]:first_new[new_of_old[o]] + 3], q_sph[first_old[o]:first_old[o] + 3])
+    assert np.array_equal(ctx.wildcard_array("analytical", 0, nA), q_wall)
+    ctx.step(5)  # the model runs on the permuted arrays
+    # UpdateClumps: forty clumps appended; old values keep their (new) places, new entries start from zero
+    extra = b.AddClumps(b.templates[0], np.array([[0.03 + 0.02 * (i % 8), 0.03 + 0.02 * (i // 8), 0.13] for i in range(40)], np.float32))  # above the bed, inside the box
+    touch_before = ctx.wildcard_array("owner", 0, nO)
+    q_before = ctx.wildcard_array("sphere", 0, nS)
+    p2, sc2 = b.UpdateClumps(ctx, 35 * p.h)
+    nO2, nS2, nC2 = int(sc2.nOwners), int(sc2.nSpheres), int(sc2.nOwnerClumps)
+    assert nC2 == nC + 40 and nS2 == nS + 120
+    t2, q2 = ctx.wildcard_array("owner", 0, nO2), ctx.wildcard_array("sphere", 0, nS2)
+    assert np.array_equal(t2[:nC], touch_before[:nC]) and (t2[nC:nC2] == 0).all() and np.array_equal(t2[nC2:], touch_before[nC:])
+    assert np.array_equal(q2[:nS], q_before) and (q2[nS:] == 0).all()
+    ctx.step(5)
