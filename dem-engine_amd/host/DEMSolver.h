@@ -1624,8 +1624,18 @@ class DEMSolver {
             lx[o] = s[0], ly[o] = s[1], lz[o] = s[2];
         };
         size_t o = 0;
+        bool warned = false;
         for (auto& b : m_batches)
             for (size_t i = 0; i < b->nClumps; i++, o++) {
+                const float3 c = b->xyz[i];
+                if (!warned && (c.x < m_user_min.x || c.y < m_user_min.y || c.z < m_user_min.z || c.x > m_user_max.x ||
+                                c.y > m_user_max.y || c.z > m_user_max.z)) {  // the reference's courtesy check, dT.cpp:739-744, 887-893
+                    std::fprintf(stderr,
+                                 "WARNING: At least one clump is initialized with a position out of the box domain you specified.\nIt is "
+                                 "found at %.5g, %.5g, %.5g (this message only shows one such example).\nThis simulation is unlikely to "
+                                 "go as planned.\n", c.x, c.y, c.z);
+                    warned = true;
+                }
                 encode(o, b->xyz[i]);
                 qw[o] = b->oriQ[i].w, qx[o] = b->oriQ[i].x, qy[o] = b->oriQ[i].y, qz[o] = b->oriQ[i].z;
                 vx[o] = b->vel[i].x, vy[o] = b->vel[i].y, vz[o] = b->vel[i].z;

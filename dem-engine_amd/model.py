@@ -747,6 +747,15 @@ class SceneBuilder:
     def Initialize(self):
         nv, l, voxel = self._figure_out_nv()
         lbf = self.target_box_min.astype(np.float32)
+        for bt in self.batches:  # the reference's courtesy check (dT.cpp:739-744, 887-893): a warning, not an error
+            out = ((bt.xyz < self.user_box_min) | (bt.xyz > self.user_box_max)).any(axis=1)
+            if out.any():
+                import warnings
+                sx = bt.xyz[np.argmax(out)]
+                warnings.warn("At least one clump is initialized with a position out of the box domain you specified. It is found at "
+                              f"{sx[0]:.5g}, {sx[1]:.5g}, {sx[2]:.5g} (this message only shows one such example). This simulation is "
+                              "unlikely to go as planned.", stacklevel=2)
+                break
 
         # templates sorted by component count (APIPrivate.cpp:696-742); stable here
         order = sorted(range(len(self.templates)), key=lambda i: len(self.templates[i].radii))

@@ -170,3 +170,11 @@ def test_resort_clumps_in_a_running_simulation(pkg):
     assert np.abs(X[new_of_old[:n]] - Xt[:n]).max() < 1e-9
     assert np.abs(gs["vZ"][new_of_old[:n]] - ts["vZ"][:n]).max() < 1e-5
     assert int(ctx.counts().nContacts) == int(twin.counts().nContacts)
+
+
+def test_clump_outside_the_box_is_warned_about(pkg):
+    """the reference's courtesy check at initialisation (dT.cpp:739-744, 887-893): a warning naming one such clump"""
+    b = pkg.model.packed_bed(50, seed=1)
+    b.batches[0].xyz[3] = (0.0, 0.0, 99.0)
+    with pytest.warns(UserWarning, match="out of the box domain"):
+        b.Initialize()
