@@ -1958,6 +1958,33 @@ class DEMTracker {
     void SetOwnerWildcardValues(const std::string& name, const std::vector<float>& wc) {
         m_sys->SetOwnerWildcardValue(GetOwnerID(0), name, wc);
     }
+    /// geometry wildcards of the tracked object's spheres / analytical components / triangles, in geometry order
+    /// (AuxClasses.h:235, 329-333)
+    std::vector<float> GetGeometryWildcardValues(const std::string& name) {
+        const std::vector<uint32_t>& own = geo_owner_list();
+        const std::vector<float> all = m_sys->get_wildcard(geo_kind(), own.size(), m_sys->m_force_model->geo_wildcards, name);
+        std::vector<float> out;
+        const size_t o0 = GetOwnerID(0);
+        for (size_t i = 0; i < own.size(); i++)
+            if (own[i] >= o0 && own[i] < o0 + m_n)
+                out.push_back(all[i]);
+        return out;
+    }
+    void SetGeometryWildcardValues(const std::string& name, const std::vector<float>& wc) {
+        const std::vector<uint32_t>& own = geo_owner_list();
+        const size_t o0 = GetOwnerID(0);
+        m_sys->edit_wildcard(geo_kind(), own.size(), m_sys->m_force_model->geo_wildcards, name, [&](std::vector<float>& a) {
+            size_t k = 0;
+            for (size_t i = 0; i < own.size() && k < wc.size(); i++)
+                if (own[i] >= o0 && own[i] < o0 + m_n)
+                    a[i] = wc[k++];
+        });
+    }
+    void SetGeometryWildcardValue(const std::string& name, float wc, size_t geo_offset = 0) {
+        std::vector<float> v = GetGeometryWildcardValues(name);
+        v.at(geo_offset) = wc;
+        SetGeometryWildcardValues(name, v);
+    }
     /// AddAcc / AddAngAcc (AuxClasses.h:264-274): extra acceleration for the coming step only (co-simulation hand-over)
     void AddAcc(float3 acc, size_t offset = 0) {
         const float v[3] = {acc.x, acc.y, acc.z};
@@ -2001,6 +2028,10 @@ class DEMTracker {
     DEMSolver* m_sys;
     int m_kind;
     size_t m_index, m_n;
+    uint32_t geo_kind() const { return m_kind == 0 ? 1u : (m_kind == 1 ? 3u : 2u); }  // spheres / analytical / triangles
+    const std::vector<uint32_t>& geo_owner_list() const {
+        return m_kind == 0 ? m_sys->m_keep.sphOwner : (m_kind == 1 ? m_sys->m_keep.objOwner : m_sys->m_keep.triOwner);
+    }
     void add_many(const std::vector<float3>& v, bool linear) {
         if (v.size() != m_n)
             throw std::runtime_error("AddAcc / AddAngAcc: one value per tracked owner is needed");

@@ -86,6 +86,13 @@ int main(int argc, char** argv) {
     DEMSim.WriteClumpFile(dir + "/clumps.csv");
     DEMSim.SetContactOutputContent(OWNER | FORCE | CNT_WILDCARD);
     DEMSim.WriteContactFile(dir + "/contacts.csv");
+    {   // the same through a tracker: geometry wildcards of the tracked batch, in geometry order
+        auto tr = DEMSim.Track(batch);
+        std::vector<float> g = tr->GetGeometryWildcardValues("charge");
+        tr->SetGeometryWildcardValue("charge", 7.5f, 3);
+        std::printf("CHECK tracker_geo %zu %.1f %.1f\n", g.size(), g[3], tr->GetGeometryWildcardValues("charge")[3]);
+        tr->SetGeometryWildcardValue("charge", g[3], 3);
+    }
     // owner-level getters / setters of the solver object (API.h:515-586, 699-709) and per-family output control
     DEMSim.SetOwnerVelocity(5, make_float3(0.f, 0.f, 1.f));
     DEMSim.SetOwnerFamily(7, 9);

@@ -139,6 +139,7 @@ def test_custom_model_demo_wildcards_from_the_script(tmp_path):
     assert 0.9 * total < sph["n_touch"].sum() <= total  # one sphere per clump here; the rest is the wall owner's counter
     clp = open(tmp_path / "clumps.csv").readline().strip()
     assert clp == "X,Y,Z,Qw,Qx,Qy,Qz,clump_type,family,n_touch"
+    assert chk["tracker_geo"] == ["600", "-1.0", "7.5"]
     # solver-level owner setters / getters, ChangeClumpFamily by region, DisableFamilyOutput
     ow = chk["owner"]
     assert float(ow[1]) == 1.0 and int(ow[3]) == 9 and int(ow[5]) == 3 * 10 * 6 and float(ow[9]) == 1.0
