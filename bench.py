@@ -441,7 +441,8 @@ def main():
         "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[4] flavour: polydisperse spheres (8 templates, r..3r) with a run-time compiled "
                                 "cohesion model" if args.config5 else
-                                "BASELINE configs[1]: 1M three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling")
+                                f"BASELINE configs[1]: {args.clumps} three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling"
+                                + (f"; one bed {world} times as long cut into {world} x-slabs (configs[2] flavour)" if world > 1 else ""))
                                + (f" + {int(sc.nTri)}-triangle plate (configs[3] flavour)" if int(sc.nTri) else ""),
                    "clumps_total": total_clumps, "owners_this_rank": int(sc.nOwners), "spheres_this_rank": int(sc.nSpheres),
                    "contacts_this_rank": int(c.nContacts), "bin_sphere_touches": int(c.nBinSphereTouches),
