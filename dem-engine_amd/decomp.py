@@ -34,6 +34,16 @@ def slab_edges(x, n_ranks):
     return qs
 
 
+def _ranges(starts, counts):
+    """concatenation of arange(starts[i], starts[i] + counts[i]) without a Python loop (millions of clumps per rank)"""
+    starts, counts = np.asarray(starts, np.int64), np.asarray(counts, np.int64)
+    total = int(counts.sum())
+    if total == 0:
+        return np.zeros(0, np.int64)
+    first = np.cumsum(counts) - counts  # where each run begins in the output
+    return np.repeat(starts - first, counts) + np.arange(total, dtype=np.int64)
+
+
 def decompose(arrays, counts, clump_x, n_ranks, halo):
     """Split a global scene.  clump_x: x of every clump centre (world frame).  Returns one dict per rank:
     arrays, counts, n_own, global_ids (own clumps' global owner ids), send/recv id lists (local owner ids)."""
@@ -69,8 +79,7 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
         fam = a["familyID"]
         fam[len(own):len(own) + len(gl) + len(gr)] = GHOST_FAMILY
         clumps_here = owners_g[:len(own) + len(gl) + len(gr)]
-        sph_idx = np.concatenate([np.arange(first_sphere[o], first_sphere[o + 1]) for o in clumps_here]) \
-            if len(clumps_here) else np.zeros(0, np.int64)
+        sph_idx = _ranges(first_sphere[clumps_here], first_sphere[clumps_here + 1] - first_sphere[clumps_here])
         for k in _SPHERE_KEYS:
             a[k] = arrays[k][sph_idx].copy()
         a["ownerClumpBody"] = new_id[arrays["ownerClumpBody"][sph_idx]].astype(np.uint32)
