@@ -543,3 +543,34 @@ def test_added_acceleration_for_one_step(pkg, orc):
     assert (dv[100:140] > 1e-5).all() and (np.abs(gs["omgBarX"][500:503] - ts["omgBarX"][500:503]) > 1e-6).all()
     with pytest.raises(pkg.abi.DemeError, match="out of range"):
         ctx.add_owner_acc(int(sc.nOwners) - 1, np.zeros((2, 3), np.float32))
+
+
+def test_mixed_multi_sphere_templates_from_the_reference_data(pkg, orc):
+    """a bed mixing the reference's own clump shapes (data/clumps: 3_clump, ellipsoid_2_1_1 with 5 components, 6_clump with 6) --
+    different component counts per clump, templates re-ordered by component count at initialisation (APIPrivate.cpp:696-742);
+    200 steps bit-identical to the oracle"""
+    import os
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data")
+    b = pkg.model.packed_bed(900, seed=17, cd_freq=0, scale=0.004, spacing_mult=2.6, init_vz=-0.6, E=1e7)  # many shapes overlap at once
+    rho, s = 2.6e3, 0.004
+    shapes = []
+    for name, vol, moi in (("ellipsoid_2_1_1.csv", 7.0, (6.0, 6.0, 3.0)), ("6_clump.csv", 2.7564385, (1.0352626, 0.9616627, 1.6978352))):
+        rel, rad = pkg.io.read_clump_template_csv(os.path.join(ref, name))
+        t = b.LoadClumpType(rho * vol, tuple(rho * m for m in moi), rad, rel, 0)
+        shapes.append(t.Scale(s))
+    assert [len(t.radii) for t in shapes] == [5, 6]
+    batch = b.batches[0]
+    rng = np.random.default_rng(3)
+    pick = rng.integers(0, 3, len(batch.xyz))
+    batch.templates = [batch.templates[i] if k == 0 else shapes[k - 1] for i, k in enumerate(pick)]
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    n_comp = np.bincount(np.asarray(b.arrays["ownerClumpBody"]), minlength=int(sc.nOwnerClumps))[:int(sc.nOwnerClumps)]
+    assert set(np.unique(n_comp).tolist()) == {3, 5, 6} and int(sc.nSpheres) == int(n_comp.sum())
+    most = 0
+    for chunk, n in enumerate((5, 15, 30, 50, 100)):
+        ctx.step(n), sim.step(n)
+        most = max(most, len(assert_same_contacts(ctx, sim)[0]))
+        gs, os_ = ctx.download_state(), sim.download_state()
+        for k in STATE_KEYS:
+            assert np.array_equal(gs[k], os_[k]), (chunk, k)
+    assert most > 300  # (the overlapping shapes push each other apart within a few dozen steps)

@@ -1,7 +1,8 @@
 """Output writers / CSV readers against the reference's own data fixtures and formats.
 
-tests/golden/ref_data/ holds three DATA files of the reference: data/sim_data/example_cnt_pairs.csv (a contact file written
-by the reference), data/clumps/3_clump.csv, and data/mesh/sphere.obj (BallDrop's projectile, tests/test_config0_balldrop.py).  CPU tests use the oracle as the state provider;
+tests/golden/ref_data/ holds DATA files of the reference: data/sim_data/example_cnt_pairs.csv (a contact file written by the
+reference), data/clumps/3_clump.csv, ellipsoid_2_1_1.csv and 6_clump.csv (tests/test_gpu_parity.py mixes the three shapes), and
+data/mesh/sphere.obj (BallDrop's projectile, tests/test_config0_balldrop.py).  CPU tests use the oracle as the state provider;
 the GPU test does a write -> read -> restart round trip through the C-ABI (deme_seed_contacts)."""
 import os
 
