@@ -103,6 +103,19 @@ int main(int argc, char** argv) {
     DEMSim.DisableFamilyOutput(3);
     DEMSim.SetOutputContent(FAMILY);
     DEMSim.WriteSphereFile(dir + "/spheres_no3.csv");
+    {   // renumbering in place: owner 3's state, counter and charge travel to its new id; the run carries on
+        const float t3 = DEMSim.GetOwnerWildcardValue(3, "n_touch")[0], q3 = DEMSim.GetSphereWildcardValue(3, "charge", 1)[0];
+        const float3 p3 = DEMSim.GetOwnerPosition(3);
+        const size_t nc = DEMSim.GetNumContacts();
+        const std::vector<bodyID_t> map = DEMSim.ResortClumps();
+        const float3 p3n = DEMSim.GetOwnerPosition(map[3]);
+        std::printf("CHECK resort moved %d same_pos %d same_touch %d same_charge %d\n", (int)(map[3] != 3 || map[4] != 4 || map[5] != 5),
+                    (int)(p3.x == p3n.x && p3.y == p3n.y && p3.z == p3n.z),
+                    (int)(DEMSim.GetOwnerWildcardValue(map[3], "n_touch")[0] == t3),
+                    (int)(DEMSim.GetSphereWildcardValue(map[3], "charge", 1)[0] == q3));  // one sphere per clump: sphere id = owner id
+        DEMSim.DoDynamicsThenSync(20 * 5e-6);
+        std::printf("CHECK resort_contacts %zu %zu\n", nc, DEMSim.GetNumContacts());
+    }
     std::printf("DEMO_OK\n");
     return 0;
 }

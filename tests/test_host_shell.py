@@ -140,6 +140,8 @@ def test_custom_model_demo_wildcards_from_the_script(tmp_path):
     clp = open(tmp_path / "clumps.csv").readline().strip()
     assert clp == "X,Y,Z,Qw,Qx,Qy,Qz,clump_type,family,n_touch"
     assert chk["tracker_geo"] == ["600", "-1.0", "7.5"]
+    assert chk["resort"] == ["moved", "1", "same_pos", "1", "same_touch", "1", "same_charge", "1"]
+    assert int(chk["resort_contacts"][0]) > 100 and int(chk["resort_contacts"][1]) > 100
     # solver-level owner setters / getters, ChangeClumpFamily by region, DisableFamilyOutput
     ow = chk["owner"]
     assert float(ow[1]) == 1.0 and int(ow[3]) == 9 and int(ow[5]) == 3 * 10 * 6 and float(ow[9]) == 1.0
