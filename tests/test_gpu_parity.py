@@ -2,8 +2,10 @@
 the C-ABI, against the CPU oracle on the same seeded inputs.
 
 Bars (BASELINE.json north_star): contact sets, bin assignments, history maps and the position codec
-are integer work -> bit-exact.  Forces / accelerations / velocities are fp32 with float atomics in
-the accumulation (order differs from the oracle's list order) -> tolerances stated per test.
+are integer work -> bit-exact.  Forces, accelerations and whole trajectories are fp32 physics over fp64 geometry; the
+accumulation is atomics-free with a fixed summation order that the oracle shares, so they are compared for EQUALITY too.
+The exceptions carry their tolerance in the test: owners reduced by the workgroup tree (more than 256 contacts) and sums
+compared with numpy.
 """
 import numpy as np
 import pytest
