@@ -148,3 +148,50 @@ def test_full_size_update_frequency_and_margins(pkg, big):
     d = np.abs(pos(tight) - pos(every)).max(1)
     assert d2 == 8 and n0 < n2 < n1
     assert (d > 0).mean() < 0.02 and d.max() < 1e-4, ((d > 0).mean(), d.max())
+
+
+@pytest.mark.gpu
+def test_mesh_flavour_at_scale_matches_oracle(pkg, orc):
+    """BASELINE configs[3] flavour at scale: 3e5 clumps settled on a wavy 30k-triangle plate (1e5 sphere-triangle contacts among
+    8e5): contact list and 15 further steps bit-identical to the oracle.  (A one-off run of the same check at 1e6 clumps + 50k
+    triangles, 5.3e5 sphere-triangle contacts, was bit-identical as well.)"""
+    import copy
+    import os
+    import bench
+    b = bench.build_bed(pkg, 300_000, 2024, 0)
+    lo, hi = b.user_box_min, b.user_box_max
+    v, f = pkg.model.plate_mesh(122, 122, float(hi[0] - lo[0]) * 0.98, float(hi[1] - lo[1]) * 0.98, z=0.0, wavy=0.002)
+    m = b.AddMeshObject(v, f, 0)
+    m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 0.021))
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_params(p), ctx.upload_scene(sc)
+    q = copy.copy(p)
+    q.cdUpdateFreq = 40
+    ctx.set_params(q)
+    ctx.step(12000)
+    ctx.set_params(p)
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+    orc.set_num_threads(min(64, os.cpu_count() or 1))
+    try:
+        st = ctx.download_state()
+        sim = orc.make_sim(pkg, p, sc)
+        sim.upload_state({k: st[k] for k in keys})
+        ctx.compute_margins(0), sim.compute_margins(0)
+        ctx.detect(), sim.detect()
+        a, bb, t, _ = ctx.contacts()
+        oa, ob, ot, _ = sim.contacts()
+        assert len(a) > 500_000 and int((t == 2).sum()) > 50_000
+        assert np.array_equal(a, oa) and np.array_equal(bb, ob) and np.array_equal(t, ot)
+        ctx.migrate(), sim.migrate()
+        for w in range(4):
+            ctx.set_wildcard(w, sim.wildcard(w))
+        ctx.step(15), sim.step(15)
+        gs, os_ = ctx.download_state(), sim.download_state()
+        for k in keys:
+            assert np.array_equal(gs[k], os_[k]), k
+        a, bb, t, _ = ctx.contacts()
+        oa, ob, ot, _ = sim.contacts()
+        assert np.array_equal(a, oa) and np.array_equal(bb, ob) and np.array_equal(t, ot)
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
