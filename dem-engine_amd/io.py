@@ -300,3 +300,32 @@ def read_obj(path):
     if len(fa) and (fa.min() < 0 or fa.max() >= len(v)):
         raise ValueError(f"{path}: face index out of range")
     return v, fa
+
+
+def write_mesh_file(path, p, meshes, counts, state):
+    """DEMSolver::WriteMeshFile -> writeMeshesAsVtk (dT.cpp:1850-1935): every mesh of the scene in one legacy-VTK
+    UNSTRUCTURED_GRID file -- POINTS (owner-local vertices rotated by the owner's quaternion, then translated to its position),
+    CELLS ("3 i j k" per facet, vertex indices offset per mesh), CELL_TYPES (5 = triangle).  `meshes`: the builder's MeshObj list
+    (vertices (n, 3), faces (m, 3)); mesh owners are the last len(meshes) owners."""
+    n_owners = int(counts["nOwners"])
+    com = decode_positions_f32(state, p)
+    q = _quat(state)
+    lines = ["# vtk DataFile Version 2.0", "VTK from DEM simulation", "ASCII", "", "", "DATASET UNSTRUCTURED_GRID"]
+    total_v = sum(len(m.vertices) for m in meshes)
+    total_f = sum(len(m.faces) for m in meshes)
+    lines.append(f"POINTS {total_v} float")
+    offs, off = [], 0
+    for i, m in enumerate(meshes):
+        owner = n_owners - len(meshes) + i
+        v = np.asarray(m.vertices, np.float32).reshape(-1, 3)
+        w = (rotate_f32(np.repeat(q[owner][None, :], len(v), 0), v) + com[owner]).astype(np.float32)
+        lines += [f"{_g(a)} {_g(b)} {_g(c)}" for a, b, c in w]
+        offs.append(off)
+        off += len(v)
+    lines += ["", "", f"CELLS {total_f} {4 * total_f}"]
+    for m, o in zip(meshes, offs):
+        lines += [f"3 {int(a) + o} {int(b) + o} {int(c) + o}" for a, b, c in np.asarray(m.faces, np.int64).reshape(-1, 3)]
+    lines += ["", "", f"CELL_TYPES {total_f}"] + ["5 "] * total_f
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return total_v, total_f

@@ -222,3 +222,27 @@ def test_update_clumps_appends_to_a_running_simulation(pkg, orc):
         assert np.array_equal(g[k], o[k]), k
     newcomers_touch = (np.isin(ctx.contacts()[0] // 3, np.arange(n_old, n_old + 300))).sum()
     assert newcomers_touch > 20  # the poured layer has landed on the bed
+
+
+def test_mesh_file_vtk(pkg, orc, tmp_path):
+    """WriteMeshFile: legacy VTK of the mesh in its current pose (vertices rotated and translated with the owner)"""
+    b = pkg.model.packed_bed(60, seed=2, cd_freq=0)
+    v, f = pkg.model.plate_mesh(3, 2, 0.06, 0.04, z=0.0, wavy=0.0)
+    m = b.AddMeshObject(v, f, 0)
+    m.SetInitPos((0.05, 0.06, 0.01))
+    m.SetInitQuat((0.0, 0.0, np.sin(np.pi / 4), np.cos(np.pi / 4)))  # 90 degrees about z
+    p, sc = b.Initialize()
+    sim = orc.make_sim(pkg, p, sc)
+    path = tmp_path / "mesh.vtk"
+    nv, nf = pkg.io.write_mesh_file(path, p, b.meshes, b.counts, sim.download_state())
+    txt = open(path).read().split("\n")
+    assert txt[0] == "# vtk DataFile Version 2.0" and txt[5] == "DATASET UNSTRUCTURED_GRID" and txt[6] == f"POINTS {nv} float"
+    pts = np.array([[float(x) for x in l.split()] for l in txt[7:7 + nv]])
+    v = np.asarray(v, np.float64)
+    expect = np.stack([-v[:, 1], v[:, 0], v[:, 2]], 1) + np.array([0.05, 0.06, 0.01])  # rotated by 90 degrees, then moved
+    assert nv == len(v) and nf == len(f) and np.abs(pts - expect).max() < 1e-6
+    i = txt.index(f"CELLS {nf} {4 * nf}")
+    cells = np.array([[int(x) for x in l.split()] for l in txt[i + 1:i + 1 + nf]])
+    assert (cells[:, 0] == 3).all() and np.array_equal(cells[:, 1:], np.asarray(f))
+    j = txt.index(f"CELL_TYPES {nf}")
+    assert all(l.strip() == "5" for l in txt[j + 1:j + 1 + nf])
