@@ -1097,6 +1097,8 @@ class DEMSolver {
     }
     /// Contacts whose |force + torque-only force| reaches force_thres; needs SetContactOutputContent before Initialize if the
     /// force / point / torque columns are wanted (per-contact records are switched on at Initialize).
+    /// every pair of the list, the potential (not touching) ones included (API.h:1110-1116)
+    void WriteContactFileIncludingPotentialPairs(const std::string& outfilename) { WriteContactFile(outfilename, -1.0f); }
     void WriteContactFile(const std::string& outfilename, float force_thres = DEME_TINY_FLOAT_HOST) {
         const Snapshot sn = snapshot(true);
         const unsigned fl = m_cnt_out_content;

@@ -214,6 +214,12 @@ def write_contact_file(path, p, arrays, counts, state, contacts, records, wildca
 
 
 # ---- readers (static members of DEMSolver, API.h:1153-1250) ---------------------------------------------------
+def write_contact_file_including_potential_pairs(path, p, arrays, counts, state, contacts, records, wildcards,
+                                                 flags=DEFAULT_CNT_OUTPUT_CONTENT):
+    """WriteContactFileIncludingPotentialPairs (API.h:1110-1116): force threshold -1, i.e. every pair of the list"""
+    return write_contact_file(path, p, arrays, counts, state, contacts, records, wildcards, flags=flags, force_thres=-1.0)
+
+
 def _read_csv(path):
     with open(path) as f:
         rows = [r for r in csv.reader(line for line in f if line.strip() and not line.lstrip().startswith("#"))]
