@@ -194,12 +194,11 @@ __global__ __launch_bounds__(256) void k_fill_incidence(const DevParams p, const
 #define SW_WPB 1  // windows per workgroup (measured: 1 -> 2.30 ms, 4 -> 2.35 ms, 16 -> 2.51 ms per detection)
 #endif
 #define SW_W (2 * SW_T)
-#define SW_OUT 1024
-#define SW_FLUSH 512
+#define SW_OUT 512
+#define SW_FLUSH 256
 
 struct SweepLDS {
-    double x[SW_W], y[SW_W], z[SW_W];
-    float r[SW_W];
+    float4 f[SW_W];  // fp32 copy for the pair loop's pre-filter: position relative to the range's first entry, inflated radius
     uint32_t owner[SW_W], sph[SW_W], bin[SW_W], fam[SW_W];
     uint32_t queue[SW_T / 64][128];  // per wavefront: pairs that passed the distance test, waiting for the exact test
     uint64_t out[SW_OUT];
@@ -216,6 +215,15 @@ __device__ inline bool pair_near(double ax, double ay, double az, float ar, uint
     const double rA = (double)ar, rB = (double)br;
     const double d2 = (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
     return !(d2 > (rA + rB) * (rA + rB));
+}
+
+// fp32 pre-filter of the pair loop: conservative (never rejects a pair the fp64 test accepts).  Positions are relative to the
+// first entry of the staged range (a few bins away at most), so their fp32 rounding is ~1e-9 m; the slack below is 1e-6 m on
+// the radius sum plus 1e-5 relative on its square.
+__device__ inline bool pair_near_f(float4 a, uint32_t ao, float4 b, uint32_t bo) {
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    const float rs = a.w + b.w + 1e-6f;
+    return (ao != bo) && (dx * dx + dy * dy + dz * dz <= rs * rs * 1.00001f);
 }
 
 __device__ inline bool pair_test(const DevParams& p, double ax, double ay, double az, float ar, uint32_t ao,
@@ -271,8 +279,8 @@ __device__ inline uint64_t ss_key(uint32_t a, uint32_t b) {
 }
 
 // all lanes of one wavefront: exact test of the first `cnt` queued pairs (entry i | entry q << 16) and emission of the hits
-__device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const uint32_t* wq, uint32_t cnt, uint32_t lane,
-                                     uint64_t* outKeys, uint64_t cap, DetectCounters* ctr) {
+__device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const GeoRec* __restrict__ geo, const uint32_t* wq, uint32_t cnt,
+                                     uint32_t lane, uint64_t* outKeys, uint64_t cap, DetectCounters* ctr) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of one wavefront complete in order: only the
     __builtin_amdgcn_wave_barrier();                         // compiler has to be kept from reordering
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -286,8 +294,8 @@ __device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const uint
         // the two entries in either order, which (measured: once per ~1e9 pair evaluations) dropped or doubled a contact.
         const uint32_t e0 = e & 0xFFFFu, e1 = e >> 16;
         const uint32_t i = min(e0, e1), q = max(e0, e1);
-        hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], L.x[q], L.y[q], L.z[q], L.r[q], L.owner[q], L.fam[q],
-                        L.bin[q]);
+        const GeoRec ga = geo[L.sph[i]], gb = geo[L.sph[q]];  // the fp64 records: only the ~3 % that pass the pre-filter need them
+        hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], gb.x, gb.y, gb.z, gb.r, L.owner[q], L.fam[q], L.bin[q]);
         if (hit)
             key = ss_key(L.sph[i], L.sph[q]);
     }
@@ -366,10 +374,11 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
         const uint32_t n_rng = end - start;  // <= 2*SW_T - 1 entries, all complete bins
         // ---- stage geometry of my range (two entries per thread)
         __syncthreads();
+        const GeoRec g0 = geo[sphIds[base + start]];  // origin of the fp32 copies (same address for all lanes: one fetch)
         for (uint32_t q = t; q < n_rng; q += SW_T) {
             const uint32_t sph = sphIds[base + start + q];
             const GeoRec g = geo[sph];
-            L.x[q] = g.x, L.y[q] = g.y, L.z[q] = g.z, L.r[q] = g.r;
+            L.f[q] = make_float4((float)(g.x - g0.x), (float)(g.y - g0.y), (float)(g.z - g0.z), g.r);
             L.owner[q] = g.owner, L.sph[q] = sph;
             L.fam[q] = p.familyTrivial ? 0u : owners[g.owner].family;
         }
@@ -413,11 +422,10 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             }
             const uint32_t half = valid ? (n - 1) / 2 : 0;
             const uint32_t trips = half + ((valid && (n & 1u) == 0 && k < n / 2) ? 1u : 0u);
-            double mx = 0, my = 0, mz = 0;
-            float mr = 0;
-            uint32_t mo = 0, mf = 0, ms = 0;
+            float4 mf4 = make_float4(0, 0, 0, 0);
+            uint32_t mo = 0;
             if (valid)
-                mx = L.x[q], my = L.y[q], mz = L.z[q], mr = L.r[q], mo = L.owner[q], mf = L.fam[q], ms = L.sph[q];
+                mf4 = L.f[q], mo = L.owner[q];
             // Two phases (only ~3 % of the pairs of a bin pass the distance test, but with 64 lanes almost every loop
             // iteration had at least one survivor and paid for the exact test -- sqrt, divisions, contact-point bin): the
             // loop only runs the distance test and queues the survivors per wavefront; the exact test then runs on full
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                     if (qq >= n)
                         qq -= n;
                     const uint32_t i = s + qq;
-                    near = pair_near(L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], mx, my, mz, mr, mo);
+                    near = pair_near_f(L.f[i], L.owner[i], mf4, mo);  // fp32, conservative; the exact fp64 test follows in phase 2
                     packed = i | (q << 16);
                 }
                 const unsigned long long nm = __ballot(near);
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                         wq[qn + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = packed;
                     qn += (uint32_t)__popcll(nm);  // wave-uniform
                     if (qn >= 64u) {
-                        sweep_confirm(p, L, wq, 64u, lane, outKeys, cap, ctr);
+                        sweep_confirm(p, L, geo, wq, 64u, lane, outKeys, cap, ctr);
                         const uint32_t rest = qn - 64u;
                         uint32_t carry = 0;
                         if (lane < rest)
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             }
         }
         if (qn) {
-            sweep_confirm(p, L, wq, qn, lane, outKeys, cap, ctr);
+            sweep_confirm(p, L, geo, wq, qn, lane, outKeys, cap, ctr);
             qn = 0;
         }
         // ---- giant bin: SW_T x SW_T tiles, A tile in LDS, each thread holds one B entry
@@ -479,7 +487,6 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                 if (t < na) {
                     const uint32_t sph = sphIds[ta + t];
                     const GeoRec g = geo[sph];
-                    L.x[t] = g.x, L.y[t] = g.y, L.z[t] = g.z, L.r[t] = g.r;
                     L.owner[t] = g.owner, L.sph[t] = sph;
                     L.fam[t] = p.familyTrivial ? 0u : owners[g.owner].family;
                 }
@@ -501,8 +508,8 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                         bool hit = false;
                         uint64_t key = 0;
                         if (act) {
-                            hit = pair_test(p, L.x[i], L.y[i], L.z[i], L.r[i], L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf,
-                                            gbin);
+                            const GeoRec ga = geo[L.sph[i]];  // same address for every lane
+                            hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf, gbin);
                             if (hit)
                                 key = ss_key(L.sph[i], ms);
                         }
