@@ -218,8 +218,8 @@ __device__ inline bool pair_near(double ax, double ay, double az, float ar, uint
 }
 
 // fp32 pre-filter of the pair loop: conservative (never rejects a pair the fp64 test accepts).  Positions are relative to the
-// first entry of the staged range (a few bins away at most), so their fp32 rounding is ~1e-9 m; the slack below is 1e-6 m on
-// the radius sum plus 1e-5 relative on its square.
+// corner of the bin the pair is tested in, so their fp32 rounding is ~1e-9 m for millimetre-to-centimetre bins; the slack
+// below is 1e-6 m on the radius sum plus 1e-5 relative on its square.
 __device__ inline bool pair_near_f(float4 a, uint32_t ao, float4 b, uint32_t bo) {
     const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
     const float rs = a.w + b.w + 1e-6f;
@@ -374,11 +374,15 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
         const uint32_t n_rng = end - start;  // <= 2*SW_T - 1 entries, all complete bins
         // ---- stage geometry of my range (two entries per thread)
         __syncthreads();
-        const GeoRec g0 = geo[sphIds[base + start]];  // origin of the fp32 copies (same address for all lanes: one fetch)
         for (uint32_t q = t; q < n_rng; q += SW_T) {
             const uint32_t sph = sphIds[base + start + q];
             const GeoRec g = geo[sph];
-            L.f[q] = make_float4((float)(g.x - g0.x), (float)(g.y - g0.y), (float)(g.z - g0.z), g.r);
+            // fp32 copy relative to the corner of the entry's OWN bin (pairs are only formed inside a bin, so both partners share
+            // the origin): magnitudes stay below a bin edge plus a radius whatever the size of the domain
+            const uint32_t bq = keys[base + start + q];
+            const uint32_t ix = bq % p.nbX, iy = (bq / p.nbX) % p.nbY, iz = bq / (p.nbX * p.nbY);
+            L.f[q] = make_float4((float)(g.x - (double)ix * p.binSize), (float)(g.y - (double)iy * p.binSize),
+                                 (float)(g.z - (double)iz * p.binSize), g.r);
             L.owner[q] = g.owner, L.sph[q] = sph;
             L.fam[q] = p.familyTrivial ? 0u : owners[g.owner].family;
         }
