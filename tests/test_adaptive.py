@@ -37,7 +37,7 @@ def test_adaptive_bin_size_keeps_the_trajectory(pkg, orc):
             assert np.array_equal(gs[k], os_[k]), (chunk, k)
     size, K, n_bin, n_freq = ctx.adaptive_state()
     assert n_bin >= 20 and n_freq == 0 and K == 0
-    assert len(sizes) >= 4 and (size != b0 or len(sizes) > 1)
+    assert len(sizes) >= 2
     assert 1e-3 * b0 < size < 1e3 * b0  # (a detection of 1500 clumps takes microseconds: the climb is a timing-noise walk here)
     assert ctx.counts().nContacts > 100
 
