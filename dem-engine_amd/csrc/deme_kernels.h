@@ -218,11 +218,13 @@ __device__ inline bool pair_near(double ax, double ay, double az, float ar, uint
 }
 
 // fp32 pre-filter of the pair loop: conservative (never rejects a pair the fp64 test accepts).  Positions are relative to the
-// corner of the bin the pair is tested in, so their fp32 rounding is ~1e-9 m for millimetre-to-centimetre bins; the slack
-// below is 1e-6 m on the radius sum plus 1e-5 relative on its square.
+// corner of the bin the pair is tested in, so their fp32 rounding is ~1e-9 m for millimetre-to-centimetre bins.
 __device__ inline bool pair_near_f(float4 a, uint32_t ao, float4 b, uint32_t bo) {
     const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    const float rs = a.w + b.w + 1e-6f;
+    // slack: 1e-6 m plus the fp32 rounding the inputs can carry at their magnitude (ulp = 1.2e-7 x |value|; taken 3x), so that
+    // the filter stays conservative for metre-sized bins and bodies as well
+    const float mag = fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(b.x) + fabsf(b.y) + fabsf(b.z) + a.w + b.w;
+    const float rs = a.w + b.w + 1e-6f + 4e-7f * mag;
     return (ao != bo) && (dx * dx + dy * dy + dz * dz <= rs * rs * 1.00001f);
 }
 
