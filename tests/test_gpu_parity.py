@@ -576,3 +576,23 @@ def test_mixed_multi_sphere_templates_from_the_reference_data(pkg, orc):
         for k in STATE_KEYS:
             assert np.array_equal(gs[k], os_[k]), (chunk, k)
     assert most > 300  # (the overlapping shapes push each other apart within a few dozen steps)
+
+
+def test_metre_scale_scene(pkg, orc):
+    """the same path at metre scale (0.4 m spheres, 2 m bins, a 100 m box): the sweep's fp32 pre-filter must stay conservative
+    when its inputs are a million times larger than in the millimetre beds -- lists and 30 steps bit-identical to the oracle"""
+    b = pkg.model.packed_bed(1200, seed=12, cd_freq=0, scale=0.5, spacing_mult=2.45, jitter=0.08, init_vz=-3.0, h=2e-4, E=1e7,
+                             bin_multiple=5.0)
+    lo, hi = b.user_box_min, b.user_box_max
+    assert float((hi - lo).max()) > 10.0
+    ctx, sim, p, sc = pair(pkg, orc, b)
+    ctx.compute_margins(0), sim.compute_margins(0)
+    ctx.detect(), sim.detect()
+    a = assert_same_contacts(ctx, sim)[0]
+    assert len(a) > 300  # the jittered lattice starts with grazing and overlapping neighbours
+    ctx.migrate(), sim.migrate()
+    ctx.step(30), sim.step(30)
+    assert_same_contacts(ctx, sim)
+    gs, os_ = ctx.download_state(), sim.download_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(gs[k], os_[k]), k
