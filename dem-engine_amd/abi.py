@@ -21,6 +21,9 @@ FORCE_HERTZIAN, FORCE_HERTZIAN_FRICTIONLESS, FORCE_CUSTOM = 0, 1, 2
 GHOST_BYTES = 56
 
 
+ARITH_FAST, ARITH_EXACT = 1, 0
+
+
 class DemeParams(C.Structure):
     _fields_ = [
         ("nvXp2", C.c_uint32), ("nvYp2", C.c_uint32), ("nvZp2", C.c_uint32),
@@ -168,7 +171,7 @@ def load_library():
     lib.deme_ctx_destroy.argtypes = [_P]
     lib.deme_ctx_destroy.restype = None
     for name, args in {
-        "deme_ctx_set_stream": [_P, _P], "deme_sync": [_P],
+        "deme_ctx_set_stream": [_P, _P], "deme_sync": [_P], "deme_set_arith_mode": [_P, C.c_int], "deme_get_arith_mode": [_P],
         "deme_set_params": [_P, C.POINTER(DemeParams)], "deme_upload_scene": [_P, C.POINTER(DemeScene)],
         "deme_upload_owner_state": [_P, C.POINTER(DemeOwnerState)],
         "deme_download_owner_state": [_P, C.POINTER(DemeOwnerState)],
@@ -274,6 +277,15 @@ class Context:
 
     def sync(self):
         self._ck(self.lib.deme_sync(self.h), "deme_sync")
+
+    def set_arith_mode(self, mode):
+        """'fast' (default: world-frame force kernel, 1-ulp physics arithmetic) or 'exact' (the reference's operation order,
+        bit-identical to the CPU oracle); include/deme_hip.h DEME_ARITH_*"""
+        m = {"fast": ARITH_FAST, "exact": ARITH_EXACT}.get(mode, mode)
+        self._ck(self.lib.deme_set_arith_mode(self.h, int(m)), "deme_set_arith_mode")
+
+    def arith_mode(self):
+        return "fast" if self.lib.deme_get_arith_mode(self.h) == ARITH_FAST else "exact"
 
     def set_params(self, p):
         self.n_wildcards = int(p.nContactWildcards)

@@ -51,6 +51,13 @@ struct ForceArgs {
     float* recCPB;
     uint32_t nContacts;
     float timeElapsed;
+    // XCD-aware launch order: 0 = hardware order (workgroup b on XCD b % 8); G > 0: every XCD works through runs of G
+    // consecutive 256-contact blocks, the eight XCDs side by side in the list (see force_block_id)
+    uint32_t xcdGroup;
+    // 1: the per-side contributions are the WORLD-frame force and torque about the owner's centre (the fast arithmetic mode:
+    // the integrator turns the per-owner sums into a and alpha, see acc_from_world); 0: a and alpha contributions as the
+    // reference's ForceInKernelReductionStrat.cu forms them per contact (the bit-exact mode)
+    uint32_t world;
     // user-model wildcards beyond the per-contact ones (Models.h:319-360): per-owner arrays, and per-geometry arrays for
     // spheres / triangles / analytical components; null when not declared
     float* ownerWc[8];
@@ -443,12 +450,20 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
         const f3 tot = force + torque_only_force;
         float4 c4;
         float2 c2;
-        side_contribution(force, tot, in.AOwnerMass, mk3(mpA.y, mpA.z, mpA.w), RAinv, in.locCPA, c4, c2);
-        outA4 = c4;
-        outA2 = c2;
         const f3 nF = mk3(-force.x, -force.y, -force.z);
-        side_contribution(nF, -1.f * tot, in.BOwnerMass, mk3(mpB.y, mpB.z, mpB.w), RBinv, in.locCPB, c4, c2);
-        conb_store(a.conB4, a.conB2, myContactID, c4, c2);
+        if (a.world) {  // world-frame force and torque (R locCP) x F_tot per side
+            const f3 tA = cross3(rot_apply(in.RA, in.locCPA), tot);
+            outA4 = make_float4(force.x, force.y, force.z, tA.x);
+            outA2 = make_float2(tA.y, tA.z);
+            const f3 tB = cross3(tot, rot_apply(in.RB, in.locCPB));
+            conb_store(a.conB4, a.conB2, myContactID, make_float4(nF.x, nF.y, nF.z, tB.x), make_float2(tB.y, tB.z));
+        } else {
+            side_contribution(force, tot, in.AOwnerMass, mk3(mpA.y, mpA.z, mpA.w), RAinv, in.locCPA, c4, c2);
+            outA4 = c4;
+            outA2 = c2;
+            side_contribution(nF, -1.f * tot, in.BOwnerMass, mk3(mpB.y, mpB.z, mpB.w), RBinv, in.locCPB, c4, c2);
+            conb_store(a.conB4, a.conB2, myContactID, c4, c2);
+        }
     } else {
         outA4 = make_float4(0, 0, 0, 0);
         outA2 = make_float2(0, 0);
@@ -485,11 +500,28 @@ __host__ __device__ inline bool a_run_in_one_block(uint32_t s, uint32_t e) {
 // Runs that straddle a block boundary (~1 owner in 60) keep the per-contact records.  The mesh-only variant
 // (CLS 1) is launched BEFORE the hot variant and leaves its A-side records in conA; the hot variant folds them
 // into the same in-order sum.
+// Which 256-contact block a workgroup takes.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
+// its own L2: with the identity map the blocks that share B-owner records (list neighbours: the same and the adjacent lattice
+// rows) sit on eight different L2s and every XCD fetches its own copy.  With G > 0, workgroup b (XCD b % 8, the (b / 8)-th on
+// it) takes block ((j / G) * 8 + xcd) * G + j % G: each XCD sweeps G consecutive blocks, the eight runs adjacent in the list,
+// so neighbours meet in one L2 while all XCDs still work on the same region of the bed.  The grid is rounded up to a multiple
+// of 8 G by the host; workgroups mapped beyond the list exit.
+__device__ inline uint32_t force_block_id(const ForceArgs& a) {
+    const uint32_t b = blockIdx.x, G = a.xcdGroup;
+    if (G == 0)
+        return b;
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    return ((j / G) * 8u + xcd) * G + (j % G);
+}
+
 template <int MODEL, int CLS>
 __device__ inline void calc_forces_block(const DevParams& p, const ForceArgs& a) {
-    if (CLS == 0 && a.blockMode && !(a.blockMode[blockIdx.x] & (1u << a.pass)))
+    const uint32_t bid = (CLS == 0) ? force_block_id(a) : blockIdx.x;
+    if (CLS == 0 && bid * DEME_FORCE_BLOCK >= a.nContacts)
+        return;
+    if (CLS == 0 && a.blockMode && !(a.blockMode[bid] & (1u << a.pass)))
         return;  // nothing of this pass in the block (workgroup-uniform)
-    uint32_t c = blockIdx.x * DEME_FORCE_BLOCK + threadIdx.x;
+    uint32_t c = bid * DEME_FORCE_BLOCK + threadIdx.x;
     if (CLS == 1) {  // mesh variant: one thread per sphere-mesh contact, through the per-detection index list
         if (c >= a.nSM)
             return;

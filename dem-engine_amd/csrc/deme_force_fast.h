@@ -1,0 +1,312 @@
+// deme_force_fast.h -- the contact-force kernel of the FAST arithmetic mode (the default; deme_set_arith_mode).
+//
+// Same physics as deme_force.h (kernel/DEMCalcForceKernels.cu:44-267 with FullHertzianForceModel.cu /
+// FrictionlessHertzianForceModel.cu), re-associated so that the per-owner work is done once per owner per step by the
+// integrator instead of once per contact end here:
+//   * owners come as KinRec (fp64 world position, world-frame angular velocity, mass) + a dense quaternion array;
+//   * everything is evaluated in the WORLD frame: the velocity of the contact point is v + w x r, the torque r x F; the
+//     per-contact contributions are the world-frame force and torque about the owner's centre, and the integrator turns
+//     their per-owner sums into a = F / m and alpha = R^T tau / I once per owner (the reference rotates every contact's
+//     force into the body frame and divides per contact: ForceInKernelReductionStrat.cu:2-33);
+//   * the overlap is formed without an fp64 square root: depth = ((rA + rB)^2 - d^2) / ((rA + rB) + |d|) with the
+//     numerator -- the only place where cancellation happens -- in fp64;
+//   * physics-only divisions and square roots use the 1-ulp hardware forms.
+// Decisions (is this pair in contact?) are the sign of the fp64 numerator: the same predicate as the reference's fp64
+// comparison.  Results differ from the bit-exact mode by fp32 rounding only; tests/test_fast_mode.py states the tolerance.
+#pragma once
+#include "deme_force.h"
+
+// this header's arithmetic is free to contract a * b + c into one FMA (the translation unit is compiled with
+// -ffp-contract=off for the decision code and the bit-exact mode)
+#pragma clang fp contract(fast)
+
+namespace deme_dev {
+
+// contracted twins of the small vector helpers (the ones of deme_device.h keep their no-contraction semantics when inlined)
+__device__ inline RotM frot_coeffs(float w, float x, float y, float z) {
+    RotM m;
+    m.xx = 2.0f * (w * w + x * x) - 1.0f;
+    m.xy = 2.0f * (x * y - w * z);
+    m.xz = 2.0f * (x * z + w * y);
+    m.yx = 2.0f * (x * y + w * z);
+    m.yy = 2.0f * (w * w + y * y) - 1.0f;
+    m.yz = 2.0f * (y * z - w * x);
+    m.zx = 2.0f * (x * z - w * y);
+    m.zy = 2.0f * (y * z + w * x);
+    m.zz = 2.0f * (w * w + z * z) - 1.0f;
+    return m;
+}
+__device__ inline f3 frot_apply(const RotM& m, f3 v) {
+    return mk3(m.xx * v.x + m.xy * v.y + m.xz * v.z, m.yx * v.x + m.yy * v.y + m.yz * v.z, m.zx * v.x + m.zy * v.y + m.zz * v.z);
+}
+__device__ inline f3 fcross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ inline float fdot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline f3 fsub(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ inline f3 fadd(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ inline f3 fscale(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ inline f3 faxpy(float s, f3 a, f3 b) { return mk3(s * a.x + b.x, s * a.y + b.y, s * a.z + b.z); }  // s a + b
+
+struct FastArgs {
+    const KinRec* kin;
+    const uint32_t* ownerTag;  // family | inertiaOff << 16
+};
+
+// LDS stride of a staged KinRec in 16-byte units: 80 bytes, so that the 64 lanes' own-record reads (ds_read_b128 at lane * 80)
+// fall on distinct banks (a 64-byte stride would put every fourth lane on the same ones)
+#define DEME_KIN_LDS_STRIDE 5
+
+__device__ inline KinRec load_kin(const KinRec* k, uint32_t o) {
+    KinRec r;
+    const uint4* p = reinterpret_cast<const uint4*>(k + o);
+    uint4* q = reinterpret_cast<uint4*>(&r);
+    q[0] = p[0];
+    q[1] = p[1];
+    q[2] = p[2];
+    q[3] = p[3];
+    return r;
+}
+
+__device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// MODEL 0: full Hertzian (history float4: delta_tan x/y/z, delta_time), 1: frictionless.  One thread per contact of the hot
+// classes (sphere-sphere, sphere-analytical).  Outputs: the A side's world-frame force and torque (the caller reduces them
+// over the owner's run), the B side's record is stored here.
+template <int MODEL>
+__device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, const FastArgs& fa, const uint32_t c, const uint4 ci,
+                                        const uint4* stagedB, float4& outA4, float2& outA2) {
+    const uint32_t cls = ci.x >> 30;
+    const uint32_t AOwner = ci.x & 0x3FFFFFFFu, BOwner = ci.y;
+    const KinRec KA = load_kin(fa.kin, AOwner);  // contacts are sorted by A: a wavefront reads ~15 distinct records here
+    const uint32_t tagA = fa.ownerTag[AOwner], tagB = fa.ownerTag[BOwner];
+    KinRec KB;  // staged through LDS by the whole wavefront (forces_fast_stage_b)
+    {
+        uint4* q = reinterpret_cast<uint4*>(&KB);
+        q[0] = stagedB[0], q[1] = stagedB[1], q[2] = stagedB[2], q[3] = stagedB[3];
+    }
+    const float massA = p.massProps[tagA >> 16].x;
+    float4 hist = make_float4(0, 0, 0, 0);
+    float4* wcp = nullptr;
+    if (MODEL == 0) {
+        wcp = reinterpret_cast<float4*>(a.wc) + c;
+        hist = *wcp;
+    }
+    const float4 cA = p.comp[ci.z & 0xFFFFu];
+    const uint32_t matA = ci.z >> 16;
+    // sphere offsets with the reference's own rounding (no contraction, deme_device.h): an offset that differs in its last bit
+    // moves the overlap by ~1e-10 m, i.e. 1e-4 of a typical overlap -- everything after this point is well conditioned
+    const RotM RA = rot_coeffs(KA.qw, KA.qx, KA.qy, KA.qz);
+    const RotM RB = rot_coeffs(KB.qw, KB.qx, KB.qy, KB.qz);
+    const f3 relA = rot_apply(RA, mk3(cA.x, cA.y, cA.z));
+    const float rA = cA.w;
+    float extraMargin = 0.f;
+    if (!p.familyTrivial) {
+        const float eA = p.familyExtra[tagA & 0xFFu], eB = p.familyExtra[tagB & 0xFFu];
+        extraMargin = fmaxf(eA, eB);
+    }
+    // owner-to-owner offset: the one fp64 difference every later vector hangs on
+    const double dOx = KA.x - KB.x, dOy = KA.y - KB.y, dOz = KA.z - KB.z;
+    const f3 dO = mk3((float)dOx, (float)dOy, (float)dOz);
+    f3 n, rAv, rBv;   // B2A, contact point relative to A's / B's centre
+    float depth, rB, massB;
+    uint32_t matB;
+    bool touching;
+    if (cls == DEME_KEY_CLASS_SS) {
+        const float4 cB = p.comp[ci.w & 0xFFFFu];
+        matB = ci.w >> 16;
+        rB = cB.w;
+        massB = p.massProps[tagB >> 16].x;
+        const f3 relB = rot_apply(RB, mk3(cB.x, cB.y, cB.z));
+        // centre-to-centre vector in fp64, as the reference forms it (DEMHelperKernels.cuh:292-326)
+        const double dx = (dOx + (double)relA.x) - (double)relB.x;
+        const double dy = (dOy + (double)relA.y) - (double)relB.y;
+        const double dz = (dOz + (double)relA.z) - (double)relB.z;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        const float sumR = rA + rB;
+        const double num = (double)sumR * (double)sumR - d2;  // > 0 iff the spheres overlap; no cancellation left after this
+        const float d2f = (float)d2;
+        const float inv = frsq(d2f);
+        const float dist = d2f * inv;
+        n = mk3((float)dx * inv, (float)dy * inv, (float)dz * inv);
+        depth = (float)num * frcp(sumR + dist);
+        touching = !(depth < -extraMargin);
+        // contact point = B's centre + (rB - depth / 2) n  (calcContactPoint), relative to the two owners
+        const float s = rB - 0.5f * depth;
+        rBv = mk3(relB.x + s * n.x, relB.y + s * n.y, relB.z + s * n.z);
+        rAv = fsub(rBv, dO);
+    } else {  // sphere-analytical (a few per cent of the list, at the walls): the reference's own arithmetic
+        const AnalObj ob = p.anal[ci.w];
+        matB = ob.mat;
+        rB = 1e15f;  // DEME_HUGE_FLOAT
+        massB = ob.mass;
+        const f3 relB = rot_apply(RB, mk3(ob.relx, ob.rely, ob.relz));
+        const f3 dir = rot_apply(RB, mk3(ob.rotx, ob.roty, ob.rotz));
+        const d3 bodyA{KA.x + (double)relA.x, KA.y + (double)relA.y, KA.z + (double)relA.z};
+        const d3 bodyB{KB.x + (double)relB.x, KB.y + (double)relB.y, KB.z + (double)relB.z};
+        d3 cp;
+        double dd;
+        sphere_entity(bodyA, rA, ob.type, bodyB, dir, ob.size1, ob.normal, 0.0f, cp, n, dd);
+        depth = (float)dd;
+        touching = !(dd < -(double)extraMargin);  // the list entry keeps its type; only the grace margin retires it
+        rAv = mk3((float)(cp.x - KA.x), (float)(cp.y - KA.y), (float)(cp.z - KA.z));
+        rBv = mk3((float)(cp.x - KB.x), (float)(cp.y - KB.y), (float)(cp.z - KB.z));
+    }
+    f3 force = mk3(0, 0, 0), torque_only = mk3(0, 0, 0);
+    if (touching) {
+        if (depth > 0.f) {
+            const MatPair mp = p.matPair[matA * p.nMat + matB];
+            const f3 wA = mk3(KA.wx, KA.wy, KA.wz), wB = mk3(KB.wx, KB.wy, KB.wz);
+            const f3 rotVelA = fcross(wA, rAv), rotVelB = fcross(wB, rBv);
+            const f3 velB2A = fsub(fadd(mk3(KA.vx, KA.vy, KA.vz), rotVelA), fadd(mk3(KB.vx, KB.vy, KB.vz), rotVelB));
+            const float projection = fdot(velB2A, n);
+            const float mass_eff = massA * massB * frcp(massA + massB);
+            const float sqrt_Rd = fsqrt(depth * (rA * rB) * frcp(rA + rB));
+            const float Sn = 2.f * mp.E_cnt * sqrt_Rd;
+            const float k_n = 0.6666666666666667f * Sn;
+            const float gamma_n = 1.825741858350554f * mp.beta * fsqrt(Sn * mass_eff);
+            const float Fn = k_n * depth + gamma_n * projection;
+            force = fscale(Fn, n);
+            if (MODEL == 0) {
+                const f3 vrel_tan = faxpy(-projection, n, velB2A);
+                f3 delta_tan = faxpy(p.h, vrel_tan, mk3(hist.x, hist.y, hist.z));
+                delta_tan = faxpy(-fdot(delta_tan, n), n, delta_tan);
+                hist.w += p.h;
+                if (mp.Crr > 0.0f) {  // FullHertzianForceModel.cu:73-100
+                    bool roll = true;
+                    const float R_eff = fsqrt((rA * rB) * frcp(rA + rB));
+                    const float kn_simple = 1.3333333333333333f * mp.E_cnt * fsqrt(R_eff);
+                    const float gn_simple = -2.f * fsqrt(1.6666666666666667f * mass_eff * mp.E_cnt) * mp.beta * fsqrt(fsqrt(R_eff));
+                    const float d_coeff = gn_simple * frcp(2.f * fsqrt(kn_simple * mass_eff));
+                    if (d_coeff < 1.0f) {
+                        const float t_collision = 3.1415926535897932f * fsqrt(mass_eff * frcp(kn_simple * (1.f - d_coeff * d_coeff)));
+                        if (hist.w <= t_collision)
+                            roll = false;
+                    }
+                    if (roll) {
+                        const f3 v_rot = fsub(rotVelB, rotVelA);
+                        const float m2 = fdot(v_rot, v_rot);
+                        if (m2 > 1e-24f)
+                            torque_only = fscale(frsq(m2) * mp.Crr * fabsf(Fn), v_rot);
+                    }
+                }
+                if (mp.mu > 0.0f) {
+                    const float kt = 8.f * mp.G_cnt * sqrt_Rd;
+                    const float gt = -1.825741858350554f * mp.beta * fsqrt(mass_eff * kt);
+                    f3 tf = faxpy(-kt, delta_tan, fscale(-gt, vrel_tan));
+                    const float ft2 = fdot(tf, tf);
+                    if (ft2 > 1e-24f) {
+                        const float ft_max = fabsf(Fn) * mp.mu;  // |force| = |Fn| |n|
+                        if (ft2 > ft_max * ft_max) {
+                            tf = fscale(ft_max * frsq(ft2), tf);
+                            delta_tan = fscale(-frcp(kt), faxpy(gt, vrel_tan, tf));
+                        }
+                    } else {
+                        tf = mk3(0, 0, 0);
+                    }
+                    force = fadd(force, tf);
+                }
+                hist.x = delta_tan.x, hist.y = delta_tan.y, hist.z = delta_tan.z;
+            }
+        } else if (MODEL == 0) {
+            hist = make_float4(0, 0, 0, 0);  // in the list, within the margin, not touching: the model resets its history
+        }
+        const f3 tot = fadd(force, torque_only);
+        const f3 tA = fcross(rAv, tot);
+        const f3 tB = fcross(tot, rBv);  // = r_B x (-F)
+        outA4 = make_float4(force.x, force.y, force.z, tA.x);
+        outA2 = make_float2(tA.y, tA.z);
+        conb_store(a.conB4, a.conB2, c, make_float4(-force.x, -force.y, -force.z, tB.x), make_float2(tB.y, tB.z));
+    } else {
+        outA4 = make_float4(0, 0, 0, 0);
+        outA2 = make_float2(0, 0);
+        conb_store(a.conB4, a.conB2, c, make_float4(0, 0, 0, 0), make_float2(0, 0));
+        hist = make_float4(0, 0, 0, 0);  // _forceModelContactWildcardDestroy_
+    }
+    if (MODEL == 0)
+        *wcp = hist;
+}
+
+// Cooperative gather of the wavefront's 64 B-owner records: four lanes per record, so one load instruction touches 16 records
+// of 64 contiguous bytes each instead of 64 scattered 16-byte pieces (the vector L1 serves one 64-byte request per cycle: per
+// wavefront 64 requests instead of 256), transposed to one record per lane through LDS.  Every lane of the wavefront must call;
+// lanes without a contact pass owner 0.
+__device__ inline const uint4* forces_fast_stage_b(const FastArgs& fa, uint32_t BOwner, uint4* stage) {
+    const uint32_t lane = threadIdx.x & 63u, piece = lane & 3u, sub = lane >> 2;
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t ob = (uint32_t)__shfl((int)BOwner, (int)(16 * k + sub));
+        v[k] = reinterpret_cast<const uint4*>(fa.kin + ob)[piece];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        stage[(16 * k + sub) * DEME_KIN_LDS_STRIDE + piece] = v[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of one wavefront complete in order: only the
+    __builtin_amdgcn_wave_barrier();                         // compiler has to be kept from reordering
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return stage + lane * DEME_KIN_LDS_STRIDE;
+}
+
+// Block structure, halo passes and the in-workgroup reduction of the A side are those of calc_forces_block<MODEL, 0>
+// (deme_force.h); sphere-mesh contacts still go through the mesh variant of the general kernel, launched first, whose
+// A-side records (world-frame too: ForceArgs::world) are folded into the same sums.
+template <int MODEL>
+__global__ __launch_bounds__(DEME_FORCE_BLOCK) void k_forces_fast(const DevParams p, const ForceArgs a, const FastArgs fa) {
+    __shared__ uint4 sB[DEME_FORCE_BLOCK / 64][64 * DEME_KIN_LDS_STRIDE];
+    __shared__ float4 s4[DEME_FORCE_BLOCK];
+    __shared__ float2 s2[DEME_FORCE_BLOCK];
+    const uint32_t bid = force_block_id(a);
+    if (bid * DEME_FORCE_BLOCK >= a.nContacts)
+        return;
+    if (a.blockMode && !(a.blockMode[bid] & (1u << a.pass)))
+        return;
+    const uint32_t c = bid * DEME_FORCE_BLOCK + threadIdx.x;
+    const bool valid = c < a.nContacts;
+    uint4 ci = make_uint4(0, 0, 0, 0);
+    bool mine = false, inPass = valid;
+    float4 c4 = make_float4(0, 0, 0, 0);
+    float2 c2 = make_float2(0, 0);
+    uint32_t s = 0, e = 0;
+    if (valid) {
+        ci = a.info[c];
+        if (a.cDefer)
+            inPass = a.cDefer[c] == a.pass;
+        mine = inPass && ((ci.x >> 30) != DEME_KEY_CLASS_SM);
+        s = a.aStart[ci.x & 0x3FFFFFFFu];
+        e = a.aStart[(ci.x & 0x3FFFFFFFu) + 1];
+    }
+    const uint4* stagedB = forces_fast_stage_b(fa, mine ? ci.y : 0u, sB[threadIdx.x >> 6]);
+    if (mine)
+        forces_fast_body<MODEL>(p, a, fa, c, ci, stagedB, c4, c2);
+    if (inPass && !mine) {  // sphere-mesh contact: evaluated by the mesh variant
+        c4 = a.conA4[c];
+        c2 = a.conA2[c];
+    }
+    s4[threadIdx.x] = c4;
+    s2[threadIdx.x] = c2;
+    __syncthreads();
+    if (!inPass)
+        return;
+    const uint32_t AOwner = ci.x & 0x3FFFFFFFu;
+    if (a_run_in_one_block(s, e)) {
+        if (c == s) {
+            float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
+            for (uint32_t i = s % DEME_FORCE_BLOCK; i <= (e - 1) % DEME_FORCE_BLOCK; i++) {
+                const float4 v4 = s4[i];
+                const float2 v2 = s2[i];
+                ax += v4.x, ay += v4.y, az += v4.z;
+                lx += v4.w, ly += v2.x, lz += v2.y;
+            }
+            a.aSum[2 * (size_t)AOwner] = make_float4(ax, ay, az, 0.f);
+            a.aSum[2 * (size_t)AOwner + 1] = make_float4(lx, ly, lz, 0.f);
+        }
+    } else if (mine) {
+        a.conA4[c] = c4;
+        a.conA2[c] = c2;
+    }
+}
+
+}  // namespace deme_dev
+
+#pragma clang fp contract(off)

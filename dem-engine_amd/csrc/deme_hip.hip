@@ -21,6 +21,7 @@
 #include "../../include/deme_hip.h"
 #include "deme_device.h"
 #include "deme_force.h"
+#include "deme_force_fast.h"
 #include "deme_jit.h"
 #include "deme_kernels.h"
 #include "deme_mesh_kernels.h"
@@ -124,8 +125,18 @@ struct deme_ctx {
     bool record = false;
     uint64_t nSteps = 0, nDetections = 0;
     uint32_t stepsSinceCD = 0;
+    // the script moved a body, changed a family or rewrote triangle nodes: the K-step list and its margins no longer cover the
+    // scene, so the next step starts with a detection (the reference: pendingCriticalUpdate / stampLastDynamicUpdateProdDate = -1,
+    // DEM/dT.cpp:2351)
+    bool listStale = false;
     uint32_t lastStatus = 0;
     double timeElapsed = 0;
+    // arithmetic mode (deme_set_arith_mode): DEME_ARITH_FAST (default) or DEME_ARITH_EXACT; the derived per-owner view of the
+    // fast force kernel and whether it has to be rebuilt from the owner records before the next force pass
+    int arith = DEME_ARITH_FAST;
+    DevBuf kin, ownerTag;
+    bool kinDirty = true;
+    uint32_t xcdGroup = 0;  // XCD-aware block order of the force kernel (ForceArgs::xcdGroup)
     int timing = 0;  // 0 off; n > 0: every n-th launch of each timed kernel is bracketed with HIP events
     std::map<std::string, TimerSlot> timers;
     std::vector<hipEvent_t> eventPool;
@@ -363,7 +374,13 @@ int do_margins(deme_ctx* c, uint32_t drift) {
 }
 
 // contactDetection() equivalent
+int do_migrate(deme_ctx* c);
 int do_detect(deme_ctx* c) {
+    // a history map nobody has applied yet (two detections in a row): apply it now, or the next map would be taken from a
+    // list whose wildcards are still stored against the list before it
+    if (c->mapFresh)
+        if (int rc = do_migrate(c))
+            return rc;
     ScopedTimer tm(c, "detect", true);  // once per K steps: always timed
     const uint32_t nS = c->nSpheres;
     DetectCounters hc{};
@@ -387,7 +404,31 @@ int do_detect(deme_ctx* c) {
         uint32_t P = 0;
         if (nS) {
             HIPCK(hipMemcpyAsync(&P, c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
             HIPCK(hipStreamSynchronize(c->stream));
+            if (hc.status & DEME_ST_INCIDENCE)
+                return fail(c, DEME_ERR_OVERFLOW,
+                            "a sphere touches more than %u bins (margin far larger than the bin size): the incidence list cannot be built",
+                            DEME_MAX_BINS_PER_SPHERE);
+            if ((uint64_t)hc.maxCount * nS > 0xFFFFFFFFull) {  // the 32-bit offsets may have wrapped: exact total in 64 bits
+                auto in64 = rocprim::make_transform_iterator(c->counts.as<uint32_t>(),
+                                                             [] __host__ __device__(uint32_t v) { return (unsigned long long)v; });
+                unsigned long long* tot = &c->ctr.as<DetectCounters>()->nContactsRaw;  // borrowed: saved and restored around the reduction (k_sphere_prep has already counted its sphere-analytical contacts here)
+                unsigned long long keep = 0, total = 0;
+                HIPCK(hipMemcpyAsync(&keep, tot, 8, hipMemcpyDeviceToHost, c->stream));
+                size_t need = 0;
+                HIPCK(rocprim::reduce(nullptr, need, in64, tot, 0ull, (size_t)nS, rocprim::plus<unsigned long long>(), c->stream));
+                if (int rc = ensure(c, c->sortTmp, need))
+                    return rc;
+                need = c->sortTmp.bytes;
+                HIPCK(rocprim::reduce(c->sortTmp.p, need, in64, tot, 0ull, (size_t)nS, rocprim::plus<unsigned long long>(), c->stream));
+                HIPCK(hipMemcpyAsync(&total, tot, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCK(hipStreamSynchronize(c->stream));
+                HIPCK(hipMemcpyAsync(tot, &keep, 8, hipMemcpyHostToDevice, c->stream));
+                HIPCK(hipStreamSynchronize(c->stream));
+                if (total > 0xFFFFFFFFull)
+                    return fail(c, DEME_ERR_OVERFLOW, "%llu bin-sphere incidences do not fit the 32-bit list offsets (use larger bins)", total);
+            }
         }
         if (P > c->incCap) {
             if (int rc = grow_incidence_arena(c, (size_t)P + P / 4 + 1024))
@@ -635,6 +676,9 @@ GatherArgs gather_args(deme_ctx* c) {
     g.conB4 = c->conB4.as<float4>(), g.conB2 = c->conB2.as<float2>();
     g.aSum = c->aSum.as<float4>();
     g.nextAcc = c->nextAccPending ? c->nextAcc.as<AccRec>() : nullptr;
+    g.world = c->arith == DEME_ARITH_FAST ? 1u : 0u;
+    g.kin = g.world ? c->kin.as<KinRec>() : nullptr;
+    g.ownerTag = g.world ? c->ownerTag.as<uint32_t>() : nullptr;
     return g;
 }
 
@@ -642,8 +686,8 @@ GatherArgs gather_args(deme_ctx* c) {
 void launch_reduce_heavy(deme_ctx* c, bool skipFixed) {
     if (c->nHeavy == 0 || (skipFixed && c->nHeavyFree == 0))
         return;
-    hipLaunchKernelGGL(k_reduce_heavy, dim3(std::min<uint32_t>(c->nHeavy, 1024)), dim3(256), 0, c->stream, gather_args(c),
-                       c->heavyList.as<uint32_t>(), &c->rangeCtr.as<RangeCounters>()->nHeavy,
+    hipLaunchKernelGGL(k_reduce_heavy, dim3(std::min<uint32_t>(c->nHeavy, 1024)), dim3(256), 0, c->stream, c->dp, gather_args(c),
+                       c->owners.as<OwnerRec>(), c->heavyList.as<uint32_t>(), &c->rangeCtr.as<RangeCounters>()->nHeavy,
                        skipFixed ? c->fixedFlag.as<uint8_t>() : (const uint8_t*)nullptr, c->acc.as<AccRec>());
 }
 
@@ -680,32 +724,52 @@ int launch_forces(deme_ctx* c, int pass = -1) {
     }
     a.nContacts = (uint32_t)c->nContacts;
     a.timeElapsed = (float)c->timeElapsed;
+    a.xcdGroup = c->xcdGroup;
+    const bool fastMode = c->arith == DEME_ARITH_FAST;
+    a.world = fastMode ? 1u : 0u;
+    // the fast kernel covers the built-in models' hot classes; contact recording (body-frame contact points) and user
+    // fragments (the reference's body-frame vocabulary) run the general kernel, with world-frame contributions in fast mode
+    const bool fastKernel = fastMode && !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM;
+    FastArgs fa{c->kin.as<KinRec>(), c->ownerTag.as<uint32_t>()};
+    if (fastKernel && c->kinDirty) {  // the script changed owner records since the integrator last wrote the derived view
+        hipLaunchKernelGGL(k_refresh_kin, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
+                           c->kin.as<KinRec>(), c->ownerTag.as<uint32_t>());
+        c->kinDirty = false;
+    }
     if (c->record) {
         a.recForce = c->rec[0].as<float>(), a.recTorque = c->rec[1].as<float>(), a.recCPA = c->rec[2].as<float>(),
         a.recCPB = c->rec[3].as<float>();
     }
     {
         ScopedTimer tm(c, "calc_forces");
-        const dim3 g(grid_for(a.nContacts, DEME_FORCE_BLOCK)), b(DEME_FORCE_BLOCK);
+        unsigned nBlk = grid_for(a.nContacts, DEME_FORCE_BLOCK);
+        if (a.xcdGroup)  // the XCD-aware block map is a bijection on multiples of 8 G blocks
+            nBlk = (nBlk + 8u * a.xcdGroup - 1u) / (8u * a.xcdGroup) * (8u * a.xcdGroup);
+        const dim3 g(nBlk), b(DEME_FORCE_BLOCK);
         // sphere-mesh contacts read no ghost owner (meshes are replicated, not ghosted): all of them go with pass 0
         const bool hasSM = c->nTri > 0 && c->nSM > 0 && pass != 1;
         const dim3 gm(grid_for(std::max<uint32_t>(c->nSM, 1u), DEME_FORCE_BLOCK));
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
             if (hasSM)  // mesh variant first: the hot variant folds its A-side records into the in-block sums
                 hipLaunchKernelGGL((k_calc_forces<0, 1>), gm, b, 0, c->stream, c->dp, a);
-            hipLaunchKernelGGL((k_calc_forces<0, 0>), g, b, 0, c->stream, c->dp, a);
+            if (fastKernel)
+                hipLaunchKernelGGL((k_forces_fast<0>), g, b, 0, c->stream, c->dp, a, fa);
+            else
+                hipLaunchKernelGGL((k_calc_forces<0, 0>), g, b, 0, c->stream, c->dp, a);
         } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN_FRICTIONLESS) {
             if (hasSM)
                 hipLaunchKernelGGL((k_calc_forces<1, 1>), gm, b, 0, c->stream, c->dp, a);
-            hipLaunchKernelGGL((k_calc_forces<1, 0>), g, b, 0, c->stream, c->dp, a);
+            if (fastKernel)
+                hipLaunchKernelGGL((k_forces_fast<1>), g, b, 0, c->stream, c->dp, a, fa);
+            else
+                hipLaunchKernelGGL((k_calc_forces<1, 0>), g, b, 0, c->stream, c->dp, a);
         }
         else {  // user model: two entry points of the same code object (hot variant, mesh variant)
             void* args0[] = {&c->dp, &a};
             if (hasSM)
                 HIPCK(hipModuleLaunchKernel(c->customFn[1], gm.x, 1, 1, DEME_FORCE_BLOCK, 1, 1, 0,
                                             c->stream, args0, nullptr));
-            HIPCK(hipModuleLaunchKernel(c->customFn[0], grid_for(a.nContacts, DEME_FORCE_BLOCK), 1, 1, DEME_FORCE_BLOCK, 1, 1, 0, c->stream,
-                                        args0, nullptr));
+            HIPCK(hipModuleLaunchKernel(c->customFn[0], g.x, 1, 1, DEME_FORCE_BLOCK, 1, 1, 0, c->stream, args0, nullptr));
         }
     }
     c->conValid = true;
@@ -785,7 +849,7 @@ int launch_integrate(deme_ctx* c, bool fused) {
 // a/alpha of every owner from the current contributions (stand-alone force pass and state downloads)
 void launch_full_reduction(deme_ctx* c) {
     hipLaunchKernelGGL(k_gather_acc, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, gather_args(c),
-                       c->acc.as<AccRec>());
+                       c->owners.as<OwnerRec>(), c->acc.as<AccRec>());
     launch_reduce_heavy(c, false);
 }
 
@@ -816,6 +880,10 @@ int deme_ctx_create(int device, deme_ctx** out) {
         return DEME_ERR_HIP;
     }
     hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->stream);
+    if (const char* e = getenv("DEME_ARITH"))  // process-wide default of deme_set_arith_mode ("exact" / "fast")
+        c->arith = (strcmp(e, "exact") == 0) ? DEME_ARITH_EXACT : DEME_ARITH_FAST;
+    if (const char* e = getenv("DEME_XCD_GROUP"))  // tuning knob (profiles/): see force_block_id
+        c->xcdGroup = (uint32_t)std::max(0, atoi(e));
     *out = c;
     return DEME_OK;
 }
@@ -843,7 +911,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
-    DevBuf* all[] = {&c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->kin, &c->ownerTag, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -879,6 +947,19 @@ int deme_ctx_set_stream(deme_ctx* c, void* s) {
     return DEME_OK;
 }
 
+int deme_set_arith_mode(deme_ctx* c, int mode) {
+    if (!c || (mode != DEME_ARITH_FAST && mode != DEME_ARITH_EXACT))
+        return DEME_ERR_INVALID;
+    if (mode != c->arith) {
+        HIPCK(hipStreamSynchronize(c->stream));
+        c->arith = mode;
+        c->kinDirty = true;
+        c->conValid = false;  // stored contributions are in the other mode's units
+    }
+    return DEME_OK;
+}
+int deme_get_arith_mode(const deme_ctx* c) { return c ? c->arith : -1; }
+
 int deme_sync(deme_ctx* c) {
     if (!c)
         return DEME_ERR_INVALID;
@@ -900,6 +981,7 @@ int deme_set_params(deme_ctx* c, const DemeParams* p) {
     c->hp = *p;
     c->timeElapsed = p->timeElapsed;
     c->haveParams = true;
+    c->kinDirty = true;  // the frame (LBF, voxel size) may have changed
     refresh_dev_params(c);
     return DEME_OK;
 }
@@ -938,6 +1020,9 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         return rc;
     if (int rc = ensure(c, c->acc, std::max<size_t>(nO, 1) * sizeof(AccRec)))
         return rc;
+    if (ensure(c, c->kin, std::max<size_t>(nO, 1) * sizeof(KinRec)) || ensure(c, c->ownerTag, std::max<size_t>(nO, 1) * 4))
+        return c->lastStatus;
+    c->kinDirty = true;
     HIPCK(hipMemsetAsync(c->acc.p, 0, c->acc.bytes, c->stream));
     if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->aSum, (nO + 1) * 32) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
         ensure(c, c->fixedFlag, nO + 1) || ensure(c, c->heavyList, 4096 * 4) || ensure(c, c->rangeCtr, sizeof(RangeCounters)))
@@ -1152,6 +1237,11 @@ static int owner_state_io(deme_ctx* c, const DemeOwnerState* st, int dir) {
 int deme_upload_owner_state(deme_ctx* c, const DemeOwnerState* st) {
     if (c && st && st->familyID)
         c->prescDirty = true;  // owners may have changed family
+    if (c && st && (st->voxelID || st->locX || st->locY || st->locZ || st->oriQw || st->oriQx || st->oriQy || st->oriQz || st->vX ||
+                    st->vY || st->vZ || st->omgBarX || st->omgBarY || st->omgBarZ || st->familyID))
+        c->listStale = true;  // pose, velocity (it sizes the margins) or family (masks) changed under the K-step list
+    if (c)
+        c->kinDirty = true;
     return owner_state_io(c, st, 0);
 }
 int deme_download_owner_state(deme_ctx* c, DemeOwnerState* st) { return owner_state_io(c, st, 1); }
@@ -1171,6 +1261,7 @@ int deme_update_tri_nodes(deme_ctx* c, const float* n1, const float* n2, const f
     hipLaunchKernelGGL(k_pack_tris, dim3(grid_for(c->nTri)), dim3(256), 0, c->stream, c->nTri, c->tris.as<TriRec>(), d,
                        d + 3 * (size_t)c->nTri, d + 6 * (size_t)c->nTri);
     HIPCK(hipStreamSynchronize(c->stream));
+    c->listStale = true;  // the facets moved under the K-step list
     return DEME_OK;
 }
 
@@ -1350,6 +1441,7 @@ static int detection_phase(deme_ctx* c) {
     if (int rc = do_migrate(c))
         return rc;
     c->stepsSinceCD = 0;
+    c->listStale = false;
     return DEME_OK;
 }
 
@@ -1428,7 +1520,7 @@ static int step_tail(deme_ctx* c) {
 
 static bool detection_due(deme_ctx* c) {
     const uint32_t K = c->hp.cdUpdateFreq;
-    return !c->haveList || c->seeded || K == 0 || c->stepsSinceCD >= K;
+    return !c->haveList || c->seeded || c->listStale || K == 0 || c->stepsSinceCD >= K;
 }
 
 static int ensure_halo_stream(deme_ctx* c) {
@@ -1468,8 +1560,8 @@ int deme_halo_unpack_async(deme_ctx* c, const uint32_t* d_ids, uint32_t n, const
     if (int rc = ensure_halo_stream(c))
         return rc;
     if (n)
-        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->haloStream, n, d_ids, c->owners.as<OwnerRec>(),
-                           (const GhostRec*)d_buf);
+        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->haloStream, c->dp, n, d_ids, c->owners.as<OwnerRec>(),
+                           (const GhostRec*)d_buf, gather_args(c).kin, gather_args(c).ownerTag);
     HIPCK(hipEventRecord(c->evHaloDone, c->haloStream));
     return DEME_OK;
 }
@@ -1623,13 +1715,28 @@ int deme_seed_contacts(deme_ctx* c, const uint32_t* idA, const uint32_t* idB, co
     if (n && (!idA || !idB || !type || (nW && !wildcards)))
         return fail(c, DEME_ERR_INVALID, "deme_seed_contacts: null input");
     std::vector<uint64_t> keys(n);
+    std::vector<uint8_t> flip(n, 0);
     for (size_t i = 0; i < n; i++) {
         const uint64_t cls = (type[i] == 1) ? DEME_KEY_CLASS_SS : (type[i] == 2) ? DEME_KEY_CLASS_SM : DEME_KEY_CLASS_SA;
         const uint32_t nB = (cls == DEME_KEY_CLASS_SS) ? c->dp.nSpheres : (cls == DEME_KEY_CLASS_SM) ? c->dp.nTri : c->dp.nAnal;
         if (idA[i] >= c->dp.nSpheres || idB[i] >= nB)
             return fail(c, DEME_ERR_INVALID, "deme_seed_contacts: pair %zu (%u, %u, type %u) is out of range", i, idA[i], idB[i],
                         (unsigned)type[i]);
-        keys[i] = make_key(cls, idA[i], idB[i]);
+        uint32_t a = idA[i], b = idB[i];
+        if (cls == DEME_KEY_CLASS_SS) {
+            if (a == b)
+                return fail(c, DEME_ERR_INVALID, "deme_seed_contacts: pair %zu joins sphere %u to itself", i, a);
+            if (a > b) {  // the sweep lists a sphere pair smaller id first (ss_key): a pair given the other way round is stored
+                          // canonically, and the B-to-A vector history of the built-in model changes sign with the roles
+                if (c->hp.forceModel == DEME_FORCE_CUSTOM && nW)
+                    return fail(c, DEME_ERR_INVALID,
+                                "deme_seed_contacts: pair %zu (%u, %u) must be given smaller sphere id first (the sign rule of a user "
+                                "model's wildcards is not known to the library)", i, a, b);
+                std::swap(a, b);
+                flip[i] = 1;
+            }
+        }
+        keys[i] = make_key(cls, a, b);
     }
     std::vector<uint32_t> perm(n);
     for (size_t i = 0; i < n; i++)
@@ -1643,6 +1750,9 @@ int deme_seed_contacts(deme_ctx* c, const uint32_t* idA, const uint32_t* idB, co
             return fail(c, DEME_ERR_INVALID, "deme_seed_contacts: duplicate pair (%u, %u)", idA[perm[i]], idB[perm[i]]);
         for (uint32_t w = 0; w < nW; w++)
             ws[i * nW + w] = wildcards[(size_t)perm[i] * nW + w];
+        if (flip[perm[i]] && c->hp.forceModel == DEME_FORCE_HERTZIAN)  // delta_tan_x/y/z (FullHertzianForceModel.cu) point B -> A
+            for (uint32_t w = 0; w < 3 && w < nW; w++)
+                ws[i * nW + w] = -ws[i * nW + w];
     }
     if (n > c->cntCap)
         if (int rc = grow_contact_arena(c, n + n / 4 + 1024))
@@ -2003,6 +2113,8 @@ int deme_change_family(deme_ctx* c, uint32_t from, uint32_t to) {
         hipLaunchKernelGGL(k_change_family, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->owners.as<OwnerRec>(),
                            (uint32_t)c->nOwners, from, to);
     c->prescDirty = true;
+    c->listStale = true;  // pairs may have become unmasked
+    c->kinDirty = true;
     return DEME_OK;
 }
 
@@ -2217,8 +2329,8 @@ int deme_halo_unpack(deme_ctx* c, const uint32_t* d_ids, uint32_t n, const void*
     if (int rc = check_ready(c))
         return rc;
     if (n)
-        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->stream, n, d_ids, c->owners.as<OwnerRec>(),
-                           (const GhostRec*)d_buf);
+        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->stream, c->dp, n, d_ids, c->owners.as<OwnerRec>(),
+                           (const GhostRec*)d_buf, gather_args(c).kin, gather_args(c).ownerTag);
     return DEME_OK;
 }
 

@@ -20,13 +20,16 @@ namespace deme_dev {
 // device status bits (host reads them at sync points)
 #define DEME_ST_VELOCITY 1u
 #define DEME_ST_NONFINITE 2u
+#define DEME_ST_INCIDENCE 4u  // a sphere touches more than DEME_MAX_BINS_PER_SPHERE bins: its count would not be trustworthy
+#define DEME_MAX_BINS_PER_SPHERE 0xFFFFFFu
 
 struct DetectCounters {  // one 64-byte block of device counters, zeroed per detection
     unsigned long long nContactsRaw;  // keys appended (may exceed capacity: then nothing was written past it)
     unsigned int nActiveBins;
     unsigned int maxInBin;
     unsigned int status;
-    unsigned int pad[11];
+    unsigned int maxCount;  // largest number of bins one sphere touches (sizing check of the 32-bit incidence offsets)
+    unsigned int pad[10];
 };
 
 // ---------------------------------------------------------------------------
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
     const bool valid = s < p.nSpheres;
     d3 pos{0, 0, 0};
     double rBin = 0;
-    uint32_t fam = 0;
+    uint32_t fam = 0, myCount = 0;
     if (valid) {
         const SphereRec sr = load_sphere(spheres, s);
         const OwnerRec o = load_owner(owners, sr.owner);
@@ -102,7 +105,18 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
         const uint32_t nx = hx - lx + 1, ny = hy - ly + 1, nz = hz - lz + 1;
         binLo[s] = make_uint4(lx, ly, lz, nx);
         binN[s] = make_uint2(ny, nz);
-        counts[s] = nx * ny * nz;
+        const uint64_t n64 = (uint64_t)nx * ny * nz;  // the product itself may not fit 32 bits (huge margin, tiny bins)
+        if (n64 > DEME_MAX_BINS_PER_SPHERE)
+            atomicOr(&ctr->status, DEME_ST_INCIDENCE);
+        myCount = (n64 > DEME_MAX_BINS_PER_SPHERE) ? 0u : (uint32_t)n64;
+        counts[s] = myCount;
+    }
+    {  // largest per-sphere count: the host multiplies it by nSpheres to decide whether the 32-bit scan needs an exact check
+        uint32_t m = myCount;
+        for (int off = 32; off > 0; off >>= 1)
+            m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        if ((threadIdx.x & 63u) == 0 && m > ctr->maxCount)  // (a stale read only costs a redundant atomic)
+            atomicMax(&ctr->maxCount, m);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         counts[p.nSpheres] = 0;  // scan sentinel: offsets[nSpheres] = total
@@ -683,7 +697,44 @@ struct GatherArgs {
     const float2* conB2;
     const float4* aSum;      // in-order sum of an A run that lies inside one force-kernel block (deme_force.h)
     const AccRec* nextAcc;   // null, or per owner: acceleration the script added for this step (deme_add_owner_acc)
+    // fast arithmetic mode: the contributions are world-frame forces and torques (ForceArgs::world); their per-owner sums
+    // become a and alpha through acc_from_world.  kin / quat: the derived per-owner view the integrator rewrites for the
+    // next force pass (deme_force_fast.h), null in the bit-exact mode
+    uint32_t world;
+    KinRec* kin;
+    uint32_t* ownerTag;
 };
+
+// per-owner conversion of the fast mode: a = F / m, alpha = R^T tau / I (body frame, like the reference's alpha)
+__device__ inline void acc_from_world(const DevParams& p, const OwnerRec& r, float4& a, float4& al) {
+    const float4 mp = p.massProps[r.inertiaOff];
+    const RotM R = rot_coeffs(r.qw, r.qx, r.qy, r.qz);
+    const f3 tl = rot_apply(rot_transpose(R), mk3(al.x, al.y, al.z));
+    a = make_float4(a.x / mp.x, a.y / mp.x, a.z / mp.x, 0.f);
+    al = make_float4(tl.x / mp.y, tl.y / mp.z, tl.z / mp.w, 0.f);
+}
+
+// the derived view of one owner (KinRec + tag) from its record
+__device__ inline void write_kin(const DevParams& p, const OwnerRec& r, uint32_t o, KinRec* kin, uint32_t* ownerTag) {
+    const d3 X = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);
+    const f3 ww = rot_apply(rot_coeffs(r.qw, r.qx, r.qy, r.qz), mk3(r.wx, r.wy, r.wz));
+    KinRec k;
+    k.x = X.x + (double)p.LBFX, k.y = X.y + (double)p.LBFY, k.z = X.z + (double)p.LBFZ;
+    k.qw = r.qw, k.qx = r.qx, k.qy = r.qy, k.qz = r.qz;
+    k.vx = r.vx, k.vy = r.vy, k.vz = r.vz;
+    k.wx = ww.x, k.wy = ww.y, k.wz = ww.z;
+    uint4* dst = reinterpret_cast<uint4*>(kin + o);
+    const uint4* src = reinterpret_cast<const uint4*>(&k);
+    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+    ownerTag[o] = make_owner_tag(r.family, r.inertiaOff);
+}
+
+__global__ __launch_bounds__(256) void k_refresh_kin(const DevParams p, const OwnerRec* __restrict__ owners, KinRec* __restrict__ kin,
+                                                     uint32_t* __restrict__ ownerTag) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < p.nOwners)
+        write_kin(p, load_owner(owners, o), o, kin, ownerTag);
+}
 
 // A-side sum of one owner: the force kernel's in-workgroup result when the run lay inside one block, else the
 // same in-order sum over the per-contact records (loads issued four at a time).
@@ -805,12 +856,15 @@ __device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint3
 }
 
 // stand-alone reduction (deme_calc_forces): a/alpha of every non-heavy owner
-__global__ __launch_bounds__(256) void k_gather_acc(const DevParams p, const GatherArgs g, AccRec* __restrict__ acc) {
+__global__ __launch_bounds__(256) void k_gather_acc(const DevParams p, const GatherArgs g, const OwnerRec* __restrict__ owners,
+                                                    AccRec* __restrict__ acc) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= p.nOwners || g.heavy[o])
         return;
     float4 a, al;
     gather_owner(g, o, a, al);
+    if (g.world)
+        acc_from_world(p, load_owner(owners, o), a, al);
     float4* ap = reinterpret_cast<float4*>(acc + o);
     ap[0] = a;
     ap[1] = al;
@@ -818,7 +872,8 @@ __global__ __launch_bounds__(256) void k_gather_acc(const DevParams p, const Gat
 
 // Owners with very many contacts (walls, large meshes): one workgroup each, fixed-shape tree
 // reduction (deterministic; summation order differs from list order).
-__global__ __launch_bounds__(256) void k_reduce_heavy(const GatherArgs g, const uint32_t* __restrict__ heavyList,
+__global__ __launch_bounds__(256) void k_reduce_heavy(const DevParams p, const GatherArgs g, const OwnerRec* __restrict__ owners,
+                                                      const uint32_t* __restrict__ heavyList,
                                                       const uint32_t* __restrict__ nHeavy,
                                                       const uint8_t* __restrict__ skip, AccRec* __restrict__ acc) {
     __shared__ float red[6][256];
@@ -858,9 +913,12 @@ __global__ __launch_bounds__(256) void k_reduce_heavy(const GatherArgs g, const 
             __syncthreads();
         }
         if (threadIdx.x == 0) {
+            float4 a = make_float4(red[0][0], red[1][0], red[2][0], 0.f), al = make_float4(red[3][0], red[4][0], red[5][0], 0.f);
+            if (g.world)
+                acc_from_world(p, load_owner(owners, o), a, al);
             float4* ap = reinterpret_cast<float4*>(acc + o);
-            ap[0] = make_float4(red[0][0], red[1][0], red[2][0], 0.f);
-            ap[1] = make_float4(red[3][0], red[4][0], red[5][0], 0.f);
+            ap[0] = a;
+            ap[1] = al;
         }
         __syncthreads();
     }
@@ -1010,6 +1068,8 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         gather_block(g, p.nOwners, o, valid && !ghost && !fixed && !hv, lds, a, al);
         if (!valid || ghost)
             return;
+        if (g.world && !fixed && !hv)
+            acc_from_world(p, r, a, al);
         if (hv) {
             const float4* ap = reinterpret_cast<const float4*>(acc + o);
             a = ap[0];
@@ -1133,6 +1193,8 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         r.qz = qz / len;
     }
     store_owner(owners, o, r);
+    if (g.kin)  // the next force pass reads the derived view, not the record
+        write_kin(p, r, o, g.kin, g.ownerTag);
 }
 
 // ---- packing between the C-ABI's SoA view and the device records -------------------------------
@@ -1290,7 +1352,8 @@ __global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const uint32_t* i
     g.vx = r.vx, g.vy = r.vy, g.vz = r.vz, g.wx = r.wx, g.wy = r.wy, g.wz = r.wz;
     buf[i] = g;
 }
-__global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n, const uint32_t* ids, OwnerRec* owners, const GhostRec* buf) {
+__global__ __launch_bounds__(256) void k_halo_unpack(const DevParams p, uint32_t n, const uint32_t* ids, OwnerRec* owners,
+                                                     const GhostRec* buf, KinRec* kin, uint32_t* ownerTag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
@@ -1302,6 +1365,8 @@ __global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n, const uint32_t*
     r->voxelID = g.voxelID, r->locX = g.locX, r->locY = g.locY, r->locZ = g.locZ;
     r->qw = g.qw, r->qx = g.qx, r->qy = g.qy, r->qz = g.qz;
     r->vx = g.vx, r->vy = g.vy, r->vz = g.vz, r->wx = g.wx, r->wy = g.wy, r->wz = g.wz;
+    if (kin)
+        write_kin(p, *r, ids[i], kin, ownerTag);
 }
 
 }  // namespace deme_dev

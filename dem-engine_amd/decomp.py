@@ -61,6 +61,14 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
                              "across slabs (a free mesh would need an all-reduce of its accelerations every step)")
     x = np.asarray(clump_x, np.float64)[:n_clumps]
     edges = slab_edges(x, n_ranks)
+    if n_ranks > 1 and (np.asarray(arrays["familyID"])[:n_clumps] == GHOST_FAMILY).any():
+        raise ValueError(f"family {GHOST_FAMILY} is reserved for ghost copies under a slab decomposition but the scene uses it")
+    # ghosts are taken from the face neighbours only: an interior slab thinner than the halo would leave clumps of the slab
+    # after next within reach of the face without a ghost copy (equal-count slabs get thin where the bed is dense)
+    widths = np.diff(edges)[1:-1]
+    if len(widths) and float(widths.min()) < halo:
+        raise ValueError(f"slab {1 + int(widths.argmin())} is {float(widths.min()):.4g} wide, thinner than the halo {halo:.4g}: "
+                         "use fewer ranks or a thinner halo")
     rank_of = np.clip(np.searchsorted(edges, x, side="right") - 1, 0, n_ranks - 1)
     sph_owner_g = arrays["ownerClumpBody"]
     first_sphere = np.searchsorted(sph_owner_g, np.arange(n_owners + 1))  # spheres are clump-major

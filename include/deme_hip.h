@@ -166,6 +166,21 @@ const char* deme_version(void);
 int deme_ctx_set_stream(deme_ctx* ctx, void* hip_stream); /* NULL = context-owned stream */
 int deme_sync(deme_ctx* ctx);
 
+/* Arithmetic mode of the per-step kernels.  Contact DETECTION (bin assignments, contact lists, history map) is the same
+ * decision code in both modes -- bit-exact against the reference's fp64 predicates.
+ *  DEME_ARITH_FAST  (default)  the contact-force kernel works from a per-owner derived view (world position in fp64, world
+ *      angular velocity, mass: rewritten by the integrator every step), evaluates contacts in the world frame with 1-ulp
+ *      hardware reciprocals / square roots and FMA contraction, and accumulates world-frame forces and torques that the
+ *      integrator converts once per owner.  Same formulas as kernel/DEMCalcForceKernels.cu + FullHertzianForceModel.cu,
+ *      re-associated: results agree with DEME_ARITH_EXACT to fp32 rounding (tolerance stated in tests/test_fast_mode.py).
+ *  DEME_ARITH_EXACT  the reference's operation order and correctly rounded division / square root throughout: owner states
+ *      bit-identical to the CPU oracle (the parity suite runs in this mode).
+ * The process-wide default can be set with the environment variable DEME_ARITH=exact|fast. */
+#define DEME_ARITH_FAST 1
+#define DEME_ARITH_EXACT 0
+int deme_set_arith_mode(deme_ctx* ctx, int mode);
+int deme_get_arith_mode(const deme_ctx* ctx);
+
 /* setSimParams / UpdateSimParams (APIPrivate.cpp:1121, dT.cpp:2463-2466) */
 int deme_set_params(deme_ctx* ctx, const DemeParams* p);
 /* allocateGPUArrays + initGPUArrays + packDataPointers (APIPrivate.cpp:1169-1290) */

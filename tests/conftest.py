@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 import __graft_entry__ as entry  # noqa: E402
 
+# The parity suite compares the HIP path with the CPU oracle BIT FOR BIT, which is what the library's exact arithmetic mode
+# is for (include/deme_hip.h, DEME_ARITH_EXACT).  The product default is the fast mode; tests/test_fast_mode.py runs that one
+# against the oracle with its stated fp32 tolerance (it selects the mode per context, overriding this process default).
+os.environ.setdefault("DEME_ARITH", "exact")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

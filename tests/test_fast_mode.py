@@ -1,0 +1,147 @@
+"""The FAST arithmetic mode (the library's default, include/deme_hip.h DEME_ARITH_FAST) against the CPU oracle.
+
+Contact detection is the same decision code in both modes: lists, bins and history maps must be bit-identical.  The per-step
+kernels re-associate the reference's formulas (world-frame evaluation, per-owner conversion, 1-ulp hardware rcp / sqrt, FMA
+contraction), so forces and trajectories agree with the oracle to fp32 rounding.  STATED TOLERANCE (north_star: "positions /
+velocities within a stated fp32 tolerance after N steps"):
+  * owner accelerations of one force evaluation: 2e-4 of the largest acceleration in the scene per component (single
+    contacts agree to ~1e-5; the bound leaves room for the sum over an owner's contacts),
+  * after N = 100 steps of a settling bed (h = 5e-6 s, clumps moving at up to 1.5 m/s): positions within 5e-8 m (one fp32
+    ulp of a coordinate in a 1 m box is 6e-8 m; 1e-5 of a sphere radius), velocities within 2e-4 m/s, contact sets identical.
+    A granular bed is chaotic: measured on this scene the fast-vs-exact difference is 3e-12 m after 1 step (one fp32 ulp in
+    the velocities), 6e-9 m after 100, 1.4e-8 m after 200, 7e-8 m after 500 -- the bound is for N = 100, not a growth law.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _positions(pkg, p, st):
+    return pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+
+
+def _bed(pkg, n=3000, cd_freq=0, **kw):
+    # the bench recipe at test size: lattice without initial overlaps, dropped at 1 m/s; ~3.5 contacts per clump once settled
+    return pkg.model.packed_bed(n, seed=11, cd_freq=cd_freq, spacing_mult=3.0, init_vz=-1.0, aspect=(1.0, 1.0, 0.25), **kw)
+
+
+def _settled(pkg, b, steps=10000):
+    """(params, scene, state) of the bed after `steps` steps in the exact mode: a packed starting point with live histories"""
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("exact")
+    ctx.set_params(p), ctx.upload_scene(sc)
+    ctx.step(steps)
+    st = ctx.download_state()
+    ctx.close()
+    return p, sc, {k: st[k] for k in st if k not in ("aX", "aY", "aZ", "alphaX", "alphaY", "alphaZ")}
+
+
+@pytest.mark.parametrize("model", ["hertz", "frictionless"])
+def test_fast_accelerations_match_oracle(pkg, orc, model):
+    b = _bed(pkg)
+    if model == "frictionless":
+        b.UseFrictionlessHertzianModel()
+    p, sc, st = _settled(pkg, b)
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    assert ctx.arith_mode() == "fast"
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st)
+    for s in (ctx, sim):
+        s.compute_margins(0), s.detect(), s.migrate(), s.calc_forces()
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert len(ga[0]) > 1500 and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))  # decisions: bit-exact
+    g, o = ctx.download_state(), sim.download_state()
+    n = int(sc.nOwnerClumps)
+    for keys in (("aX", "aY", "aZ"), ("alphaX", "alphaY", "alphaZ")):
+        G = np.stack([g[k][:n] for k in keys], 1).astype(np.float64)
+        O = np.stack([o[k][:n] for k in keys], 1).astype(np.float64)
+        scale = np.abs(O).max()
+        assert scale > 0
+        print(f"{model} {keys[0][:-1]}: max |fast - oracle| / max |oracle| = {np.abs(G - O).max() / scale:.3e} (scale {scale:.3e})")
+        assert np.abs(G - O).max() <= 2e-4 * scale, (keys, np.abs(G - O).max() / scale)
+    # the wall owner (one heavy owner, tree reduction): same bound as in the exact mode's test
+    assert abs(g["aZ"][n] - o["aZ"][n]) <= 1e-3 * max(1.0, abs(o["aZ"][n]))
+    if model == "hertz":  # contact history written by the fast kernel
+        for w in range(4):
+            gw, ow = ctx.wildcard(w), sim.wildcard(w)
+            print(f"wildcard {w}: max diff {np.abs(gw - ow).max():.3e} of {np.abs(ow).max():.3e}")
+            assert np.abs(gw - ow).max() <= 1e-5 * max(np.abs(ow).max(), 1e-12) + 1e-12
+    ctx.close()
+
+
+@pytest.mark.parametrize("cd_freq", [0, 10])
+def test_fast_trajectory_within_stated_tolerance(pkg, orc, cd_freq):
+    b = _bed(pkg, cd_freq=cd_freq)
+    if cd_freq:
+        b.SetExpandSafetyAdder(0.5)
+    p, sc, st = _settled(pkg, b)
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st)
+    N = 100
+    ctx.step(N), sim.step(N)
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert len(ga[0]) == len(oa[0]) and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    g, o = ctx.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g) - _positions(pkg, p, o)).max()
+    dv = max(np.abs(g[k] - o[k]).max() for k in ("vX", "vY", "vZ"))
+    dw = max(np.abs(g[k] - o[k]).max() for k in ("omgBarX", "omgBarY", "omgBarZ"))
+    dq = max(np.abs(g[k] - o[k]).max() for k in ("oriQw", "oriQx", "oriQy", "oriQz"))
+    print(f"fast vs oracle after {N} steps (K={cd_freq}): |dx| {dx:.3e} m, |dv| {dv:.3e} m/s, |dw| {dw:.3e} rad/s, |dq| {dq:.3e}")
+    assert dx <= 5e-8 and dv <= 2e-4 and dw <= 5e-2 and dq <= 2e-5
+    ctx.close()
+
+
+def test_fast_and_exact_modes_share_the_contact_path(pkg):
+    """switching the mode on a live context: the list is untouched, the next step runs the other kernels"""
+    b = _bed(pkg, n=1500, cd_freq=50)
+    b.SetExpandSafetyAdder(1.0)
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("exact")
+    ctx.set_params(p), ctx.upload_scene(sc)
+    ctx.step(280)  # detections at steps 0, 50, ..., 250
+    a0 = ctx.contacts()
+    ctx.set_arith_mode("fast")
+    ctx.step(3)
+    ctx.set_arith_mode("exact")
+    ctx.step(2)  # 285 steps: the list is still the one of step 250
+    a1 = ctx.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(a0[:3], a1[:3]))
+    st = ctx.download_state()
+    assert np.isfinite(st["vZ"]).all()
+    ctx.close()
+
+
+def test_fast_mode_with_mesh_planes_and_families(pkg, orc):
+    """sphere-mesh contacts (general kernel, world-frame contributions), a non-trivial family table and a cylinder in fast mode"""
+    b = pkg.model.packed_bed(1200, seed=11, cd_freq=0, spacing_mult=3.0, init_vz=-1.0, aspect=(1.0, 1.0, 0.45))
+    lo, hi = b.user_box_min, b.user_box_max
+    v, f = pkg.model.plate_mesh(12, 12, float(hi[0] - lo[0]) * 0.9, float(hi[1] - lo[1]) * 0.9, z=0.0, wavy=0.001)
+    m = b.AddMeshObject(v, f, 0)
+    m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, float(lo[2]) + 0.004))
+    m.SetFamily(3)
+    b.SetFamilyFixed(3)
+    b.SetFamilyExtraMargin(0, 1e-5)
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc)
+    sim = orc.make_sim(pkg, p, sc)
+    N = 2500
+    ctx.step(N), sim.step(N)
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert (ga[2] == 2).sum() > 20, "the bed should be resting on the plate"
+    assert len(ga[0]) == len(oa[0]) and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    g, o = ctx.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g) - _positions(pkg, p, o)).max()
+    dv = max(np.abs(g[k] - o[k]).max() for k in ("vX", "vY", "vZ"))
+    print(f"fast vs oracle, mesh scene after {N} steps: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
+    assert dx <= 5e-8 and dv <= 5e-5
+    ctx.close()
