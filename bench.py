@@ -494,7 +494,7 @@ def main():
     out = {
         "metric": "clump*steps/s", "value": value, "unit": "clump*steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "data": "synthetic",
+        "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "arith_mode": ctx.arith_mode(), "data": "synthetic",
         "config": {"workload": ("BASELINE configs[4] flavour: polydisperse spheres (8 templates, r..3r) with a run-time compiled "
                                 "cohesion model" if args.config5 else
                                 f"BASELINE configs[1]: {args.clumps} three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling"
@@ -510,7 +510,7 @@ def main():
                                 {"mode": args.adaptive, "bin_size": adaptive_state[0], "cd_every": adaptive_state[1],
                                  "bin_size_changes": adaptive_state[2], "update_freq_changes": adaptive_state[3]}),
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
-        "roofline": {"kernel": "deme_custom_forces_ss (hipRTC)" if args.config5 else "k_calc_forces<0, 0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "deme_custom_forces_ss (hipRTC)" if args.config5 else ("k_forces_fast<0>" if ctx.arith_mode() == "fast" else "k_calc_forces<0, 0>"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),
                      "launch_sampling": f"every {stride}{'th' if stride > 3 else ('st', 'nd', 'rd')[stride - 1]} launch inside the timed region is bracketed with HIP events"},

@@ -39,20 +39,6 @@ struct __attribute__((aligned(16))) OwnerRec {
 };
 static_assert(sizeof(OwnerRec) == 64, "OwnerRec must be 64 bytes");
 
-// Derived per-owner view for the FAST contact-force kernel (deme_force_fast.h), rewritten by the integrator every step:
-// what a contact needs of an owner with the per-owner work already done -- the position decoded to fp64 (LBF included) and the
-// angular velocity rotated into the world frame -- in ONE 64-byte record (half a cache line: a wavefront fetches sixteen of
-// them per load instruction, four lanes per record).  Family and mass-property index sit in a dense 4-byte array beside it.
-struct __attribute__((aligned(16))) KinRec {
-    double x, y, z;
-    float qw, qx, qy, qz;
-    float vx, vy, vz;
-    float wx, wy, wz;  // WORLD frame (OwnerRec keeps the body-frame omgBar)
-};
-static_assert(sizeof(KinRec) == 64, "KinRec must be 64 bytes");
-// ownerTag[o] = family | inertiaOff << 16
-__host__ __device__ inline uint32_t make_owner_tag(uint32_t family, uint32_t inertiaOff) { return (family & 0xFFu) | (inertiaOff << 16); }
-
 struct SphereRec {  // 8 bytes: ownerClumpBody + clumpComponentOffset + sphereMaterialOffset
     uint32_t owner;
     uint16_t comp;

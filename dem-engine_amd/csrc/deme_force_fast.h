@@ -3,7 +3,12 @@
 // Same physics as deme_force.h (kernel/DEMCalcForceKernels.cu:44-267 with FullHertzianForceModel.cu /
 // FrictionlessHertzianForceModel.cu), re-associated so that the per-owner work is done once per owner per step by the
 // integrator instead of once per contact end here:
-//   * owners come as KinRec (fp64 world position, world-frame angular velocity, mass) + a dense quaternion array;
+//   * the two owner records of a contact are fetched by the whole wavefront, four lanes per 64-byte record (one load
+//     instruction touches 16 full records instead of 64 scattered 16-byte pieces: the vector L1 serves one 64-byte request per
+//     cycle, and this kernel is bound by that request rate and by memory latency, not by arithmetic), and transposed to one
+//     record per lane through LDS;
+//   * the owner-to-owner offset is the EXACT integer difference of the two encoded positions times l (one rounding), not the
+//     difference of two decoded fp64 positions;
 //   * everything is evaluated in the WORLD frame: the velocity of the contact point is v + w x r, the torque r x F; the
 //     per-contact contributions are the world-frame force and torque about the owner's centre, and the integrator turns
 //     their per-owner sums into a = F / m and alpha = R^T tau / I once per owner (the reference rotates every contact's
@@ -46,46 +51,78 @@ __device__ inline f3 fadd(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b
 __device__ inline f3 fscale(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
 __device__ inline f3 faxpy(float s, f3 a, f3 b) { return mk3(s * a.x + b.x, s * a.y + b.y, s * a.z + b.z); }  // s a + b
 
-struct FastArgs {
-    const KinRec* kin;
-    const uint32_t* ownerTag;  // family | inertiaOff << 16
-};
-
-// LDS stride of a staged KinRec in 16-byte units: 80 bytes, so that the 64 lanes' own-record reads (ds_read_b128 at lane * 80)
+// LDS stride of a staged OwnerRec in 16-byte units: 80 bytes, so that the 64 lanes' own-record reads (ds_read_b128 at lane * 80)
 // fall on distinct banks (a 64-byte stride would put every fourth lane on the same ones)
-#define DEME_KIN_LDS_STRIDE 5
-
-__device__ inline KinRec load_kin(const KinRec* k, uint32_t o) {
-    KinRec r;
-    const uint4* p = reinterpret_cast<const uint4*>(k + o);
-    uint4* q = reinterpret_cast<uint4*>(&r);
-    q[0] = p[0];
-    q[1] = p[1];
-    q[2] = p[2];
-    q[3] = p[3];
-    return r;
-}
+#define DEME_REC_LDS_STRIDE 5
 
 __device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ inline float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// voxel coordinates of an encoded position (IDChopper, DEMHelperKernels.cuh:92-114) as sub-voxel counts: v * 2^16 + loc
+__device__ inline void pos_units(const OwnerRec& r, const DevParams& p, int64_t& ux, int64_t& uy, int64_t& uz) {
+    const uint64_t id = r.voxelID;
+    ux = (int64_t)(((id & (((uint64_t)1 << p.nvXp2) - 1)) << 16) | r.locX);
+    uy = (int64_t)((((id >> p.nvXp2) & (((uint64_t)1 << p.nvYp2) - 1)) << 16) | r.locY);
+    uz = (int64_t)(((id >> (p.nvXp2 + p.nvYp2)) << 16) | r.locZ);
+}
+
+// Cooperative fetch of the 2 x 64 owner records a wavefront needs (A's and B's owner of each lane's contact): four lanes per
+// record, all eight load instructions issued before anything waits, then two transposes through the wavefront's LDS area.
+// Every lane of the wavefront must call; lanes without a contact pass owner 0.
+__device__ inline void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of one wavefront complete in order: only the
+    __builtin_amdgcn_wave_barrier();                         // compiler has to be kept from reordering
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#ifndef DEME_FAST_STAGE_A
+#define DEME_FAST_STAGE_A 0  // A's owners: ~15 distinct records per wavefront (the list is sorted by A), loaded directly
+#endif
+__device__ inline void stage_owner_records(const OwnerRec* owners, uint32_t ownerA, uint32_t ownerB, uint4* stage, OwnerRec& OA,
+                                           OwnerRec& OB) {
+    const uint32_t lane = threadIdx.x & 63u, piece = lane & 3u, sub = lane >> 2;
+    uint4 vb[4];
+#if DEME_FAST_STAGE_A
+    uint4 va[4];
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t ob = (uint32_t)__shfl((int)ownerB, (int)(16 * k + sub));
+        vb[k] = reinterpret_cast<const uint4*>(owners + ob)[piece];
+#if DEME_FAST_STAGE_A
+        const uint32_t oa = (uint32_t)__shfl((int)ownerA, (int)(16 * k + sub));
+        va[k] = reinterpret_cast<const uint4*>(owners + oa)[piece];
+#endif
+    }
+    const uint4* mine = stage + lane * DEME_REC_LDS_STRIDE;
+    uint4* q;
+#if DEME_FAST_STAGE_A
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        stage[(16 * k + sub) * DEME_REC_LDS_STRIDE + piece] = va[k];
+    wave_lds_fence();
+    q = reinterpret_cast<uint4*>(&OA);
+    q[0] = mine[0], q[1] = mine[1], q[2] = mine[2], q[3] = mine[3];
+    wave_lds_fence();
+#else
+    OA = load_owner(owners, ownerA);
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        stage[(16 * k + sub) * DEME_REC_LDS_STRIDE + piece] = vb[k];
+    wave_lds_fence();
+    q = reinterpret_cast<uint4*>(&OB);
+    q[0] = mine[0], q[1] = mine[1], q[2] = mine[2], q[3] = mine[3];
+}
+
 // MODEL 0: full Hertzian (history float4: delta_tan x/y/z, delta_time), 1: frictionless.  One thread per contact of the hot
 // classes (sphere-sphere, sphere-analytical).  Outputs: the A side's world-frame force and torque (the caller reduces them
 // over the owner's run), the B side's record is stored here.
 template <int MODEL>
-__device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, const FastArgs& fa, const uint32_t c, const uint4 ci,
-                                        const uint4* stagedB, float4& outA4, float2& outA2) {
+__device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, const uint32_t c, const uint4 ci, const OwnerRec& OA,
+                                        const OwnerRec& OB, float4& outA4, float2& outA2) {
     const uint32_t cls = ci.x >> 30;
-    const uint32_t AOwner = ci.x & 0x3FFFFFFFu, BOwner = ci.y;
-    const KinRec KA = load_kin(fa.kin, AOwner);  // contacts are sorted by A: a wavefront reads ~15 distinct records here
-    const uint32_t tagA = fa.ownerTag[AOwner], tagB = fa.ownerTag[BOwner];
-    KinRec KB;  // staged through LDS by the whole wavefront (forces_fast_stage_b)
-    {
-        uint4* q = reinterpret_cast<uint4*>(&KB);
-        q[0] = stagedB[0], q[1] = stagedB[1], q[2] = stagedB[2], q[3] = stagedB[3];
-    }
-    const float massA = p.massProps[tagA >> 16].x;
+    const float massA = p.massProps[OA.inertiaOff].x;
     float4 hist = make_float4(0, 0, 0, 0);
     float4* wcp = nullptr;
     if (MODEL == 0) {
@@ -96,17 +133,23 @@ __device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, 
     const uint32_t matA = ci.z >> 16;
     // sphere offsets with the reference's own rounding (no contraction, deme_device.h): an offset that differs in its last bit
     // moves the overlap by ~1e-10 m, i.e. 1e-4 of a typical overlap -- everything after this point is well conditioned
-    const RotM RA = rot_coeffs(KA.qw, KA.qx, KA.qy, KA.qz);
-    const RotM RB = rot_coeffs(KB.qw, KB.qx, KB.qy, KB.qz);
+    const RotM RA = rot_coeffs(OA.qw, OA.qx, OA.qy, OA.qz);
+    const RotM RB = rot_coeffs(OB.qw, OB.qx, OB.qy, OB.qz);
     const f3 relA = rot_apply(RA, mk3(cA.x, cA.y, cA.z));
     const float rA = cA.w;
     float extraMargin = 0.f;
     if (!p.familyTrivial) {
-        const float eA = p.familyExtra[tagA & 0xFFu], eB = p.familyExtra[tagB & 0xFFu];
+        const float eA = p.familyExtra[OA.family & 0xFFu], eB = p.familyExtra[OB.family & 0xFFu];
         extraMargin = fmaxf(eA, eB);
     }
-    // owner-to-owner offset: the one fp64 difference every later vector hangs on
-    const double dOx = KA.x - KB.x, dOy = KA.y - KB.y, dOz = KA.z - KB.z;
+    // owner-to-owner offset: the one long difference every later vector hangs on, taken exactly in sub-voxel units
+    double dOx, dOy, dOz;
+    {
+        int64_t uAx, uAy, uAz, uBx, uBy, uBz;
+        pos_units(OA, p, uAx, uAy, uAz);
+        pos_units(OB, p, uBx, uBy, uBz);
+        dOx = (double)(uAx - uBx) * p.l, dOy = (double)(uAy - uBy) * p.l, dOz = (double)(uAz - uBz) * p.l;
+    }
     const f3 dO = mk3((float)dOx, (float)dOy, (float)dOz);
     f3 n, rAv, rBv;   // B2A, contact point relative to A's / B's centre
     float depth, rB, massB;
@@ -116,7 +159,7 @@ __device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, 
         const float4 cB = p.comp[ci.w & 0xFFFFu];
         matB = ci.w >> 16;
         rB = cB.w;
-        massB = p.massProps[tagB >> 16].x;
+        massB = p.massProps[OB.inertiaOff].x;
         const f3 relB = rot_apply(RB, mk3(cB.x, cB.y, cB.z));
         // centre-to-centre vector in fp64, as the reference forms it (DEMHelperKernels.cuh:292-326)
         const double dx = (dOx + (double)relA.x) - (double)relB.x;
@@ -142,23 +185,26 @@ __device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, 
         massB = ob.mass;
         const f3 relB = rot_apply(RB, mk3(ob.relx, ob.rely, ob.relz));
         const f3 dir = rot_apply(RB, mk3(ob.rotx, ob.roty, ob.rotz));
-        const d3 bodyA{KA.x + (double)relA.x, KA.y + (double)relA.y, KA.z + (double)relA.z};
-        const d3 bodyB{KB.x + (double)relB.x, KB.y + (double)relB.y, KB.z + (double)relB.z};
+        d3 PA = decode_pos(OA.voxelID, OA.locX, OA.locY, OA.locZ, p), PB = decode_pos(OB.voxelID, OB.locX, OB.locY, OB.locZ, p);
+        PA.x += p.LBFX, PA.y += p.LBFY, PA.z += p.LBFZ;
+        PB.x += p.LBFX, PB.y += p.LBFY, PB.z += p.LBFZ;
+        const d3 bodyA{PA.x + (double)relA.x, PA.y + (double)relA.y, PA.z + (double)relA.z};
+        const d3 bodyB{PB.x + (double)relB.x, PB.y + (double)relB.y, PB.z + (double)relB.z};
         d3 cp;
         double dd;
         sphere_entity(bodyA, rA, ob.type, bodyB, dir, ob.size1, ob.normal, 0.0f, cp, n, dd);
         depth = (float)dd;
         touching = !(dd < -(double)extraMargin);  // the list entry keeps its type; only the grace margin retires it
-        rAv = mk3((float)(cp.x - KA.x), (float)(cp.y - KA.y), (float)(cp.z - KA.z));
-        rBv = mk3((float)(cp.x - KB.x), (float)(cp.y - KB.y), (float)(cp.z - KB.z));
+        rAv = mk3((float)(cp.x - PA.x), (float)(cp.y - PA.y), (float)(cp.z - PA.z));
+        rBv = mk3((float)(cp.x - PB.x), (float)(cp.y - PB.y), (float)(cp.z - PB.z));
     }
     f3 force = mk3(0, 0, 0), torque_only = mk3(0, 0, 0);
     if (touching) {
         if (depth > 0.f) {
             const MatPair mp = p.matPair[matA * p.nMat + matB];
-            const f3 wA = mk3(KA.wx, KA.wy, KA.wz), wB = mk3(KB.wx, KB.wy, KB.wz);
+            const f3 wA = frot_apply(RA, mk3(OA.wx, OA.wy, OA.wz)), wB = frot_apply(RB, mk3(OB.wx, OB.wy, OB.wz));  // world frame
             const f3 rotVelA = fcross(wA, rAv), rotVelB = fcross(wB, rBv);
-            const f3 velB2A = fsub(fadd(mk3(KA.vx, KA.vy, KA.vz), rotVelA), fadd(mk3(KB.vx, KB.vy, KB.vz), rotVelB));
+            const f3 velB2A = fsub(fadd(mk3(OA.vx, OA.vy, OA.vz), rotVelA), fadd(mk3(OB.vx, OB.vy, OB.vz), rotVelB));
             const float projection = fdot(velB2A, n);
             const float mass_eff = massA * massB * frcp(massA + massB);
             const float sqrt_Rd = fsqrt(depth * (rA * rB) * frcp(rA + rB));
@@ -227,33 +273,15 @@ __device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, 
         *wcp = hist;
 }
 
-// Cooperative gather of the wavefront's 64 B-owner records: four lanes per record, so one load instruction touches 16 records
-// of 64 contiguous bytes each instead of 64 scattered 16-byte pieces (the vector L1 serves one 64-byte request per cycle: per
-// wavefront 64 requests instead of 256), transposed to one record per lane through LDS.  Every lane of the wavefront must call;
-// lanes without a contact pass owner 0.
-__device__ inline const uint4* forces_fast_stage_b(const FastArgs& fa, uint32_t BOwner, uint4* stage) {
-    const uint32_t lane = threadIdx.x & 63u, piece = lane & 3u, sub = lane >> 2;
-    uint4 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t ob = (uint32_t)__shfl((int)BOwner, (int)(16 * k + sub));
-        v[k] = reinterpret_cast<const uint4*>(fa.kin + ob)[piece];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        stage[(16 * k + sub) * DEME_KIN_LDS_STRIDE + piece] = v[k];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of one wavefront complete in order: only the
-    __builtin_amdgcn_wave_barrier();                         // compiler has to be kept from reordering
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return stage + lane * DEME_KIN_LDS_STRIDE;
-}
-
 // Block structure, halo passes and the in-workgroup reduction of the A side are those of calc_forces_block<MODEL, 0>
 // (deme_force.h); sphere-mesh contacts still go through the mesh variant of the general kernel, launched first, whose
 // A-side records (world-frame too: ForceArgs::world) are folded into the same sums.
+#ifndef DEME_FAST_WAVES
+#define DEME_FAST_WAVES 1
+#endif
 template <int MODEL>
-__global__ __launch_bounds__(DEME_FORCE_BLOCK) void k_forces_fast(const DevParams p, const ForceArgs a, const FastArgs fa) {
-    __shared__ uint4 sB[DEME_FORCE_BLOCK / 64][64 * DEME_KIN_LDS_STRIDE];
+__global__ __launch_bounds__(DEME_FORCE_BLOCK, DEME_FAST_WAVES) void k_forces_fast(const DevParams p, const ForceArgs a) {
+    __shared__ uint4 sRec[DEME_FORCE_BLOCK / 64][64 * DEME_REC_LDS_STRIDE];
     __shared__ float4 s4[DEME_FORCE_BLOCK];
     __shared__ float2 s2[DEME_FORCE_BLOCK];
     const uint32_t bid = force_block_id(a);
@@ -276,9 +304,10 @@ __global__ __launch_bounds__(DEME_FORCE_BLOCK) void k_forces_fast(const DevParam
         s = a.aStart[ci.x & 0x3FFFFFFFu];
         e = a.aStart[(ci.x & 0x3FFFFFFFu) + 1];
     }
-    const uint4* stagedB = forces_fast_stage_b(fa, mine ? ci.y : 0u, sB[threadIdx.x >> 6]);
+    OwnerRec OA, OB;
+    stage_owner_records(a.owners, mine ? (ci.x & 0x3FFFFFFFu) : 0u, mine ? ci.y : 0u, sRec[threadIdx.x >> 6], OA, OB);
     if (mine)
-        forces_fast_body<MODEL>(p, a, fa, c, ci, stagedB, c4, c2);
+        forces_fast_body<MODEL>(p, a, c, ci, OA, OB, c4, c2);
     if (inPass && !mine) {  // sphere-mesh contact: evaluated by the mesh variant
         c4 = a.conA4[c];
         c2 = a.conA2[c];

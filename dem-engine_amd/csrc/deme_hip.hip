@@ -131,11 +131,8 @@ struct deme_ctx {
     bool listStale = false;
     uint32_t lastStatus = 0;
     double timeElapsed = 0;
-    // arithmetic mode (deme_set_arith_mode): DEME_ARITH_FAST (default) or DEME_ARITH_EXACT; the derived per-owner view of the
-    // fast force kernel and whether it has to be rebuilt from the owner records before the next force pass
+    // arithmetic mode (deme_set_arith_mode): DEME_ARITH_FAST (default) or DEME_ARITH_EXACT
     int arith = DEME_ARITH_FAST;
-    DevBuf kin, ownerTag;
-    bool kinDirty = true;
     uint32_t xcdGroup = 0;  // XCD-aware block order of the force kernel (ForceArgs::xcdGroup)
     int timing = 0;  // 0 off; n > 0: every n-th launch of each timed kernel is bracketed with HIP events
     std::map<std::string, TimerSlot> timers;
@@ -677,8 +674,6 @@ GatherArgs gather_args(deme_ctx* c) {
     g.aSum = c->aSum.as<float4>();
     g.nextAcc = c->nextAccPending ? c->nextAcc.as<AccRec>() : nullptr;
     g.world = c->arith == DEME_ARITH_FAST ? 1u : 0u;
-    g.kin = g.world ? c->kin.as<KinRec>() : nullptr;
-    g.ownerTag = g.world ? c->ownerTag.as<uint32_t>() : nullptr;
     return g;
 }
 
@@ -730,12 +725,7 @@ int launch_forces(deme_ctx* c, int pass = -1) {
     // the fast kernel covers the built-in models' hot classes; contact recording (body-frame contact points) and user
     // fragments (the reference's body-frame vocabulary) run the general kernel, with world-frame contributions in fast mode
     const bool fastKernel = fastMode && !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM;
-    FastArgs fa{c->kin.as<KinRec>(), c->ownerTag.as<uint32_t>()};
-    if (fastKernel && c->kinDirty) {  // the script changed owner records since the integrator last wrote the derived view
-        hipLaunchKernelGGL(k_refresh_kin, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
-                           c->kin.as<KinRec>(), c->ownerTag.as<uint32_t>());
-        c->kinDirty = false;
-    }
+
     if (c->record) {
         a.recForce = c->rec[0].as<float>(), a.recTorque = c->rec[1].as<float>(), a.recCPA = c->rec[2].as<float>(),
         a.recCPB = c->rec[3].as<float>();
@@ -753,14 +743,14 @@ int launch_forces(deme_ctx* c, int pass = -1) {
             if (hasSM)  // mesh variant first: the hot variant folds its A-side records into the in-block sums
                 hipLaunchKernelGGL((k_calc_forces<0, 1>), gm, b, 0, c->stream, c->dp, a);
             if (fastKernel)
-                hipLaunchKernelGGL((k_forces_fast<0>), g, b, 0, c->stream, c->dp, a, fa);
+                hipLaunchKernelGGL((k_forces_fast<0>), g, b, 0, c->stream, c->dp, a);
             else
                 hipLaunchKernelGGL((k_calc_forces<0, 0>), g, b, 0, c->stream, c->dp, a);
         } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN_FRICTIONLESS) {
             if (hasSM)
                 hipLaunchKernelGGL((k_calc_forces<1, 1>), gm, b, 0, c->stream, c->dp, a);
             if (fastKernel)
-                hipLaunchKernelGGL((k_forces_fast<1>), g, b, 0, c->stream, c->dp, a, fa);
+                hipLaunchKernelGGL((k_forces_fast<1>), g, b, 0, c->stream, c->dp, a);
             else
                 hipLaunchKernelGGL((k_calc_forces<1, 0>), g, b, 0, c->stream, c->dp, a);
         }
@@ -911,7 +901,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
-    DevBuf* all[] = {&c->kin, &c->ownerTag, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -953,7 +943,6 @@ int deme_set_arith_mode(deme_ctx* c, int mode) {
     if (mode != c->arith) {
         HIPCK(hipStreamSynchronize(c->stream));
         c->arith = mode;
-        c->kinDirty = true;
         c->conValid = false;  // stored contributions are in the other mode's units
     }
     return DEME_OK;
@@ -981,7 +970,6 @@ int deme_set_params(deme_ctx* c, const DemeParams* p) {
     c->hp = *p;
     c->timeElapsed = p->timeElapsed;
     c->haveParams = true;
-    c->kinDirty = true;  // the frame (LBF, voxel size) may have changed
     refresh_dev_params(c);
     return DEME_OK;
 }
@@ -1020,9 +1008,6 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         return rc;
     if (int rc = ensure(c, c->acc, std::max<size_t>(nO, 1) * sizeof(AccRec)))
         return rc;
-    if (ensure(c, c->kin, std::max<size_t>(nO, 1) * sizeof(KinRec)) || ensure(c, c->ownerTag, std::max<size_t>(nO, 1) * 4))
-        return c->lastStatus;
-    c->kinDirty = true;
     HIPCK(hipMemsetAsync(c->acc.p, 0, c->acc.bytes, c->stream));
     if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->aSum, (nO + 1) * 32) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
         ensure(c, c->fixedFlag, nO + 1) || ensure(c, c->heavyList, 4096 * 4) || ensure(c, c->rangeCtr, sizeof(RangeCounters)))
@@ -1240,8 +1225,6 @@ int deme_upload_owner_state(deme_ctx* c, const DemeOwnerState* st) {
     if (c && st && (st->voxelID || st->locX || st->locY || st->locZ || st->oriQw || st->oriQx || st->oriQy || st->oriQz || st->vX ||
                     st->vY || st->vZ || st->omgBarX || st->omgBarY || st->omgBarZ || st->familyID))
         c->listStale = true;  // pose, velocity (it sizes the margins) or family (masks) changed under the K-step list
-    if (c)
-        c->kinDirty = true;
     return owner_state_io(c, st, 0);
 }
 int deme_download_owner_state(deme_ctx* c, DemeOwnerState* st) { return owner_state_io(c, st, 1); }
@@ -1560,8 +1543,8 @@ int deme_halo_unpack_async(deme_ctx* c, const uint32_t* d_ids, uint32_t n, const
     if (int rc = ensure_halo_stream(c))
         return rc;
     if (n)
-        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->haloStream, c->dp, n, d_ids, c->owners.as<OwnerRec>(),
-                           (const GhostRec*)d_buf, gather_args(c).kin, gather_args(c).ownerTag);
+        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->haloStream, n, d_ids, c->owners.as<OwnerRec>(),
+                           (const GhostRec*)d_buf);
     HIPCK(hipEventRecord(c->evHaloDone, c->haloStream));
     return DEME_OK;
 }
@@ -2114,7 +2097,6 @@ int deme_change_family(deme_ctx* c, uint32_t from, uint32_t to) {
                            (uint32_t)c->nOwners, from, to);
     c->prescDirty = true;
     c->listStale = true;  // pairs may have become unmasked
-    c->kinDirty = true;
     return DEME_OK;
 }
 
@@ -2329,8 +2311,8 @@ int deme_halo_unpack(deme_ctx* c, const uint32_t* d_ids, uint32_t n, const void*
     if (int rc = check_ready(c))
         return rc;
     if (n)
-        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->stream, c->dp, n, d_ids, c->owners.as<OwnerRec>(),
-                           (const GhostRec*)d_buf, gather_args(c).kin, gather_args(c).ownerTag);
+        hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(n)), dim3(256), 0, c->stream, n, d_ids, c->owners.as<OwnerRec>(),
+                           (const GhostRec*)d_buf);
     return DEME_OK;
 }
 

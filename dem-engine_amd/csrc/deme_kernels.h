@@ -698,11 +698,8 @@ struct GatherArgs {
     const float4* aSum;      // in-order sum of an A run that lies inside one force-kernel block (deme_force.h)
     const AccRec* nextAcc;   // null, or per owner: acceleration the script added for this step (deme_add_owner_acc)
     // fast arithmetic mode: the contributions are world-frame forces and torques (ForceArgs::world); their per-owner sums
-    // become a and alpha through acc_from_world.  kin / quat: the derived per-owner view the integrator rewrites for the
-    // next force pass (deme_force_fast.h), null in the bit-exact mode
+    // become a and alpha through acc_from_world
     uint32_t world;
-    KinRec* kin;
-    uint32_t* ownerTag;
 };
 
 // per-owner conversion of the fast mode: a = F / m, alpha = R^T tau / I (body frame, like the reference's alpha)
@@ -714,27 +711,6 @@ __device__ inline void acc_from_world(const DevParams& p, const OwnerRec& r, flo
     al = make_float4(tl.x / mp.y, tl.y / mp.z, tl.z / mp.w, 0.f);
 }
 
-// the derived view of one owner (KinRec + tag) from its record
-__device__ inline void write_kin(const DevParams& p, const OwnerRec& r, uint32_t o, KinRec* kin, uint32_t* ownerTag) {
-    const d3 X = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);
-    const f3 ww = rot_apply(rot_coeffs(r.qw, r.qx, r.qy, r.qz), mk3(r.wx, r.wy, r.wz));
-    KinRec k;
-    k.x = X.x + (double)p.LBFX, k.y = X.y + (double)p.LBFY, k.z = X.z + (double)p.LBFZ;
-    k.qw = r.qw, k.qx = r.qx, k.qy = r.qy, k.qz = r.qz;
-    k.vx = r.vx, k.vy = r.vy, k.vz = r.vz;
-    k.wx = ww.x, k.wy = ww.y, k.wz = ww.z;
-    uint4* dst = reinterpret_cast<uint4*>(kin + o);
-    const uint4* src = reinterpret_cast<const uint4*>(&k);
-    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
-    ownerTag[o] = make_owner_tag(r.family, r.inertiaOff);
-}
-
-__global__ __launch_bounds__(256) void k_refresh_kin(const DevParams p, const OwnerRec* __restrict__ owners, KinRec* __restrict__ kin,
-                                                     uint32_t* __restrict__ ownerTag) {
-    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < p.nOwners)
-        write_kin(p, load_owner(owners, o), o, kin, ownerTag);
-}
 
 // A-side sum of one owner: the force kernel's in-workgroup result when the run lay inside one block, else the
 // same in-order sum over the per-contact records (loads issued four at a time).
@@ -1193,8 +1169,6 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         r.qz = qz / len;
     }
     store_owner(owners, o, r);
-    if (g.kin)  // the next force pass reads the derived view, not the record
-        write_kin(p, r, o, g.kin, g.ownerTag);
 }
 
 // ---- packing between the C-ABI's SoA view and the device records -------------------------------
@@ -1352,8 +1326,7 @@ __global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const uint32_t* i
     g.vx = r.vx, g.vy = r.vy, g.vz = r.vz, g.wx = r.wx, g.wy = r.wy, g.wz = r.wz;
     buf[i] = g;
 }
-__global__ __launch_bounds__(256) void k_halo_unpack(const DevParams p, uint32_t n, const uint32_t* ids, OwnerRec* owners,
-                                                     const GhostRec* buf, KinRec* kin, uint32_t* ownerTag) {
+__global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n, const uint32_t* ids, OwnerRec* owners, const GhostRec* buf) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
@@ -1365,8 +1338,6 @@ __global__ __launch_bounds__(256) void k_halo_unpack(const DevParams p, uint32_t
     r->voxelID = g.voxelID, r->locX = g.locX, r->locY = g.locY, r->locZ = g.locZ;
     r->qw = g.qw, r->qx = g.qx, r->qy = g.qy, r->qz = g.qz;
     r->vx = g.vx, r->vy = g.vy, r->vz = g.vz, r->wx = g.wx, r->wy = g.wy, r->wz = g.wz;
-    if (kin)
-        write_kin(p, *r, ids[i], kin, ownerTag);
 }
 
 }  // namespace deme_dev
