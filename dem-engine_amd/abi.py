@@ -192,6 +192,8 @@ def load_library():
         "deme_halo_unpack_async": [_P, _P, C.c_uint32, _P], "deme_halo_sync": [_P],
         "deme_step_overlap_begin": [_P, C.POINTER(C.c_int)], "deme_step_overlap_end": [_P],
         "deme_compile_family_rules": [_P, C.c_char_p], "deme_change_family": [_P, C.c_uint32, C.c_uint32],
+        "deme_set_family_material": [_P, C.c_uint32, C.c_uint32, C.c_int],
+        "deme_device_memory": [_P, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
         "deme_set_adaptive": [_P, C.POINTER(DemeAdaptive)],
         "deme_get_adaptive_state": [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "deme_mark_persistent_contacts": [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_int],
@@ -419,6 +421,9 @@ class Context:
     def compile_family_rules(self, rules):
         """ChangeFamilyWhen rules: the _familyChangeRules_ text of equipFamilyOnFlyChanges (see include/deme_hip.h)."""
         self._ck(self.lib.deme_compile_family_rules(self.h, rules.encode()), "deme_compile_family_rules")
+
+    def set_family_material(self, family, material, meshes=False):
+        self._ck(self.lib.deme_set_family_material(self.h, int(family), int(material), 1 if meshes else 0), "deme_set_family_material")
 
     def change_family(self, frm, to):
         self._ck(self.lib.deme_change_family(self.h, int(frm), int(to)), "deme_change_family")

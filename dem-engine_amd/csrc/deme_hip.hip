@@ -2100,6 +2100,34 @@ int deme_change_family(deme_ctx* c, uint32_t from, uint32_t to) {
     return DEME_OK;
 }
 
+int deme_set_family_material(deme_ctx* c, uint32_t family, uint32_t material, int kind) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (family > 255 || material >= c->nMat || (kind != 0 && kind != 1))
+        return fail(c, DEME_ERR_INVALID, "deme_set_family_material: family %u, material %u of %u, kind %d", family, material, c->nMat, kind);
+    if (kind == 0 && c->nSpheres)
+        hipLaunchKernelGGL(k_family_material_spheres, dim3(grid_for(c->nSpheres)), dim3(256), 0, c->stream, c->nSpheres,
+                           c->spheres.as<SphereRec>(), c->owners.as<OwnerRec>(), family, material);
+    if (kind == 1 && c->nTri)
+        hipLaunchKernelGGL(k_family_material_tris, dim3(grid_for(c->nTri)), dim3(256), 0, c->stream, c->nTri, c->tris.as<TriRec>(),
+                           c->owners.as<OwnerRec>(), family, material);
+    c->listStale = true;  // the per-contact gather records hold the materials
+    return DEME_OK;
+}
+
+int deme_device_memory(deme_ctx* c, size_t* usedBytes, size_t* totalBytes) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    size_t fr = 0, tot = 0;
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipMemGetInfo(&fr, &tot));
+    if (usedBytes)
+        *usedBytes = tot - fr;
+    if (totalBytes)
+        *totalBytes = tot;
+    return DEME_OK;
+}
+
 int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,
                    char* log, size_t logCap) {
     deme_jit::MaterialTables mt;

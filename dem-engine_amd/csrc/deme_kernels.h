@@ -1244,6 +1244,14 @@ __global__ __launch_bounds__(256) void k_change_family(OwnerRec* __restrict__ ow
         owners[o].family = to;
 }
 
+// SetFamilyClumpMaterial / SetFamilyMeshMaterial: geometries whose owner is of `family` take `material`
+__global__ __launch_bounds__(256) void k_family_material_spheres(uint32_t n, SphereRec* __restrict__ spheres,
+                                                                 const OwnerRec* __restrict__ owners, uint32_t family, uint32_t material) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n && (owners[spheres[s].owner].family & 0xFFu) == family)
+        spheres[s].mat = (uint16_t)material;
+}
+
 // ---- inspectors: DEMSphereQueryKernels.cu:13-54 / DEMOwnerQueryKernels.cu:11-63 with the quantity fragments of
 // AuxClasses.cpp:19-92.  Elements that do not take part get the reduction's identity.
 __global__ __launch_bounds__(256) void k_inspect_sphere(const DevParams p, const OwnerRec* __restrict__ owners,

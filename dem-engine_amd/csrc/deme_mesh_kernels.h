@@ -218,4 +218,11 @@ __global__ __launch_bounds__(256) void k_pack_tris(uint32_t nTri, TriRec* tris, 
     }
 }
 
+__global__ __launch_bounds__(256) void k_family_material_tris(uint32_t n, TriRec* __restrict__ tris, const OwnerRec* __restrict__ owners,
+                                                              uint32_t family, uint32_t material) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && (owners[tris[t].owner].family & 0xFFu) == family)
+        tris[t].mat = material;
+}
+
 }  // namespace deme_dev

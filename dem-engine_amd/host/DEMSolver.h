@@ -16,10 +16,13 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <cassert>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <filesystem>
 #include <fstream>
+#include <iostream>
 #include <map>
 #include <memory>
 #include <set>
@@ -45,9 +48,32 @@ inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z,
 inline float3 operator*(float3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline float3 operator+(float3 a, float3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline float3 operator-(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+// the rest of the float3 algebra the reference's scripts use (core/utils/CUDAMathHelpers.cuh on the host side)
+inline float3 operator*(float s, float3 a) { return {a.x * s, a.y * s, a.z * s}; }
+inline float3 operator*(float3 a, float3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline float3 operator/(float3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline float3 operator/(float3 a, float3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline float3 operator-(float3 a) { return {-a.x, -a.y, -a.z}; }
+inline float3& operator+=(float3& a, float3 b) { a.x += b.x, a.y += b.y, a.z += b.z; return a; }
+inline float3& operator-=(float3& a, float3 b) { a.x -= b.x, a.y -= b.y, a.z -= b.z; return a; }
+inline float3& operator*=(float3& a, float s) { a.x *= s, a.y *= s, a.z *= s; return a; }
+inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float3 cross(float3 a, float3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float length(float3 a) { return std::sqrt(dot(a, a)); }
+inline float3 normalize(float3 a) { return a / length(a); }
 #endif
 
 namespace deme {
+
+constexpr double PI = 3.1415926535897932385;  // DEM/Defines.h:43
+
+// Where the data files of the scripts live (reference: GET_DATA_PATH() = the build's data directory, DEM/Models.h:177;
+// GetDEMEDataFile, core/utils/DEMEPaths.h:32).  Here: $DEME_DATA_PATH, else ./data.
+inline std::filesystem::path GET_DATA_PATH() {
+    const char* e = std::getenv("DEME_DATA_PATH");
+    return std::filesystem::path(e ? e : "data");
+}
+inline std::string GetDEMEDataFile(const std::string& filename) { return (GET_DATA_PATH() / filename).string(); }
 
 enum class TIME_INTEGRATOR { FORWARD_EULER, CENTERED_DIFFERENCE, EXTENDED_TAYLOR };
 enum class FORCE_MODEL { HERTZIAN, HERTZIAN_FRICTIONLESS, CUSTOM };
@@ -58,8 +84,12 @@ enum OUTPUT_CONTENT { XYZ = 0, QUAT = 1, ABSV = 2, VEL = 4, ANG_VEL = 8, ABS_ACC
 enum CNT_OUTPUT_CONTENT { CNT_TYPE = 0, FORCE = 1, CNT_POINT = 2, COMPONENT = 4, NORMAL = 8, TORQUE = 16, CNT_WILDCARD = 32, OWNER = 64,
                           GEO_ID = 128, NICKNAME = 256 };
 enum class OUTPUT_FORMAT { CSV, BINARY, CHPF };
+enum class MESH_FORMAT { VTK, OBJ };
 typedef unsigned int bodyID_t;
+typedef uint8_t notStupidBool_t;
 constexpr float DEME_TINY_FLOAT_HOST = 1e-12f;
+constexpr float DEME_TINY_FLOAT = 1e-12f;  // DEM/Defines.h
+constexpr float DEME_HUGE_FLOAT = 1e15f;
 constexpr unsigned int RESERVED_FAMILY_NUM = 255;
 const bool ENTITY_NORMAL_INWARD = false;
 const bool ENTITY_NORMAL_OUTWARD = true;
@@ -123,13 +153,59 @@ struct DEMClumpBatch {
         oriQ.assign(n, {0, 0, 0, 1});
         families.assign(n, 0);
     }
-    void SetVel(const std::vector<float3>& v) { vel = v; }
+    void SetTypes(const std::vector<std::shared_ptr<DEMClumpTemplate>>& t) { check_len(t.size(), "SetTypes"), types = t; }
+    void SetTypes(const std::shared_ptr<DEMClumpTemplate>& t) { types.assign(nClumps, t); }
+    void SetType(const std::shared_ptr<DEMClumpTemplate>& t) { SetTypes(t); }
+    void SetPos(const std::vector<float3>& p) { check_len(p.size(), "SetPos"), xyz = p; }
+    void SetPos(float3 p) { xyz.assign(nClumps, p); }
+    void SetVel(const std::vector<float3>& v) { check_len(v.size(), "SetVel"), vel = v; }
     void SetVel(float3 v) { vel.assign(nClumps, v); }
-    void SetAngVel(const std::vector<float3>& v) { angVel = v; }
-    void SetOriQ(const std::vector<float4>& q) { oriQ = q; }
+    void SetAngVel(const std::vector<float3>& v) { check_len(v.size(), "SetAngVel"), angVel = v; }
+    void SetAngVel(float3 v) { angVel.assign(nClumps, v); }
+    void SetOriQ(const std::vector<float4>& q) { check_len(q.size(), "SetOriQ"), oriQ = q; }
+    void SetOriQ(float4 q) { oriQ.assign(nClumps, q); }
+    void check_len(size_t n, const char* who) const {
+        if (n != nClumps)
+            throw std::runtime_error(std::string(who) + ": the input has " + std::to_string(n) + " entries but this batch has " +
+                                     std::to_string(nClumps) + " clumps");
+    }
+    // initial geometry-wildcard values, one per sphere of the batch in clump-major order (Structs.h:908-930)
+    void SetGeometryWildcards(const std::unordered_map<std::string, std::vector<float>>& w) {
+        for (auto& kv : w)
+            AddGeometryWildcard(kv.first, kv.second);
+    }
+    void AddGeometryWildcard(const std::string& name, const std::vector<float>& vals) {
+        if (vals.size() != GetNumSpheres())
+            throw std::runtime_error("Input geometry wildcard array in a AddGeometryWildcard call must have the same size as the number "
+                                     "of spheres in this batch.");
+        geo_wildcards[name] = vals;
+    }
+    void AddGeometryWildcard(const std::string& name, float val) { AddGeometryWildcard(name, std::vector<float>(GetNumSpheres(), val)); }
+    std::unordered_map<std::string, std::vector<float>> geo_wildcards;
     void SetFamilies(const std::vector<unsigned int>& f) { families = f; }
     void SetFamily(unsigned int f) { families.assign(nClumps, f); }
+    void SetFamilies(unsigned int f) { SetFamily(f); }
     size_t GetNumClumps() const { return nClumps; }
+    size_t GetNumSpheres() const {
+        size_t n = 0;
+        for (auto& t : types)
+            n += t->nComp;
+        return n;
+    }
+    // initial owner-wildcard values of the batch's clumps (Structs.h:885-906); applied once the force model is compiled
+    void SetOwnerWildcards(const std::unordered_map<std::string, std::vector<float>>& w) {
+        for (auto& kv : w)
+            AddOwnerWildcard(kv.first, kv.second);
+    }
+    void AddOwnerWildcard(const std::string& name, const std::vector<float>& vals) {
+        if (vals.size() != nClumps)
+            throw std::runtime_error("Input owner wildcard array in a AddOwnerWildcard call must have the same size as the number of "
+                                     "clumps in this batch.\nHere, the input array has length " + std::to_string(vals.size()) +
+                                     " but this batch has " + std::to_string(nClumps) + " clumps.");
+        owner_wildcards[name] = vals;
+    }
+    void AddOwnerWildcard(const std::string& name, float val) { AddOwnerWildcard(name, std::vector<float>(nClumps, val)); }
+    std::unordered_map<std::string, std::vector<float>> owner_wildcards;
     // restart data (Structs.h:857-880): sphere-sphere pairs by geometry id within this batch + their wildcards
     void SetExistingContacts(const std::vector<std::pair<bodyID_t, bodyID_t>>& pairs) { contact_pairs = pairs; }
     void SetExistingContactWildcards(const std::unordered_map<std::string, std::vector<float>>& w) {
@@ -171,6 +247,7 @@ struct DEMExternObj {
         AddCylinder(pos, {0, 0, 1}, rad, m, normal);
     }
     void SetFamily(unsigned int f) { family_code = f; }
+    void SetFamilies(unsigned int f) { family_code = f; }
     void SetInitPos(float3 p) { init_pos = p; }
     void SetMass(float m) { mass = m; }
     void SetMOI(float3 m) { MOI = m; }
@@ -222,10 +299,52 @@ struct DEMMeshConnected {
         for (auto& v : vertices)
             v = v * s;
     }
+    void Scale(float3 s) {  // per-axis (BdrsAndObjs.h: Scale(float3))
+        for (auto& v : vertices)
+            v = v * s;
+    }
     void SetFamily(unsigned int f) { family_code = f; }
+    void SetFamilies(unsigned int f) { family_code = f; }
     void SetInitPos(float3 p) { init_pos = p; }
+    void SetInitQuat(float4 q) { init_oriQ = q; }
     void SetMass(float m) { mass = m; }
     void SetMOI(float3 m) { MOI = m; }
+    const std::vector<float3>& GetCoordsVertices() const { return vertices; }
+    std::vector<float3>& GetCoordsVertices() { return vertices; }
+    const std::vector<std::array<int, 3>>& GetIndicesVertexes() const { return faces; }
+    static void rotate_node(float3& v, float4 q) {  // applyOriQToVector3 (DEMHelperKernels.cuh:161-173); q = (x, y, z, w)
+        const float w = q.w, x = q.x, y = q.y, z = q.z;
+        const float ox = (2.0f * (w * w + x * x) - 1.0f) * v.x + (2.0f * (x * y - w * z)) * v.y + (2.0f * (x * z + w * y)) * v.z;
+        const float oy = (2.0f * (x * y + w * z)) * v.x + (2.0f * (w * w + y * y) - 1.0f) * v.y + (2.0f * (y * z - w * x)) * v.z;
+        const float oz = (2.0f * (x * z - w * y)) * v.x + (2.0f * (y * z + w * x)) * v.y + (2.0f * (w * w + z * z) - 1.0f) * v.z;
+        v = {ox, oy, oz};
+    }
+    /// InformCentroidPrincipal (BdrsAndObjs.h:420): the nodes were given in a frame whose origin / axes are not the mesh's
+    /// centroid / principal axes; move them into that frame (translate by -center, rotate by the inverse of prin_Q)
+    void InformCentroidPrincipal(float3 center, float4 prin_Q) {
+        for (auto& n : vertices) {
+            n = n - center;
+            rotate_node(n, make_float4(-prin_Q.x, -prin_Q.y, -prin_Q.z, prin_Q.w));
+        }
+    }
+    /// Move (BdrsAndObjs.h:437): rotate the nodes by rot_Q, then translate by vec
+    void Move(float3 vec, float4 rot_Q) {
+        for (auto& n : vertices) {
+            rotate_node(n, rot_Q);
+            n = n + vec;
+        }
+    }
+    void Mirror(float3 plane_point, float3 plane_normal) {  // BdrsAndObjs.h: reflect across a plane, keep the facets' outward side
+        const float inv = 1.0f / std::sqrt(plane_normal.x * plane_normal.x + plane_normal.y * plane_normal.y + plane_normal.z * plane_normal.z);
+        const float3 nn = plane_normal * inv;
+        for (auto& v : vertices) {
+            const float3 d = v - plane_point;
+            const float t = d.x * nn.x + d.y * nn.y + d.z * nn.z;
+            v = v - nn * (2.f * t);
+        }
+        for (auto& f : faces)
+            std::swap(f[1], f[2]);
+    }
 };
 
 class DEMForceModel {
@@ -255,6 +374,9 @@ class DEMForceModel {
     }
     void DefineCustomModelPrerequisites(const std::string& util) { prerequisites = util; }
     void SetMustPairwiseMatProp(const std::set<std::string>& props) { pairwise_props.insert(props.begin(), props.end()); }
+    /// material properties every loaded material must then define (AuxClasses.h: SetMustHaveMatProp); checked at Initialize
+    void SetMustHaveMatProp(const std::set<std::string>& props) { must_have_props.insert(props.begin(), props.end()); }
+    std::set<std::string> must_have_props;
     void SetPerContactWildcards(const std::set<std::string>& wc) { contact_wildcards = wc; }
     void SetPerOwnerWildcards(const std::set<std::string>& wc) { owner_wildcards = wc; }
     void SetPerGeometryWildcards(const std::set<std::string>& wc) { geo_wildcards = wc; }
@@ -279,7 +401,29 @@ class DEMSolver {
     DEMSolver& operator=(const DEMSolver&) = delete;
 
     void SetVerbosity(int) {}
-    void SetVerbosity(const std::string&) {}
+    void SetVerbosity(VERBOSITY) {}
+    void SetVerbosity(const std::string& verbose) {  // API.h:1337: the level names; this build only reports errors (exceptions)
+        static const std::set<std::string> ok = {"QUIET", "ERROR", "WARNING", "INFO", "STEP_ANOMALY", "STEP_METRIC", "DEBUG", "STEP_DEBUG"};
+        if (!ok.count(upper(verbose)))
+            throw std::runtime_error("Instruction " + verbose + " is unknown in SetVerbosity call.");
+    }
+    // knobs of the reference's run-time compiler and of its two-thread scheduler: nothing to configure in this build
+    // (templates and mass properties always live in device tables; there is no second thread to drift ahead of)
+    void SetJitifyClumpTemplates(bool = true) {}
+    void DisableJitifyClumpTemplates() {}
+    void SetJitifyMassProperties(bool = true) {}
+    void DisableJitifyMassProperties() {}
+    void EnsureKernelErrMsgLineNum(bool = true) {}
+    std::vector<std::string> GetJitifyOptions() const { return {"--offload-arch=gfx950", "-O3", "-std=c++17"}; }  // what hipRTC is given
+    void SetJitifyOptions(const std::vector<std::string>&) {}
+    void AddKernelInclude(const std::string&) {}
+    void SetKernelInclude(const std::string&) {}
+    void RemoveKernelInclude() {}
+    void PrintKinematicScratchSpaceUsage() const {}
+    void SetCDNumStepsMaxDriftAheadOfAvg(float) {}
+    void SetCDNumStepsMaxDriftMultipleOfAvg(float) {}
+    void SetCDNumStepsMaxDriftHistorySize(unsigned int) {}
+    bool GetInitStatus() const { return m_initialized; }
 
     // ---- domain (APIPublic.cpp:845-904)
     void InstructBoxDomainDimension(float x, float y, float z) {
@@ -305,6 +449,19 @@ class DEMSolver {
         m_materials.push_back(m);
         return m;
     }
+    std::shared_ptr<DEMMaterial> LoadMaterial(DEMMaterial& a_material) { return LoadMaterial(a_material.mat_prop); }
+    /// Duplicate (API.h:402-410, APIPublic.cpp:397-411): a deep copy, loaded as a new object
+    std::shared_ptr<DEMMaterial> Duplicate(const std::shared_ptr<DEMMaterial>& ptr) { return LoadMaterial(ptr->mat_prop); }
+    std::shared_ptr<DEMClumpTemplate> Duplicate(const std::shared_ptr<DEMClumpTemplate>& ptr) {
+        auto t = std::make_shared<DEMClumpTemplate>(*ptr);
+        m_templates.push_back(t);
+        return t;
+    }
+    std::shared_ptr<DEMClumpBatch> Duplicate(const std::shared_ptr<DEMClumpBatch>& ptr) {
+        auto b = std::make_shared<DEMClumpBatch>(*ptr);
+        m_batches.push_back(b);
+        return b;
+    }
     void SetMaterialPropertyPair(const std::string& name, const std::shared_ptr<DEMMaterial>& a, const std::shared_ptr<DEMMaterial>& b, float v) {
         m_pair_overrides[name][{a->load_order, b->load_order}] = v;
         m_pair_overrides[name][{b->load_order, a->load_order}] = v;
@@ -327,6 +484,24 @@ class DEMSolver {
         m_templates.push_back(t);
         return t;
     }
+    std::shared_ptr<DEMClumpTemplate> LoadClumpType(float mass, float3 moi, const std::vector<float>& radii,
+                                                    const std::vector<float3>& relPos,
+                                                    const std::vector<std::shared_ptr<DEMMaterial>>& mats) {
+        if (mats.size() != radii.size() || relPos.size() != radii.size())
+            throw std::runtime_error("LoadClumpType: radii, positions and materials must have the same length");
+        auto t = std::make_shared<DEMClumpTemplate>();
+        t->mass = mass, t->MOI = moi, t->radii = radii, t->relPos = relPos, t->nComp = (unsigned)radii.size(), t->materials = mats;
+        m_templates.push_back(t);
+        return t;
+    }
+    std::shared_ptr<DEMClumpTemplate> LoadClumpType(DEMClumpTemplate& clump) {  // API.h:322: a copy of a user-built template
+        auto t = std::make_shared<DEMClumpTemplate>(clump);
+        t->nComp = (unsigned)t->radii.size();
+        if (t->materials.size() != t->radii.size())
+            throw std::runtime_error("LoadClumpType: the template's materials do not match its components");
+        m_templates.push_back(t);
+        return t;
+    }
     std::shared_ptr<DEMClumpTemplate> LoadSphereType(float mass, float radius, const std::shared_ptr<DEMMaterial>& mat) {
         const float I = 2.f / 5.f * mass * radius * radius;
         return LoadClumpType(mass, {I, I, I}, std::vector<float>{radius}, std::vector<float3>{{0, 0, 0}}, mat);
@@ -343,6 +518,36 @@ class DEMSolver {
     }
     std::shared_ptr<DEMClumpBatch> AddClumps(const std::shared_ptr<DEMClumpTemplate>& type, const std::vector<float3>& xyz) {
         return AddClumps(std::vector<std::shared_ptr<DEMClumpTemplate>>(xyz.size(), type), xyz);
+    }
+    // the other input forms of API.h:588-634
+    std::shared_ptr<DEMClumpBatch> AddClumps(const std::shared_ptr<DEMClumpTemplate>& type, float3 xyz) {
+        return AddClumps(std::vector<std::shared_ptr<DEMClumpTemplate>>(1, type), std::vector<float3>(1, xyz));
+    }
+    std::shared_ptr<DEMClumpBatch> AddClumps(const std::shared_ptr<DEMClumpTemplate>& type, const std::vector<float>& xyz) {
+        if (xyz.size() != 3)
+            throw std::runtime_error("AddClumps: input_xyz must have 3 elements");
+        return AddClumps(type, make_float3(xyz[0], xyz[1], xyz[2]));
+    }
+    static std::vector<float3> to_float3(const std::vector<std::vector<float>>& v, const char* who) {
+        std::vector<float3> out(v.size());
+        for (size_t i = 0; i < v.size(); i++) {
+            if (v[i].size() != 3)
+                throw std::runtime_error(std::string(who) + ": every position must have 3 elements");
+            out[i] = make_float3(v[i][0], v[i][1], v[i][2]);
+        }
+        return out;
+    }
+    std::shared_ptr<DEMClumpBatch> AddClumps(const std::shared_ptr<DEMClumpTemplate>& type, const std::vector<std::vector<float>>& xyz) {
+        return AddClumps(type, to_float3(xyz, "AddClumps"));
+    }
+    std::shared_ptr<DEMClumpBatch> AddClumps(const std::vector<std::shared_ptr<DEMClumpTemplate>>& types,
+                                             const std::vector<std::vector<float>>& xyz) {
+        return AddClumps(types, to_float3(xyz, "AddClumps"));
+    }
+    std::shared_ptr<DEMClumpBatch> AddClumps(DEMClumpBatch& input_batch) {
+        auto b = std::make_shared<DEMClumpBatch>(input_batch);
+        m_batches.push_back(b);
+        return b;
     }
     std::shared_ptr<DEMExternObj> AddExternalObject() {
         m_ext.push_back(std::make_shared<DEMExternObj>());
@@ -387,7 +592,9 @@ class DEMSolver {
     void SetGravitationalAcceleration(float3 g) { m_G = g; }
     void SetCDUpdateFreq(int k) { m_cd_freq = k < 0 ? 0 : (unsigned)k; }
     void SetInitBinSize(double s) { m_bin_size = s; }
-    void SetInitBinSizeAsMultipleOfSmallestSphere(float m) { m_bin_multiple = m, m_bin_size = -1; }
+    void SetInitBinSizeAsMultipleOfSmallestSphere(float m) { m_bin_multiple = m, m_bin_size = -1, m_bin_num_target = 0; }
+    /// SetInitBinNumTarget (API.h:151): the initial bin size is chosen so that the domain holds about this many bins
+    void SetInitBinNumTarget(size_t num) { m_bin_num_target = num, m_bin_size = -1; }
     void SetExpandSafetyMultiplier(float m) { m_safety_multi = m; }
     void SetExpandSafetyAdder(float a) { m_safety_adder = a; }
     void SetMaxVelocity(float v) { m_max_vel = v; }
@@ -399,6 +606,17 @@ class DEMSolver {
     void EnableFamilyOutput(unsigned int fam) { m_no_output_families.erase(fam & 255u); }
     void SetErrorOutVelocity(float v) { m_err_vel = v; }
     void SetIntegrator(TIME_INTEGRATOR i) { m_integrator = i; }
+    void SetIntegrator(const std::string& intg) {  // API.h:124, APIPublic.cpp SetIntegrator(string)
+        const std::string u = upper(intg);
+        if (u == "FORWARD_EULER")
+            m_integrator = TIME_INTEGRATOR::FORWARD_EULER;
+        else if (u == "CENTERED_DIFFERENCE")
+            m_integrator = TIME_INTEGRATOR::CENTERED_DIFFERENCE;
+        else if (u == "EXTENDED_TAYLOR")
+            m_integrator = TIME_INTEGRATOR::EXTENDED_TAYLOR;
+        else
+            throw std::runtime_error("Integration type " + intg + " is unknown. Please select another via SetIntegrator.");
+    }
     void SetFamilyFixed(unsigned int f) { m_family_flags[f & 255] |= DEME_FAMILY_FIXED; }
 
     // ---- family motion prescriptions and on-the-fly family changes (API.h:720-838, 1024-1028; APIPublic.cpp:1013-1330)
@@ -435,6 +653,21 @@ class DEMSolver {
         q.s["oriQ"] = q_formula;
         if (q_formula != "none") q.flag[9] = true;
     }
+    // "keep as is": the components are marked prescribed with no expression, so the contact forces stop changing them
+    // (API.h:712-778, APIPublic.cpp:1056-1362)
+    void SetFamilyPrescribedLinVel(unsigned int ID) { keep_as_is(ID, {0, 1, 2}); }
+    void SetFamilyPrescribedLinVelX(unsigned int ID) { keep_as_is(ID, {0}); }
+    void SetFamilyPrescribedLinVelY(unsigned int ID) { keep_as_is(ID, {1}); }
+    void SetFamilyPrescribedLinVelZ(unsigned int ID) { keep_as_is(ID, {2}); }
+    void SetFamilyPrescribedAngVel(unsigned int ID) { keep_as_is(ID, {3, 4, 5}); }
+    void SetFamilyPrescribedAngVelX(unsigned int ID) { keep_as_is(ID, {3}); }
+    void SetFamilyPrescribedAngVelY(unsigned int ID) { keep_as_is(ID, {4}); }
+    void SetFamilyPrescribedAngVelZ(unsigned int ID) { keep_as_is(ID, {5}); }
+    void SetFamilyPrescribedPosition(unsigned int ID) { keep_as_is(ID, {6, 7, 8}); }
+    void SetFamilyPrescribedPositionX(unsigned int ID) { keep_as_is(ID, {6}); }
+    void SetFamilyPrescribedPositionY(unsigned int ID) { keep_as_is(ID, {7}); }
+    void SetFamilyPrescribedPositionZ(unsigned int ID) { keep_as_is(ID, {8}); }
+    void SetFamilyPrescribedQuaternion(unsigned int ID) { keep_as_is(ID, {9}); }
     void AddFamilyPrescribedAcc(unsigned int ID, const std::string& X, const std::string& Y, const std::string& Z,
                                 const std::string& pre = "none") {
         Presc& q = new_presc(ID);
@@ -533,6 +766,11 @@ class DEMSolver {
             std::swap(a, b);
         m_family_masks[(1 + b) * b / 2 + a] = 1;  // locateMaskPair, DEMHelperKernels.cuh:57-62
     }
+    void EnableContactBetweenFamilies(unsigned int a, unsigned int b) {
+        if (a > b)
+            std::swap(a, b);
+        m_family_masks[(1 + b) * b / 2 + a] = 0;
+    }
     void SetFamilyExtraMargin(unsigned int f, float m) { m_family_extra[f & 255] = m; }
     // ---- adaptive controllers (API.h:253-309) on device timers: deme_set_adaptive.  The reference switches both on by
     // default; here they are opt-in so that runs are reproducible step for step unless asked otherwise.
@@ -567,7 +805,13 @@ class DEMSolver {
     void SetCollectAccRightAfterForceCalc(bool = true) {}
 
     // ---- run
+    void Initialize(bool dry_run_before_simulation) { (void)dry_run_before_simulation, Initialize(); }
     void Initialize() {
+        for (auto& prop : m_force_model->must_have_props)
+            for (auto& m : m_materials)
+                if (!m->mat_prop.count(prop))
+                    throw std::runtime_error("A material is loaded without the property " + prop + " that the force model requires "
+                                             "(SetMustHaveMatProp)");
         initialize_impl();
         m_initialized = true;
         push_adaptive();
@@ -660,10 +904,19 @@ class DEMSolver {
         m_meshes.push_back(m);
         return m;
     }
-    enum class MESH_FORMAT { VTK, OBJ };
+    using MESH_FORMAT = deme::MESH_FORMAT;
     void SetMeshOutputFormat(MESH_FORMAT f) {
         if (f != MESH_FORMAT::VTK)
             throw std::runtime_error("only MESH_FORMAT::VTK is implemented");
+    }
+    void SetMeshOutputFormat(const std::string& format) {  // API.h:1354
+        const std::string u = upper(format);
+        if (u == "VTK")
+            SetMeshOutputFormat(MESH_FORMAT::VTK);
+        else if (u == "OBJ")
+            SetMeshOutputFormat(MESH_FORMAT::OBJ);
+        else
+            throw std::runtime_error("Instruction " + format + " is unknown in SetMeshOutputFormat call.");
     }
     /// writeMeshesAsVtk (dT.cpp:1850-1935): all meshes in one legacy-VTK unstructured grid, nodes in the global frame
     void WriteMeshFile(const std::string& outfilename) {
@@ -1026,6 +1279,38 @@ class DEMSolver {
                     (unsigned long long)c.nDetections, m_cd_freq, (unsigned long long)c.nContacts);
     }
     void ShowAnomalies() {}
+    std::shared_ptr<DEMForceModel> GetContactForceModel() { return m_force_model; }
+    void EnableOwnerWildcardOutput(bool enable = true) { m_out_content = enable ? (m_out_content | OWNER_WILDCARD) : (m_out_content & ~OWNER_WILDCARD); }
+    void EnableGeometryWildcardOutput(bool enable = true) { m_out_content = enable ? (m_out_content | GEO_WILDCARD) : (m_out_content & ~GEO_WILDCARD); }
+    void EnableContactWildcardOutput(bool enable = true) {
+        m_cnt_out_content = enable ? (m_cnt_out_content | CNT_WILDCARD) : (m_cnt_out_content & ~CNT_WILDCARD);
+    }
+    /// ShowMemStats (API.h:584): device memory in use by this process, as the HIP runtime reports it through the library
+    void ShowMemStats() const {
+        size_t used = 0, total = 0;
+        if (deme_device_memory(m_ctx, &used, &total) == DEME_OK)
+            std::printf("Device memory in use: %.1f MiB of %.1f MiB\n", used / 1048576.0, total / 1048576.0);
+    }
+    /// average number of contacts per sphere (kT's avgCntsPerSphere, API.h:251): contacts of the current list / spheres
+    float GetAvgSphContacts() {
+        DemeCounts c{};
+        check(deme_get_counts(m_ctx, &c));
+        return m_keep.sphOwner.empty() ? 0.f : (float)((double)c.nContacts / (double)m_keep.sphOwner.size());
+    }
+    /// SetFamilyClumpMaterial / SetFamilyMeshMaterial (API.h:970-974, dT::setFamilyClumpMaterial): every sphere (triangle) whose
+    /// owner is of family N takes the material, from the next step on
+    void SetFamilyClumpMaterial(unsigned int N, const std::shared_ptr<DEMMaterial>& mat) {
+        require_init("SetFamilyClumpMaterial");
+        check(deme_set_family_material(m_ctx, N, mat->load_order, 0));
+    }
+    void SetFamilyMeshMaterial(unsigned int N, const std::shared_ptr<DEMMaterial>& mat) {
+        require_init("SetFamilyMeshMaterial");
+        check(deme_set_family_material(m_ctx, N, mat->load_order, 1));
+    }
+    void require_init(const char* who) const {
+        if (!m_initialized)
+            throw std::runtime_error(std::string(who) + " can only be called after the simulation system is initialized");
+    }
     void ClearTimingStats() { deme_kernel_time_reset(m_ctx); }
     void ClearThreadCollaborationStats() {}
     void UseCubForceCollection(bool = true) {}  // accumulation is atomics-free here: nothing to choose
@@ -1046,6 +1331,45 @@ class DEMSolver {
     void SetContactOutputFormat(OUTPUT_FORMAT f) { require_csv(f); }
     void SetOutputContent(unsigned int content) { m_out_content = content; }
     void SetContactOutputContent(unsigned int content) { m_cnt_out_content = content; }
+    // the string forms (API.h:1340-1352, APIPublic.cpp): format names and lists of content names
+    static OUTPUT_FORMAT format_from(const std::string& f, const char* who) {
+        const std::string u = upper(f);
+        if (u == "CSV")
+            return OUTPUT_FORMAT::CSV;
+        if (u == "BINARY")
+            return OUTPUT_FORMAT::BINARY;
+        if (u == "CHPF")
+            return OUTPUT_FORMAT::CHPF;
+        throw std::runtime_error("Instruction " + f + " is unknown in " + who + " call.");
+    }
+    void SetOutputFormat(const std::string& format) { SetOutputFormat(format_from(format, "SetOutputFormat")); }
+    void SetContactOutputFormat(const std::string& format) { SetContactOutputFormat(format_from(format, "SetContactOutputFormat")); }
+    void SetOutputContent(const std::vector<std::string>& content) {
+        static const std::map<std::string, unsigned int> names = {{"XYZ", XYZ}, {"QUAT", QUAT}, {"ABSV", ABSV}, {"VEL", VEL},
+            {"ANG_VEL", ANG_VEL}, {"ABS_ACC", ABS_ACC}, {"ACC", ACC}, {"ANG_ACC", ANG_ACC}, {"FAMILY", FAMILY}, {"MAT", MAT},
+            {"OWNER_WILDCARD", OWNER_WILDCARD}, {"GEO_WILDCARD", GEO_WILDCARD}};
+        unsigned int c = XYZ;
+        for (auto& n : content) {
+            auto it = names.find(upper(n));
+            if (it == names.end())
+                throw std::runtime_error("Instruction " + n + " is unknown in SetOutputContent call.");
+            c |= it->second;
+        }
+        m_out_content = c;
+    }
+    void SetContactOutputContent(const std::vector<std::string>& content) {
+        static const std::map<std::string, unsigned int> names = {{"CNT_TYPE", CNT_TYPE}, {"FORCE", FORCE}, {"POINT", CNT_POINT},
+            {"COMPONENT", COMPONENT}, {"NORMAL", NORMAL}, {"TORQUE", TORQUE}, {"CNT_WILDCARD", CNT_WILDCARD}, {"OWNER", OWNER},
+            {"GEO_ID", GEO_ID}, {"NICKNAME", NICKNAME}};
+        unsigned int c = CNT_TYPE;
+        for (auto& n : content) {
+            auto it = names.find(upper(n));
+            if (it == names.end())
+                throw std::runtime_error("Instruction " + n + " is unknown in SetContactOutputContent call.");
+            c |= it->second;
+        }
+        m_cnt_out_content = c;
+    }
     void WriteSphereFile(const std::string& outfilename) {
         Snapshot sn = snapshot(false);
         if (m_out_content & OWNER_WILDCARD)
@@ -1221,6 +1545,7 @@ class DEMSolver {
     float3 m_G{0, 0, -9.81f};
     unsigned m_cd_freq = 20;
     double m_bin_size = -1;
+    size_t m_bin_num_target = 0;
     float m_bin_multiple = 8.0f, m_safety_multi = 1.f, m_safety_adder = 0.f, m_max_vel = 1e15f, m_err_vel = 1e15f;
     TIME_INTEGRATOR m_integrator = TIME_INTEGRATOR::EXTENDED_TAYLOR;
     uint8_t m_family_masks[DEME_FAMILY_MASK_ENTRIES] = {0};
@@ -1354,6 +1679,16 @@ class DEMSolver {
     };
     std::vector<Presc> m_presc_inputs;
     std::vector<FamilyRule> m_family_rules;
+    void keep_as_is(unsigned int ID, std::initializer_list<int> flags) {
+        Presc& q = new_presc(ID);
+        for (int f : flags)
+            q.flag[f] = true;
+    }
+    static std::string upper(std::string s) {
+        for (auto& ch : s)
+            ch = (char)std::toupper((unsigned char)ch);
+        return s;
+    }
     Presc& new_presc(unsigned int ID) {
         if (ID > 255)
             throw std::runtime_error("You applied prescribed motion to family " + std::to_string(ID) +
@@ -1757,6 +2092,10 @@ class DEMSolver {
         if (Radii.size() > 65535)
             throw std::runtime_error("more than 65535 clump components");
         double bin = m_bin_size > 0 ? m_bin_size : (double)m_bin_multiple * smallest;
+        if (m_bin_size <= 0 && m_bin_num_target) {  // DEMSolver::decideBinSize (APIPrivate.cpp): cube root of the volume per bin
+            const double vol = (double)(m_target_max.x - m_target_min.x) * (double)(m_target_max.y - m_target_min.y) * (double)(m_target_max.z - m_target_min.z);
+            bin = std::cbrt(vol / (double)m_bin_num_target);
+        }
         auto nbins = [&](uint32_t nb[3]) {
             for (int k = 0; k < 3; k++)
                 nb[k] = (uint32_t)(voxel * (double)(1ull << nv[k]) / bin) + 1;
@@ -1984,6 +2323,37 @@ class DEMSolver {
         }
         m_n_clumps = nC, m_n_owners = nO;
         m_state_fresh = false;
+        {  // initial owner-wildcard values the batches carry (DEMClumpBatch::AddOwnerWildcard)
+            size_t first = 0;
+            for (auto& bt : m_batches) {
+                for (auto& kv : bt->owner_wildcards) {
+                    if (!m_force_model->owner_wildcards.count(kv.first))
+                        throw std::runtime_error("Owner wildcard " + kv.first + " is given to a clump batch but the force model does not "
+                                                 "declare it (SetPerOwnerWildcards)");
+                    const size_t f0 = first;
+                    edit_wildcard(0, nO, m_force_model->owner_wildcards, kv.first, [&](std::vector<float>& a) {
+                        for (size_t i = 0; i < bt->nClumps; i++)
+                            a[f0 + i] = kv.second[i];
+                    });
+                }
+                first += bt->nClumps;
+            }
+            size_t firstSph = 0;
+            for (auto& bt : m_batches) {
+                const size_t nSph = bt->GetNumSpheres();
+                for (auto& kv : bt->geo_wildcards) {
+                    if (!m_force_model->geo_wildcards.count(kv.first))
+                        throw std::runtime_error("Geometry wildcard " + kv.first + " is given to a clump batch but the force model does not "
+                                                 "declare it (SetPerGeometryWildcards)");
+                    const size_t f0 = firstSph;
+                    edit_wildcard(1, sphOwner.size(), m_force_model->geo_wildcards, kv.first, [&](std::vector<float>& a) {
+                        for (size_t i = 0; i < nSph; i++)
+                            a[f0 + i] = kv.second[i];
+                    });
+                }
+                firstSph += nSph;
+            }
+        }
         compile_prescriptions_and_rules();
         m_keep.sphOwner = sphOwner, m_keep.sphComp = sphComp, m_keep.inert = inert, m_keep.objOwner = objOwner, m_keep.triOwner = triOwner;
         m_keep.Radii = Radii, m_keep.rx = rx, m_keep.ry = ry, m_keep.rz = rz, m_keep.mass = mass;
@@ -2071,6 +2441,18 @@ class DEMTracker {
     DEMTracker(DEMSolver* sys, int kind, size_t index, size_t n) : m_sys(sys), m_kind(kind), m_index(index), m_n(n) {}
     bodyID_t GetOwnerID(size_t offset = 0) const { return (bodyID_t)(m_sys->tracker_first_owner(m_kind, m_index) + in_range(offset)); }
     size_t GetNumOwners() const { return m_n; }
+    std::vector<bodyID_t> GetOwnerIDs() const {
+        std::vector<bodyID_t> ids(m_n);
+        for (size_t i = 0; i < m_n; i++)
+            ids[i] = GetOwnerID(i);
+        return ids;
+    }
+    std::vector<unsigned int> GetFamilies() {
+        std::vector<unsigned int> f(m_n);
+        for (size_t i = 0; i < m_n; i++)
+            f[i] = GetFamily(i);
+        return f;
+    }
     float3 Pos(size_t offset = 0) { return m_sys->GetOwnerPosition(GetOwnerID(offset)); }
     float3 Vel(size_t offset = 0) { return m_sys->GetOwnerVelocity(GetOwnerID(offset)); }
     float3 AngVelLocal(size_t offset = 0) { return column3(offset, 2); }
@@ -2210,6 +2592,32 @@ class DEMTracker {
         if (m_kind != 2)
             throw std::runtime_error("UpdateMesh needs a tracker of a mesh");
         m_sys->update_mesh_nodes(m_index, new_nodes);
+    }
+    /// UpdateMeshByIncrement (AuxClasses.h:306): add a deformation to every node
+    void UpdateMeshByIncrement(const std::vector<float3>& deformation) {
+        std::vector<float3> nodes = GetMesh()->vertices;
+        if (deformation.size() != nodes.size())
+            throw std::runtime_error("UpdateMeshByIncrement: the deformation count does not match the mesh");
+        for (size_t i = 0; i < nodes.size(); i++)
+            nodes[i] = nodes[i] + deformation[i];
+        UpdateMesh(nodes);
+    }
+    /// the mesh a mesh tracker follows (AuxClasses.h:310)
+    std::shared_ptr<DEMMeshConnected>& GetMesh() {
+        if (m_kind != 2)
+            throw std::runtime_error("GetMesh needs a tracker of a mesh");
+        return m_sys->m_meshes.at(m_index);
+    }
+    /// current node positions in the global frame: owner-local nodes rotated by the owner's orientation, moved to its position
+    std::vector<float3> GetMeshNodesGlobal() {
+        std::vector<float3> nodes = GetMesh()->vertices;
+        const float3 pos = Pos();
+        const float4 q = OriQ();
+        for (auto& n : nodes) {
+            DEMSolver::rotate(n, q);
+            n = n + pos;
+        }
+        return nodes;
     }
 
   private:

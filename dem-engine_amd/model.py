@@ -339,7 +339,10 @@ class SceneBuilder:
         self.err_out_vel = float(v)
 
     def SetIntegrator(self, which):
-        self.integrator = {"FORWARD_EULER": 0, "CENTERED_DIFFERENCE": 1, "EXTENDED_TAYLOR": 2}.get(which, which)
+        key = which.upper() if isinstance(which, str) else which  # the reference takes the names in lower case (API.h:124)
+        self.integrator = {"FORWARD_EULER": 0, "CENTERED_DIFFERENCE": 1, "EXTENDED_TAYLOR": 2}.get(key, key)
+        if not isinstance(self.integrator, int):
+            raise ValueError(f"Integration type {which} is unknown")
 
     def UseFrictionalHertzianModel(self):
         self.force_model = abi.FORCE_HERTZIAN

@@ -320,6 +320,13 @@ int deme_compile_force_model_ex(deme_ctx* ctx, const char* src, size_t len, cons
 int deme_upload_wildcard_array(deme_ctx* ctx, uint32_t kind, uint32_t index, const float* in, size_t n);
 int deme_download_wildcard_array(deme_ctx* ctx, uint32_t kind, uint32_t index, float* out, size_t cap);
 
+/* SetFamilyClumpMaterial / SetFamilyMeshMaterial (DEM/API.h:970-974; dT::setFamilyClumpMaterial, dT.cpp): every sphere
+ * (kind 0) or triangle (kind 1) whose owner currently belongs to `family` takes material index `material` (load order, < nMat).
+ * The per-contact records carry materials, so the next step starts with a contact detection. */
+int deme_set_family_material(deme_ctx* ctx, uint32_t family, uint32_t material, int kind);
+/* device memory in use / in total, as hipMemGetInfo reports it for the context's device (DEMSolver::ShowMemStats, API.h:584) */
+int deme_device_memory(deme_ctx* ctx, size_t* usedBytes, size_t* totalBytes);
+
 /* compile-only check of a fragment (no context, no GPU needed): same generator and hipRTC options,
  * 2 dummy materials; the compiler log is copied into `log`. */
 int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,
