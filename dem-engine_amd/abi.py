@@ -215,6 +215,8 @@ def load_library():
         "deme_kernel_time_reset": [_P], "deme_set_timing": [_P, C.c_int],
         "deme_halo_pack": [_P, _P, C.c_uint32, _P], "deme_halo_unpack": [_P, _P, C.c_uint32, _P],
         "deme_jit_probe": [C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t],
+        "deme_jit_probe_ex": [C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32,
+                              C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t],
     }.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -235,12 +237,15 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
-def jit_probe(src, wildcard_names=(), prerequisites=""):
+def jit_probe(src, wildcard_names=(), prerequisites="", owner_wildcards=(), geo_wildcards=()):
     """Compile-only check of a user force fragment (hipRTC, gfx950); needs no GPU.  Returns (ok, log)."""
     lib = load_library()
-    names = (C.c_char_p * max(1, len(wildcard_names)))(*[s.encode() for s in wildcard_names])
+
+    def arr(ns):
+        return (C.c_char_p * max(1, len(ns)))(*[s.encode() for s in ns])
     log = C.create_string_buffer(8192)
-    rc = lib.deme_jit_probe(src.encode(), names, len(wildcard_names), prerequisites.encode(), log, len(log))
+    rc = lib.deme_jit_probe_ex(src.encode(), arr(wildcard_names), len(wildcard_names), arr(owner_wildcards), len(owner_wildcards),
+                               arr(geo_wildcards), len(geo_wildcards), prerequisites.encode(), log, len(log))
     return rc == 0, log.value.decode(errors="replace")
 
 

@@ -2128,18 +2128,22 @@ int deme_device_memory(deme_ctx* c, size_t* usedBytes, size_t* totalBytes) {
     return DEME_OK;
 }
 
-int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,
-                   char* log, size_t logCap) {
+int deme_jit_probe_ex(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* const* ownerNames,
+                      uint32_t nOwnerWc, const char* const* geoNames, uint32_t nGeoWc, const char* prerequisites, char* log, size_t logCap) {
     deme_jit::MaterialTables mt;
     mt.nMat = 2;
     mt.E = {1e8f, 1e9f}, mt.nu = {0.3f, 0.3f};
     mt.CoR = {0.5f, 0.6f, 0.6f, 0.7f}, mt.mu = {0.2f, 0.3f, 0.3f, 0.4f}, mt.Crr = {0.f, 0.f, 0.f, 0.f};
-    std::vector<std::string> names;
+    std::vector<std::string> names, onames, gnames;
     for (uint32_t i = 0; i < nWildcards; i++)
         names.emplace_back(wildcardNames[i] ? wildcardNames[i] : "");
+    for (uint32_t i = 0; i < nOwnerWc; i++)
+        onames.emplace_back(ownerNames[i] ? ownerNames[i] : "");
+    for (uint32_t i = 0; i < nGeoWc; i++)
+        gnames.emplace_back(geoNames[i] ? geoNames[i] : "");
     std::string gen, err, clog;
     std::vector<char> code;
-    int rc = deme_jit::generate_source(src ? src : "", names, prerequisites ? prerequisites : "", mt, gen, err);
+    int rc = deme_jit::generate_source(src ? src : "", names, prerequisites ? prerequisites : "", mt, gen, err, onames, gnames);
     if (!rc) {
         rc = deme_jit::compile(gen, code, clog);
         err = clog;
@@ -2148,6 +2152,11 @@ int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t n
         snprintf(log, logCap, "%s", err.c_str());
     }
     return rc ? DEME_ERR_COMPILE : DEME_OK;
+}
+
+int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,
+                   char* log, size_t logCap) {
+    return deme_jit_probe_ex(src, wildcardNames, nWildcards, nullptr, 0, nullptr, 0, prerequisites, log, logCap);
 }
 
 int deme_set_timing(deme_ctx* c, int enable) {

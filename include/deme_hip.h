@@ -331,6 +331,10 @@ int deme_device_memory(deme_ctx* ctx, size_t* usedBytes, size_t* totalBytes);
  * 2 dummy materials; the compiler log is copied into `log`. */
 int deme_jit_probe(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* prerequisites,
                    char* log, size_t logCap);
+/* the same with owner and geometry wildcards declared (DEMForceModel::SetPerOwnerWildcards / SetPerGeometryWildcards) */
+int deme_jit_probe_ex(const char* src, const char* const* wildcardNames, uint32_t nWildcards, const char* const* ownerNames,
+                      uint32_t nOwnerWc, const char* const* geoNames, uint32_t nGeoWc, const char* prerequisites, char* log,
+                      size_t logCap);
 
 /* Inspectors (DEMInspector, AuxClasses.cpp:19-170; kernels DEMSphereQueryKernels.cu:13-54,
  * DEMOwnerQueryKernels.cu:11-63; reduction dT.cpp:2556-2640): a per-sphere or per-owner quantity evaluated on

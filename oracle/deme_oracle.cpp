@@ -628,6 +628,11 @@ struct Sim {
     std::vector<uint32_t> pA, pB;  // previous list (history source)
     std::vector<uint8_t> pType;
     std::vector<float> wc[DEME_MAX_WILDCARD_NUM];
+    // DEME_FORCE_CUSTOM in a parametric form (the oracle cannot take a C++ fragment): customKind 1 = the fragment of
+    // kernel/DEMUserScripts/ForceModelWithCohesion.cu's normal part as bench.py's configs[4] flavour writes it -- frictionless
+    // Hertz + a pairwise `Cohesion` material property pulling along -B2A + one contact wildcard counting the contact's age
+    int customKind = 0;
+    std::vector<float> cohesion;  // nMat * nMat
     // per-contact records
     std::vector<float> recF, recT, recCPA, recCPB;
     uint64_t nSteps = 0, nDetections = 0;
@@ -1011,9 +1016,14 @@ void calc_forces(Sim& s, bool record) {
     std::vector<uint8_t> live(nC, 0);
     std::vector<uint32_t> ownA(nC), ownB(nC);
     const bool hist = (s.p.forceModel == DEME_FORCE_HERTZIAN);
+    const bool cohesive = (s.p.forceModel == DEME_FORCE_CUSTOM && s.customKind == 1);
+    if (s.p.forceModel == DEME_FORCE_CUSTOM && !cohesive)
+        throw std::runtime_error("oracle: DEME_FORCE_CUSTOM needs a parametric model (orc_sim_set_custom_model)");
     if (hist)
         for (int w = 0; w < 4; w++)
             s.wc[w].resize(nC, 0.f);
+    if (cohesive)
+        s.wc[0].resize(nC, 0.f);
 
 #pragma omp parallel for schedule(static)
     for (int64_t ci = 0; ci < (int64_t)nC; ci++) {
@@ -1113,6 +1123,7 @@ void calc_forces(Sim& s, bool record) {
         ForceHist h{};
         if (hist)
             h = {s.wc[0][c], s.wc[1][c], s.wc[2][c], s.wc[3][c]};
+        float contact_age = cohesive ? s.wc[0][c] : 0.f;
         if (type != DEME_NOT_A_CONTACT) {
             V3f force{0, 0, 0}, torque{0, 0, 0};
             in.locCPA = rotate_q_inv(in.AOriQ, {(float)(contactPnt.x - AOwnerPos.x), (float)(contactPnt.y - AOwnerPos.y),
@@ -1128,7 +1139,15 @@ void calc_forces(Sim& s, bool record) {
             in.Crr = s.Crr[matA * s.nMat + matB];
             if (s.p.forceModel == DEME_FORCE_HERTZIAN)
                 force_hertz_full(in, h, force, torque);
-            else
+            else if (cohesive) {
+                // the user fragment: the frictionless Hertzian statements, then `force += -Cohesion[A][B] * B2A;` and
+                // `contact_age += ts;` inside the same `if (overlapDepth > 0)` block
+                force_hertz_frictionless(in, force);
+                if (in.overlapDepth > 0) {
+                    force = force + (-s.cohesion[matA * s.nMat + matB]) * in.B2A;
+                    contact_age += in.ts;
+                }
+            } else
                 force_hertz_frictionless(in, force);
             F[c * 3] = force.x, F[c * 3 + 1] = force.y, F[c * 3 + 2] = force.z;
             T[c * 3] = torque.x, T[c * 3 + 1] = torque.y, T[c * 3 + 2] = torque.z;
@@ -1137,7 +1156,10 @@ void calc_forces(Sim& s, bool record) {
             live[c] = 1;
         } else {
             h = {0, 0, 0, 0};  // _forceModelContactWildcardDestroy_, DEM/Models.h:363-378
+            contact_age = 0.f;
         }
+        if (cohesive)
+            s.wc[0][c] = contact_age;
         if (hist) {
             s.wc[0][c] = h.delta_tan_x;
             s.wc[1][c] = h.delta_tan_y;
@@ -1629,6 +1651,11 @@ void* orc_sim_create(const DemeParams* p, const DemeScene* sc) {
 }
 void orc_sim_destroy(void* h) { delete (Sim*)h; }
 void orc_sim_set_params(void* h, const DemeParams* p) { ((Sim*)h)->p = *p; }
+void orc_sim_set_custom_model(void* h, int kind, const float* cohesion, size_t n) {
+    Sim& s = *(Sim*)h;
+    s.customKind = kind;
+    s.cohesion.assign(cohesion, cohesion + n);
+}
 void orc_sim_set_margins(void* h, const float* m) {
     Sim* s = (Sim*)h;
     s->margin.assign(m, m + s->nOwners);

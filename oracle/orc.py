@@ -223,6 +223,13 @@ class OracleSim:
     def set_params(self, p):
         self.L.orc_sim_set_params(C.c_void_p(self.h), C.byref(p))
 
+    def set_custom_model(self, kind, cohesion):
+        """DEME_FORCE_CUSTOM in parametric form; kind 1 = frictionless Hertz + pairwise cohesion + a contact-age wildcard
+        (the fragment of bench.py's configs[4] flavour); cohesion: nMat x nMat"""
+        c = np.ascontiguousarray(cohesion, np.float32).reshape(-1)
+        self.L.orc_sim_set_custom_model.restype = None
+        self.L.orc_sim_set_custom_model(C.c_void_p(self.h), C.c_int(int(kind)), _p(c), C.c_size_t(c.size))
+
     def set_margins(self, m):
         m = np.ascontiguousarray(m, np.float32)
         self.L.orc_sim_set_margins(C.c_void_p(self.h), _p(m))
