@@ -221,8 +221,91 @@ def load_library():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.deme_halo_unique_id.argtypes = [_P]
+    lib.deme_halo_unique_id.restype = C.c_int
+    lib.deme_halo_group_create.argtypes = [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]
+    lib.deme_halo_group_create.restype = C.c_int
+    lib.deme_halo_group_destroy.argtypes = [_P]
+    lib.deme_halo_group_destroy.restype = None
+    lib.deme_halo_group_last_error.argtypes = [_P]
+    lib.deme_halo_group_last_error.restype = C.c_char_p
+    lib.deme_halo_group_attach.argtypes = [_P, _P, C.c_int, _P, _P, C.c_uint32, _P, C.c_uint32, C.c_int, _P, _P, C.c_uint32, _P, C.c_uint32]
+    lib.deme_halo_group_attach.restype = C.c_int
+    for name, args in {"deme_halo_group_step": [_P, C.c_uint32], "deme_halo_group_exchange": [_P], "deme_halo_group_sync": [_P],
+                       "deme_halo_group_stats": [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]}.items():
+        getattr(lib, name).argtypes = args
+        getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+def halo_unique_id():
+    """ncclGetUniqueId through the library: 128 bytes rank 0 hands to the other ranks"""
+    buf = (C.c_ubyte * 128)()
+    if load_library().deme_halo_unique_id(buf) != 0:
+        raise DemeError("RCCL is not available (deme_halo_unique_id)")
+    return bytes(buf)
+
+
+class HaloGroup:
+    """The library-side ghost exchange (include/deme_hip.h, deme_halo_group_*): one RCCL communicator + the slabs this process
+    holds.  unique_id None with world 1: a one-rank communicator (slabs of one process exchange by sends to self)."""
+
+    def __init__(self, rank=0, world=1, device=0, unique_id=None):
+        self.lib = load_library()
+        h = _P()
+        idbuf = None if unique_id is None else (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        rc = self.lib.deme_halo_group_create(idbuf, int(rank), int(world), int(device), C.byref(h))
+        self.h = h
+        self.rank, self.world = rank, world
+        self._ck(rc, "deme_halo_group_create")
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            msg = self.lib.deme_halo_group_last_error(self.h) if self.h else b""
+            raise DemeError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+    def attach(self, ctx, part, left=None, right=None):
+        """part: one entry of decomp.decompose(); left / right: the neighbour as a rank (int, another process) or as the
+        Context of a slab this process holds too, None at the ends of the chain"""
+        def side(nb, send, recv):
+            s = np.ascontiguousarray(send, np.uint32)
+            r = np.ascontiguousarray(recv, np.uint32)
+            if nb is None:
+                return -1, None, s, r
+            if isinstance(nb, Context):
+                return self.rank, nb.h, s, r
+            return int(nb), None, s, r
+        lr, lc, ls, lrv = side(left, part["send_left"], part["recv_left"])
+        rr, rc_, rs, rrv = side(right, part["send_right"], part["recv_right"])
+        self._keep = getattr(self, "_keep", []) + [(ls, lrv, rs, rrv)]
+        self._ck(self.lib.deme_halo_group_attach(self.h, ctx.h, lr, lc, _ptr(ls), ls.size, _ptr(lrv), lrv.size, rr, rc_, _ptr(rs),
+                                                  rs.size, _ptr(rrv), rrv.size), "deme_halo_group_attach")
+
+    def step(self, n):
+        self._ck(self.lib.deme_halo_group_step(self.h, int(n)), "deme_halo_group_step")
+
+    def exchange(self):
+        self._ck(self.lib.deme_halo_group_exchange(self.h), "deme_halo_group_exchange")
+
+    def sync(self):
+        self._ck(self.lib.deme_halo_group_sync(self.h), "deme_halo_group_sync")
+
+    def stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.lib.deme_halo_group_stats(self.h, C.byref(a), C.byref(b)), "deme_halo_group_stats")
+        return int(a.value), int(b.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.deme_halo_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def exported_symbols():

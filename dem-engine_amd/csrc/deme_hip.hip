@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -1583,6 +1584,348 @@ int deme_step_overlap_end(deme_ctx* c) {
     if (int rc = launch_forces(c, 1))
         return rc;
     return step_tail(c);
+}
+
+// ================================================================================================
+// Slab halo exchange driven from the library: RCCL send / recv of the packed ghost records between face neighbours, on its own
+// stream, overlapped with the interior force evaluation (north_star; SURVEY 8e "ncclGroupStart; ncclSend/ncclRecv ...").
+// RCCL is bound at run time (dlopen): a process that has PyTorch loaded shares PyTorch's copy, and libdeme_hip.so has no
+// link-time dependency on it.
+// ================================================================================================
+namespace {
+typedef struct ncclComm* ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId_t;
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId_t*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_t, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    if (api.lib || !api.err.empty())
+        return &api;
+    // PyTorch's copy first if the process already holds it, then the ROCm installation's
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        if (h)
+            break;
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!h) {
+        api.err = std::string("RCCL could not be loaded: ") + (dlerror() ? dlerror() : "librccl.so not found");
+        return &api;
+    }
+    bool ok = true;
+    auto sym = [&](const char* n) {
+        void* p = dlsym(h, n);
+        ok = ok && p;
+        return p;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) {
+        api.err = "librccl.so lacks one of the point-to-point entry points";
+        return &api;
+    }
+    api.lib = h;
+    return &api;
+}
+constexpr int kNcclUint8 = 1;  // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
+
+struct HaloSide {
+    int peerRank = -1;          // rank that holds the neighbouring slab, -1: none (end of the chain)
+    deme_ctx* peerLocal = nullptr;  // the neighbour's context when this process holds it too
+    void *sendIds = nullptr, *recvIds = nullptr, *sendBuf = nullptr, *recvBuf = nullptr;
+    uint32_t nSend = 0, nRecv = 0;
+};
+struct HaloSlab {
+    deme_ctx* ctx = nullptr;
+    HaloSide side[2];  // 0 left, 1 right
+    hipEvent_t evPacked = nullptr;
+};
+}  // namespace
+
+struct deme_halo_group {
+    RcclApi* api = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t xstream = nullptr;  // the exchange runs here: after every slab's pack, before every slab's unpack
+    hipEvent_t evExchanged = nullptr;
+    std::vector<HaloSlab> slabs;
+    std::string err;
+    uint64_t nExchanges = 0, bytesPerStep = 0;
+};
+
+namespace {
+int gfail(deme_halo_group* g, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (g)
+        g->err = buf;
+    return code;
+}
+#define GHIP(call)                                                                                             \
+    do {                                                                                                       \
+        hipError_t _e = (call);                                                                                \
+        if (_e != hipSuccess)                                                                                  \
+            return gfail(g, DEME_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define GNCCL(call)                                                                                             \
+    do {                                                                                                        \
+        int _r = (call);                                                                                        \
+        if (_r != 0)                                                                                            \
+            return gfail(g, DEME_ERR_HIP, "%s failed: %s (%s:%d)", #call, g->api->GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+}  // namespace
+
+int deme_halo_unique_id(unsigned char* id128) {
+    RcclApi* api = rccl_api();
+    if (!api->lib || !id128)
+        return DEME_ERR_HIP;
+    ncclUniqueId_t id;
+    if (api->GetUniqueId(&id) != 0)
+        return DEME_ERR_HIP;
+    memcpy(id128, id.internal, 128);
+    return DEME_OK;
+}
+
+int deme_halo_group_create(const unsigned char* id128, int rank, int world, int device, deme_halo_group** out) {
+    if (!out || world < 1 || rank < 0 || rank >= world)
+        return DEME_ERR_INVALID;
+    *out = nullptr;
+    deme_halo_group* g = new deme_halo_group();
+    g->api = rccl_api();
+    g->rank = rank, g->world = world, g->device = device;
+    *out = g;  // returned even on failure so that deme_halo_group_last_error can report
+    if (!g->api->lib)
+        return gfail(g, DEME_ERR_HIP, "%s", g->api->err.c_str());
+    GHIP(hipSetDevice(device));
+    ncclUniqueId_t id;
+    if (id128)
+        memcpy(id.internal, id128, 128);
+    else if (world == 1)
+        GNCCL(g->api->GetUniqueId(&id));  // a one-rank communicator: sends to self serve the slabs one process holds
+    else
+        return gfail(g, DEME_ERR_INVALID, "a communicator of %d ranks needs the unique id rank 0 generated", world);
+    GNCCL(g->api->CommInitRank(&g->comm, world, id, rank));
+    GHIP(hipStreamCreateWithFlags(&g->xstream, hipStreamNonBlocking));
+    GHIP(hipEventCreateWithFlags(&g->evExchanged, hipEventDisableTiming));
+    return DEME_OK;
+}
+
+void deme_halo_group_destroy(deme_halo_group* g) {
+    if (!g)
+        return;
+    hipSetDevice(g->device);
+    if (g->xstream)
+        hipStreamSynchronize(g->xstream);
+    for (auto& s : g->slabs) {
+        if (s.ctx && s.ctx->haloStream)
+            hipStreamSynchronize(s.ctx->haloStream);
+        for (auto& sd : s.side)
+            for (void* p : {sd.sendIds, sd.recvIds, sd.sendBuf, sd.recvBuf})
+                if (p)
+                    hipFree(p);
+        if (s.evPacked)
+            hipEventDestroy(s.evPacked);
+    }
+    if (g->comm)
+        g->api->CommDestroy(g->comm);
+    if (g->evExchanged)
+        hipEventDestroy(g->evExchanged);
+    if (g->xstream)
+        hipStreamDestroy(g->xstream);
+    delete g;
+}
+
+const char* deme_halo_group_last_error(const deme_halo_group* g) { return g ? g->err.c_str() : "null halo group"; }
+
+int deme_halo_group_attach(deme_halo_group* g, deme_ctx* c, int leftRank, deme_ctx* leftLocal, const uint32_t* sendLeft,
+                           uint32_t nSendLeft, const uint32_t* recvLeft, uint32_t nRecvLeft, int rightRank, deme_ctx* rightLocal,
+                           const uint32_t* sendRight, uint32_t nSendRight, const uint32_t* recvRight, uint32_t nRecvRight) {
+    if (!g || !c || !g->comm)
+        return DEME_ERR_INVALID;
+    if (int rc = check_ready(c))
+        return gfail(g, rc, "attach: %s", c->err.c_str());
+    if (int rc = ensure_halo_stream(c))
+        return gfail(g, rc, "attach: %s", c->err.c_str());
+    HaloSlab s;
+    s.ctx = c;
+    GHIP(hipEventCreateWithFlags(&s.evPacked, hipEventDisableTiming));
+    const int peer[2] = {leftRank, rightRank};
+    deme_ctx* local[2] = {leftLocal, rightLocal};
+    const uint32_t* sIds[2] = {sendLeft, sendRight};
+    const uint32_t* rIds[2] = {recvLeft, recvRight};
+    const uint32_t nS[2] = {nSendLeft, nSendRight}, nR[2] = {nRecvLeft, nRecvRight};
+    for (int k = 0; k < 2; k++) {
+        HaloSide& sd = s.side[k];
+        sd.peerRank = peer[k], sd.peerLocal = local[k], sd.nSend = nS[k], sd.nRecv = nR[k];
+        if (peer[k] < 0)
+            continue;
+        if (peer[k] >= g->world || (peer[k] == g->rank) != (local[k] != nullptr))
+            return gfail(g, DEME_ERR_INVALID, "attach: neighbour rank %d of %d; a neighbour on this rank must be given as a context", peer[k], g->world);
+        for (uint32_t i = 0; i < nS[k]; i++)
+            if (sIds[k][i] >= c->nOwners)
+                return gfail(g, DEME_ERR_INVALID, "attach: send id %u out of range", sIds[k][i]);
+        for (uint32_t i = 0; i < nR[k]; i++)
+            if (rIds[k][i] >= c->nOwners)
+                return gfail(g, DEME_ERR_INVALID, "attach: receive id %u out of range", rIds[k][i]);
+        GHIP(hipMalloc(&sd.sendIds, std::max<size_t>(nS[k], 1) * 4));
+        GHIP(hipMalloc(&sd.recvIds, std::max<size_t>(nR[k], 1) * 4));
+        GHIP(hipMalloc(&sd.sendBuf, std::max<size_t>(nS[k], 1) * sizeof(GhostRec)));
+        GHIP(hipMalloc(&sd.recvBuf, std::max<size_t>(nR[k], 1) * sizeof(GhostRec)));
+        if (nS[k])
+            GHIP(hipMemcpy(sd.sendIds, sIds[k], (size_t)nS[k] * 4, hipMemcpyHostToDevice));
+        if (nR[k])
+            GHIP(hipMemcpy(sd.recvIds, rIds[k], (size_t)nR[k] * 4, hipMemcpyHostToDevice));
+        g->bytesPerStep += (uint64_t)nS[k] * sizeof(GhostRec);
+    }
+    g->slabs.push_back(s);
+    return DEME_OK;
+}
+
+// one exchange of every slab's ghost records: pack on each slab's halo stream, all transfers in ONE RCCL group on the exchange
+// stream, unpack on each slab's halo stream again
+static int halo_exchange(deme_halo_group* g) {
+    for (auto& s : g->slabs) {
+        deme_ctx* c = s.ctx;
+        GHIP(hipStreamWaitEvent(c->haloStream, c->evStepDone, 0));  // the owners' state of the step just integrated
+        for (auto& sd : s.side)
+            if (sd.peerRank >= 0 && sd.nSend)
+                hipLaunchKernelGGL(k_halo_pack, dim3(grid_for(sd.nSend)), dim3(256), 0, c->haloStream, sd.nSend, (const uint32_t*)sd.sendIds,
+                                   c->owners.as<OwnerRec>(), (GhostRec*)sd.sendBuf);
+        GHIP(hipEventRecord(s.evPacked, c->haloStream));
+        GHIP(hipStreamWaitEvent(g->xstream, s.evPacked, 0));
+    }
+    auto find = [&](deme_ctx* c) -> HaloSlab* {
+        for (auto& s : g->slabs)
+            if (s.ctx == c)
+                return &s;
+        return nullptr;
+    };
+    GNCCL(g->api->GroupStart());
+    for (auto& s : g->slabs) {
+        // the right-hand edge of every slab (each edge once).  A neighbour in this process: the two transfers go to self, and
+        // sends to self meet receives from self in posting order -- so each send is posted right before the receive it feeds
+        HaloSide& r = s.side[1];
+        if (r.peerRank >= 0) {
+            if (r.peerLocal) {
+                HaloSlab* nb = find(r.peerLocal);
+                if (!nb)
+                    return gfail(g, DEME_ERR_INVALID, "a local neighbour context is not attached to the group");
+                HaloSide& l = nb->side[0];
+                if (l.nRecv != r.nSend || l.nSend != r.nRecv)
+                    return gfail(g, DEME_ERR_INVALID, "ghost lists of two neighbouring slabs do not match (%u/%u vs %u/%u)", r.nSend, r.nRecv, l.nRecv, l.nSend);
+                if (r.nSend) {
+                    GNCCL(g->api->Send(r.sendBuf, (size_t)r.nSend * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
+                    GNCCL(g->api->Recv(l.recvBuf, (size_t)l.nRecv * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
+                }
+                if (l.nSend) {
+                    GNCCL(g->api->Send(l.sendBuf, (size_t)l.nSend * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
+                    GNCCL(g->api->Recv(r.recvBuf, (size_t)r.nRecv * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
+                }
+            } else {
+                if (r.nSend)
+                    GNCCL(g->api->Send(r.sendBuf, (size_t)r.nSend * sizeof(GhostRec), kNcclUint8, r.peerRank, g->comm, g->xstream));
+                if (r.nRecv)
+                    GNCCL(g->api->Recv(r.recvBuf, (size_t)r.nRecv * sizeof(GhostRec), kNcclUint8, r.peerRank, g->comm, g->xstream));
+            }
+        }
+        HaloSide& l = s.side[0];
+        if (l.peerRank >= 0 && !l.peerLocal) {  // a left neighbour on another rank (a local one was served as its right edge)
+            if (l.nSend)
+                GNCCL(g->api->Send(l.sendBuf, (size_t)l.nSend * sizeof(GhostRec), kNcclUint8, l.peerRank, g->comm, g->xstream));
+            if (l.nRecv)
+                GNCCL(g->api->Recv(l.recvBuf, (size_t)l.nRecv * sizeof(GhostRec), kNcclUint8, l.peerRank, g->comm, g->xstream));
+        }
+    }
+    GNCCL(g->api->GroupEnd());
+    GHIP(hipEventRecord(g->evExchanged, g->xstream));
+    for (auto& s : g->slabs) {
+        deme_ctx* c = s.ctx;
+        GHIP(hipStreamWaitEvent(c->haloStream, g->evExchanged, 0));
+        for (auto& sd : s.side)
+            if (sd.peerRank >= 0 && sd.nRecv)
+                hipLaunchKernelGGL(k_halo_unpack, dim3(grid_for(sd.nRecv)), dim3(256), 0, c->haloStream, sd.nRecv, (const uint32_t*)sd.recvIds,
+                                   c->owners.as<OwnerRec>(), (const GhostRec*)sd.recvBuf);
+        GHIP(hipEventRecord(c->evHaloDone, c->haloStream));
+    }
+    g->nExchanges++;
+    return DEME_OK;
+}
+
+// nsteps time steps of every slab this process holds, each with its ghost exchange: interior force pass on the compute streams
+// while the records travel, the ghost-dependent pass and the integration after they have arrived.  Asynchronous like deme_step.
+int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
+    if (!g || !g->comm)
+        return DEME_ERR_INVALID;
+    GHIP(hipSetDevice(g->device));
+    for (uint32_t i = 0; i < nsteps; i++) {
+        for (auto& s : g->slabs)
+            if (int rc = deme_step_overlap_begin(s.ctx, nullptr))
+                return gfail(g, rc, "step (interior forces): %s", s.ctx->err.c_str());
+        if (int rc = halo_exchange(g))
+            return rc;
+        for (auto& s : g->slabs)
+            if (int rc = deme_step_overlap_end(s.ctx))
+                return gfail(g, rc, "step (boundary forces, integration): %s", s.ctx->err.c_str());
+    }
+    return DEME_OK;
+}
+
+int deme_halo_group_exchange(deme_halo_group* g) {  // ghosts refreshed without a step (after uploads; tests)
+    if (!g || !g->comm)
+        return DEME_ERR_INVALID;
+    GHIP(hipSetDevice(g->device));
+    for (auto& s : g->slabs)
+        if (s.ctx->evStepDone)
+            GHIP(hipEventRecord(s.ctx->evStepDone, s.ctx->stream));
+    if (int rc = halo_exchange(g))
+        return rc;
+    for (auto& s : g->slabs)
+        GHIP(hipStreamWaitEvent(s.ctx->stream, s.ctx->evHaloDone, 0));
+    return DEME_OK;
+}
+
+int deme_halo_group_sync(deme_halo_group* g) {
+    if (!g)
+        return DEME_ERR_INVALID;
+    for (auto& s : g->slabs) {
+        GHIP(hipStreamSynchronize(s.ctx->stream));
+        if (s.ctx->haloStream)
+            GHIP(hipStreamSynchronize(s.ctx->haloStream));
+    }
+    if (g->xstream)
+        GHIP(hipStreamSynchronize(g->xstream));
+    return DEME_OK;
+}
+
+int deme_halo_group_stats(const deme_halo_group* g, uint64_t* exchanges, uint64_t* bytesSentPerStep) {
+    if (!g)
+        return DEME_ERR_INVALID;
+    if (exchanges)
+        *exchanges = g->nExchanges;
+    if (bytesSentPerStep)
+        *bytesSentPerStep = g->bytesPerStep;
+    return DEME_OK;
 }
 
 int deme_get_counts(deme_ctx* c, DemeCounts* out) {

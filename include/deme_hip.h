@@ -392,6 +392,34 @@ int deme_halo_sync(deme_ctx* ctx);
 int deme_step_overlap_begin(deme_ctx* ctx, int* detectionDue);
 int deme_step_overlap_end(deme_ctx* ctx);
 
+
+/* ---- the exchange driven from the library (north_star: "RCCL halo exchange of ghost clumps over xGMI ... overlapped with
+ * interior force evaluation on a second HIP stream", host orchestration in C++).  A halo group = one RCCL communicator + the
+ * slabs this process holds (normally one: one process per GPU; several slabs in one process exchange by sends to self, which is
+ * how the path is tested on a single GPU).  RCCL is bound at run time (a process with PyTorch loaded shares PyTorch's copy).
+ *   deme_halo_unique_id       ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to the other ranks (any side channel)
+ *   deme_halo_group_create    ncclCommInitRank(world, id, rank) on `device`; id == NULL with world == 1: a one-rank communicator
+ *   deme_halo_group_attach    a slab: its context, and per side the neighbour's rank (-1: none; the own rank together with the
+ *                             neighbour's context when this process holds it), the LOCAL owner ids whose records are sent there
+ *                             and the local owner ids (ghost copies) that take the records arriving from there; lists in the
+ *                             same clump order on both sides (dem-engine_amd/decomp.py builds them)
+ *   deme_halo_group_step      nsteps x { interior force pass | pack -> ncclGroupStart, ncclSend / ncclRecv per face,
+ *                             ncclGroupEnd -> unpack | ghost-dependent force pass, integration } for every attached slab;
+ *                             asynchronous like deme_step (deme_halo_group_sync waits)
+ *   deme_halo_group_exchange  the exchange alone (ghost copies refreshed after an upload) */
+typedef struct deme_halo_group deme_halo_group;
+int deme_halo_unique_id(unsigned char* id128);
+int deme_halo_group_create(const unsigned char* id128, int rank, int world, int device, deme_halo_group** out);
+void deme_halo_group_destroy(deme_halo_group* g);
+const char* deme_halo_group_last_error(const deme_halo_group* g);
+int deme_halo_group_attach(deme_halo_group* g, deme_ctx* ctx, int leftRank, deme_ctx* leftLocal, const uint32_t* sendLeft,
+                           uint32_t nSendLeft, const uint32_t* recvLeft, uint32_t nRecvLeft, int rightRank, deme_ctx* rightLocal,
+                           const uint32_t* sendRight, uint32_t nSendRight, const uint32_t* recvRight, uint32_t nRecvRight);
+int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps);
+int deme_halo_group_exchange(deme_halo_group* g);
+int deme_halo_group_sync(deme_halo_group* g);
+int deme_halo_group_stats(const deme_halo_group* g, uint64_t* exchanges, uint64_t* bytesSentPerStep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,164 @@
+"""BASELINE configs[2] (the bed cut into x-slabs with a ghost halo, RCCL exchange every step) through the LIBRARY-side loop
+(deme_halo_group_*: C++ orchestration, ncclSend / ncclRecv in one group per step on an exchange stream, overlapped with the
+interior force pass).  One GPU is available to the tests, so the slabs are contexts of one process and their records travel
+through RCCL sends to self on a one-rank communicator -- the same code path, peers aside, as one process per GPU.
+
+  * small: 2 and 3 slabs, 60 steps with detection every 7: bit-identical to the ordered pack -> unpack -> deme_step loop;
+  * full size: 1e6 clumps (configs[1] recipe, packed) cut into 2 and into 8 slabs -- the union of the slabs' contact lists,
+    mapped to global ids, equals the single-domain ORACLE list pair for pair, and after 100 steps every clump is within the
+    stated tolerance of the oracle's single-domain run."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_decomp import GKEYS, build_global, gather_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(pkg, p, scene, mode="exact"):
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode(mode)
+    ctx.set_params(p), ctx.upload_scene(scene)
+    return ctx
+
+
+def _group(pkg, ctxs, parts):
+    g = pkg.abi.HaloGroup(rank=0, world=1, device=0)
+    for i, (c, pt) in enumerate(zip(ctxs, parts)):
+        g.attach(c, pt, left=ctxs[i - 1] if i > 0 else None, right=ctxs[i + 1] if i + 1 < len(ctxs) else None)
+    return g
+
+
+@pytest.mark.parametrize("n_slabs", [2, 3])
+def test_library_halo_loop_equals_ordered_exchange(pkg, n_slabs):
+    import ctypes as C
+    b, p, sc, x = build_global(pkg, n=3000, seed=6, cd_freq=7)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, n_slabs, halo=0.035)
+    hip = C.CDLL("libamdhip64.so")
+
+    def dev(host=None, nbytes=0):
+        ptr = C.c_void_p()
+        nbytes = host.nbytes if host is not None else nbytes
+        assert hip.hipMalloc(C.byref(ptr), C.c_size_t(max(nbytes, 16))) == 0
+        if host is not None and host.nbytes:
+            assert hip.hipMemcpy(ptr, C.c_void_p(host.ctypes.data), C.c_size_t(host.nbytes), 1) == 0
+        return ptr.value
+
+    steps = 60
+    plain = [_make(pkg, p, pt["scene"]) for pt in parts]
+    ids = [{k: dev(np.ascontiguousarray(pt[k].astype(np.uint32))) for k in ("send_left", "send_right", "recv_left", "recv_right")}
+           for pt in parts]
+    bufs = [(dev(nbytes=len(parts[i]["send_right"]) * pkg.abi.GHOST_BYTES), dev(nbytes=len(parts[i + 1]["send_left"]) * pkg.abi.GHOST_BYTES))
+            for i in range(n_slabs - 1)]
+    for _ in range(steps):
+        for i in range(n_slabs - 1):
+            plain[i].halo_pack(ids[i]["send_right"], len(parts[i]["send_right"]), bufs[i][0])
+            plain[i + 1].halo_pack(ids[i + 1]["send_left"], len(parts[i + 1]["send_left"]), bufs[i][1])
+        for c in plain:
+            c.sync()
+        for i in range(n_slabs - 1):
+            plain[i + 1].halo_unpack(ids[i + 1]["recv_left"], len(parts[i]["send_right"]), bufs[i][0])
+            plain[i].halo_unpack(ids[i]["recv_right"], len(parts[i + 1]["send_left"]), bufs[i][1])
+        for c in plain:
+            c.step(1)
+    lib = [_make(pkg, p, pt["scene"]) for pt in parts]
+    g = _group(pkg, lib, parts)
+    g.step(steps)
+    g.sync()
+    n_ex, nbytes = g.stats()
+    assert n_ex == steps and nbytes == sum(len(pt["send_left"]) + len(pt["send_right"]) for pt in parts) * pkg.abi.GHOST_BYTES
+    for a, b_ in zip(plain, lib):
+        sa, sb = a.download_state(), b_.download_state()
+        for k in GKEYS:
+            assert np.array_equal(sa[k], sb[k]), k
+        assert int(a.counts().nContacts) == int(b_.counts().nContacts) > 100
+        assert np.array_equal(a.wildcard(3), b_.wildcard(3))
+    g.close()
+
+
+@pytest.fixture(scope="module")
+def packed_million(pkg):
+    """configs[1] bed, settled on one GPU context (exact mode): params, scene, builder, state, contact list + history"""
+    import bench
+    b = bench.build_bed(pkg, 1_000_000, 2024, 40)
+    p, sc = b.Initialize()
+    ctx = _make(pkg, p, sc)
+    ctx.step(22000)
+    st = ctx.download_state()
+    cnt = ctx.contacts()
+    W = np.stack([ctx.wildcard(w) for w in range(4)], 1)
+    ctx.close()
+    return b, p, sc, st, cnt, W
+
+
+def _global_pairs(part, ctx):
+    """the slab's contact list in global ids: (sphere A, geometry B, type) rows, sphere pairs smaller id first"""
+    a, bb, t, _ = ctx.contacts()
+    sg = part["sphere_global"]
+    ss = t == 1
+    gA = sg[a]
+    gB = np.where(ss, sg[np.where(ss, bb, 0)], bb.astype(np.int64))
+    lo, hi = np.where(ss & (gA > gB), gB, gA), np.where(ss & (gA > gB), gA, gB)
+    return np.stack([lo, hi, t.astype(np.int64)], 1)
+
+
+@pytest.mark.parametrize("n_slabs", [2, 8])
+def test_million_clumps_in_slabs_against_single_domain_oracle(pkg, orc, packed_million, n_slabs):
+    """STATED TOLERANCE: contact sets identical (every pair of the single-domain oracle list is found by the slab that owns
+    either clump, and nothing else is); after 100 steps (h = 5e-6 s, detection every 40 with the bench's margins) positions
+    within 5e-9 m and velocities within 5e-6 m/s of the oracle's single-domain run.  The slabs number their clumps locally, so
+    an owner's contributions are summed in another order than in the single domain: fp32 rounding, then the bed's own
+    sensitivity -- not an error of the exchange (the small test above is bit-identical to the ordered exchange)."""
+    b, p, sc, st, cnt, W = packed_million
+    nc = int(sc.nOwnerClumps)
+    g_arrays = dict(b.arrays)
+    for k in GKEYS:
+        g_arrays[k] = np.asarray(st[k]).copy()
+    X0 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    x_now = X0[:nc, 0] + p.LBFX
+    # the single domain as a one-slab decomposition gives the payload format the re-decomposition takes: state + history in
+    # global ids; cutting it into n slabs hands every slab its clumps, its ghosts and its share of the contact history
+    one = pkg.decomp.decompose(g_arrays, b.counts, x_now, 1, halo=0.03)[0]
+    payload = pkg.decomp.owned_payload(one, st, cnt, W)
+    halo = 0.03
+    _, parts, seeds = pkg.decomp.redecompose(g_arrays, b.counts, [payload], n_slabs, halo,
+                                             lambda arr: pkg.model.decode_positions(arr["voxelID"], arr["locX"], arr["locY"], arr["locZ"], p.nvXp2,
+                                                                                     p.nvYp2, p.voxelSize, p.l)[:, 0] + p.LBFX)
+    ctxs = [_make(pkg, p, pt["scene"]) for pt in parts]
+    for c, sd in zip(ctxs, seeds):
+        c.seed_contacts(*sd)
+    grp = _group(pkg, ctxs, parts)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state({k: st[k] for k in GKEYS})
+    sim.seed_contacts(cnt[0], cnt[1], cnt[2], W)
+    orc.set_num_threads(min(64, os.cpu_count() or 1))
+    try:
+        grp.step(1), sim.step(1)  # the first step detects: the lists of this state
+        grp.sync()
+        ref = sim.contacts()
+        ref_rows = np.stack([ref[0].astype(np.int64), ref[1].astype(np.int64), ref[2].astype(np.int64)], 1)
+        rows = np.unique(np.concatenate([_global_pairs(pt, c) for pt, c in zip(parts, ctxs)]), axis=0)
+        # a slab also lists ghost-wall pairs of its ghosts?  No: a ghost's sphere-analytical contacts belong to its owner rank, but
+        # the slab evaluates them too (forces on ghosts are discarded) -- as a set the union is still the single-domain list
+        ref_sorted = np.unique(ref_rows, axis=0)
+        assert rows.shape == ref_sorted.shape and np.array_equal(rows, ref_sorted), (rows.shape, ref_sorted.shape)
+        n_cross = sum(int(((pt["arrays"]["ownerClumpBody"][c.contacts()[1][c.contacts()[2] == 1]] >= pt["n_own"])).sum()) for pt, c in zip(parts, ctxs))
+        assert n_cross > 1000 * (n_slabs - 1)  # thousands of contacts straddle every cut
+        N = 100
+        grp.step(N - 1), sim.step(N - 1)
+        grp.sync()
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+    X, V = gather_positions(pkg, parts, ctxs, p, nc)
+    so = sim.download_state()
+    Xo = pkg.model.decode_positions(so["voxelID"], so["locX"], so["locY"], so["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:nc]
+    Vo = np.stack([so["vX"], so["vY"], so["vZ"]], 1)[:nc]
+    dx, dv = np.abs(X - Xo).max(), np.abs(V - Vo).max()
+    print(f"configs[2], {n_slabs} slabs x {[pt['n_own'] for pt in parts][:3]}... clumps, {len(ref[0])} contacts, {n_cross} across cuts: "
+          f"|dx| {dx:.3e} m, |dv| {dv:.3e} m/s after {N} steps vs the single-domain oracle")
+    assert dx <= 5e-9 and dv <= 5e-6
+    grp.close()
+    for c in ctxs:
+        c.close()
