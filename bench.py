@@ -327,12 +327,24 @@ def main():
                     help="let the engine tune the bin size / the update frequency on device timers during the pre-settling and "
                          "warm-up (the reference's default mode); frozen before the timed region.  Default: off (fixed K and bin size)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: order the ghost exchange on the compute stream")
+    ap.add_argument("--halo", default="library", choices=["library", "python"],
+                    help="N > 1: who drives the per-step ghost exchange -- the library's C++ loop calling RCCL itself "
+                         "(deme_halo_group_step, default) or the round-1 Python loop over torch.distributed P2P")
+    ap.add_argument("--slabs", type=int, default=1,
+                    help="1-GPU harness of the N > 1 path: cut this rank's bed into S x-slabs held by this one process, exchanged "
+                         "through RCCL sends to self by the library loop (measures the loop's host cost; not a scaling number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--state-cache", default="",
                     help="profiling aid (1 GPU): file that keeps the pre-settled bed (owner state, contact list, wildcards) so "
                          "that repeated rocprofv3 passes of the same command skip the 30 000 untimed steps; created when absent")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+
+    # Only the JSON line may reach stdout: RCCL prints a version banner there when a communicator is created.  The real stdout
+    # is kept aside and file descriptor 1 points at stderr for everything else this process (and its C libraries) writes.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -370,11 +382,18 @@ def main():
         m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 0.021))  # just under the lowest spheres of the lattice
     p, sc = b.Initialize()
     halo, part = None, None
+    group, extra_ctx, slab_parts = None, [], None
     if world > 1:
         x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
         part = pkg.decomp.decompose(b.arrays, b.counts, x, world, HALO)[rank]
         sc = part["scene"]
         n_own = part["n_own"]
+    elif args.slabs > 1:
+        x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+        slab_parts = pkg.decomp.decompose(b.arrays, b.counts, x, args.slabs, HALO)
+        n_own = int(sc.nOwnerClumps)
+        sc_full = sc
+        sc = slab_parts[0]["scene"]
     else:
         n_own = int(sc.nOwnerClumps)
     ctx = pkg.Context(local_rank)
@@ -390,19 +409,44 @@ def main():
     if args.adaptive != "off":
         ctx.set_adaptive(bin_size=args.adaptive in ("bin", "both"), update_freq=args.adaptive in ("freq", "both"),
                          bin_observe=5, max_update_freq=200, freq_observe=3)
-    if world > 1:
+    if world > 1 and args.halo == "library" and not via_host:
+        # the library's own loop: RCCL communicator from a unique id that rank 0 generates and torch.distributed hands round
+        uid = [pkg.abi.halo_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        group = pkg.abi.HaloGroup(rank=rank, world=world, device=local_rank, unique_id=uid[0])
+        group.attach(ctx, part, left=rank - 1 if rank > 0 else None, right=rank + 1 if rank + 1 < world else None)
+    elif world > 1:
         halo = Halo(pkg, ctx, part, rank, world, torch, dist, via_host=via_host, overlap=not args.no_overlap)
         if not via_host:
             halo.probe_overlap()
+    elif slab_parts is not None:
+        for pt in slab_parts[1:]:
+            c2 = pkg.Context(local_rank)
+            c2.set_params(p), c2.upload_scene(pt["scene"])
+            b.compile_into(c2)
+            extra_ctx.append(c2)
+        all_ctx = [ctx] + extra_ctx
+        group = pkg.abi.HaloGroup(rank=0, world=1, device=local_rank)
+        for i, (c_, pt) in enumerate(zip(all_ctx, slab_parts)):
+            group.attach(c_, pt, left=all_ctx[i - 1] if i else None, right=all_ctx[i + 1] if i + 1 < len(all_ctx) else None)
+
+    host_enqueue = {"s": 0.0, "steps": 0}
 
     def run(n):
-        if halo is None:
+        if group is not None:
+            t_ = time.perf_counter()
+            group.step(n)
+            host_enqueue["s"] += time.perf_counter() - t_
+            host_enqueue["steps"] += n
+        elif halo is None:
             ctx.step(n)
         else:
             for _ in range(n):
                 halo.step()
 
     def barrier():
+        if group is not None:
+            group.sync()
         ctx.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -422,7 +466,7 @@ def main():
         chunk = min(1000, args.presettle - done)
         run(chunk)
         done += chunk
-        nc = int(ctx.counts().nContacts)
+        nc = int(ctx.counts().nContacts) + sum(int(c_.counts().nContacts) for c_ in extra_ctx)
         if world > 1:  # the same stopping rule on the job's total, so that every N times a bed in the same state
             tot_nc = torch.tensor([float(nc)], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tot_nc, op=dist.ReduceOp.SUM)
@@ -467,6 +511,9 @@ def main():
     ctx.set_timing(0 if os.environ.get("DEME_BENCH_NO_KERNEL_TIMING") else stride)
     ctx.kernel_time_reset()
     det_before = int(ctx.counts().nDetections)
+    host_enqueue["s"], host_enqueue["steps"] = 0.0, 0
+    if group is not None:
+        group.host_time(reset=True)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -488,6 +535,15 @@ def main():
     fbytes = force_kernel_bytes(int(sc.nOwners), int(sc.nSpheres), int(c.nContacts), int(p.nContactWildcards))
     achieved = fbytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
     par = f"{world} x-slab(s)"
+    if group is not None:
+        n_ex, ex_bytes = group.stats()
+        nst = max(1, host_enqueue["steps"])
+        phases = " / ".join("%.1f" % (u / nst) for u in group.host_time())
+        par = (f"{world if world > 1 else args.slabs} x-slab(s){' held by ONE process on one GPU (harness)' if world == 1 else ''}; ghost exchange every "
+               f"step by the library's C++ loop: ncclSend / ncclRecv in one group on an exchange stream, overlapped with the interior "
+               f"force pass ({ex_bytes} B sent per step by this process); host time to enqueue a step "
+               f"{1e6 * host_enqueue['s'] / nst:.1f} us (interior pass / pack / RCCL group / unpack + boundary pass + integration: "
+               f"{phases} us)")
     if halo:
         par += (", overlapped with the interior force evaluation on a second stream" if halo.overlap else "")
         par += f", ghost exchange every step over {'gloo via host memory (PLUMBING TEST, not a measurement)' if via_host else 'RCCL'} ({halo.bytes_per_step} B sent per step by rank 0)"
@@ -526,7 +582,7 @@ def main():
         pmc_calibration(torch)
     if rank == 0:
         out["cpu_baseline"] = cpu_baseline(pkg, args.seed, args.cd_freq) if (not args.no_cpu_baseline and world == 1) else None
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

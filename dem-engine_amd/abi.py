@@ -296,6 +296,13 @@ class HaloGroup:
         self._ck(self.lib.deme_halo_group_stats(self.h, C.byref(a), C.byref(b)), "deme_halo_group_stats")
         return int(a.value), int(b.value)
 
+    def host_time(self, reset=False):
+        """host microseconds spent enqueuing: (interior passes, packs, RCCL group, unpack + boundary pass + integration)"""
+        us = (C.c_double * 4)()
+        self.lib.deme_halo_group_host_time.argtypes = [_P, C.POINTER(C.c_double), C.c_int]
+        self._ck(self.lib.deme_halo_group_host_time(self.h, us, 1 if reset else 0), "deme_halo_group_host_time")
+        return tuple(us)
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.deme_halo_group_destroy(self.h)

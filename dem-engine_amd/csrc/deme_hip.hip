@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
@@ -1669,6 +1670,7 @@ struct deme_halo_group {
     std::vector<HaloSlab> slabs;
     std::string err;
     uint64_t nExchanges = 0, bytesPerStep = 0;
+    double hostUs[4] = {0, 0, 0, 0};  // host time spent enqueuing: interior pass, pack, RCCL group, unpack + boundary pass + integration
 };
 
 namespace {
@@ -1804,7 +1806,11 @@ int deme_halo_group_attach(deme_halo_group* g, deme_ctx* c, int leftRank, deme_c
 
 // one exchange of every slab's ghost records: pack on each slab's halo stream, all transfers in ONE RCCL group on the exchange
 // stream, unpack on each slab's halo stream again
+static inline double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 static int halo_exchange(deme_halo_group* g) {
+    const double t0 = now_us();
     for (auto& s : g->slabs) {
         deme_ctx* c = s.ctx;
         GHIP(hipStreamWaitEvent(c->haloStream, c->evStepDone, 0));  // the owners' state of the step just integrated
@@ -1821,6 +1827,8 @@ static int halo_exchange(deme_halo_group* g) {
                 return &s;
         return nullptr;
     };
+    const double t1 = now_us();
+    g->hostUs[1] += t1 - t0;
     GNCCL(g->api->GroupStart());
     for (auto& s : g->slabs) {
         // the right-hand edge of every slab (each edge once).  A neighbour in this process: the two transfers go to self, and
@@ -1859,6 +1867,8 @@ static int halo_exchange(deme_halo_group* g) {
     }
     GNCCL(g->api->GroupEnd());
     GHIP(hipEventRecord(g->evExchanged, g->xstream));
+    const double t2 = now_us();
+    g->hostUs[2] += t2 - t1;
     for (auto& s : g->slabs) {
         deme_ctx* c = s.ctx;
         GHIP(hipStreamWaitEvent(c->haloStream, g->evExchanged, 0));
@@ -1869,6 +1879,7 @@ static int halo_exchange(deme_halo_group* g) {
         GHIP(hipEventRecord(c->evHaloDone, c->haloStream));
     }
     g->nExchanges++;
+    g->hostUs[3] += now_us() - t2;
     return DEME_OK;
 }
 
@@ -1879,14 +1890,18 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
         return DEME_ERR_INVALID;
     GHIP(hipSetDevice(g->device));
     for (uint32_t i = 0; i < nsteps; i++) {
+        const double t0 = now_us();
         for (auto& s : g->slabs)
             if (int rc = deme_step_overlap_begin(s.ctx, nullptr))
                 return gfail(g, rc, "step (interior forces): %s", s.ctx->err.c_str());
+        g->hostUs[0] += now_us() - t0;
         if (int rc = halo_exchange(g))
             return rc;
+        const double t1 = now_us();
         for (auto& s : g->slabs)
             if (int rc = deme_step_overlap_end(s.ctx))
                 return gfail(g, rc, "step (boundary forces, integration): %s", s.ctx->err.c_str());
+        g->hostUs[3] += now_us() - t1;
     }
     return DEME_OK;
 }
@@ -1915,6 +1930,17 @@ int deme_halo_group_sync(deme_halo_group* g) {
     }
     if (g->xstream)
         GHIP(hipStreamSynchronize(g->xstream));
+    return DEME_OK;
+}
+
+int deme_halo_group_host_time(deme_halo_group* g, double us[4], int reset) {
+    if (!g || !us)
+        return DEME_ERR_INVALID;
+    for (int k = 0; k < 4; k++) {
+        us[k] = g->hostUs[k];
+        if (reset)
+            g->hostUs[k] = 0;
+    }
     return DEME_OK;
 }
 

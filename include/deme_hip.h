@@ -419,6 +419,9 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps);
 int deme_halo_group_exchange(deme_halo_group* g);
 int deme_halo_group_sync(deme_halo_group* g);
 int deme_halo_group_stats(const deme_halo_group* g, uint64_t* exchanges, uint64_t* bytesSentPerStep);
+/* host microseconds spent enqueuing since creation / the last reset: [0] interior force passes, [1] packs, [2] the RCCL group,
+ * [3] unpacks + boundary passes + integration */
+int deme_halo_group_host_time(deme_halo_group* g, double us[4], int reset);
 
 #ifdef __cplusplus
 }
