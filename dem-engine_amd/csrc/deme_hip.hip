@@ -541,8 +541,9 @@ int do_detect(deme_ctx* c) {
         }
         const int next = c->keysCur ^ 1;
         if (nC) {
-            // key = A << 33 | class << 31 | B with A, B < 2^bits(ids): bits [bitsB, 31) and [33 + bitsA, 64) are zero, so the 64-bit
-            // order is reached by two stable LSD sorts over the occupied ranges only (6 radix passes instead of 8 at 3e6 spheres)
+            // key = A << 33 | class << 31 | B.  One radix sort over the occupied upper bits [31, 33 + bits(A)) groups the keys by
+            // (sphere A, class) -- 3 passes at 3e6 spheres, where a full 64-bit order took 6 to 8 -- and k_segment_rank_sort puts each
+            // group's few partners in order (DEMCubContactDetection.cu:811-1110 runs five full sorts for the same list order)
             auto bits_of = [](uint64_t n) {
                 unsigned b = 1;
                 while (b < 31 && (1ull << b) < n)
@@ -550,18 +551,15 @@ int do_detect(deme_ctx* c) {
                 return b;
             };
             const unsigned bitsA = bits_of(c->dp.nSpheres);
-            const unsigned bitsB = bits_of(std::max<uint64_t>({c->dp.nSpheres, c->dp.nTri, c->dp.nAnal, 1u}));
             uint64_t* mid = c->conA4.as<uint64_t>();  // 16 B per contact of scratch: the contribution records are dead until the next force pass
-            size_t need = 0, needHi = 0;
-            HIPCK(rocprim::radix_sort_keys(nullptr, need, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 0, bitsB, c->stream));
-            HIPCK(rocprim::radix_sort_keys(nullptr, needHi, mid, c->keysSorted[next].as<uint64_t>(), (size_t)nC, 31, 33 + bitsA,
-                                           c->stream));
-            if (int rc = ensure(c, c->sortTmp, std::max(need, needHi)))
+            size_t needHi = 0;
+            HIPCK(rocprim::radix_sort_keys(nullptr, needHi, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 31, 33 + bitsA, c->stream));
+            if (int rc = ensure(c, c->sortTmp, needHi))
                 return rc;
-            need = needHi = c->sortTmp.bytes;
-            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, need, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 0, bitsB, c->stream));
-            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, needHi, mid, c->keysSorted[next].as<uint64_t>(), (size_t)nC, 31, 33 + bitsA,
-                                           c->stream));
+            needHi = c->sortTmp.bytes;
+            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, needHi, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 31, 33 + bitsA, c->stream));
+            hipLaunchKernelGGL(k_segment_rank_sort, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC, mid,
+                               c->keysSorted[next].as<uint64_t>());
             if (nPersist) {  // a marked contact the sweep found as well appears once (markDuplicateContacts)
                 unsigned long long* cnt = &c->ctr.as<DetectCounters>()->nContactsRaw;
                 size_t need2 = 0;
@@ -619,6 +617,15 @@ int do_detect(deme_ctx* c) {
             if (ensure(c, c->cDefer, c->cntCap) || ensure(c, c->blockMode, (c->cntCap / DEME_FORCE_BLOCK + 2) * 4))
                 return c->lastStatus;
             HIPCK(hipMemsetAsync(c->blockMode.p, 0, c->blockMode.bytes, c->stream));
+        }
+        if (nC) {
+            hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC, c->ownerA.as<uint32_t>(),
+                               c->nOwners, c->aStart.as<uint32_t>());
+            hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC, c->ownerB[1].as<uint32_t>(),
+                               c->nOwners, c->bStart.as<uint32_t>());
+        } else {
+            HIPCK(hipMemsetAsync(c->aStart.p, 0, ((size_t)c->nOwners + 1) * 4, c->stream));
+            HIPCK(hipMemsetAsync(c->bStart.p, 0, ((size_t)c->nOwners + 1) * 4, c->stream));
         }
         hipLaunchKernelGGL(k_owner_ranges, dim3(grid_for((size_t)c->nOwners + 1)), dim3(256), 0, c->stream, c->dp,
                            (uint32_t)nC, c->ownerA.as<uint32_t>(), c->ownerB[1].as<uint32_t>(), c->owners.as<OwnerRec>(),

@@ -111,13 +111,10 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
         myCount = (n64 > DEME_MAX_BINS_PER_SPHERE) ? 0u : (uint32_t)n64;
         counts[s] = myCount;
     }
-    {  // largest per-sphere count: the host multiplies it by nSpheres to decide whether the 32-bit scan needs an exact check
-        uint32_t m = myCount;
-        for (int off = 32; off > 0; off >>= 1)
-            m = max(m, (uint32_t)__shfl_xor((int)m, off));
-        if ((threadIdx.x & 63u) == 0 && m > ctr->maxCount)  // (a stale read only costs a redundant atomic)
-            atomicMax(&ctr->maxCount, m);
-    }
+    // largest per-sphere count, recorded only when it is large enough for nSpheres such counts to overflow the 32-bit offsets
+    // of the scan (never in a sanely binned scene: no atomic, no extra load on the normal path); the host then checks the total
+    if (myCount > 0xFFFFFFFFu / max(p.nSpheres, 1u))
+        atomicMax(&ctr->maxCount, myCount);
     if (blockIdx.x == 0 && threadIdx.x == 0)
         counts[p.nSpheres] = 0;  // scan sentinel: offsets[nSpheres] = total
 
@@ -632,6 +629,32 @@ __global__ __launch_bounds__(256) void k_bin_stats_final(const uint2* __restrict
     }
 }
 
+// Second half of the contact-key sort.  The radix sort orders the keys by their upper part only (sphere A, type class: the
+// occupied bits above bit 31); a segment of equal (A, class) holds a sphere's handful of partners in arbitrary order.  Every
+// key finds its segment by walking to its ends and takes the number of keys that go before it as its rank (ties by position) -- a
+// few compares per key instead of three more radix passes over the list.
+__global__ __launch_bounds__(256) void k_segment_rank_sort(uint32_t n, const uint64_t* __restrict__ in, uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint64_t k = in[i], seg = k >> 31;
+    uint32_t s = i, rank = 0;
+    while (s > 0) {
+        const uint64_t q = in[s - 1];
+        if ((q >> 31) != seg)
+            break;
+        rank += (q <= k) ? 1u : 0u;  // an equal key further left goes first (persistent marks repeat keys the sweep found too)
+        s--;
+    }
+    for (uint32_t j = i + 1; j < n; j++) {
+        const uint64_t q = in[j];
+        if ((q >> 31) != seg)
+            break;
+        rank += (q < k) ? 1u : 0u;
+    }
+    out[s + rank] = k;
+}
+
 // ---------------------------------------------------------------------------
 // History map + wildcard migration.  Semantics of kernel/DEMHistoryMappingKernels.cu:17-61
 // ("same (A, B, type) as in the previous list") and kernel/DEMPrepForceKernels.cu:46-68
@@ -644,7 +667,40 @@ __global__ __launch_bounds__(256) void k_history(uint32_t nNew, const uint64_t* 
     if (c >= nNew)
         return;
     const uint64_t k = newKeys[c];
-    uint32_t lo = 0, hi = nPrev;
+    // both lists are sorted and mostly the same pairs: contact c of the new list sits near c * nPrev / nNew in the previous one.
+    // Gallop outwards from that guess to bracket the key, then bisect the bracket (a handful of probes, neighbouring lanes on
+    // neighbouring addresses, instead of log2(nPrev) dependent probes across the whole list)
+    uint32_t lo = 0, hi = nPrev;  // invariant: the first index with prevKeys >= k lies in [lo, hi]
+    if (nPrev) {
+        uint32_t g = (uint32_t)(((uint64_t)c * nPrev) / nNew);
+        g = min(g, nPrev - 1);
+        if (prevKeys[g] < k) {
+            lo = g + 1;
+            uint32_t step = 8;
+            while (lo < nPrev) {
+                const uint32_t j = (lo + step < nPrev) ? lo + step : nPrev - 1;
+                if (prevKeys[j] < k) {
+                    lo = j + 1;
+                    step <<= 2;
+                } else {
+                    hi = j;
+                    break;
+                }
+            }
+        } else {
+            hi = g;
+            uint32_t step = 8;
+            while (hi > 0) {
+                const uint32_t j = (hi > step) ? hi - step : 0;
+                if (prevKeys[j] < k) {
+                    lo = j + 1;
+                    break;
+                }
+                hi = j;
+                step <<= 2;
+            }
+        }
+    }
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if (prevKeys[mid] < k)
@@ -976,7 +1032,23 @@ struct RangeCounters {
     unsigned int pad[12];
 };
 
-// aStart / bStart by binary search (once per detection), plus the heavy-owner list.
+// start[o] = first index i with owner[i] >= o, for o = 0 .. nOwners (owner[] ascending): every element fills the owners that
+// begin at it -- one store per element where four binary searches per owner used to walk the arrays
+__global__ __launch_bounds__(256) void k_run_starts(uint32_t n, const uint32_t* __restrict__ owner, uint32_t nOwners,
+                                                    uint32_t* __restrict__ start) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t cur = owner[i];
+    const uint32_t first = (i == 0) ? 0u : owner[i - 1] + 1u;
+    for (uint32_t o = first; o <= cur && o <= nOwners; o++)
+        start[o] = i;
+    if (i == n - 1)
+        for (uint32_t o = cur + 1; o <= nOwners; o++)
+            start[o] = n;
+}
+
+// aStart / bStart (k_run_starts) -> per-owner flags, the heavy-owner list, the halo split (once per detection).
 __global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_t nC, const uint32_t* __restrict__ ownerA,
                                                       const uint32_t* __restrict__ ownerBSorted,
                                                       const OwnerRec* __restrict__ owners, uint32_t* __restrict__ aStart,
@@ -988,15 +1060,10 @@ __global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o > p.nOwners)
         return;
-    if (o == p.nOwners) {
-        aStart[o] = nC;
-        bStart[o] = nC;
+    if (o == p.nOwners)
         return;
-    }
-    const uint32_t a0 = lower_bound_u32(ownerA, nC, o), a1 = lower_bound_u32(ownerA, nC, o + 1);
-    const uint32_t b0 = lower_bound_u32(ownerBSorted, nC, o), b1 = lower_bound_u32(ownerBSorted, nC, o + 1);
-    aStart[o] = a0;
-    bStart[o] = b0;
+    const uint32_t a0 = aStart[o], a1 = aStart[o + 1];
+    const uint32_t b0 = bStart[o], b1 = bStart[o + 1];
     const bool isFixed = (p.familyFlags[owners[o].family] & 3u) != 0;  // fixed or ghost: a/alpha never integrated here
     fixedFlag[o] = isFixed ? 1 : 0;
     if (cDefer) {  // halo overlap: an owner run that reads any ghost owner is evaluated after the ghost records arrive
