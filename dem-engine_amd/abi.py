@@ -54,7 +54,7 @@ class DemeScene(C.Structure):
                    "objRotX", "objRotY", "objRotZ", "objSize1", "objSize2", "objSize3", "objMass",
                    "E", "nu", "CoR", "mu", "Crr",
                    "familyMasks", "familyExtraMarginSize", "familyFlags",
-                   "ownerMesh", "triNode1", "triNode2", "triNode3", "triMaterialOffset")]
+                   "ownerMesh", "triNode1", "triNode2", "triNode3", "triMaterialOffset", "ownerGhost")]
 
 
 # field name -> numpy dtype, for building DemeScene / DemeOwnerState from arrays
@@ -75,6 +75,7 @@ SCENE_DTYPES = {
     "familyMasks": np.uint8, "familyExtraMarginSize": np.float32, "familyFlags": np.uint8,
     "ownerMesh": np.uint32, "triNode1": np.float32, "triNode2": np.float32, "triNode3": np.float32,
     "triMaterialOffset": np.uint16,
+    "ownerGhost": np.uint8,
 }
 
 STATE_DTYPES = {

@@ -33,11 +33,15 @@ struct __attribute__((aligned(16))) OwnerRec {
     uint16_t inertiaOff;         // index into the mass-property table
     float qw, qx, qy, qz;        // orientation
     float vx, vy, vz;            // linear velocity
-    uint32_t family;             // family id (8 bits used)
+    uint32_t family;             // bits 0-7 family id; bit 8: ghost copy of a clump another rank owns (OWNER_GHOST_BIT)
     float wx, wy, wz;            // body-frame angular velocity (omgBar)
     float margin;                // contact-detection margin (kT's marginSize)
 };
 static_assert(sizeof(OwnerRec) == 64, "OwnerRec must be 64 bytes");
+
+#define OWNER_GHOST_BIT 0x100u
+__host__ __device__ inline uint32_t fam_of(uint32_t familyWord) { return familyWord & 0xFFu; }
+__host__ __device__ inline bool ghost_of(uint32_t familyWord) { return (familyWord & OWNER_GHOST_BIT) != 0; }
 
 struct SphereRec {  // 8 bytes: ownerClumpBody + clumpComponentOffset + sphereMaterialOffset
     uint32_t owner;
@@ -97,6 +101,7 @@ struct DevParams {
     uint32_t nOwners, nSpheres, nAnal, nMat;
     uint32_t errOutBinSphNum;
     uint32_t familyTrivial;  // 1: all masks allow and all extra margins are 0 -> skip family logic
+    uint32_t hasGhosts;      // some owners are ghost copies: the sweep reads the family words to leave ghost-ghost pairs out
     // tables
     const float4* comp;       // per component: relx, rely, relz, radius
     const float4* massProps;  // per mass property: mass, moiX, moiY, moiZ

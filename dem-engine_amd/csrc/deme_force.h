@@ -280,7 +280,7 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
         bodyAPos = {AOwnerPos.x + (double)rel.x, AOwnerPos.y + (double)rel.y, AOwnerPos.z + (double)rel.z};
         in.ARadius = c.w;
     }
-    const uint32_t AOwnerFamily = oA.family;
+    const uint32_t AOwnerFamily = fam_of(oA.family);
     float extraMarginSize = p.familyTrivial ? 0.f : p.familyExtra[AOwnerFamily];
     const uint32_t bodyAMatType = sA.mat;
     uint32_t bodyBMatType = 0;
@@ -305,7 +305,7 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
         in.BRadius = c.w;
         bodyBMatType = sB.mat;
         if (!p.familyTrivial) {
-            const float eB = p.familyExtra[oB.family];
+            const float eB = p.familyExtra[fam_of(oB.family)];
             extraMarginSize = (extraMarginSize > eB) ? extraMarginSize : eB;
         }
         spheres_overlap(bodyAPos.x, bodyAPos.y, bodyAPos.z, (double)in.ARadius, bodyBPos.x, bodyBPos.y, bodyBPos.z,
@@ -327,7 +327,7 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
         const f3 rel = rot_apply(in.RB, mk3(ob.relx, ob.rely, ob.relz));
         bodyBPos = {BOwnerPos.x + (double)rel.x, BOwnerPos.y + (double)rel.y, BOwnerPos.z + (double)rel.z};
         if (!p.familyTrivial) {
-            const float eB = p.familyExtra[oB.family];
+            const float eB = p.familyExtra[fam_of(oB.family)];
             extraMarginSize = (extraMarginSize > eB) ? extraMarginSize : eB;
         }
         const f3 rot = rot_apply(in.RB, mk3(ob.rotx, ob.roty, ob.rotz));
@@ -346,7 +346,7 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
         in.BRadius = 1e15f;  // DEME_HUGE_FLOAT
         bodyBMatType = tr.mat;
         if (!p.familyTrivial) {
-            const float eB = p.familyExtra[oB.family];
+            const float eB = p.familyExtra[fam_of(oB.family)];
             extraMarginSize = (extraMarginSize > eB) ? extraMarginSize : eB;
         }
         BOwnerPos = decode_pos(oB.voxelID, oB.locX, oB.locY, oB.locZ, p);
@@ -412,7 +412,7 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
             io.AOriQ = make_float4(oA.qx, oA.qy, oA.qz, oA.qw);  // float4 is (x, y, z, w)
             io.BOriQ = make_float4(oB.qx, oB.qy, oB.qz, oB.qw);
             io.bodyAMatType = (uint16_t)bodyAMatType, io.bodyBMatType = (uint16_t)bodyBMatType;
-            io.ContactType = (uint8_t)ContactType, io.AOwnerFamily = (uint8_t)AOwnerFamily, io.BOwnerFamily = (uint8_t)oB.family;
+            io.ContactType = (uint8_t)ContactType, io.AOwnerFamily = (uint8_t)AOwnerFamily, io.BOwnerFamily = (uint8_t)fam_of(oB.family);
             io.locCPA = make_float3(in.locCPA.x, in.locCPA.y, in.locCPA.z);
             io.locCPB = make_float3(in.locCPB.x, in.locCPB.y, in.locCPB.z);
             io.force = make_float3(0, 0, 0), io.torque_only_force = make_float3(0, 0, 0);

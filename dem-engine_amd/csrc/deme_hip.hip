@@ -1087,8 +1087,17 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     if (s->familyFlags)
         memcpy(c->hostFamFlags, s->familyFlags, DEME_NUM_FAMILIES);
     c->hasGhosts = false;
-    for (int f = 0; f < DEME_NUM_FAMILIES; f++)
-        c->hasGhosts = c->hasGhosts || (c->hostFamFlags[f] & DEME_FAMILY_GHOST);
+    if (s->ownerGhost) {
+        for (size_t i = 0; i < nO && !c->hasGhosts; i++)
+            c->hasGhosts = s->ownerGhost[i] != 0;
+        if (c->hasGhosts) {
+            if (int rc = ensure(c, c->stage, std::max<size_t>(nO, 16)))
+                return rc;
+            HIPCK(hipMemcpyAsync(c->stage.p, s->ownerGhost, nO, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_set_ghost_bits, dim3(grid_for(nO)), dim3(256), 0, c->stream, (uint32_t)nO, c->owners.as<OwnerRec>(),
+                               c->stage.as<uint8_t>());
+        }
+    }
     c->prescDirty = true;
     bool trivial = true;
     if (s->familyMasks)
@@ -1098,6 +1107,7 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         for (size_t i = 0; i < DEME_NUM_FAMILIES && trivial; i++)
             trivial = s->familyExtraMarginSize[i] == 0.f;
     c->dp.familyTrivial = trivial ? 1u : 0u;
+    c->dp.hasGhosts = c->hasGhosts ? 1u : 0u;
     // detection scratch
     if (ensure(c, c->geo, std::max<size_t>(nS, 1) * sizeof(GeoRec)) || ensure(c, c->binLo, std::max<size_t>(nS, 1) * 16) ||
         ensure(c, c->binN, std::max<size_t>(nS, 1) * 8) || ensure(c, c->counts, (nS + 1) * 4) ||

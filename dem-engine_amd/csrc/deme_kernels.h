@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_margins(const DevParams p, OwnerRec* ow
         atomicOr(&ctr->status, DEME_ST_VELOCITY);
     if (absv > p.approxMaxVel)
         absv = p.approxMaxVel;
-    const float extra = p.familyTrivial ? 0.f : p.familyExtra[r->family];
+    const float extra = p.familyTrivial ? 0.f : p.familyExtra[fam_of(r->family)];
     r->margin = (float)((double)(absv * p.expSafetyMulti + p.expSafetyAdder) * (double)p.h * (double)drift + (double)extra);
 }
 
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
         rBin += o.margin;  // fp64 sum, DEMBinSphereKernels.cu:36
         float rSweep = c.w;
         rSweep += o.margin;  // fp32 sum, DEMContactKernels_SphereSphere.cu:40
-        fam = o.family;
+        fam = fam_of(o.family);
         GeoRec g;
         g.x = pos.x, g.y = pos.y, g.z = pos.z, g.r = rSweep, g.owner = sr.owner;
         geo[s] = g;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
             w.x = op.x + (double)rp.x, w.y = op.y + (double)rp.y, w.z = op.z + (double)rp.z;
             w.dx = rd.x, w.dy = rd.y, w.dz = rd.z;
             w.size1 = ob.size1, w.nsign = ob.normal, w.margin = o.margin;
-            w.type = ob.type, w.family = o.family;
+            w.type = ob.type, w.family = fam_of(o.family);
             sObj[threadIdx.x] = w;
         }
         __syncthreads();
@@ -250,7 +250,10 @@ __device__ inline bool pair_test(const DevParams& p, double ax, double ay, doubl
     if (d2 > (rA + rB) * (rA + rB))
         return false;
     float am = 0.f;
+    if (ghost_of(af) && ghost_of(bf))
+        return false;  // both are copies of clumps other ranks own: the pair is theirs
     if (!p.familyTrivial) {
+        af = fam_of(af), bf = fam_of(bf);
         if (p.familyMasks[mask_pair(af, bf)] != 0)
             return false;
         const float ea = p.familyExtra[af], eb = p.familyExtra[bf];
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             L.f[q] = make_float4((float)(g.x - (double)ix * p.binSize), (float)(g.y - (double)iy * p.binSize),
                                  (float)(g.z - (double)iz * p.binSize), g.r);
             L.owner[q] = g.owner, L.sph[q] = sph;
-            L.fam[q] = p.familyTrivial ? 0u : owners[g.owner].family;
+            L.fam[q] = (p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family;
         }
         // keys were loaded at offset `start`: shift so that L.bin[q] matches entry q of the range
         uint32_t b0 = DEME_NULL_BINID_DEV, b1 = DEME_NULL_BINID_DEV;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                     const uint32_t sph = sphIds[ta + t];
                     const GeoRec g = geo[sph];
                     L.owner[t] = g.owner, L.sph[t] = sph;
-                    L.fam[t] = p.familyTrivial ? 0u : owners[g.owner].family;
+                    L.fam[t] = (p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family;
                 }
                 __syncthreads();
                 for (uint32_t tb = ta; tb < ge; tb += SW_T) {
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                         ms = sphIds[jb];
                         const GeoRec g = geo[ms];
                         mx = g.x, my = g.y, mz = g.z, mr = g.r, mo = g.owner;
-                        mf = p.familyTrivial ? 0u : owners[g.owner].family;
+                        mf = (p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family;
                     }
                     for (uint32_t i = 0; i < na; i++) {  // uniform trip count
                         const bool act = valid && (ta + i < jb);  // each unordered pair once
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_persist_flags(const DevParams p, uint32
         ob = p.anal[key_b(k)].owner;
     else
         ob = reinterpret_cast<const uint32_t*>(p.tris)[12 * (size_t)key_b(k) + 9];
-    const uint32_t fA = owners[oa].family, fB = owners[ob].family;
+    const uint32_t fA = fam_of(owners[oa].family), fB = fam_of(owners[ob].family);
     const bool q = mode == 0 || (mode == 1 && (fA == N1 || fB == N1)) || (mode == 2 && fA == N1 && fB == N1) ||
                    (mode == 3 && ((fA == N1 && fB == N2) || (fA == N2 && fB == N1)));
     flag[c] = q ? 1 : 0;
@@ -1064,12 +1067,13 @@ __global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_
         return;
     const uint32_t a0 = aStart[o], a1 = aStart[o + 1];
     const uint32_t b0 = bStart[o], b1 = bStart[o + 1];
-    const bool isFixed = (p.familyFlags[owners[o].family] & 3u) != 0;  // fixed or ghost: a/alpha never integrated here
+    const uint32_t fw = owners[o].family;
+    const bool isFixed = (p.familyFlags[fam_of(fw)] & 1u) != 0 || ghost_of(fw);  // fixed or ghost: a/alpha never integrated here
     fixedFlag[o] = isFixed ? 1 : 0;
     if (cDefer) {  // halo overlap: an owner run that reads any ghost owner is evaluated after the ghost records arrive
-        bool d = (p.familyFlags[owners[o].family] & 2u) != 0;
+        bool d = ghost_of(fw);
         for (uint32_t c = a0; c < a1 && !d; c++)
-            d = (p.familyFlags[owners[info[c].y].family] & 2u) != 0;  // info.y: B's owner (k_contact_owners)
+            d = ghost_of(owners[info[c].y].family);  // info.y: B's owner (k_contact_owners)
         for (uint32_t c = a0; c < a1; c++) {
             cDefer[c] = d ? 1 : 0;
             if (c == a0 || (c % DEME_FORCE_BLOCK) == 0)
@@ -1098,8 +1102,8 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = o < p.nOwners;
     OwnerRec r = load_owner(owners, valid ? o : 0u);
-    const uint32_t fflags = p.familyFlags[r.family];
-    const bool ghost = (fflags & 2u) != 0;  // its owner rank integrates it; refreshed by deme_halo_unpack
+    const uint32_t fflags = p.familyFlags[fam_of(r.family)];
+    const bool ghost = ghost_of(r.family);  // its owner rank integrates it; refreshed by deme_halo_unpack
     const bool fixed = (fflags & 1u) != 0;
     float4 a = make_float4(0, 0, 0, 0), al = a;
     if (FUSED) {
@@ -1270,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owner
         if (s.omgBarX) r.wx = s.omgBarX[o];
         if (s.omgBarY) r.wy = s.omgBarY[o];
         if (s.omgBarZ) r.wz = s.omgBarZ[o];
-        if (s.familyID) r.family = s.familyID[o];
+        if (s.familyID) r.family = (r.family & OWNER_GHOST_BIT) | s.familyID[o];
         if (s.inertiaPropOffsets) r.inertiaOff = s.inertiaPropOffsets[o];
         if (s.aX) a.ax = s.aX[o];
         if (s.aY) a.ay = s.aY[o];
@@ -1307,8 +1311,14 @@ __global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owner
 
 __global__ __launch_bounds__(256) void k_change_family(OwnerRec* __restrict__ owners, uint32_t n, uint32_t from, uint32_t to) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < n && owners[o].family == from)
-        owners[o].family = to;
+    if (o < n && fam_of(owners[o].family) == from)
+        owners[o].family = (owners[o].family & OWNER_GHOST_BIT) | to;
+}
+
+__global__ __launch_bounds__(256) void k_set_ghost_bits(uint32_t n, OwnerRec* __restrict__ owners, const uint8_t* __restrict__ flag) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < n)
+        owners[o].family = fam_of(owners[o].family) | (flag[o] ? OWNER_GHOST_BIT : 0u);
 }
 
 // SetFamilyClumpMaterial / SetFamilyMeshMaterial: geometries whose owner is of `family` take `material`
@@ -1329,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_inspect_sphere(const DevParams p, const
         return;
     const SphereRec sr = spheres[s];
     const OwnerRec o = load_owner(owners, sr.owner);
-    if (p.familyFlags[o.family] & 2u) {  // ghost copy: its owner rank reports it
+    if (ghost_of(o.family)) {  // ghost copy: its owner rank reports it
         out[s] = identity;
         return;
     }
@@ -1359,7 +1369,7 @@ __global__ __launch_bounds__(256) void k_inspect_owner(const DevParams p, const 
         return;
     const OwnerRec o = load_owner(owners, i);
     const bool clumpOnly = quantity == 3u || quantity == 5u || quantity == 7u;  // OWNER_T_CLUMP quantities
-    if ((p.familyFlags[o.family] & 2u) || (clumpOnly && i >= nClumps)) {
+    if (ghost_of(o.family) || (clumpOnly && i >= nClumps)) {
         out[i] = identity;
         return;
     }
@@ -1396,7 +1406,7 @@ __global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const uint32_t* i
         return;
     const OwnerRec r = load_owner(owners, ids[i]);
     GhostRec g;
-    g.voxelID = r.voxelID, g.locX = r.locX, g.locY = r.locY, g.locZ = r.locZ, g.family = (uint16_t)r.family;
+    g.voxelID = r.voxelID, g.locX = r.locX, g.locY = r.locY, g.locZ = r.locZ, g.family = (uint16_t)fam_of(r.family);
     g.qw = r.qw, g.qx = r.qx, g.qy = r.qy, g.qz = r.qz;
     g.vx = r.vx, g.vy = r.vy, g.vz = r.vz, g.wx = r.wx, g.wy = r.wy, g.wz = r.wz;
     buf[i] = g;
@@ -1407,9 +1417,8 @@ __global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n, const uint32_t*
         return;
     const GhostRec g = buf[i];
     OwnerRec* r = owners + ids[i];
-    // the ghost copy keeps its LOCAL family (the ghost family: never integrated here, left out of inspections, and what
-    // marks an owner run as halo-dependent); the owner rank's family travels in the record but is not applied -- family-
-    // specific contact masks are therefore not honoured across a cut
+    // the copy follows its owner rank's record, family included (on-the-fly family changes travel with the state)
+    r->family = (r->family & OWNER_GHOST_BIT) | g.family;
     r->voxelID = g.voxelID, r->locX = g.locX, r->locY = g.locY, r->locZ = g.locZ;
     r->qw = g.qw, r->qx = g.qx, r->qy = g.qy, r->qz = g.qz;
     r->vx = g.vx, r->vy = g.vy, r->vz = g.vz, r->wx = g.wx, r->wy = g.wy, r->wz = g.wz;

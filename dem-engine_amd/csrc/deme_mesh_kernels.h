@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_tri_prep(const DevParams p, uint32_t nT
         dst[k][0] = (float)(op.x + r.x), dst[k][1] = (float)(op.y + r.y), dst[k][2] = (float)(op.z + r.z);
     }
     w.owner = tr.owner;
-    w.family = o.family;
+    w.family = fam_of(o.family);
     tw[t] = w;
     int L[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, U[3] = {-1, -1, -1};
     tri_bin_bounds(p, w.a1, w.a2, w.a3, L, U);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t T
             bool ok = g.owner != w.owner;
             float am = 0.f;
             if (ok && !p.familyTrivial) {
-                const uint32_t fS = owners[g.owner].family;
+                const uint32_t fS = fam_of(owners[g.owner].family);
                 ok = p.familyMasks[mask_pair(fS, w.family)] == 0;
                 const float ea = p.familyExtra[fS], eb = p.familyExtra[w.family];
                 am = (ea < eb) ? ea : eb;

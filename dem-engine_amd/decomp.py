@@ -3,11 +3,11 @@ reference only splits kT/dT across two devices, DEM/APIPublic.cpp:22-72).
 
 The global scene (arrays of SceneBuilder.Initialize()) is cut into N slabs along x.  A rank's scene is
 [its own clumps | ghosts from the left neighbour | ghosts from the right neighbour | analytical owners].
-Ghosts are copies of neighbour-owned clumps whose centre lies within `halo` of the shared face; they carry
-family GHOST_FAMILY (flag DEME_FAMILY_GHOST: never integrated locally) and are refreshed every step from
-their owner rank (56-byte ghost records: pose, velocities, family; deme_halo_pack / deme_halo_unpack).
-A local-ghost contact is evaluated on both ranks, each applying the force to its own clump only;
-ghost-ghost contacts are masked out.
+Ghosts are copies of neighbour-owned clumps whose centre lies within `halo` of the shared face; they are marked per owner
+(DemeScene.ownerGhost: never integrated locally, left out of inspections), keep their TRUE family -- contact masks and family
+margins hold across a cut exactly as inside a slab -- and are refreshed every step from their owner rank (56-byte ghost
+records: pose, velocities, family; deme_halo_pack / deme_halo_unpack).  A local-ghost contact is evaluated on both ranks,
+each applying the force to its own clump only; ghost-ghost pairs are left to the ranks that own the clumps.
 
 Ownership and ghost lists are fixed between re-decompositions, so a clump must not drift further than `halo`
 minus its reach before the next one.  `redecompose` (every few thousand steps, or when the maximum displacement
@@ -19,8 +19,6 @@ import numpy as np
 
 from . import abi
 
-GHOST_FAMILY = 254
-FAMILY_GHOST_FLAG = 2
 
 _OWNER_KEYS = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ",
                "omgBarX", "omgBarY", "omgBarZ", "familyID", "inertiaPropOffsets")
@@ -61,8 +59,6 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
                              "across slabs (a free mesh would need an all-reduce of its accelerations every step)")
     x = np.asarray(clump_x, np.float64)[:n_clumps]
     edges = slab_edges(x, n_ranks)
-    if n_ranks > 1 and (np.asarray(arrays["familyID"])[:n_clumps] == GHOST_FAMILY).any():
-        raise ValueError(f"family {GHOST_FAMILY} is reserved for ghost copies under a slab decomposition but the scene uses it")
     # ghosts are taken from the face neighbours only: an interior slab thinner than the halo would leave clumps of the slab
     # after next within reach of the face without a ghost copy (equal-count slabs get thin where the bed is dense)
     widths = np.diff(edges)[1:-1]
@@ -84,8 +80,9 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
         a = dict(arrays)
         for k in _OWNER_KEYS:
             a[k] = arrays[k][owners_g].copy()
-        fam = a["familyID"]
-        fam[len(own):len(own) + len(gl) + len(gr)] = GHOST_FAMILY
+        ghost = np.zeros(len(owners_g), np.uint8)
+        ghost[len(own):len(own) + len(gl) + len(gr)] = 1
+        a["ownerGhost"] = ghost
         clumps_here = owners_g[:len(own) + len(gl) + len(gr)]
         sph_idx = _ranges(first_sphere[clumps_here], first_sphere[clumps_here + 1] - first_sphere[clumps_here])
         for k in _SPHERE_KEYS:
@@ -94,11 +91,6 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
         a["objOwner"] = new_id[arrays["objOwner"]].astype(np.uint32)
         if int(counts.get("nTri", 0)):
             a["ownerMesh"] = new_id[arrays["ownerMesh"]].astype(np.uint32)
-        flags = arrays["familyFlags"].copy()
-        flags[GHOST_FAMILY] |= FAMILY_GHOST_FLAG
-        masks = arrays["familyMasks"].copy()
-        masks[(1 + GHOST_FAMILY) * GHOST_FAMILY // 2 + GHOST_FAMILY] = 1  # ghost-ghost pairs are someone else's job
-        a["familyFlags"], a["familyMasks"] = flags, masks
         c = dict(counts)
         c.update({"nOwners": len(owners_g), "nOwnerClumps": len(clumps_here), "nSpheres": len(sph_idx)})
         out.append({"arrays": a, "counts": c, "n_own": len(own), "global_ids": own, "ghost_left_g": gl, "ghost_right_g": gr,
@@ -121,7 +113,7 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
 
 
 GHOST_STATE_KEYS = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ",
-                    "omgBarX", "omgBarY", "omgBarZ")
+                    "omgBarX", "omgBarY", "omgBarZ", "familyID")
 
 
 def exchange_host(parts, states):

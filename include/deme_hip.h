@@ -51,7 +51,7 @@ extern "C" {
  * reference JIT-compiles into integrateOwners (DEMIntegrationKernels.cu:26-33,
  * APIPublic.cpp:980-1011 SetFamilyFixed). */
 #define DEME_FAMILY_FIXED 1
-/* copy of a clump that another rank owns and integrates (slab decomposition): never integrated here */
+/* (retired: ghost copies are marked per owner, DemeScene.ownerGhost, and keep their own family) */
 #define DEME_FAMILY_GHOST 2
 #define DEME_FAMILY_PRESCRIBED 4 /* the family has a compiled motion prescription (deme_compile_prescriptions) */
 
@@ -130,6 +130,10 @@ typedef struct DemeScene {
     const uint32_t* ownerMesh;
     const float *triNode1, *triNode2, *triNode3; /* nTri*3 floats each, xyz interleaved */
     const uint16_t* triMaterialOffset;
+    /* per owner, may be NULL: 1 = a ghost copy of a clump that another rank owns and integrates (slab decomposition, SURVEY
+     * 8e).  A ghost keeps its TRUE family -- contact masks and family margins apply across a cut as inside a slab -- and is
+     * refreshed from its owner rank every step (family included); ghost-ghost pairs are left to the ranks that own them. */
+    const uint8_t* ownerGhost;
 } DemeScene;
 
 /* mutable owner state for download/upload round trips */

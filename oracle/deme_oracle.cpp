@@ -597,6 +597,7 @@ struct Sim {
     std::vector<uint16_t> locX, locY, locZ;
     std::vector<float> oriQw, oriQx, oriQy, oriQz, vX, vY, vZ, omgX, omgY, omgZ, aX, aY, aZ, alX, alY, alZ;
     std::vector<uint8_t> familyID;
+    std::vector<uint8_t> ghost;  // per owner: copy of a clump another rank owns (DemeScene.ownerGhost); empty = none
     std::vector<uint16_t> inertiaOff;
     std::vector<float> margin;
     // spheres
@@ -832,6 +833,8 @@ int detect(Sim& s) {
                 if (oA == oB)
                     continue;
                 const unsigned fB = s.familyID[oB];
+                if (!s.ghost.empty() && s.ghost[oA] && s.ghost[oB])
+                    continue;  // both are copies of clumps other ranks own: the pair is theirs
                 if (s.masks[mask_pair(fA, fB)] != 0)
                     continue;
                 double cx, cy, cz, depth;
@@ -1237,7 +1240,7 @@ void integrate(Sim& s) {
 #pragma omp parallel for schedule(static)
     for (int64_t oi = 0; oi < (int64_t)s.nOwners; oi++) {
         const uint32_t o = (uint32_t)oi;
-        if (s.famFlags[s.familyID[o]] & DEME_FAMILY_GHOST)
+        if (!s.ghost.empty() && s.ghost[o])
             continue;  // ghost of a clump another rank integrates (slab decomposition)
         const bool fixed = (s.famFlags[s.familyID[o]] & DEME_FAMILY_FIXED) != 0;
         V3f old_v{s.vX[o], s.vY[o], s.vZ[o]};
@@ -1647,6 +1650,8 @@ void* orc_sim_create(const DemeParams* p, const DemeScene* sc) {
     assign(s->tri1, sc->triNode1, (size_t)sc->nTri * 3), assign(s->tri2, sc->triNode2, (size_t)sc->nTri * 3),
         assign(s->tri3, sc->triNode3, (size_t)sc->nTri * 3);
     assign(s->triMat, sc->triMaterialOffset, (size_t)sc->nTri);
+    if (sc->ownerGhost)
+        s->ghost.assign(sc->ownerGhost, sc->ownerGhost + sc->nOwners);
     return s;
 }
 void orc_sim_destroy(void* h) { delete (Sim*)h; }
@@ -1798,7 +1803,7 @@ size_t orc_sim_inspect_region(void* h, uint32_t q, const float* lo, const float*
         const uint32_t o = perSphere ? s.ownerOfSphere[i] : (uint32_t)i;
         float v;
         const bool clumpOnly = q == DEME_INSPECT_CLUMP_MASS || q == DEME_INSPECT_CLUMP_KINETIC_ENERGY || q == DEME_INSPECT_CLUMP_VOLUME;
-        if ((s.famFlags[s.familyID[o]] & DEME_FAMILY_GHOST) || (clumpOnly && o >= s.nOwnerClumps)) {
+        if ((!s.ghost.empty() && s.ghost[o]) || (clumpOnly && o >= s.nOwnerClumps)) {
             v = identity;
         } else if (perSphere) {
             const uint16_t c = s.compOff[i];

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.test_decomp import GKEYS, build_global, gather_positions
+from tests.test_decomp import GKEYS, _global_rows, _two_family_bed, build_global, gather_positions
 
 pytestmark = pytest.mark.gpu
 
@@ -75,6 +75,33 @@ def test_library_halo_loop_equals_ordered_exchange(pkg, n_slabs):
             assert np.array_equal(sa[k], sb[k]), k
         assert int(a.counts().nContacts) == int(b_.counts().nContacts) > 100
         assert np.array_equal(a.wildcard(3), b_.wildcard(3))
+    g.close()
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_family_masks_and_margins_hold_across_cuts_on_the_gpu(pkg, orc, mode):
+    """three slabs through the library loop, two families that must not touch and a family margin: the union of the slabs'
+    contact lists equals the single-domain ORACLE list (ghost copies keep their family; ghost-ghost pairs are nobody's here)"""
+    b, p, sc, x = _two_family_bed(pkg, n=3000, seed=6, cd_freq=5)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=0.035)
+    ctxs = [_make(pkg, p, pt["scene"], mode) for pt in parts]
+    g = _group(pkg, ctxs, parts)
+    one = orc.make_sim(pkg, p, sc)
+    steps = 61  # detections at steps 0, 5, ..., 60: the lists below are of the same instant
+    g.step(steps), one.step(steps)
+    g.sync()
+    rows = np.unique(np.concatenate([_global_rows(pt, c) for pt, c in zip(parts, ctxs)]), axis=0)
+    a, bb, t, _ = one.contacts()
+    ref = np.unique(np.stack([a.astype(np.int64), bb.astype(np.int64), t.astype(np.int64)], 1), axis=0)
+    assert len(ref) > 300 and np.array_equal(rows, ref)
+    own, fam = np.asarray(b.arrays["ownerClumpBody"], np.int64), np.asarray(b.arrays["familyID"])
+    ss = ref[:, 2] == 1
+    assert ss.sum() > 100 and (fam[own[ref[ss, 0]]] == fam[own[ref[ss, 1]]]).all()
+    X, V = gather_positions(pkg, parts, ctxs, p, sc.nOwnerClumps)
+    st = one.download_state()
+    n = sc.nOwnerClumps
+    X1 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
+    assert np.abs(X - X1).max() < 2e-7
     g.close()
 
 

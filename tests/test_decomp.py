@@ -30,7 +30,10 @@ def test_decomposition_bookkeeping(pkg):
     for r, pt in enumerate(parts):
         a, c = pt["arrays"], pt["counts"]
         assert len(a["voxelID"]) == c["nOwners"] and len(a["ownerClumpBody"]) == c["nSpheres"] == 3 * c["nOwnerClumps"]
-        assert (a["familyID"][pt["n_own"]:c["nOwnerClumps"]] == pkg.decomp.GHOST_FAMILY).all()
+        gh = a["ownerGhost"]
+        assert gh[pt["n_own"]:c["nOwnerClumps"]].all() and not gh[:pt["n_own"]].any() and not gh[c["nOwnerClumps"]:].any()
+        gids = np.concatenate([pt["ghost_left_g"], pt["ghost_right_g"]])
+        assert (a["familyID"][pt["n_own"]:c["nOwnerClumps"]] == b.arrays["familyID"][gids]).all()  # ghosts keep their family
         assert a["objOwner"].min() >= c["nOwnerClumps"]  # walls renumbered behind the clumps
         if r + 1 < len(parts):  # what I send right is what my right neighbour receives from its left, same order
             nb = parts[r + 1]
@@ -88,6 +91,59 @@ def test_two_slabs_equal_single_domain_oracle(pkg, orc):
     cross = ((own[a] < parts[0]["n_own"]) != (own[bb] < parts[0]["n_own"])) & (t == 1)
     assert cross.sum() > 5
     assert np.abs(X - X1).max() < 2e-7 and np.abs(V - V1).max() < 2e-3
+
+
+def _two_family_bed(pkg, n=1600, seed=4, cd_freq=0):
+    """the bed of build_global with its clumps dealt into families 1 and 2 (checkerboard by id), contacts between the two
+    families disabled and an extra margin on family 2: the family tables are not trivial on either side of any cut"""
+    b = pkg.model.packed_bed(n, seed=seed, cd_freq=cd_freq, spacing_mult=2.5, init_vz=-0.4, aspect=(2.0, 1.0, 0.5))
+    fam = (1 + (np.arange(len(b.batches[0].xyz)) % 2)).astype(np.uint8)
+    b.batches[0].SetFamily(fam)
+    b.DisableContactBetweenFamilies(1, 2)
+    b.SetFamilyExtraMargin(2, 2e-4)
+    p, sc = b.Initialize()
+    x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+    return b, p, sc, x
+
+
+def _global_rows(part, sim):
+    a, bb, t, _ = sim.contacts()
+    sg = part["sphere_global"]
+    ss = t == 1
+    gA = sg[a]
+    gB = np.where(ss, sg[np.where(ss, bb, 0)], bb.astype(np.int64))
+    flip = ss & (gA > gB)
+    return np.stack([np.where(flip, gB, gA), np.where(flip, gA, gB), t.astype(np.int64)], 1)
+
+
+def test_family_masks_and_margins_hold_across_a_cut_oracle(pkg, orc):
+    """ghost copies keep their family (DemeScene.ownerGhost marks them): a contact mask between two families and a family's
+    extra margin act across a slab cut as inside a slab -- the union of the slabs' contact lists equals the single-domain list,
+    and it holds no pair of the masked families"""
+    b, p, sc, x = _two_family_bed(pkg)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=0.035)
+    steps = 60
+    sims = run_slabs(pkg, lambda pp, s: orc.make_sim(pkg, pp, s), parts, p, steps, host_exchange(pkg, parts))
+    one = orc.make_sim(pkg, p, sc)
+    one.step(steps)
+    rows = np.unique(np.concatenate([_global_rows(pt, s) for pt, s in zip(parts, sims)]), axis=0)
+    a, bb, t, _ = one.contacts()
+    ref = np.unique(np.stack([a.astype(np.int64), bb.astype(np.int64), t.astype(np.int64)], 1), axis=0)
+    assert len(ref) > 150 and np.array_equal(rows, ref)
+    own = np.asarray(b.arrays["ownerClumpBody"], np.int64)
+    fam = np.asarray(b.arrays["familyID"])
+    ss = ref[:, 2] == 1
+    fa, fb = fam[own[ref[ss, 0]]], fam[own[ref[ss, 1]]]
+    assert ss.sum() > 50 and not ((fa != fb)).any()  # families 1 and 2 never meet; same-family pairs do
+    # and pairs straddle the cuts
+    a0, b0, t0, _ = sims[0].contacts()
+    o0 = parts[0]["arrays"]["ownerClumpBody"]
+    assert (((o0[a0] < parts[0]["n_own"]) != (o0[b0] < parts[0]["n_own"])) & (t0 == 1)).sum() > 3
+    X, V = gather_positions(pkg, parts, sims, p, sc.nOwnerClumps)
+    st = one.download_state()
+    n = sc.nOwnerClumps
+    X1 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
+    assert np.abs(X - X1).max() < 2e-7
 
 
 def test_gloo_world2_halo_exchange(pkg):
