@@ -319,6 +319,10 @@ def main():
                     help="order in which the caller hands the clumps over (experiment)")
     ap.add_argument("--mesh-triangles", type=int, default=0,
                     help="BASELINE configs[3] flavour: put a wavy, fixed plate of about this many triangles under the bed")
+    ap.add_argument("--mesh-update-every", type=int, default=0,
+                    help="with --mesh-triangles: the plate is a DEFORMABLE mesh whose node coordinates the script rewrites every this "
+                         "many steps (a travelling ripple, through deme_update_tri_nodes = DEMTracker::UpdateMesh, the pattern of "
+                         "DEMdemo_FlexibleMesh.cpp:203-255); every update makes the next step start with a contact detection")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE configs[4] flavour: polydisperse spheres + a user cohesion model compiled at run time")
     ap.add_argument("--bin-multiple", type=float, default=4.0,
@@ -374,12 +378,14 @@ def main():
         b = build_config5(pkg, args.clumps * world, args.seed, args.cd_freq)
     else:
         b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order, bin_multiple=args.bin_multiple)
+    mesh_obj = None
     if args.mesh_triangles:
         lo, hi = b.user_box_min, b.user_box_max
         n_side = max(2, int(round((args.mesh_triangles / 2) ** 0.5)))
         v, f = pkg.model.plate_mesh(n_side, n_side, float(hi[0] - lo[0]) * 0.98, float(hi[1] - lo[1]) * 0.98, z=0.0, wavy=0.002)
         m = b.AddMeshObject(v, f, 0)
         m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 0.021))  # just under the lowest spheres of the lattice
+        mesh_obj = m
     p, sc = b.Initialize()
     halo, part = None, None
     group, extra_ctx, slab_parts = None, [], None
@@ -431,8 +437,30 @@ def main():
             group.attach(c_, pt, left=all_ctx[i - 1] if i else None, right=all_ctx[i + 1] if i + 1 < len(all_ctx) else None)
 
     host_enqueue = {"s": 0.0, "steps": 0}
+    mesh_state = {"since": 0, "updates": 0, "t": 0.0}
+
+    def deform_mesh():
+        # the plate's nodes in the mesh's own frame with a ripple that travels in x: what a co-simulated structural solver would
+        # hand back (DEMdemo_FlexibleMesh.cpp:216-250)
+        mesh_state["t"] += args.mesh_update_every * float(p.h)
+        v = mesh_obj.vertices.copy()
+        v[:, 2] += np.float32(2e-4) * np.sin(np.float32(40.0) * v[:, 0] - np.float32(2000.0 * mesh_state["t"])).astype(np.float32)
+        f = mesh_obj.faces
+        ctx.update_tri_nodes(v[f[:, 0]], v[f[:, 1]], v[f[:, 2]])
+        mesh_state["updates"] += 1
 
     def run(n):
+        if mesh_obj is not None and args.mesh_update_every > 0 and halo is None and group is None:
+            left = n
+            while left > 0:
+                k = min(left, args.mesh_update_every - mesh_state["since"])
+                ctx.step(k)
+                left -= k
+                mesh_state["since"] += k
+                if mesh_state["since"] >= args.mesh_update_every:
+                    deform_mesh()
+                    mesh_state["since"] = 0
+            return
         if group is not None:
             t_ = time.perf_counter()
             group.step(n)
@@ -555,7 +583,9 @@ def main():
                                 "cohesion model" if args.config5 else
                                 f"BASELINE configs[1]: {args.clumps} three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling"
                                 + (f"; one bed {world} times as long cut into {world} x-slabs (configs[2] flavour)" if world > 1 else ""))
-                               + (f" + {int(sc.nTri)}-triangle plate (configs[3] flavour)" if int(sc.nTri) else ""),
+                               + (f" + {int(sc.nTri)}-triangle plate (configs[3] flavour)" if int(sc.nTri) else "")
+                               + (f", a deformable mesh: nodes rewritten every {args.mesh_update_every} steps ({mesh_state['updates']} updates so far)"
+                                  if (int(sc.nTri) and args.mesh_update_every) else ""),
                    "clumps_total": total_clumps, "owners_this_rank": int(sc.nOwners), "spheres_this_rank": int(sc.nSpheres),
                    "contacts_this_rank": int(c.nContacts), "bin_sphere_touches": int(c.nBinSphereTouches),
                    "triangles": int(sc.nTri), "cd_every": args.cd_freq, "presettle_steps": args.presettle,

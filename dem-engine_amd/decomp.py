@@ -94,7 +94,7 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
         c = dict(counts)
         c.update({"nOwners": len(owners_g), "nOwnerClumps": len(clumps_here), "nSpheres": len(sph_idx)})
         out.append({"arrays": a, "counts": c, "n_own": len(own), "global_ids": own, "ghost_left_g": gl, "ghost_right_g": gr,
-                    "new_id": new_id, "edges": (edges[r], edges[r + 1]), "sphere_global": sph_idx.astype(np.int64),
+                    "new_id": new_id, "edges": (edges[r], edges[r + 1]), "all_edges": edges, "sphere_global": sph_idx.astype(np.int64),
                     "owner_global": owners_g})
     # send lists: what my neighbour holds as ghosts, in the neighbour's slot order (ascending global id on both sides)
     for r in range(n_ranks):
@@ -272,3 +272,244 @@ def redecompose_distributed(dist, rank, world, global_arrays, counts, part, stat
                                                    **{k: kw.pop(k) for k in ("persistent", "owner_wildcards", "sphere_wildcards") if k in kw}))
     g, parts, seeds = redecompose(global_arrays, counts, payloads, world, halo, decode_x, **kw)
     return g, parts[rank], seeds[rank]
+
+
+# ---- neighbour-to-neighbour migration ("at re-bin: migration lists") ---------------------------------------------
+# The all-gather above hands every rank the whole job's state: fine for tests and small jobs, O(N_total) per rank.  The functions
+# below re-decompose with FIXED slab edges and face-neighbour traffic only: a clump whose centre crossed a face moves to that
+# neighbour with its state, its template data and the history of its contacts; every rank then tells its neighbours which of its
+# clumps lie within the halo of the shared face (the new ghost sets, with their data).  Per rank the work and the traffic are
+# O(own clumps + boundary layer).  `transport(rank, to_left, to_right) -> (from_left, from_right)` moves picklable packets.
+_STATIC_OWNER_KEYS = ("inertiaPropOffsets",)
+
+
+def _first_sphere(part):
+    own = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
+    return np.searchsorted(own, np.arange(int(part["counts"]["nOwnerClumps"]) + 1))  # spheres are clump-major
+
+
+def _clump_packet(part, state, local_ids, first_sphere):
+    """everything another rank needs to hold these clumps (as its own or as ghosts): global ids, state, template data, spheres"""
+    ids = np.asarray(local_ids, np.int64)
+    a = part["arrays"]
+    nsph = first_sphere[ids + 1] - first_sphere[ids]
+    sidx = _ranges(first_sphere[ids], nsph)
+    return {"gid": np.asarray(part["owner_global"], np.int64)[ids], "state": {k: np.asarray(state[k])[ids].copy() for k in GHOST_STATE_KEYS},
+            "inertia": np.asarray(a["inertiaPropOffsets"])[ids].copy(), "nsph": nsph,
+            "comp": np.asarray(a["clumpComponentOffset"])[sidx].copy(), "mat": np.asarray(a["sphereMaterialOffset"])[sidx].copy(),
+            "sgid": np.asarray(part["sphere_global"], np.int64)[sidx]}
+
+
+def _cat_packets(pk):
+    pk = [q for q in pk if q is not None and len(q["gid"])]
+    if not pk:
+        return None
+    out = {k: np.concatenate([q[k] for q in pk]) for k in ("gid", "inertia", "nsph", "comp", "mat", "sgid")}
+    out["state"] = {k: np.concatenate([q["state"][k] for q in pk]) for k in GHOST_STATE_KEYS}
+    return out
+
+
+def _empty_packet(part):
+    a = part["arrays"]
+    return {"gid": np.zeros(0, np.int64), "inertia": np.zeros(0, np.asarray(a["inertiaPropOffsets"]).dtype), "nsph": np.zeros(0, np.int64),
+            "comp": np.zeros(0, np.asarray(a["clumpComponentOffset"]).dtype), "mat": np.zeros(0, np.asarray(a["sphereMaterialOffset"]).dtype),
+            "sgid": np.zeros(0, np.int64), "state": {k: np.zeros(0, abi.STATE_DTYPES[k]) for k in GHOST_STATE_KEYS}}
+
+
+def migration_packets(part, state, contacts, wildcards, edges, rank, x_own, flip_sign_wildcards=(0, 1, 2)):
+    """Phase 1, per rank.  x_own: current world x of the own clumps.  Returns (stay_ids, to_left, to_right, rows) where the two
+    packets carry the clumps that crossed the left / right face together with the history of every contact they take part in, and
+    rows = this rank's whole contact history in global sphere ids (gA, gB, type, wildcards; sphere pairs smaller id first)."""
+    n_own = part["n_own"]
+    x = np.asarray(x_own, np.float64)[:n_own]
+    go_l = x < edges[rank]
+    go_r = x >= edges[rank + 1]
+    fs = _first_sphere(part)
+    idA, idB, ctype = (np.asarray(v) for v in contacts[:3])
+    W = np.asarray(wildcards, np.float32).reshape(len(idA), -1)
+    sg = np.asarray(part["sphere_global"], np.int64)
+    ss = ctype == 1
+    gA = sg[idA]
+    gB = np.where(ss, sg[np.where(ss, idB, 0)], idB.astype(np.int64))
+    flip = ss & (gA > gB)
+    Wg = W.copy()
+    for k in flip_sign_wildcards:
+        if k < Wg.shape[1]:
+            Wg[flip, k] = -Wg[flip, k]
+    rows = {"gA": np.where(flip, gB, gA), "gB": np.where(flip, gA, gB), "type": ctype.astype(np.uint8), "wc": Wg}
+    local_owner = np.asarray(part["arrays"]["ownerClumpBody"], np.int64)
+    oA = local_owner[idA]
+    oB = np.where(ss, local_owner[np.where(ss, idB, 0)], -1)
+    out = []
+    for sel in (go_l, go_r):
+        ids = np.nonzero(sel)[0]
+        pk = _clump_packet(part, state, ids, fs) if len(ids) else _empty_packet(part)
+        moving = np.zeros(int(part["counts"]["nOwners"]) + 1, bool)
+        moving[ids] = True
+        involved = moving[oA] | np.where(oB >= 0, moving[np.maximum(oB, 0)], False)
+        pk["rows"] = {k: v[involved] for k, v in rows.items()}
+        out.append(pk)
+    stay = np.nonzero(~(go_l | go_r))[0]
+    return stay, out[0], out[1], rows
+
+
+def ghost_packets(own_packet, edges, rank, n_ranks, halo, x_own):
+    """Phase 2, per rank: of the clumps this rank owns now (own_packet, x_own their world x), those within `halo` of the left /
+    right face, as packets, plus their positions in own_packet (the send lists)."""
+    x = np.asarray(x_own, np.float64)
+    sel_l = np.nonzero(x < edges[rank] + halo)[0] if rank > 0 else np.zeros(0, np.int64)
+    sel_r = np.nonzero(x >= edges[rank + 1] - halo)[0] if rank + 1 < n_ranks else np.zeros(0, np.int64)
+
+    def sub(sel):
+        first = np.cumsum(own_packet["nsph"]) - own_packet["nsph"]
+        sidx = _ranges(first[sel], own_packet["nsph"][sel])
+        return {"gid": own_packet["gid"][sel], "inertia": own_packet["inertia"][sel], "nsph": own_packet["nsph"][sel],
+                "comp": own_packet["comp"][sidx], "mat": own_packet["mat"][sidx], "sgid": own_packet["sgid"][sidx],
+                "state": {k: own_packet["state"][k][sel] for k in GHOST_STATE_KEYS}}
+    return sel_l, sub(sel_l), sel_r, sub(sel_r)
+
+
+def assemble_part(old_part, own_packet, send_l, send_r, ghosts_l, ghosts_r, rows_list, flip_sign_wildcards=(0, 1, 2)):
+    """New local scene of a rank: [own | ghosts from the left | ghosts from the right | replicated owners (walls, meshes)], its
+    exchange lists, and the contact history to seed: every known row (own history first, then what arrived) whose spheres are
+    present and that involves an own clump.  Returns (part, seed = (idA, idB, type, wildcards))."""
+    a_old, c_old = old_part["arrays"], old_part["counts"]
+    n_cl_old, n_ow_old = int(c_old["nOwnerClumps"]), int(c_old["nOwners"])
+    packs = [own_packet, ghosts_l, ghosts_r]
+    n_own, n_gl, n_gr = (len(q["gid"]) for q in packs)
+    n_cl = n_own + n_gl + n_gr
+    extras = np.arange(n_cl_old, n_ow_old)
+    a = dict(a_old)
+    for k in GHOST_STATE_KEYS:
+        a[k] = np.concatenate([q["state"][k] for q in packs] + [np.asarray(a_old[k])[extras]]).astype(np.asarray(a_old[k]).dtype)
+    a["inertiaPropOffsets"] = np.concatenate([q["inertia"] for q in packs] + [np.asarray(a_old["inertiaPropOffsets"])[extras]]).astype(
+        np.asarray(a_old["inertiaPropOffsets"]).dtype)
+    ghost = np.zeros(n_cl + len(extras), np.uint8)
+    ghost[n_own:n_cl] = 1
+    a["ownerGhost"] = ghost
+    nsph = np.concatenate([q["nsph"] for q in packs]).astype(np.int64)
+    a["ownerClumpBody"] = np.repeat(np.arange(n_cl, dtype=np.uint32), nsph)
+    a["clumpComponentOffset"] = np.concatenate([q["comp"] for q in packs]).astype(np.asarray(a_old["clumpComponentOffset"]).dtype)
+    a["sphereMaterialOffset"] = np.concatenate([q["mat"] for q in packs]).astype(np.asarray(a_old["sphereMaterialOffset"]).dtype)
+    shift = n_cl - n_cl_old
+    a["objOwner"] = (np.asarray(a_old["objOwner"], np.int64) + shift).astype(np.uint32)
+    if int(c_old.get("nTri", 0)):
+        a["ownerMesh"] = (np.asarray(a_old["ownerMesh"], np.int64) + shift).astype(np.uint32)
+    c = dict(c_old)
+    c.update({"nOwners": n_cl + len(extras), "nOwnerClumps": n_cl, "nSpheres": int(nsph.sum())})
+    sphere_global = np.concatenate([q["sgid"] for q in packs]).astype(np.int64)
+    owner_global = np.concatenate([q["gid"] for q in packs] + [np.asarray(old_part["owner_global"], np.int64)[extras]])
+    part = {"arrays": a, "counts": c, "n_own": n_own, "global_ids": own_packet["gid"].copy(), "ghost_left_g": ghosts_l["gid"].copy(),
+            "ghost_right_g": ghosts_r["gid"].copy(), "edges": old_part["edges"], "all_edges": old_part.get("all_edges"),
+            "sphere_global": sphere_global, "owner_global": owner_global,
+            "send_left": np.asarray(send_l, np.uint32), "send_right": np.asarray(send_r, np.uint32),
+            "recv_left": np.arange(n_own, n_own + n_gl, dtype=np.uint32), "recv_right": np.arange(n_own + n_gl, n_cl, dtype=np.uint32)}
+    part["scene"] = abi.make_scene_struct(a, c)
+    # history: rows in global ids -> local ids of the new numbering
+    gA = np.concatenate([r["gA"] for r in rows_list])
+    gB = np.concatenate([r["gB"] for r in rows_list])
+    ty = np.concatenate([r["type"] for r in rows_list])
+    wc = np.concatenate([r["wc"] for r in rows_list]) if rows_list else np.zeros((0, 0), np.float32)
+    order = np.argsort(sphere_global, kind="stable")
+    sorted_g = sphere_global[order]
+
+    def loc(g):
+        pos = np.searchsorted(sorted_g, g)
+        pos = np.minimum(pos, len(sorted_g) - 1) if len(sorted_g) else pos
+        ok = (sorted_g[pos] == g) if len(sorted_g) else np.zeros(len(g), bool)
+        return np.where(ok, order[pos], -1)
+    ss = ty == 1
+    la = loc(gA)
+    lb = np.where(ss, loc(np.where(ss, gB, sphere_global[0] if len(sphere_global) else 0)), gB)
+    present = (la >= 0) & (lb >= 0)
+    own_of = a["ownerClumpBody"].astype(np.int64)
+    own_a = np.zeros(len(la), bool)
+    own_a[present] = own_of[la[present]] < n_own
+    own_b = np.zeros(len(la), bool)
+    sel = present & ss
+    own_b[sel] = own_of[lb[sel]] < n_own
+    keep = present & (own_a | own_b)
+    # one row per pair: the first occurrence wins (this rank's own history comes first in rows_list)
+    key = np.stack([gA[keep], gB[keep], ty[keep].astype(np.int64)], 1)
+    _, first = np.unique(key, axis=0, return_index=True)
+    first.sort()
+    la, lb, tk, w = la[keep][first], lb[keep][first], ty[keep][first], wc[keep][first].copy()
+    flip = (tk == 1) & (la > lb)
+    la2, lb2 = np.where(flip, lb, la), np.where(flip, la, lb)
+    for k in flip_sign_wildcards:
+        if k < w.shape[1]:
+            w[flip, k] = -w[flip, k]
+    return part, (la2.astype(np.uint32), lb2.astype(np.uint32), tk.astype(np.uint8), w)
+
+
+def migrate_neighbours(rank, n_ranks, part, state, contacts, wildcards, edges, halo, decode_x, transport,
+                       flip_sign_wildcards=(0, 1, 2)):
+    """One rank's re-decomposition with face-neighbour traffic only (fixed slab edges).  decode_x(state-like dict) -> world x per
+    owner.  transport(tag, to_left, to_right) -> (from_left, from_right) exchanges picklable packets with the face neighbours
+    (None at the ends of the chain).  Returns (new part, seed) for upload_scene + seed_contacts."""
+    x_all = decode_x(state)
+    stay, to_l, to_r, rows = migration_packets(part, state, contacts, wildcards, edges, rank, x_all, flip_sign_wildcards)
+    from_l, from_r = transport("migrants", to_l if rank > 0 else None, to_r if rank + 1 < n_ranks else None)
+    if (rank == 0 and len(to_l["gid"])) or (rank + 1 == n_ranks and len(to_r["gid"])):
+        raise ValueError("a clump left the decomposed range")
+    fs = _first_sphere(part)
+    own = _cat_packets([_clump_packet(part, state, stay, fs), from_l, from_r]) or _empty_packet(part)
+    x_own = decode_x(own["state"])
+    if ((x_own < edges[rank]) | (x_own >= edges[rank + 1])).any():
+        raise ValueError("a clump moved further than one slab between two re-decompositions")
+    sel_l, gp_l, sel_r, gp_r = ghost_packets(own, edges, rank, n_ranks, halo, x_own)
+    gh_l, gh_r = transport("ghosts", gp_l if rank > 0 else None, gp_r if rank + 1 < n_ranks else None)
+    rows_list = [rows] + [q["rows"] for q in (from_l, from_r) if q is not None]
+    return assemble_part(part, own, sel_l, sel_r, gh_l or _empty_packet(part), gh_r or _empty_packet(part), rows_list, flip_sign_wildcards)
+
+
+def torch_transport(dist, rank, n_ranks):
+    """transport for migrate_neighbours over torch.distributed point-to-point object messages (any backend): both directions
+    of the chain in two sweeps, even ranks sending first"""
+    def move(tag, to_left, to_right):
+        got = {"l": None, "r": None}
+
+        def send(obj, dst):
+            dist.send_object_list([obj], dst=dst)
+
+        def recv(src):
+            box = [None]
+            dist.recv_object_list(box, src=src)
+            return box[0]
+        for phase in (0, 1):
+            if rank % 2 == phase:
+                if rank + 1 < n_ranks:
+                    send(to_right, rank + 1)
+                    got["r"] = recv(rank + 1)
+            else:
+                if rank > 0:
+                    got["l"] = recv(rank - 1)
+                    send(to_left, rank - 1)
+        return got["l"], got["r"]
+    return move
+
+
+def migrate_neighbours_in_process(parts, states, contacts, wildcards, edges, halo, decode_x, flip_sign_wildcards=(0, 1, 2)):
+    """all slabs held by one process (tests, the one-GPU harness): the same per-rank functions with lists as the transport"""
+    n = len(parts)
+    phase1 = [migration_packets(parts[r], states[r], contacts[r], wildcards[r], edges, r, decode_x(states[r]), flip_sign_wildcards)
+              for r in range(n)]
+    owns, xs = [], []
+    for r in range(n):
+        stay, to_l, to_r, rows = phase1[r]
+        if (r == 0 and len(to_l["gid"])) or (r + 1 == n and len(to_r["gid"])):
+            raise ValueError("a clump left the decomposed range")
+        from_l = phase1[r - 1][2] if r > 0 else None
+        from_r = phase1[r + 1][1] if r + 1 < n else None
+        own = _cat_packets([_clump_packet(parts[r], states[r], stay, _first_sphere(parts[r])), from_l, from_r]) or _empty_packet(parts[r])
+        owns.append((own, from_l, from_r))
+        xs.append(decode_x(own["state"]))
+    gp = [ghost_packets(owns[r][0], edges, r, n, halo, xs[r]) for r in range(n)]
+    out = []
+    for r in range(n):
+        own, from_l, from_r = owns[r]
+        gh_l = gp[r - 1][3] if r > 0 else _empty_packet(parts[r])
+        gh_r = gp[r + 1][1] if r + 1 < n else _empty_packet(parts[r])
+        rows_list = [phase1[r][3]] + [q["rows"] for q in (from_l, from_r) if q is not None]
+        out.append(assemble_part(parts[r], own, gp[r][0], gp[r][2], gh_l, gh_r, rows_list, flip_sign_wildcards))
+    return [o[0] for o in out], [o[1] for o in out]

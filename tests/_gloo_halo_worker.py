@@ -138,6 +138,33 @@ def redecomposition_run(rank, world, dist, torch, pkg, orc):
         assert total_moved > 3, total_moved
         assert err < 1e-9, err  # 5e-6 if the history is not carried (tests/test_decomp.py)
         print(f"GLOO_REDECOMP_OK max|dx|={err:.3e} moved={total_moved}")
+    # ---- the same migration with face-neighbour traffic only (decomp.migrate_neighbours over point-to-point object messages):
+    # fixed edges, so the ownership it produces is compared with the edges, and the run with the same yardstick
+    def state_x(st):
+        return pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize,
+                                          p.l)[:, 0] + p.LBFX
+    sim_c = orc.make_sim(pkg, p, me["scene"])
+    exchange_and_step(sim_c, me, rank, dist, torch, STEPS_A)
+    cnt_c = sim_c.contacts()
+    W_c = np.stack([sim_c.wildcard(w) for w in range(int(p.nContactWildcards))], 1)
+    me3, seed3 = pkg.decomp.migrate_neighbours(rank, world, me, sim_c.download_state(), cnt_c, W_c, me["all_edges"], 0.035, state_x,
+                                               pkg.decomp.torch_transport(dist, rank, world))
+    sim3 = orc.make_sim(pkg, p, me3["scene"])
+    sim3.seed_contacts(*seed3)
+    exchange_and_step(sim3, me3, rank, dist, torch, STEPS_B)
+    exchange_and_step(sim_c, me, rank, dist, torch, STEPS_B)
+    moved3 = len(np.setdiff1d(me3["global_ids"], me["global_ids"]))
+    gathered = [None, None]
+    dist.all_gather_object(gathered, (me3["global_ids"], owned_x(sim3, me3), me["global_ids"], owned_x(sim_c, me), moved3))
+    if rank == 0:
+        Xn, Xo = np.zeros((nC, 3)), np.zeros((nC, 3))
+        for ids2, x2, ids1, x1, _ in gathered:
+            Xn[ids2], Xo[ids1] = x2, x1
+        assert sorted(np.concatenate([g[0] for g in gathered]).tolist()) == list(range(nC))
+        err = float(np.abs(Xn - Xo).max())
+        total_moved = sum(g[4] for g in gathered)
+        assert total_moved > 3 and err < 1e-9, (total_moved, err)
+        print(f"GLOO_NEIGHBOUR_MIGRATION_OK max|dx|={err:.3e} moved={total_moved}")
 
 
 if __name__ == "__main__":

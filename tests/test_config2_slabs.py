@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.test_decomp import GKEYS, _global_rows, _two_family_bed, build_global, gather_positions
+from tests.test_decomp import GKEYS, _global_rows, _sheared_bed, _state_x, _two_family_bed, build_global, gather_positions
 
 pytestmark = pytest.mark.gpu
 
@@ -103,6 +103,36 @@ def test_family_masks_and_margins_hold_across_cuts_on_the_gpu(pkg, orc, mode):
     X1 = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
     assert np.abs(X - X1).max() < 2e-7
     g.close()
+
+
+def test_neighbour_migration_between_slabs_on_the_gpu(pkg):
+    """a sheared bed in three slabs through the library loop: after 150 steps clumps have crossed the cuts; they move to the face
+    neighbour with state, template data and contact history (decomp.migrate_neighbours_in_process: the per-rank functions of the
+    distributed path, lists as the transport), new contexts take over, and 20 steps later every clump is where the old slabs,
+    simply continuing, put it -- to fp32 summation order (local numbering differs)"""
+    b, p, sc, x = _sheared_bed(pkg, 3000, 6)
+    halo = 0.035
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=halo)
+    ctxs = [_make(pkg, p, pt["scene"]) for pt in parts]
+    g = _group(pkg, ctxs, parts)
+    g.step(150)
+    g.sync()
+    states = [c.download_state() for c in ctxs]
+    cnts = [c.contacts() for c in ctxs]
+    Ws = [np.stack([c.wildcard(w) for w in range(4)], 1) for c in ctxs]
+    parts2, seeds = pkg.decomp.migrate_neighbours_in_process(parts, states, cnts, Ws, parts[0]["all_edges"], halo, _state_x(pkg, p))
+    moved = sum(len(np.setdiff1d(a["global_ids"], b_["global_ids"])) for a, b_ in zip(parts2, parts))
+    assert moved >= 3
+    ctxs2 = [_make(pkg, p, pt["scene"]) for pt in parts2]
+    for c, sd in zip(ctxs2, seeds):
+        c.seed_contacts(*sd)
+    g2 = _group(pkg, ctxs2, parts2)
+    g.step(20), g2.step(20)
+    g.sync(), g2.sync()
+    X, V = gather_positions(pkg, parts2, ctxs2, p, sc.nOwnerClumps)
+    X0, V0 = gather_positions(pkg, parts, ctxs, p, sc.nOwnerClumps)
+    assert np.abs(X - X0).max() < 1e-9 and np.abs(V - V0).max() < 1e-5, (np.abs(X - X0).max(), np.abs(V - V0).max())
+    g.close(), g2.close()
 
 
 @pytest.fixture(scope="module")

@@ -153,6 +153,7 @@ def test_gloo_world2_halo_exchange(pkg):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "GLOO_HALO_OK" in out.stdout
     assert "GLOO_REDECOMP_OK" in out.stdout  # clumps and their contact history migrated between the two processes
+    assert "GLOO_NEIGHBOUR_MIGRATION_OK" in out.stdout  # ... and again with face-neighbour messages only (migrate_neighbours)
 
 
 @pytest.mark.gpu
@@ -508,3 +509,57 @@ def test_redecomposition_carries_wildcard_arrays_and_persistent_marks(pkg, orc):
         listed = set(zip(a.tolist(), bb.tolist(), t.tolist()))
         assert set(zip(*[x.tolist() for x in s.persistent_contacts()])) <= listed
     assert after == before
+
+
+def _state_x(pkg, p):
+    def f(st):
+        X = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+        return X[:, 0] + p.LBFX
+    return f
+
+
+def _migration_run(pkg, make_sim, n_ranks, steps_a, steps_b, halo=0.035):
+    """steps_a steps on the initial slabs of a sheared bed, then a neighbour-to-neighbour migration (fixed edges: crossed clumps
+    move to the face neighbour with state, template data and contact history; ghost sets rebuilt from neighbour packets) and
+    steps_b more -- next to the SAME slabs simply continuing (the drift stays far below the halo, so they remain exact)"""
+    b, p, sc, x = _sheared_bed(pkg, 1600, 4)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, n_ranks, halo=halo)
+    edges = parts[0]["all_edges"]
+    sims = run_slabs(pkg, make_sim, parts, p, steps_a, host_exchange(pkg, parts))
+    nW = int(p.nContactWildcards)
+    states = [s.download_state() for s in sims]
+    cnts = [s.contacts() for s in sims]
+    Ws = [np.stack([s.wildcard(w) for w in range(nW)], 1) for s in sims]
+    parts2, seeds = pkg.decomp.migrate_neighbours_in_process(parts, states, cnts, Ws, edges, halo, _state_x(pkg, p))
+    moved = sum(len(np.setdiff1d(a["global_ids"], b_["global_ids"])) for a, b_ in zip(parts2, parts))
+    sims2 = []
+    for pt, sd in zip(parts2, seeds):
+        s = make_sim(p, pt["scene"])
+        s.seed_contacts(*sd)
+        sims2.append(s)
+    ex, ex2 = host_exchange(pkg, parts), host_exchange(pkg, parts2)
+    for _ in range(steps_b):
+        ex(sims), ex2(sims2)
+        for s in sims + sims2:
+            s.step(1)
+    X, V = gather_positions(pkg, parts2, sims2, p, sc.nOwnerClumps)
+    X0, V0 = gather_positions(pkg, parts, sims, p, sc.nOwnerClumps)
+    return parts, parts2, X, V, X0, V0, moved, sc
+
+
+def test_neighbour_migration_oracle(pkg, orc):
+    parts, parts2, X, V, X0, V0, moved, sc = _migration_run(pkg, lambda pp, s: orc.make_sim(pkg, pp, s), 3, 150, 20)
+    assert moved >= 3, moved  # clumps really changed rank
+    n = int(sc.nOwnerClumps)
+    own = np.sort(np.concatenate([pt["global_ids"] for pt in parts2]))
+    assert np.array_equal(own, np.arange(n))  # every clump owned exactly once afterwards
+    for r, pt in enumerate(parts2):  # ownership follows the fixed edges; ghost lists pair up
+        lo, hi = pt["edges"]
+        if r + 1 < len(parts2):
+            nb = parts2[r + 1]
+            assert np.array_equal(pt["global_ids"][pt["send_right"]], nb["ghost_left_g"])
+            assert np.array_equal(nb["global_ids"][nb["send_left"]], pt["ghost_right_g"])
+        assert pt["arrays"]["ownerGhost"][pt["n_own"]:pt["counts"]["nOwnerClumps"]].all()
+    # the history travelled: with it the two runs agree to fp32 summation order (different local numbering); without it a
+    # migrated clump's tangential springs would restart from zero (1e-6 m after 20 steps in the all-gather twin of this test)
+    assert np.abs(X - X0).max() < 1e-9 and np.abs(V - V0).max() < 1e-5
