@@ -155,19 +155,25 @@ def cpu_baseline(pkg, seed, cd_freq, budget_s=24.0):
     return out
 
 
-def pmc_traffic(n_contacts):
+def pmc_traffic(n_contacts, kernel):
     """roofline.traffic: HBM bytes per launch of the force kernel from the rocprofv3 PMC passes of this same
     command (FETCH_SIZE and WRITE_SIZE in separate passes, corrected with the factors calibrated in the same
     passes; profiles/<round>/traffic.json written by profiles/make_traffic.py).  Counters cannot be read from
-    inside the process, so the committed summary is quoted -- only when it was taken on the same workload."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-    if not os.path.exists(path):
+    inside the process, so the committed summary of the newest round is quoted -- only when it was taken on the same
+    kernel and workload."""
+    rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
+    if not rounds:
         return {"traffic": None}
+    path = os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")
     t = json.load(open(path))
+    if t.get("force_kernel", "k_calc_forces<0, 0>") != kernel:
+        return {"traffic": None, "traffic_note": f"profiles/{rounds[-1]}/traffic.json was taken on {t.get('force_kernel')}"}
     if abs(t["contacts"] - n_contacts) > 0.05 * n_contacts:
-        return {"traffic": None, "traffic_note": "profiles/r01/traffic.json was taken on a different workload"}
-    return {"traffic": t["traffic_bytes_per_launch"], "traffic_source": "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE, "
-            "WRITE_SIZE; calibrated)"}
+        return {"traffic": None, "traffic_note": f"profiles/{rounds[-1]}/traffic.json was taken on a different workload"}
+    lo = t["kernels"][kernel].get("traffic_lower_bound")
+    return {"traffic": t["traffic_bytes_per_launch"], "traffic_lower_bound": lo,
+            "traffic_source": f"profiles/{rounds[-1]}/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; 2 x FETCH + WRITE as the guide prescribes -- "
+                              "an upper bound here: the in-pass calibration shows gathers are not half-counted like streams; lower bound beside it)"}
 
 
 def pmc_calibration(torch):
@@ -607,7 +613,7 @@ def main():
                        "detections_in_timed_region": int(n_det)},
     }
     assert n_det >= 1 or args.adaptive != "off", "the timed region contains no contact detection: the phase alignment failed"
-    out["roofline"].update(pmc_traffic(int(c.nContacts)))
+    out["roofline"].update(pmc_traffic(int(c.nContacts), out["roofline"]["kernel"]))
     if os.environ.get("DEME_PMC_CALIB") == "1":
         pmc_calibration(torch)
     if rank == 0:

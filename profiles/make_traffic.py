@@ -18,28 +18,37 @@ import re
 import sys
 
 
-def read(path):
-    rows = {}
+def read(path, counter):
+    """{kernel: (calls, value of `counter`)} from a summarize_pmc.py table (any number of counter columns)"""
+    rows, cols = {}, None
     for line in open(path):
-        if line.startswith("#") or line.startswith("kernel"):
+        if line.startswith("#"):
             continue
-        m = re.match(r"(.+?)\s+(\d+)\s+([\d.]+)\s*$", line.rstrip())
-        if m:
-            rows[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
+        if line.startswith("kernel"):
+            cols = line.split()[2:]
+            continue
+        parts = line.rstrip().split()
+        n = len(cols)
+        vals = parts[-n:]
+        rows[" ".join(parts[:-(n + 1)])] = (int(parts[-(n + 1)]), float(vals[cols.index(counter)]))
     return rows
 
 
 def main():
     d, tag = sys.argv[1], sys.argv[2]
-    fetch, write = read(f"{d}/{tag}_fetch_pmc.txt"), read(f"{d}/{tag}_write_pmc.txt")
+    fetch, write = read(f"{d}/{tag}_fetch_pmc.txt", "FETCH_SIZE"), read(f"{d}/{tag}_write_pmc.txt", "WRITE_SIZE")
     bench = json.load(open(f"{d}/{tag}_bench.json"))
     nc = bench["config"]["contacts_this_rank"]
     out = {"contacts": nc, "source": [f"{tag}_fetch_pmc.txt", f"{tag}_write_pmc.txt"], "unit": "bytes per launch", "kernels": {}}
-    for k in ("k_calc_forces<0, 0>", "k_integrate<true>", "k_sweep"):
+    force = "k_forces_fast<0>" if "k_forces_fast<0>" in fetch else "k_calc_forces<0, 0>"
+    out["force_kernel"] = force
+    for k in (force, "k_integrate<true>", "k_sweep"):
+        if k not in fetch or k not in write:
+            continue
         f_kib, w_kib = fetch[k][1], write[k][1]
         out["kernels"][k] = {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "traffic_prescribed": int((2 * f_kib + w_kib) * 1024)}
     # force kernel: coalesced 16 B/lane streams read per contact = gather record (16) + wildcards (16)
-    fk = out["kernels"]["k_calc_forces<0, 0>"]
+    fk = out["kernels"][force]
     stream_read = nc * 32
     raw = fk["FETCH_SIZE_KiB"] * 1024
     fk["traffic_lower_bound"] = int(stream_read + max(0.0, raw - stream_read / 2) + fk["WRITE_SIZE_KiB"] * 1024)
@@ -47,6 +56,7 @@ def main():
     out["calibration"] = {"copy_1GiB_FETCH_KiB": fetch.get("__amd_rocclr_copyBuffer"), "copy_1GiB_WRITE_KiB": write.get("__amd_rocclr_copyBuffer"),
                           "gather_4Mi_rows_64B_FETCH_KiB": fetch.get("at::native::vectorized_gather_kernel<16, long>"),
                           "note": "copyBuffer rows average 3 calibration copies of 1 GiB with small state copies; see module docstring"}
+    out["integrator"] = out["kernels"].get("k_integrate<true>")
     json.dump(out, open(f"{d}/traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 
