@@ -55,6 +55,47 @@ __device__ inline f3 faxpy(float s, f3 a, f3 b) { return mk3(s * a.x + b.x, s * 
 // fall on distinct banks (a 64-byte stride would put every fourth lane on the same ones)
 #define DEME_REC_LDS_STRIDE 5
 
+// streamed-once data (gather records, history, contribution records) can bypass the caches' retention so that the owner records
+// several contacts share stay resident: non-temporal loads and stores for the streams (measured: force pass -2.3 %, the integrator that
+// gathers the B-side records afterwards -2 %)
+#ifndef DEME_FAST_NT
+#define DEME_FAST_NT 1
+#endif
+typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int nt_u2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ inline T stream_load(const T* p) {
+#if DEME_FAST_NT
+    static_assert(sizeof(T) == 16 || sizeof(T) == 8, "16- or 8-byte records");
+    T out;
+    if (sizeof(T) == 16) {
+        const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p));
+        __builtin_memcpy(&out, &v, 16);
+    } else {
+        const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p));
+        __builtin_memcpy(&out, &v, 8);
+    }
+    return out;
+#else
+    return *p;
+#endif
+}
+template <typename T>
+__device__ inline void stream_store(T* p, T v) {
+#if DEME_FAST_NT
+    if (sizeof(T) == 16) {
+        nt_u4 w;
+        __builtin_memcpy(&w, &v, 16);
+        __builtin_nontemporal_store(w, reinterpret_cast<nt_u4*>(p));
+    } else {
+        nt_u2 w;
+        __builtin_memcpy(&w, &v, 8);
+        __builtin_nontemporal_store(w, reinterpret_cast<nt_u2*>(p));
+    }
+#else
+    *p = v;
+#endif
+}
 __device__ inline float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ inline float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ inline float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -127,7 +168,7 @@ __device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, 
     float4* wcp = nullptr;
     if (MODEL == 0) {
         wcp = reinterpret_cast<float4*>(a.wc) + c;
-        hist = *wcp;
+        hist = stream_load(wcp);
     }
     const float4 cA = p.comp[ci.z & 0xFFFFu];
     const uint32_t matA = ci.z >> 16;
@@ -262,15 +303,17 @@ __device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, 
         const f3 tB = fcross(tot, rBv);  // = r_B x (-F)
         outA4 = make_float4(force.x, force.y, force.z, tA.x);
         outA2 = make_float2(tA.y, tA.z);
-        conb_store(a.conB4, a.conB2, c, make_float4(-force.x, -force.y, -force.z, tB.x), make_float2(tB.y, tB.z));
+        stream_store(a.conB4 + c, make_float4(-force.x, -force.y, -force.z, tB.x));
+        stream_store(a.conB2 + c, make_float2(tB.y, tB.z));
     } else {
         outA4 = make_float4(0, 0, 0, 0);
         outA2 = make_float2(0, 0);
-        conb_store(a.conB4, a.conB2, c, make_float4(0, 0, 0, 0), make_float2(0, 0));
+        stream_store(a.conB4 + c, make_float4(0, 0, 0, 0));
+        stream_store(a.conB2 + c, make_float2(0, 0));
         hist = make_float4(0, 0, 0, 0);  // _forceModelContactWildcardDestroy_
     }
     if (MODEL == 0)
-        *wcp = hist;
+        stream_store(wcp, hist);
 }
 
 // Block structure, halo passes and the in-workgroup reduction of the A side are those of calc_forces_block<MODEL, 0>
@@ -297,7 +340,7 @@ __global__ __launch_bounds__(DEME_FORCE_BLOCK, DEME_FAST_WAVES) void k_forces_fa
     float2 c2 = make_float2(0, 0);
     uint32_t s = 0, e = 0;
     if (valid) {
-        ci = a.info[c];
+        ci = stream_load(a.info + c);
         if (a.cDefer)
             inPass = a.cDefer[c] == a.pass;
         mine = inPass && ((ci.x >> 30) != DEME_KEY_CLASS_SM);
