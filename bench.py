@@ -422,12 +422,33 @@ def main():
         ctx.set_adaptive(bin_size=args.adaptive in ("bin", "both"), update_freq=args.adaptive in ("freq", "both"),
                          bin_observe=5, max_update_freq=200, freq_observe=3)
     if world > 1 and args.halo == "library" and not via_host:
-        # the library's own loop: RCCL communicator from a unique id that rank 0 generates and torch.distributed hands round
-        uid = [pkg.abi.halo_unique_id() if rank == 0 else None]
+        # the library's own loop: RCCL communicator from a unique id that rank 0 generates and torch.distributed hands round.
+        # Whatever goes wrong while setting it up (RCCL not loadable, communicator refused) is agreed on by all ranks, which then
+        # fall back to the Python loop over torch.distributed -- a scaling run should not die of a set-up problem.
+        ok = 1
+        try:
+            uid = [pkg.abi.halo_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: {e}", file=sys.stderr, flush=True)
+            uid, ok = [None], 0
         dist.broadcast_object_list(uid, src=0)
-        group = pkg.abi.HaloGroup(rank=rank, world=world, device=local_rank, unique_id=uid[0])
-        group.attach(ctx, part, left=rank - 1 if rank > 0 else None, right=rank + 1 if rank + 1 < world else None)
-    elif world > 1:
+        if uid[0] is None:
+            ok = 0
+        if ok:
+            try:
+                group = pkg.abi.HaloGroup(rank=rank, world=world, device=local_rank, unique_id=uid[0])
+                group.attach(ctx, part, left=rank - 1 if rank > 0 else None, right=rank + 1 if rank + 1 < world else None)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: library halo loop unavailable ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            if group is not None:
+                group.close()
+            group = None
+            args.halo = "python"
+    if world > 1 and group is None:
         halo = Halo(pkg, ctx, part, rank, world, torch, dist, via_host=via_host, overlap=not args.no_overlap)
         if not via_host:
             halo.probe_overlap()
