@@ -347,6 +347,52 @@ struct DEMMeshConnected {
     }
 };
 
+/// Per-contact information of the current contact list, one entry per contact pair (reference: ContactInfoContainer,
+/// DEM/Structs.h:1049-1107; filled by DEMSolver::GetContactDetailedInfo).  A field exists when the contact output content
+/// (SetContactOutputContent) asks for it -- the contact type and the owners' families always do; asking for an absent field
+/// throws like the reference's on_missing_key.
+class ContactInfoContainer {
+  public:
+    explicit ContactInfoContainer(unsigned int cnt_out_content) : m_content(cnt_out_content) {}
+    std::vector<std::string>& GetContactType() { return m_type; }
+    std::vector<float3>& GetPoint() { return need(CNT_POINT, "Point"), m_point; }
+    std::vector<bodyID_t>& GetAOwner() { return need(OWNER, "AOwner"), m_ownerA; }
+    std::vector<bodyID_t>& GetBOwner() { return need(OWNER, "BOwner"), m_ownerB; }
+    std::vector<bodyID_t>& GetAGeo() { return need(GEO_ID, "AGeo"), m_geoA; }
+    std::vector<bodyID_t>& GetBGeo() { return need(GEO_ID, "BGeo"), m_geoB; }
+    std::vector<uint8_t>& GetAOwnerFamily() { return m_famA; }
+    std::vector<uint8_t>& GetBOwnerFamily() { return m_famB; }
+    std::vector<float3>& GetForce() { return need(FORCE, "Force"), m_force; }
+    std::vector<float3>& GetTorque() { return need(TORQUE, "Torque"), m_torque; }
+    std::vector<float3>& GetNormal() { return need(NORMAL, "Normal"), m_normal; }
+    /// a contact wildcard by name (the reference's Get<float>(name))
+    std::vector<float>& GetWildcard(const std::string& name) {
+        auto it = m_wc.find(name);
+        if (it == m_wc.end())
+            missing(name);
+        return it->second;
+    }
+    size_t Size() const { return m_type.size(); }
+
+  private:
+    friend class DEMSolver;
+    void need(unsigned int bit, const char* key) const {
+        if (!(m_content & bit))
+            missing(key);
+    }
+    [[noreturn]] static void missing(const std::string& key) {
+        throw std::runtime_error("ContactInfoContainer does not have field: '" + key +
+                                 "', you may need to turn on the output of this field by correctly calling "
+                                 "SetContactOutputContent before Initialize().");
+    }
+    unsigned int m_content;
+    std::vector<std::string> m_type;
+    std::vector<float3> m_point, m_force, m_torque, m_normal;
+    std::vector<bodyID_t> m_ownerA, m_ownerB, m_geoA, m_geoB;
+    std::vector<uint8_t> m_famA, m_famB;
+    std::map<std::string, std::vector<float>> m_wc;
+};
+
 class DEMForceModel {
   public:
     FORCE_MODEL type = FORCE_MODEL::HERTZIAN;
@@ -1475,6 +1521,60 @@ class DEMSolver {
             o << "\n";
         }
         flush(outfilename, o);
+    }
+
+    /// GetContactDetailedInfo (API.h: the contact list with everything WriteContactFile would print, as vectors): contacts whose
+    /// force (incl. the torque-only part) is below force_thres are left out, like in the contact file
+    std::shared_ptr<ContactInfoContainer> GetContactDetailedInfo(float force_thres = DEME_TINY_FLOAT_HOST) const {
+        DEMSolver* self = const_cast<DEMSolver*>(this);  // queries download device state: logically const
+        const Snapshot sn = self->snapshot(true);
+        const unsigned fl = m_cnt_out_content;
+        auto out = std::make_shared<ContactInfoContainer>(fl);
+        const auto fam = self->owner_families();
+        std::vector<std::string> wnames(m_force_model->contact_wildcards.begin(), m_force_model->contact_wildcards.end());
+        for (size_t c = 0; c < sn.idA.size(); c++) {
+            const float3 F = {sn.F[3 * c], sn.F[3 * c + 1], sn.F[3 * c + 2]}, T = {sn.T[3 * c], sn.T[3 * c + 1], sn.T[3 * c + 2]};
+            const float3 tot = F + T;
+            if (std::sqrt(tot.x * tot.x + tot.y * tot.y + tot.z * tot.z) < force_thres)
+                continue;
+            const uint8_t ty = sn.type[c];
+            const uint32_t oA = m_keep.sphOwner[sn.idA[c]];
+            const uint32_t oB = ty == 1 ? m_keep.sphOwner[sn.idB[c]] : ty == 2 ? m_keep.triOwner[sn.idB[c]] : m_keep.objOwner[sn.idB[c]];
+            out->m_type.push_back(ty == 1 ? "SS" : ty == 2 ? "SM" : "SA");
+            out->m_famA.push_back((uint8_t)fam.at(oA)), out->m_famB.push_back((uint8_t)fam.at(oB));
+            if (fl & OWNER)
+                out->m_ownerA.push_back(oA), out->m_ownerB.push_back(oB);
+            if (fl & GEO_ID)
+                out->m_geoA.push_back(sn.idA[c]), out->m_geoB.push_back(sn.idB[c]);
+            if (fl & FORCE)
+                out->m_force.push_back(F);
+            const float3 loc = {sn.cpA[3 * c], sn.cpA[3 * c + 1], sn.cpA[3 * c + 2]};
+            float3 pnt = loc;
+            rotate(pnt, sn.q[oA]);
+            pnt = pnt + sn.com[oA];
+            if (fl & CNT_POINT)
+                out->m_point.push_back(pnt);
+            if (fl & NORMAL) {
+                const uint16_t cp = m_keep.sphComp[sn.idA[c]];
+                float3 d = {m_keep.rx[cp], m_keep.ry[cp], m_keep.rz[cp]};
+                rotate(d, sn.q[oA]);
+                const float3 n = pnt - (sn.com[oA] + d);
+                const float inv = 1.0f / std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+                out->m_normal.push_back({n.x * inv, n.y * inv, n.z * inv});
+            }
+            if (fl & TORQUE) {
+                float3 t = T;
+                const float4 qa = sn.q[oA];
+                rotate(t, {-qa.x, -qa.y, -qa.z, qa.w});
+                t = {loc.y * t.z - loc.z * t.y, loc.z * t.x - loc.x * t.z, loc.x * t.y - loc.y * t.x};
+                rotate(t, qa);
+                out->m_torque.push_back(t);
+            }
+            if (fl & CNT_WILDCARD)
+                for (size_t w = 0; w < sn.wc.size() && w < wnames.size(); w++)
+                    out->m_wc[wnames[w]].push_back(sn.wc[w][c]);
+        }
+        return out;
     }
 
     // ---- CSV readers (static members of the reference's DEMSolver, API.h:1153-1250)

@@ -86,6 +86,23 @@ int main(int argc, char** argv) {
     DEMSim.WriteClumpFile(dir + "/clumps.csv");
     DEMSim.SetContactOutputContent(OWNER | FORCE | CNT_WILDCARD);
     DEMSim.WriteContactFile(dir + "/contacts.csv");
+    {   // the same list as vectors (GetContactDetailedInfo): same rows as the file, absent fields throw
+        auto info = DEMSim.GetContactDetailedInfo();
+        double fsum = 0;
+        size_t nSS = 0;
+        for (size_t i = 0; i < info->Size(); i++) {
+            const float3 f = info->GetForce()[i];
+            fsum += std::sqrt((double)f.x * f.x + (double)f.y * f.y + (double)f.z * f.z);
+            nSS += info->GetContactType()[i] == "SS" && info->GetAOwner()[i] < info->GetBOwner()[i];
+        }
+        bool threw = false;
+        try {
+            info->GetPoint();
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        std::printf("CHECK contact_info %zu %zu %.9e %zu %d\n", info->Size(), nSS, fsum, info->GetWildcard("contact_age").size(), (int)threw);
+    }
     {   // the same through a tracker: geometry wildcards of the tracked batch, in geometry order
         auto tr = DEMSim.Track(batch);
         std::vector<float> g = tr->GetGeometryWildcardValues("charge");
