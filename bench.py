@@ -34,7 +34,7 @@ README_CLUMP_STEPS_PER_S = 1e6 * 1e6 / 3600.0  # reference README.md:48, two RTX
 HALO = 0.03  # ghost layer thickness [m]: two lattice spacings (clump reach 7.3 mm)
 
 
-def build_bed(pkg, n_clumps, seed, cd_freq, x_mult=1, order="lattice", bin_multiple=4.0):
+def build_bed(pkg, n_clumps, seed, cd_freq, x_mult=1, order="lattice", bin_multiple=5.0):
     b = pkg.model.packed_bed(n_clumps * x_mult, seed=seed, cd_freq=cd_freq, aspect=(1.0 * x_mult, 1.0, 0.05),
                              spacing_mult=3.0, jitter=0.05, bin_multiple=bin_multiple, init_vz=-1.0, order=order)
     b.SetExpandSafetyMultiplier(1.2)
@@ -331,7 +331,7 @@ def main():
                          "DEMdemo_FlexibleMesh.cpp:203-255); every update makes the next step start with a contact detection")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE configs[4] flavour: polydisperse spheres + a user cohesion model compiled at run time")
-    ap.add_argument("--bin-multiple", type=float, default=4.0,
+    ap.add_argument("--bin-multiple", type=float, default=5.0,
                     help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
     ap.add_argument("--adaptive", default="off", choices=["off", "bin", "freq", "both"],
                     help="let the engine tune the bin size / the update frequency on device timers during the pre-settling and "

@@ -92,6 +92,7 @@ struct MatPair {  // per (matA, matB): everything the Hertzian models derive fro
 struct DevParams {
     uint32_t nvXp2, nvYp2;
     uint32_t nbX, nbY, nbZ;
+    uint32_t mNbX, mNbXY;  // floor(2^32 / nbX), floor(2^32 / (nbX * nbY)) for fast_div (refresh_dev_params)
     double l, voxelSize, binSize;
     float LBFX, LBFY, LBFZ;
     float Gx, Gy, Gz;
@@ -118,6 +119,14 @@ struct DevParams {
     const void* tris;  // TriRec[nTri] (deme_mesh.h)
     uint32_t nTri;
 };
+
+// n / d for a run-time divisor without the ~35-instruction integer division: m = floor(2^32 / d) (0xFFFFFFFF for d = 1) gives
+// umulhi(n, m) in {q - 1, q}; one correction step makes it exact for every 32-bit n
+__host__ __device__ inline uint32_t fast_div_magic(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / d); }
+__device__ inline uint32_t fast_div(uint32_t n, uint32_t d, uint32_t m) {
+    const uint32_t q = __umulhi(n, m);
+    return (n - q * d >= d) ? q + 1u : q;
+}
 
 // contact key: sphere A (31 bits) | type class (2 bits) | B (31 bits).  Sorting keys ascending yields the
 // canonical list order: by A, then sphere-sphere / sphere-mesh / sphere-analytical, then B.  Spheres are

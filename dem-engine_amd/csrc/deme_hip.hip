@@ -252,6 +252,7 @@ void refresh_dev_params(deme_ctx* c) {
     const DemeParams& h = c->hp;
     d.nvXp2 = h.nvXp2, d.nvYp2 = h.nvYp2;
     d.nbX = h.nbX, d.nbY = h.nbY, d.nbZ = h.nbZ;
+    d.mNbX = fast_div_magic(h.nbX), d.mNbXY = fast_div_magic(h.nbX * h.nbY);
     d.l = h.l, d.voxelSize = h.voxelSize, d.binSize = h.binSize;
     d.LBFX = h.LBFX, d.LBFY = h.LBFY, d.LBFZ = h.LBFZ;
     d.Gx = h.Gx, d.Gy = h.Gy, d.Gz = h.Gz;
@@ -454,17 +455,15 @@ int do_detect(deme_ctx* c) {
                                             c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
                                             c->stream));
             sortedIdx = 1;
-            {
-                const unsigned nb = std::min<unsigned>(grid_for(P), 8192u);
-                if (int rc = ensure(c, c->binStat, 8192 * sizeof(uint2)))
-                    return rc;
-                hipLaunchKernelGGL(k_bin_stats, dim3(nb), dim3(256), 0, c->stream, c->incKeys[1].as<uint32_t>(), P, c->binStat.as<uint2>());
-                hipLaunchKernelGGL(k_bin_stats_final, dim3(1), dim3(256), 0, c->stream, c->binStat.as<uint2>(), nb,
-                                   c->ctr.as<DetectCounters>());
-            }
-            hipLaunchKernelGGL(k_sweep, dim3((grid_for(P, SW_T) + SW_WPB - 1) / SW_WPB), dim3(SW_T), 0, c->stream, c->dp,
+            const uint32_t nWin = (uint32_t)grid_for(P, SW_T);
+            if (int rc = ensure(c, c->binStat, (size_t)nWin * sizeof(uint2)))
+                return rc;
+            static_assert(SW_WPB == 1, "k_sweep writes one statistics record per window");
+            hipLaunchKernelGGL(k_sweep, dim3(nWin), dim3(SW_T), 0, c->stream, c->dp,
                                c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
                                c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
+                               c->ctr.as<DetectCounters>(), c->binStat.as<uint2>());
+            hipLaunchKernelGGL(k_bin_stats_final, dim3((nWin + 2047u) / 2048u), dim3(256), 0, c->stream, c->binStat.as<uint2>(), nWin,
                                c->ctr.as<DetectCounters>());
         }
         (void)sortedIdx;

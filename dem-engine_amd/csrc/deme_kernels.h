@@ -205,17 +205,20 @@ __global__ __launch_bounds__(256) void k_fill_incidence(const DevParams p, const
 #define SW_WPB 1  // windows per workgroup (measured: 1 -> 2.30 ms, 4 -> 2.35 ms, 16 -> 2.51 ms per detection)
 #endif
 #define SW_W (2 * SW_T)
-#define SW_OUT 512
-#define SW_FLUSH 256
+#define SW_OUT 256  // with the rest of SweepLDS: 19.6 KB, eight workgroups per CU
+#define SW_FLUSH 128
 
 struct SweepLDS {
     float4 f[SW_W];  // fp32 copy for the pair loop's pre-filter: position relative to the range's first entry, inflated radius
-    uint32_t owner[SW_W], sph[SW_W], bin[SW_W], fam[SW_W];
+    uint32_t owner[SW_W], sph[SW_W], bin[SW_W];
+    uint16_t fam[SW_W];  // family word: family | ghost bit (9 bits)
     uint32_t queue[SW_T / 64][128];  // per wavefront: pairs that passed the distance test, waiting for the exact test
     uint64_t out[SW_OUT];
     unsigned long long gBase;
+    unsigned long long headMask[SW_W / 64];  // per 64 entries of the range: which of them are first entries of a bin
     uint32_t nOut;
     uint32_t start, endIdx, giant;
+    uint32_t pop;  // largest bin population this workgroup has seen
 };
 
 // The cheap half of pair_test: different owners and centres closer than the sum of the inflated radii.
@@ -229,14 +232,18 @@ __device__ inline bool pair_near(double ax, double ay, double az, float ar, uint
 }
 
 // fp32 pre-filter of the pair loop: conservative (never rejects a pair the fp64 test accepts).  Positions are relative to the
-// corner of the bin the pair is tested in, so their fp32 rounding is ~1e-9 m for millimetre-to-centimetre bins.
+// corner of the bin the pair is tested in, so their fp32 rounding is ~1e-9 m for millimetre-to-centimetre bins.  The slack is a
+// sum of per-entry terms, so each entry carries its share in w (sweep_radius): 0.5e-6 m plus the fp32 rounding its coordinates can
+// carry at their magnitude (ulp = 1.2e-7 x |value|; taken 3x) -- conservative for metre-sized bins and bodies as well -- times
+// (1 + 1e-5) for the rounding of the test itself.
+__device__ inline float sweep_radius(float x, float y, float z, float r) {
+    const float mag = fabsf(x) + fabsf(y) + fabsf(z) + r;
+    return (r + 0.5e-6f + 4e-7f * mag) * 1.00001f;
+}
 __device__ inline bool pair_near_f(float4 a, uint32_t ao, float4 b, uint32_t bo) {
     const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    // slack: 1e-6 m plus the fp32 rounding the inputs can carry at their magnitude (ulp = 1.2e-7 x |value|; taken 3x), so that
-    // the filter stays conservative for metre-sized bins and bodies as well
-    const float mag = fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(b.x) + fabsf(b.y) + fabsf(b.z) + a.w + b.w;
-    const float rs = a.w + b.w + 1e-6f + 4e-7f * mag;
-    return (ao != bo) && (dx * dx + dy * dy + dz * dz <= rs * rs * 1.00001f);
+    const float rs = a.w + b.w;
+    return (ao != bo) & (dx * dx + dy * dy + dz * dz <= rs * rs);
 }
 
 __device__ inline bool pair_test(const DevParams& p, double ax, double ay, double az, float ar, uint32_t ao,
@@ -338,7 +345,8 @@ __device__ inline void sweep_flush(SweepLDS& L, uint32_t t, uint64_t* outKeys, u
 __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_t* __restrict__ keys,
                                                 const uint32_t* __restrict__ sphIds, uint32_t P,
                                                 const GeoRec* __restrict__ geo, const OwnerRec* __restrict__ owners,
-                                                uint64_t* __restrict__ outKeys, uint64_t cap, DetectCounters* ctr) {
+                                                uint64_t* __restrict__ outKeys, uint64_t cap, DetectCounters* ctr,
+                                                uint2* __restrict__ winStats) {
     __shared__ SweepLDS L;
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & 63u;
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             L.start = SW_W;
             L.endIdx = SW_W;
             L.giant = 0;
+            L.pop = 0;
         }
         __syncthreads();
         const uint32_t prev0 = (t == 0) ? (base == 0 ? DEME_NULL_BINID_DEV : keys[base - 1]) : L.bin[t - 1];
@@ -373,8 +382,11 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             atomicMin(&L.endIdx, t);  // the list ends inside my own window
         __syncthreads();
         const uint32_t start = L.start;
-        if (start >= SW_T)
-            continue;  // no bin begins here: an earlier workgroup owns everything in this window
+        if (start >= SW_T) {  // no bin begins here: an earlier workgroup owns everything in this window
+            if (t == 0)
+                winStats[win] = make_uint2(0u, 0u);
+            continue;
+        }
         uint32_t end = L.endIdx;
         uint32_t giantStart = SW_W;
         if (end >= SW_W) {
@@ -396,11 +408,14 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             // fp32 copy relative to the corner of the entry's OWN bin (pairs are only formed inside a bin, so both partners share
             // the origin): magnitudes stay below a bin edge plus a radius whatever the size of the domain
             const uint32_t bq = keys[base + start + q];
-            const uint32_t ix = bq % p.nbX, iy = (bq / p.nbX) % p.nbY, iz = bq / (p.nbX * p.nbY);
-            L.f[q] = make_float4((float)(g.x - (double)ix * p.binSize), (float)(g.y - (double)iy * p.binSize),
-                                 (float)(g.z - (double)iz * p.binSize), g.r);
+            const uint32_t nbXY = p.nbX * p.nbY;
+            const uint32_t iz = fast_div(bq, nbXY, p.mNbXY), rem = bq - iz * nbXY;
+            const uint32_t iy = fast_div(rem, p.nbX, p.mNbX), ix = rem - iy * p.nbX;
+            const float fx = (float)(g.x - (double)ix * p.binSize), fy = (float)(g.y - (double)iy * p.binSize),
+                        fz = (float)(g.z - (double)iz * p.binSize);
+            L.f[q] = make_float4(fx, fy, fz, sweep_radius(fx, fy, fz, g.r));
             L.owner[q] = g.owner, L.sph[q] = sph;
-            L.fam[q] = (p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family;
+            L.fam[q] = (uint16_t)((p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family);
         }
         // keys were loaded at offset `start`: shift so that L.bin[q] matches entry q of the range
         uint32_t b0 = DEME_NULL_BINID_DEV, b1 = DEME_NULL_BINID_DEV;
@@ -412,33 +427,36 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
         L.bin[t] = b0;
         L.bin[SW_T + t] = b1;
         __syncthreads();
+        // ---- bins of the range: entry q is a head if its key differs from its left neighbour's; one ballot per 64 entries
+        for (uint32_t q = t; q < SW_W; q += SW_T) {
+            const bool head = q < n_rng && (q == 0 || L.bin[q] != L.bin[q - 1]);
+            const unsigned long long hm = __ballot(head);
+            if (lane == 0)
+                L.headMask[q >> 6] = hm;
+        }
+        __syncthreads();
         // ---- balanced cyclic pairing, entries q = t and q = t + SW_T
         uint32_t* wq = L.queue[t >> 6];
         uint32_t qn = 0;  // entries in my wavefront's queue (wave-uniform)
+        uint32_t popMine = 0;
         for (uint32_t q = t; q < SW_W; q += SW_T) {
             const bool valid = q < n_rng;
-            uint32_t s = 0, n = 1, k = 0, myBin = DEME_NULL_BINID_DEV;
+            uint32_t s = 0, n = 1, k = 0;
             if (valid) {
-                myBin = L.bin[q];
-                uint32_t lo = 0, hi = q;  // first index with bin == myBin
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (L.bin[mid] < myBin)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                s = lo;
-                lo = q + 1, hi = n_rng;  // first index with bin > myBin
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (L.bin[mid] <= myBin)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                n = lo - s;
+                // my bin = [s, e): s the last head at or before q, e the first head after q (or the end of the range)
+                int ch = (int)(q >> 6);
+                unsigned long long mm = L.headMask[ch] & ((2ull << lane) - 1ull);
+                while (!mm)
+                    mm = L.headMask[--ch];  // entry 0 of the range is a head: terminates
+                s = (uint32_t)ch * 64u + (63u - (uint32_t)__clzll((long long)mm));
+                ch = (int)(q >> 6);
+                mm = (lane < 63u) ? (L.headMask[ch] & ~((2ull << lane) - 1ull)) : 0ull;
+                while (!mm && ++ch < (int)(SW_W / 64))
+                    mm = L.headMask[ch];
+                const uint32_t e = mm ? min((uint32_t)ch * 64u + (uint32_t)__ffsll((long long)mm) - 1u, n_rng) : n_rng;
+                n = e - s;
                 k = q - s;
+                popMine = max(popMine, n);
             }
             const uint32_t half = valid ? (n - 1) / 2 : 0;
             const uint32_t trips = half + ((valid && (n & 1u) == 0 && k < n / 2) ? 1u : 0u);
@@ -450,20 +468,17 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             // iteration had at least one survivor and paid for the exact test -- sqrt, divisions, contact-point bin): the
             // loop only runs the distance test and queues the survivors per wavefront; the exact test then runs on full
             // wavefronts of survivors.
-            for (uint32_t m = 1;; m++) {
-                const bool act = m <= trips;
-                if (!__any(act))
-                    break;
-                bool near = false;
-                uint32_t packed = 0;
-                if (act) {
-                    uint32_t qq = k + ((m <= half) ? m : n / 2);
-                    if (qq >= n)
-                        qq -= n;
-                    const uint32_t i = s + qq;
-                    near = pair_near_f(L.f[i], L.owner[i], mf4, mo);  // fp32, conservative; the exact fp64 test follows in phase 2
-                    packed = i | (q << 16);
-                }
+            // Two partners per trip of the loop, their four LDS reads issued together; the trip count is the wavefront's largest.
+            uint32_t tripsMax = trips;
+            for (int off = 32; off > 0; off >>= 1)
+                tripsMax = max(tripsMax, (uint32_t)__shfl_xor((int)tripsMax, off));
+            const uint32_t qSelf = valid ? q : 0u;  // an idle lane reads its own entry: same owner, never near
+            const uint32_t qTag = q << 16;
+            auto partner = [&](uint32_t m) {
+                const uint32_t qq = k + ((m <= half) ? m : n / 2);
+                return s + min(qq, qq - n);  // qq - n wraps to a huge value when qq < n
+            };
+            auto enqueue = [&](bool near, uint32_t packed) {
                 const unsigned long long nm = __ballot(near);
                 if (nm) {
                     if (near)
@@ -482,12 +497,26 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                         qn = rest;
                     }
                 }
+            };
+            for (uint32_t m = 1; m <= tripsMax; m += 2) {
+                const bool act0 = m <= trips, act1 = m + 1 <= trips;
+                const uint32_t i0 = act0 ? partner(m) : qSelf, i1 = act1 ? partner(m + 1) : qSelf;
+                const float4 f0 = L.f[i0], f1 = L.f[i1];
+                const uint32_t o0 = L.owner[i0], o1 = L.owner[i1];
+                // fp32, conservative; the exact fp64 test follows in phase 2
+                enqueue(act0 & pair_near_f(f0, o0, mf4, mo), i0 | qTag);
+                enqueue(act1 & pair_near_f(f1, o1, mf4, mo), i1 | qTag);
             }
         }
         if (qn) {
             sweep_confirm(p, L, geo, wq, qn, lane, outKeys, cap, ctr);
             qn = 0;
         }
+        for (int off = 32; off > 0; off >>= 1)
+            popMine = max(popMine, (uint32_t)__shfl_xor((int)popMine, off));
+        if (lane == 0 && popMine)
+            atomicMax(&L.pop, popMine);
+        uint32_t giantPop = 0;
         // ---- giant bin: SW_T x SW_T tiles, A tile in LDS, each thread holds one B entry
         if (giantStart < SW_W) {
             const uint32_t gs = base + giantStart;
@@ -501,6 +530,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                     hi = mid;
             }
             const uint32_t ge = lo;
+            giantPop = ge - gs;
             for (uint32_t ta = gs; ta < ge; ta += SW_T) {
                 __syncthreads();
                 const uint32_t na = min((uint32_t)SW_T, ge - ta);
@@ -508,7 +538,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                     const uint32_t sph = sphIds[ta + t];
                     const GeoRec g = geo[sph];
                     L.owner[t] = g.owner, L.sph[t] = sph;
-                    L.fam[t] = (p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family;
+                    L.fam[t] = (uint16_t)((p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family);
                 }
                 __syncthreads();
                 for (uint32_t tb = ta; tb < ge; tb += SW_T) {
@@ -542,6 +572,12 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             }
         }
         __syncthreads();
+        if (t == 0) {  // active bins and the largest population among the bins this window owns (k_bin_stats_final adds them up)
+            uint32_t heads = (giantStart < SW_W) ? 1u : 0u;
+            for (uint32_t ch = 0; ch < SW_W / 64; ch++)
+                heads += (uint32_t)__popcll(L.headMask[ch]);
+            winStats[win] = make_uint2(heads, max(L.pop, giantPop));
+        }
         if (L.nOut >= SW_FLUSH)  // uniform: read after the barrier
             sweep_flush(L, t, outKeys, cap, ctr);
     }
@@ -549,49 +585,25 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
     sweep_flush(L, t, outKeys, cap, ctr);
 }
 
-// Active-bin count and the largest bin population (numSpheresBinTouches statistics of
-// DEMCubContactDetection.cu:195-230; the population check feeds errOutBinSphNum).
-__global__ __launch_bounds__(256) void k_bin_stats(const uint32_t* __restrict__ keys, uint32_t P, uint2* __restrict__ perBlock) {
+// Active-bin count and the largest bin population (numSpheresBinTouches statistics of DEMCubContactDetection.cu:195-230; the
+// population check feeds errOutBinSphNum): k_sweep leaves one (bins, largest population) record per window, added up here.
+__global__ __launch_bounds__(256) void k_bin_stats_final(const uint2* __restrict__ perBlock, uint32_t nBlocks, DetectCounters* ctr) {
     __shared__ uint32_t sHeads[4], sPop[4];
     uint32_t heads = 0, pop = 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nWaves = (gridDim.x * 256u) >> 6;
-    // a wavefront takes 64 consecutive entries per iteration (coalesced, no workgroup barrier: a barrier per 256 entries made
-    // this kernel latency-bound, 89 us for 41 MB); a bin's population is the distance to the next head, found in the wave's
-    // head mask; a bin that runs past the wave's 64 entries looks further with a gallop + bisection over the sorted keys
-    for (uint32_t base = wave * 64u; base < P; base += nWaves * 64u) {
-        const uint32_t j = base + lane;
-        const bool valid = j < P;
-        const uint32_t b = valid ? keys[j] : 0xFFFFFFFFu;
-        const bool isHead = valid && (j == 0 || keys[j - 1] != b);
-        const unsigned long long m = __ballot(isHead);
-        if (isHead) {
-            heads++;
-            const unsigned long long mine = (lane < 63u) ? (m >> (lane + 1u)) : 0ull;
-            uint32_t len;
-            if (mine) {
-                len = (uint32_t)__ffsll((long long)mine);
-            } else {
-                const uint32_t end = min(base + 64u, P);
-                uint32_t lo = end, hi = P;  // first index >= end with key > b
-                if (lo < hi && keys[lo] == b) {
-                    uint32_t step = 32;
-                    while (lo + step < hi && keys[lo + step - 1] == b) {
-                        lo += step;
-                        step <<= 1;
-                    }
-                    hi = min(hi, lo + step);
-                    while (lo < hi) {
-                        const uint32_t mid = lo + ((hi - lo) >> 1);
-                        if (keys[mid] <= b)
-                            lo = mid + 1;
-                        else
-                            hi = mid;
-                    }
-                }
-                len = lo - j;
-            }
-            pop = max(pop, len);
+    // a workgroup per 2048 records, eight independent loads in flight per thread; one pair of atomics per workgroup (a few dozen
+    // in all: same-address atomics serialise at ~12 ns each)
+    {
+        const uint32_t i0 = blockIdx.x * 2048u;
+        uint2 v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t i = i0 + k * 256u + threadIdx.x;
+            v[k] = (i < nBlocks) ? perBlock[i] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            heads += v[k].x;
+            pop = max(pop, v[k].y);
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -603,32 +615,11 @@ __global__ __launch_bounds__(256) void k_bin_stats(const uint32_t* __restrict__ 
         sPop[threadIdx.x >> 6] = pop;
     }
     __syncthreads();
-    if (threadIdx.x == 0)  // one record per workgroup, reduced by k_bin_stats_final: thousands of same-address atomics would
-        perBlock[blockIdx.x] = make_uint2(sHeads[0] + sHeads[1] + sHeads[2] + sHeads[3],  // serialise at ~12 ns each
-                                          max(max(sPop[0], sPop[1]), max(sPop[2], sPop[3])));
-}
-
-__global__ __launch_bounds__(256) void k_bin_stats_final(const uint2* __restrict__ perBlock, uint32_t nBlocks, DetectCounters* ctr) {
-    __shared__ uint32_t sHeads[4], sPop[4];
-    uint32_t heads = 0, pop = 0;
-    for (uint32_t i = threadIdx.x; i < nBlocks; i += 256u) {
-        const uint2 v = perBlock[i];
-        heads += v.x;
-        pop = max(pop, v.y);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        heads += (uint32_t)__shfl_xor((int)heads, off);
-        pop = max(pop, (uint32_t)__shfl_xor((int)pop, off));
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        sHeads[threadIdx.x >> 6] = heads;
-        sPop[threadIdx.x >> 6] = pop;
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        ctr->nActiveBins = sHeads[0] + sHeads[1] + sHeads[2] + sHeads[3];
+        atomicAdd(&ctr->nActiveBins, sHeads[0] + sHeads[1] + sHeads[2] + sHeads[3]);
         const uint32_t m = max(max(sPop[0], sPop[1]), max(sPop[2], sPop[3]));
-        ctr->maxInBin = m > 1 ? m : 0u;
+        if (m > 1)
+            atomicMax(&ctr->maxInBin, m);
     }
 }
 

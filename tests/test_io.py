@@ -126,9 +126,10 @@ def test_writers_headers_and_round_trip(pkg, orc, tmp_path):
 
 
 @pytest.mark.gpu
-def test_restart_from_files_on_gpu(pkg, tmp_path):
+def test_restart_from_files_on_gpu(pkg, orc, tmp_path):
     """write clump + contact files after N steps, rebuild the scene from them (ReadClump*FromCsv, SetExistingContacts /
-    SetExistingContactWildcards -> deme_seed_contacts), continue, and compare with the uninterrupted run"""
+    SetExistingContactWildcards -> deme_seed_contacts), continue, and compare (a) with the oracle restarted from the same files
+    and seed list -- bit for bit (exact arithmetic mode) -- and (b) with the uninterrupted run, within the file format's rounding"""
     io = pkg.io
     b = pkg.model.packed_bed(1500, seed=5, cd_freq=0, spacing_mult=2.4, init_vz=-0.5, aspect=(1.0, 1.0, 0.6))
     p, sc = b.Initialize()
@@ -166,14 +167,22 @@ def test_restart_from_files_on_gpu(pkg, tmp_path):
     W = np.stack([np.r_[w_ss[n], w_sa[n]] for n in WC], 1)
     assert len(ida) == len(cnt[0])
     ctx2.seed_contacts(ida, idb, ty, W)
-    ctx2.step(1)
+    sim = orc.make_sim(pkg, p2, sc2)  # the oracle, restarted from the same files
+    sim.seed_contacts(ida, idb, ty, W)
+    ctx2.step(1), sim.step(1)
+    assert np.array_equal(ctx2.wildcard(3), sim.wildcard(3)) and all(np.array_equal(x, y) for x, y in zip(ctx2.contacts(), sim.contacts()))
     # the seeded history was found by the first detection: delta_time kept counting instead of restarting at h
     ctx.step(1)
     dt_a, dt_b = ctx.wildcard(3), ctx2.wildcard(3)
     assert len(dt_a) == len(dt_b) and (dt_b > 10 * p.h).sum() > 100
     assert np.allclose(dt_a, dt_b, rtol=1e-6, atol=1e-9)
-    ctx.step(99), ctx2.step(99)
-    sa, sb = ctx.download_state(), ctx2.download_state()
+    ctx.step(99), ctx2.step(99), sim.step(99)
+    sa, sb, so = ctx.download_state(), ctx2.download_state(), sim.download_state()
+    assert int(ctx2.counts().nContacts) == int(sim.counts().nContacts)
+    for k in ("voxelID", "locX", "locY", "locZ", "vX", "vY", "vZ", "oriQw", "oriQx", "omgBarX", "omgBarZ"):
+        assert np.array_equal(sb[k], so[k]), k
+    for w in range(len(WC)):
+        assert np.array_equal(ctx2.wildcard(w), sim.wildcard(w)), WC[w]
     n = int(sc.nOwnerClumps)
     Xa = pkg.model.decode_positions(sa["voxelID"], sa["locX"], sa["locY"], sa["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
     Xb = pkg.model.decode_positions(sb["voxelID"], sb["locX"], sb["locY"], sb["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
