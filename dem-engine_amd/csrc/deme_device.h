@@ -33,15 +33,20 @@ struct __attribute__((aligned(16))) OwnerRec {
     uint16_t inertiaOff;         // index into the mass-property table
     float qw, qx, qy, qz;        // orientation
     float vx, vy, vz;            // linear velocity
-    uint32_t family;             // bits 0-7 family id; bit 8: ghost copy of a clump another rank owns (OWNER_GHOST_BIT)
+    uint32_t family;             // bits 0-7 family id; bit 8: ghost copy of a clump another rank owns; bit 9: replicated owner (OWNER_*_BIT)
     float wx, wy, wz;            // body-frame angular velocity (omgBar)
     float margin;                // contact-detection margin (kT's marginSize)
 };
 static_assert(sizeof(OwnerRec) == 64, "OwnerRec must be 64 bytes");
 
 #define OWNER_GHOST_BIT 0x100u
+// a free body every slab keeps a replica of (a mesh or an analytical object that moves under contact forces): each slab sums the
+// contributions of the spheres it owns, the sums are added up across slabs every step, and every replica is integrated alike
+#define OWNER_SHARED_BIT 0x200u
+#define OWNER_FLAG_BITS (OWNER_GHOST_BIT | OWNER_SHARED_BIT)
 __host__ __device__ inline uint32_t fam_of(uint32_t familyWord) { return familyWord & 0xFFu; }
 __host__ __device__ inline bool ghost_of(uint32_t familyWord) { return (familyWord & OWNER_GHOST_BIT) != 0; }
+__host__ __device__ inline bool shared_of(uint32_t familyWord) { return (familyWord & OWNER_SHARED_BIT) != 0; }
 
 struct SphereRec {  // 8 bytes: ownerClumpBody + clumpComponentOffset + sphereMaterialOffset
     uint32_t owner;

@@ -447,10 +447,12 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
             r[0] = in.locCPB.x, r[1] = in.locCPB.y, r[2] = in.locCPB.z;
         }
         // _forceCollectInPlaceStrat_ -> per-side contributions
-        const f3 tot = force + torque_only_force;
+        f3 tot = force + torque_only_force;
         float4 c4;
         float2 c2;
-        const f3 nF = mk3(-force.x, -force.y, -force.z);
+        f3 nF = mk3(-force.x, -force.y, -force.z);
+        if (ghost_of(oA.family) && shared_of(oB.family))  // a ghost sphere on a replicated free body: the sphere's own rank adds
+            nF = mk3(0, 0, 0), tot = mk3(0, 0, 0);         // this contact to the body's sum (A's side is a ghost's: never used)
         if (a.world) {  // world-frame force and torque (R locCP) x F_tot per side
             const f3 tA = cross3(rot_apply(in.RA, in.locCPA), tot);
             outA4 = make_float4(force.x, force.y, force.z, tA.x);

@@ -300,9 +300,11 @@ __device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, 
         }
         const f3 tot = fadd(force, torque_only);
         const f3 tA = fcross(rAv, tot);
-        const f3 tB = fcross(tot, rBv);  // = r_B x (-F)
+        f3 tB = fcross(tot, rBv);  // = r_B x (-F)
         outA4 = make_float4(force.x, force.y, force.z, tA.x);
         outA2 = make_float2(tA.y, tA.z);
+        if (ghost_of(OA.family) && shared_of(OB.family))  // a ghost sphere on a replicated free body: the sphere's own rank adds it
+            force = mk3(0, 0, 0), tB = mk3(0, 0, 0);
         stream_store(a.conB4 + c, make_float4(-force.x, -force.y, -force.z, tB.x));
         stream_store(a.conB2 + c, make_float2(tB.y, tB.z));
     } else {

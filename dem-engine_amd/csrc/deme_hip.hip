@@ -101,6 +101,10 @@ struct deme_ctx {
     DevBuf userWc[4][8];  // [kind: owners, spheres, triangles, analytical][index]
     uint32_t nOwnerWc = 0, nGeoWc = 0;
     bool hasGhosts = false;  // a family carries DEME_FAMILY_GHOST: force passes can be split for the halo overlap
+    std::vector<uint32_t> hShared;  // replicated free owners (DemeScene.ownerGhost bit 1): their a / alpha are summed across slabs
+    DevBuf sharedIds, sharedBuf;
+    bool tailFused = true;
+    bool inGroupStep = false;
     hipStream_t haloStream = nullptr;
     hipEvent_t evStepDone = nullptr, evHaloDone = nullptr;
     bool overlapDetect = false;  // the step opened by deme_step_overlap_begin needs a detection first
@@ -809,7 +813,7 @@ int rebuild_presc_list(deme_ctx* c) {
     return DEME_OK;
 }
 
-int launch_integrate(deme_ctx* c, bool fused) {
+int launch_integrate(deme_ctx* c, bool fused, bool heavyDone = false) {
     ScopedTimer tm(c, "integrate");
     PrescArgs pa{nullptr, nullptr};
     if (c->prescFn) {
@@ -829,7 +833,8 @@ int launch_integrate(deme_ctx* c, bool fused) {
         }
     }
     if (fused) {
-        launch_reduce_heavy(c, true);
+        if (!heavyDone)
+            launch_reduce_heavy(c, true);
         hipLaunchKernelGGL(k_integrate<true>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
                            c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c), pa);
     } else {
@@ -1086,16 +1091,25 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     if (s->familyFlags)
         memcpy(c->hostFamFlags, s->familyFlags, DEME_NUM_FAMILIES);
     c->hasGhosts = false;
-    if (s->ownerGhost) {
-        for (size_t i = 0; i < nO && !c->hasGhosts; i++)
-            c->hasGhosts = s->ownerGhost[i] != 0;
-        if (c->hasGhosts) {
-            if (int rc = ensure(c, c->stage, std::max<size_t>(nO, 16)))
+    c->hShared.clear();
+    {   // per-owner flags: bit 0 ghost copy, bit 1 replicated free owner.  Always written: a context may be given a new scene
+        std::vector<uint8_t> fl(std::max<size_t>(nO, 16), 0);
+        if (s->ownerGhost)
+            for (size_t i = 0; i < nO; i++) {
+                fl[i] = s->ownerGhost[i] & 3u;
+                c->hasGhosts = c->hasGhosts || (fl[i] & 1u);
+                if (fl[i] & 2u)
+                    c->hShared.push_back((uint32_t)i);
+            }
+        if (int rc = ensure(c, c->stage, fl.size()))
+            return rc;
+        HIPCK(hipMemcpyAsync(c->stage.p, fl.data(), nO, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_set_ghost_bits, dim3(grid_for(nO)), dim3(256), 0, c->stream, (uint32_t)nO, c->owners.as<OwnerRec>(),
+                           c->stage.as<uint8_t>());
+        HIPCK(hipStreamSynchronize(c->stream));  // fl is a local
+        if (!c->hShared.empty())
+            if (int rc = upload(c, c->sharedIds, c->hShared.data(), c->hShared.size()))
                 return rc;
-            HIPCK(hipMemcpyAsync(c->stage.p, s->ownerGhost, nO, hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(k_set_ghost_bits, dim3(grid_for(nO)), dim3(256), 0, c->stream, (uint32_t)nO, c->owners.as<OwnerRec>(),
-                               c->stage.as<uint8_t>());
-        }
     }
     c->prescDirty = true;
     bool trivial = true;
@@ -1473,6 +1487,8 @@ int deme_get_adaptive_state(deme_ctx* c, double* binSize, uint32_t* cdUpdateFreq
 int deme_step(deme_ctx* c, uint32_t nsteps) {
     if (int rc = check_ready(c))
         return rc;
+    if (!c->hShared.empty())
+        return fail(c, DEME_ERR_INVALID, "this slab holds replicated free owners: step it through deme_halo_group_step, which adds their accelerations up across the slabs");
     for (uint32_t i = 0; i < nsteps; i++) {
         if (detection_due(c))
             if (int rc = detection_phase(c))
@@ -1494,29 +1510,40 @@ static int launch_family_rules(deme_ctx* c, const AccRec* accp) {
     return DEME_OK;
 }
 
-// rules + integration + bookkeeping of one step (after the force evaluation)
-static int step_tail(deme_ctx* c) {
-    {
-        bool fused = true;
-        if (c->rulesFn) {  // routineChecks(): applyFamilyChanges between forces and integration (dT.cpp:2437-2443)
-            const AccRec* accp = nullptr;
-            if (c->rulesNeedAcc) {
-                launch_full_reduction(c);
-                accp = c->acc.as<AccRec>();
-                fused = false;
-            }
-            if (int rc = launch_family_rules(c, accp))
-                return rc;
+// rules + integration + bookkeeping of one step (after the force evaluation), in two halves: everything that produces the
+// separately reduced a / alpha (heavy and replicated owners), then the integration.  A slab group adds the replicated owners'
+// sums up across slabs between the two (deme_halo_group_step).
+static int step_tail_pre(deme_ctx* c) {
+    bool fused = true;
+    if (c->rulesFn) {  // routineChecks(): applyFamilyChanges between forces and integration (dT.cpp:2437-2443)
+        const AccRec* accp = nullptr;
+        if (c->rulesNeedAcc) {
+            launch_full_reduction(c);
+            accp = c->acc.as<AccRec>();
+            fused = false;
         }
-        if (int rc = launch_integrate(c, fused))
+        if (int rc = launch_family_rules(c, accp))
             return rc;
-        c->stepsSinceCD++;
-        c->nSteps++;
-        c->timeElapsed += (double)c->hp.h;
     }
+    c->tailFused = fused;
+    if (fused)
+        launch_reduce_heavy(c, true);
+    return DEME_OK;
+}
+static int step_tail_post(deme_ctx* c) {
+    if (int rc = launch_integrate(c, c->tailFused, true))
+        return rc;
+    c->stepsSinceCD++;
+    c->nSteps++;
+    c->timeElapsed += (double)c->hp.h;
     if (c->evStepDone)
         HIPCK(hipEventRecord(c->evStepDone, c->stream));
     return DEME_OK;
+}
+static int step_tail(deme_ctx* c) {
+    if (int rc = step_tail_pre(c))
+        return rc;
+    return step_tail_post(c);
 }
 
 static bool detection_due(deme_ctx* c) {
@@ -1588,7 +1615,8 @@ int deme_step_overlap_begin(deme_ctx* c, int* detectionDue) {
     return launch_forces(c, 0);
 }
 
-int deme_step_overlap_end(deme_ctx* c) {
+// second half of an overlapped step up to (not including) the tail: the detection if one is due, the remaining force pass
+static int overlap_forces(deme_ctx* c) {
     if (int rc = check_ready(c))
         return rc;
     if (int rc = ensure_halo_stream(c))
@@ -1596,9 +1624,18 @@ int deme_step_overlap_end(deme_ctx* c) {
     HIPCK(hipStreamWaitEvent(c->stream, c->evHaloDone, 0));
     if (c->overlapDetect) {
         c->overlapDetect = false;
-        return deme_step(c, 1);
+        if (detection_due(c))
+            if (int rc = detection_phase(c))
+                return rc;
+        return launch_forces(c);
     }
-    if (int rc = launch_forces(c, 1))
+    return launch_forces(c, 1);
+}
+
+int deme_step_overlap_end(deme_ctx* c) {
+    if (c && !c->hShared.empty() && !c->inGroupStep)
+        return fail(c, DEME_ERR_INVALID, "this slab holds replicated free owners: step it through deme_halo_group_step, which adds their accelerations up across the slabs");
+    if (int rc = overlap_forces(c))
         return rc;
     return step_tail(c);
 }
@@ -1623,6 +1660,7 @@ struct RcclApi {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
 };
@@ -1654,15 +1692,17 @@ RcclApi* rccl_api() {
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.Send = (decltype(api.Send))sym("ncclSend");
     api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
     if (!ok) {
-        api.err = "librccl.so lacks one of the point-to-point entry points";
+        api.err = "librccl.so lacks one of the entry points (send / recv / all-reduce)";
         return &api;
     }
     api.lib = h;
     return &api;
 }
 constexpr int kNcclUint8 = 1;  // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;  // rccl.h: ncclFloat32 = 7; ncclSum = 0
 
 struct HaloSide {
     int peerRank = -1;          // rank that holds the neighbouring slab, -1: none (end of the chain)
@@ -1674,6 +1714,7 @@ struct HaloSlab {
     deme_ctx* ctx = nullptr;
     HaloSide side[2];  // 0 left, 1 right
     hipEvent_t evPacked = nullptr;
+    hipEvent_t evAcc = nullptr;  // this slab's share of the replicated owners' a / alpha is in its buffer
 };
 }  // namespace
 
@@ -1684,8 +1725,11 @@ struct deme_halo_group {
     hipStream_t xstream = nullptr;  // the exchange runs here: after every slab's pack, before every slab's unpack
     hipEvent_t evExchanged = nullptr;
     std::vector<HaloSlab> slabs;
+    uint32_t nShared = 0;            // replicated free owners (the same on every slab): a / alpha summed across slabs every step
+    void* sharedSum = nullptr;       // nShared x AccRec
+    hipEvent_t evReduced = nullptr;
     std::string err;
-    uint64_t nExchanges = 0, bytesPerStep = 0;
+    uint64_t nExchanges = 0, nReductions = 0, bytesPerStep = 0;
     double hostUs[4] = {0, 0, 0, 0};  // host time spent enqueuing: interior pass, pack, RCCL group, unpack + boundary pass + integration
 };
 
@@ -1764,7 +1808,13 @@ void deme_halo_group_destroy(deme_halo_group* g) {
                     hipFree(p);
         if (s.evPacked)
             hipEventDestroy(s.evPacked);
+        if (s.evAcc)
+            hipEventDestroy(s.evAcc);
     }
+    if (g->sharedSum)
+        hipFree(g->sharedSum);
+    if (g->evReduced)
+        hipEventDestroy(g->evReduced);
     if (g->comm)
         g->api->CommDestroy(g->comm);
     if (g->evExchanged)
@@ -1788,6 +1838,21 @@ int deme_halo_group_attach(deme_halo_group* g, deme_ctx* c, int leftRank, deme_c
     HaloSlab s;
     s.ctx = c;
     GHIP(hipEventCreateWithFlags(&s.evPacked, hipEventDisableTiming));
+    GHIP(hipEventCreateWithFlags(&s.evAcc, hipEventDisableTiming));
+    {   // replicated free owners: the same list, in the same order, on every slab of every rank (decomp.py keeps them so)
+        const uint32_t n = (uint32_t)c->hShared.size();
+        if (!g->slabs.empty() && n != g->nShared)
+            return gfail(g, DEME_ERR_INVALID, "attach: this slab has %u replicated free owners, the slabs before it %u", n, g->nShared);
+        g->nShared = n;
+        if (n) {
+            if (ensure(c, c->sharedBuf, (size_t)n * sizeof(AccRec)))
+                return gfail(g, c->lastStatus, "attach: %s", c->err.c_str());
+            if (!g->sharedSum) {
+                GHIP(hipMalloc(&g->sharedSum, (size_t)n * sizeof(AccRec)));
+                GHIP(hipEventCreateWithFlags(&g->evReduced, hipEventDisableTiming));
+            }
+        }
+    }
     const int peer[2] = {leftRank, rightRank};
     deme_ctx* local[2] = {leftLocal, rightLocal};
     const uint32_t* sIds[2] = {sendLeft, sendRight};
@@ -1899,6 +1964,41 @@ static int halo_exchange(deme_halo_group* g) {
     return DEME_OK;
 }
 
+// Second half of a step when the scene has replicated free owners (a mesh or an analytical body that moves under contact forces,
+// kept on every slab): every slab finishes its force passes and reduces its own spheres' contributions to those owners; the
+// per-slab sums are added up -- first across the slabs of this process, in slab order, then across the ranks with one all-reduce --
+// and every slab integrates its replica with the same total.  (the only all-reduce of the path.)
+static int shared_tail(deme_halo_group* g) {
+    const uint32_t n = g->nShared, n4 = 2 * n;
+    for (auto& s : g->slabs) {
+        deme_ctx* c = s.ctx;
+        if (int rc = overlap_forces(c))
+            return gfail(g, rc, "step (boundary forces): %s", c->err.c_str());
+        if (int rc = step_tail_pre(c))
+            return gfail(g, rc, "step (reductions): %s", c->err.c_str());
+        hipLaunchKernelGGL(k_shared_pack, dim3(grid_for(n4)), dim3(256), 0, c->stream, n, c->sharedIds.as<uint32_t>(), c->acc.as<AccRec>(),
+                           c->sharedBuf.as<float4>());
+        GHIP(hipEventRecord(s.evAcc, c->stream));
+        GHIP(hipStreamWaitEvent(g->xstream, s.evAcc, 0));
+    }
+    GHIP(hipMemcpyAsync(g->sharedSum, g->slabs[0].ctx->sharedBuf.p, (size_t)n * sizeof(AccRec), hipMemcpyDeviceToDevice, g->xstream));
+    for (size_t k = 1; k < g->slabs.size(); k++)
+        hipLaunchKernelGGL(k_shared_add, dim3(grid_for(n4)), dim3(256), 0, g->xstream, n4, (float4*)g->sharedSum,
+                           g->slabs[k].ctx->sharedBuf.as<float4>());
+    GNCCL(g->api->AllReduce(g->sharedSum, g->sharedSum, (size_t)n * 8, kNcclFloat32, kNcclSum, g->comm, g->xstream));
+    GHIP(hipEventRecord(g->evReduced, g->xstream));
+    g->nReductions++;
+    for (auto& s : g->slabs) {
+        deme_ctx* c = s.ctx;
+        GHIP(hipStreamWaitEvent(c->stream, g->evReduced, 0));
+        hipLaunchKernelGGL(k_shared_unpack, dim3(grid_for(n4)), dim3(256), 0, c->stream, n, c->sharedIds.as<uint32_t>(), c->acc.as<AccRec>(),
+                           (const float4*)g->sharedSum);
+        if (int rc = step_tail_post(c))
+            return gfail(g, rc, "step (integration): %s", c->err.c_str());
+    }
+    return DEME_OK;
+}
+
 // nsteps time steps of every slab this process holds, each with its ghost exchange: interior force pass on the compute streams
 // while the records travel, the ghost-dependent pass and the integration after they have arrived.  Asynchronous like deme_step.
 int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
@@ -1914,9 +2014,17 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
         if (int rc = halo_exchange(g))
             return rc;
         const double t1 = now_us();
-        for (auto& s : g->slabs)
-            if (int rc = deme_step_overlap_end(s.ctx))
-                return gfail(g, rc, "step (boundary forces, integration): %s", s.ctx->err.c_str());
+        if (g->nShared == 0) {
+            for (auto& s : g->slabs) {
+                s.ctx->inGroupStep = true;
+                const int rc = deme_step_overlap_end(s.ctx);
+                s.ctx->inGroupStep = false;
+                if (rc)
+                    return gfail(g, rc, "step (boundary forces, integration): %s", s.ctx->err.c_str());
+            }
+        } else if (int rc = shared_tail(g)) {
+            return rc;
+        }
         g->hostUs[3] += now_us() - t1;
     }
     return DEME_OK;

@@ -1071,7 +1071,8 @@ __global__ __launch_bounds__(256) void k_owner_ranges(const DevParams p, uint32_
                 atomicOr(&blockMode[c / DEME_FORCE_BLOCK], d ? 2u : 1u);
         }
     }
-    const bool hv = (a1 - a0) + (b1 - b0) > DEME_HEAVY_THRESHOLD;
+    // a replicated free owner always takes the separate reduction: its sum has to exist in memory for the cross-slab addition
+    const bool hv = (a1 - a0) + (b1 - b0) > DEME_HEAVY_THRESHOLD || shared_of(fw);
     heavy[o] = hv ? 1 : 0;
     if (hv) {
         const unsigned int slot = atomicAdd(&rc->nHeavy, 1u);
@@ -1265,7 +1266,7 @@ __global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owner
         if (s.omgBarX) r.wx = s.omgBarX[o];
         if (s.omgBarY) r.wy = s.omgBarY[o];
         if (s.omgBarZ) r.wz = s.omgBarZ[o];
-        if (s.familyID) r.family = (r.family & OWNER_GHOST_BIT) | s.familyID[o];
+        if (s.familyID) r.family = (r.family & OWNER_FLAG_BITS) | s.familyID[o];
         if (s.inertiaPropOffsets) r.inertiaOff = s.inertiaPropOffsets[o];
         if (s.aX) a.ax = s.aX[o];
         if (s.aY) a.ay = s.aY[o];
@@ -1303,13 +1304,35 @@ __global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owner
 __global__ __launch_bounds__(256) void k_change_family(OwnerRec* __restrict__ owners, uint32_t n, uint32_t from, uint32_t to) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o < n && fam_of(owners[o].family) == from)
-        owners[o].family = (owners[o].family & OWNER_GHOST_BIT) | to;
+        owners[o].family = (owners[o].family & OWNER_FLAG_BITS) | to;
 }
 
 __global__ __launch_bounds__(256) void k_set_ghost_bits(uint32_t n, OwnerRec* __restrict__ owners, const uint8_t* __restrict__ flag) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o < n)
-        owners[o].family = fam_of(owners[o].family) | (flag[o] ? OWNER_GHOST_BIT : 0u);
+        owners[o].family = fam_of(owners[o].family) | ((flag[o] & 1u) ? OWNER_GHOST_BIT : 0u) | ((flag[o] & 2u) ? OWNER_SHARED_BIT : 0u);
+}
+
+// cross-slab addition of the replicated free owners' a / alpha: rows of the owners' AccRec to and from a contiguous buffer, and
+// the sum of the buffers of the slabs one process holds (slab order: the same on every rank)
+__global__ __launch_bounds__(256) void k_shared_pack(uint32_t n, const uint32_t* __restrict__ ids, const AccRec* __restrict__ acc, float4* __restrict__ buf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n)
+        return;
+    buf[i] = reinterpret_cast<const float4*>(acc + ids[i >> 1])[i & 1u];
+}
+__global__ __launch_bounds__(256) void k_shared_unpack(uint32_t n, const uint32_t* __restrict__ ids, AccRec* __restrict__ acc, const float4* __restrict__ buf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n)
+        return;
+    reinterpret_cast<float4*>(acc + ids[i >> 1])[i & 1u] = buf[i];
+}
+__global__ __launch_bounds__(256) void k_shared_add(uint32_t n4, float4* __restrict__ into, const float4* __restrict__ other) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4)
+        return;
+    const float4 a = into[i], b = other[i];
+    into[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
 // SetFamilyClumpMaterial / SetFamilyMeshMaterial: geometries whose owner is of `family` take `material`
@@ -1409,7 +1432,7 @@ __global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n, const uint32_t*
     const GhostRec g = buf[i];
     OwnerRec* r = owners + ids[i];
     // the copy follows its owner rank's record, family included (on-the-fly family changes travel with the state)
-    r->family = (r->family & OWNER_GHOST_BIT) | g.family;
+    r->family = (r->family & OWNER_FLAG_BITS) | g.family;
     r->voxelID = g.voxelID, r->locX = g.locX, r->locY = g.locY, r->locZ = g.locZ;
     r->qw = g.qw, r->qx = g.qx, r->qy = g.qy, r->qz = g.qz;
     r->vx = g.vx, r->vy = g.vy, r->vz = g.vz, r->wx = g.wx, r->wy = g.wy, r->wz = g.wz;

@@ -42,21 +42,25 @@ def _ranges(starts, counts):
     return np.repeat(starts - first, counts) + np.arange(total, dtype=np.int64)
 
 
-def decompose(arrays, counts, clump_x, n_ranks, halo):
+def decompose(arrays, counts, clump_x, n_ranks, halo, shared_free=False):
     """Split a global scene.  clump_x: x of every clump centre (world frame).  Returns one dict per rank:
-    arrays, counts, n_own, global_ids (own clumps' global owner ids), send/recv id lists (local owner ids)."""
+    arrays, counts, n_own, global_ids (own clumps' global owner ids), send/recv id lists (local owner ids).
+    shared_free: allow replicated owners that move under contact forces (see below); the slabs must then be stepped by
+    abi.HaloGroup (deme_halo_group_step), which adds their accelerations up across the slabs every step."""
     n_clumps = int(counts["nOwnerClumps"])
     n_owners = int(counts["nOwners"])
-    # Meshes are replicated on every rank like the analytical owners.  That is exact when a mesh's motion does not depend on
-    # the contact forces it receives (fixed, or every velocity component dictated by a prescription): each rank applies
-    # the mesh's force to its own clumps, and the mesh's own a/alpha -- which would need an all-reduce -- are never used.
-    if int(counts.get("nTri", 0)):
-        flags = np.asarray(arrays["familyFlags"])
-        mesh_owners = np.unique(np.asarray(arrays["ownerMesh"]))
-        free = [int(o) for o in mesh_owners if not (flags[arrays["familyID"][o]] & (abi.FAMILY_FIXED | abi.FAMILY_PRESCRIBED))]
-        if free:
-            raise ValueError(f"mesh owner(s) {free} move under contact forces: only fixed or prescribed meshes can be replicated "
-                             "across slabs (a free mesh would need an all-reduce of its accelerations every step)")
+    # Analytical owners and meshes are replicated on every rank.  That is exact as it stands when the owner's motion does not
+    # depend on the contact forces it receives (fixed, or every velocity component dictated by a prescription): each rank applies
+    # the owner's force to its own clumps, and the owner's own a/alpha are never used.  A replicated owner that moves under
+    # contact forces is flagged (ownerGhost bit 1): every rank sums the contributions of the spheres it owns -- a ghost sphere's
+    # contact with such an owner is left to the sphere's own rank -- and the per-rank sums are all-reduced before the integration,
+    # so that every replica takes the same step.
+    flags = np.asarray(arrays["familyFlags"])
+    fam = np.asarray(arrays["familyID"])
+    free = [int(o) for o in range(n_clumps, n_owners) if not (flags[fam[o]] & (abi.FAMILY_FIXED | abi.FAMILY_PRESCRIBED))]
+    if free and not shared_free:
+        raise ValueError(f"replicated owner(s) {free} (meshes / analytical bodies) move under contact forces: decompose(..., "
+                         "shared_free=True) and step the slabs with abi.HaloGroup, which all-reduces their accelerations every step")
     x = np.asarray(clump_x, np.float64)[:n_clumps]
     edges = slab_edges(x, n_ranks)
     # ghosts are taken from the face neighbours only: an interior slab thinner than the halo would leave clumps of the slab
@@ -82,6 +86,8 @@ def decompose(arrays, counts, clump_x, n_ranks, halo):
             a[k] = arrays[k][owners_g].copy()
         ghost = np.zeros(len(owners_g), np.uint8)
         ghost[len(own):len(own) + len(gl) + len(gr)] = 1
+        if free:
+            ghost[new_id[np.asarray(free, np.int64)]] = 2  # replicated free owners: summed across slabs (OWNER_SHARED_BIT)
         a["ownerGhost"] = ghost
         clumps_here = owners_g[:len(own) + len(gl) + len(gr)]
         sph_idx = _ranges(first_sphere[clumps_here], first_sphere[clumps_here + 1] - first_sphere[clumps_here])
@@ -386,6 +392,8 @@ def assemble_part(old_part, own_packet, send_l, send_r, ghosts_l, ghosts_r, rows
         np.asarray(a_old["inertiaPropOffsets"]).dtype)
     ghost = np.zeros(n_cl + len(extras), np.uint8)
     ghost[n_own:n_cl] = 1
+    if "ownerGhost" in a_old:  # replicated free owners stay flagged
+        ghost[n_cl:] = np.asarray(a_old["ownerGhost"])[extras] & 2
     a["ownerGhost"] = ghost
     nsph = np.concatenate([q["nsph"] for q in packs]).astype(np.int64)
     a["ownerClumpBody"] = np.repeat(np.arange(n_cl, dtype=np.uint32), nsph)

@@ -132,7 +132,11 @@ typedef struct DemeScene {
     const uint16_t* triMaterialOffset;
     /* per owner, may be NULL: 1 = a ghost copy of a clump that another rank owns and integrates (slab decomposition, SURVEY
      * 8e).  A ghost keeps its TRUE family -- contact masks and family margins apply across a cut as inside a slab -- and is
-     * refreshed from its owner rank every step (family included); ghost-ghost pairs are left to the ranks that own them. */
+     * refreshed from its owner rank every step (family included); ghost-ghost pairs are left to the ranks that own them.
+     * 2 = a replicated owner that moves under contact forces (a free mesh or analytical body kept on every slab): each slab
+     * sums the contributions of the spheres it owns (a ghost sphere's contact with it is left to the sphere's own rank), and
+     * deme_halo_group_step adds the per-slab sums up (one ncclAllReduce of 8 floats per such owner) before every replica is
+     * integrated with the total.  A context holding such owners can only be stepped through a halo group. */
     const uint8_t* ownerGhost;
 } DemeScene;
 
@@ -408,8 +412,9 @@ int deme_step_overlap_end(deme_ctx* ctx);
  *                             and the local owner ids (ghost copies) that take the records arriving from there; lists in the
  *                             same clump order on both sides (dem-engine_amd/decomp.py builds them)
  *   deme_halo_group_step      nsteps x { interior force pass | pack -> ncclGroupStart, ncclSend / ncclRecv per face,
- *                             ncclGroupEnd -> unpack | ghost-dependent force pass, integration } for every attached slab;
- *                             asynchronous like deme_step (deme_halo_group_sync waits)
+ *                             ncclGroupEnd -> unpack | ghost-dependent force pass, [ncclAllReduce of the replicated free
+ *                             owners' a / alpha,] integration } for every attached slab; asynchronous like deme_step
+ *                             (deme_halo_group_sync waits)
  *   deme_halo_group_exchange  the exchange alone (ghost copies refreshed after an upload) */
 typedef struct deme_halo_group deme_halo_group;
 int deme_halo_unique_id(unsigned char* id128);

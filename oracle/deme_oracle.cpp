@@ -833,7 +833,7 @@ int detect(Sim& s) {
                 if (oA == oB)
                     continue;
                 const unsigned fB = s.familyID[oB];
-                if (!s.ghost.empty() && s.ghost[oA] && s.ghost[oB])
+                if (!s.ghost.empty() && (s.ghost[oA] & 1) && (s.ghost[oB] & 1))
                     continue;  // both are copies of clumps other ranks own: the pair is theirs
                 if (s.masks[mask_pair(fA, fB)] != 0)
                     continue;
@@ -1240,7 +1240,7 @@ void integrate(Sim& s) {
 #pragma omp parallel for schedule(static)
     for (int64_t oi = 0; oi < (int64_t)s.nOwners; oi++) {
         const uint32_t o = (uint32_t)oi;
-        if (!s.ghost.empty() && s.ghost[o])
+        if (!s.ghost.empty() && (s.ghost[o] & 1))
             continue;  // ghost of a clump another rank integrates (slab decomposition)
         const bool fixed = (s.famFlags[s.familyID[o]] & DEME_FAMILY_FIXED) != 0;
         V3f old_v{s.vX[o], s.vY[o], s.vZ[o]};
@@ -1803,7 +1803,7 @@ size_t orc_sim_inspect_region(void* h, uint32_t q, const float* lo, const float*
         const uint32_t o = perSphere ? s.ownerOfSphere[i] : (uint32_t)i;
         float v;
         const bool clumpOnly = q == DEME_INSPECT_CLUMP_MASS || q == DEME_INSPECT_CLUMP_KINETIC_ENERGY || q == DEME_INSPECT_CLUMP_VOLUME;
-        if ((!s.ghost.empty() && s.ghost[o]) || (clumpOnly && o >= s.nOwnerClumps)) {
+        if ((!s.ghost.empty() && (s.ghost[o] & 1)) || (clumpOnly && o >= s.nOwnerClumps)) {
             v = identity;
         } else if (perSphere) {
             const uint16_t c = s.compOff[i];

@@ -105,6 +105,50 @@ def test_family_masks_and_margins_hold_across_cuts_on_the_gpu(pkg, orc, mode):
     g.close()
 
 
+@pytest.mark.parametrize("mode,n_slabs", [("exact", 2), ("fast", 3)])
+def test_free_mesh_body_across_slabs(pkg, orc, mode, n_slabs):
+    """A mesh body that moves under contact forces (a plate lying on the bed, wider than any slab) is kept on every slab
+    (DemeScene.ownerGhost = 2): each slab sums the forces of its own spheres on it, deme_halo_group_step all-reduces the sums, and
+    every replica takes the same step.  Against the single-domain oracle: same contact list, plate and clumps within the stated
+    tolerance (the per-slab sums are added in a different order than the single domain's one sum: fp32 rounding of a 0.5 kg
+    body's acceleration), replicas bit-identical to each other."""
+    from tests.test_mesh import mesh_bed
+    b = mesh_bed(pkg, 1500, seed=3, cd_freq=5, fixed=False)
+    p, sc = b.Initialize()
+    x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+    with pytest.raises(ValueError, match="move under contact forces"):
+        pkg.decomp.decompose(b.arrays, b.counts, x, n_slabs, halo=0.035)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, n_slabs, halo=0.035, shared_free=True)
+    mesh_local = [int(np.nonzero(pt["arrays"]["ownerGhost"] == 2)[0][0]) for pt in parts]
+    ctxs = [_make(pkg, p, pt["scene"], mode) for pt in parts]
+    with pytest.raises(RuntimeError, match="replicated free owners"):
+        ctxs[0].step(1)  # its share of the plate's force alone would be integrated
+    g = _group(pkg, ctxs, parts)
+    one = orc.make_sim(pkg, p, sc)
+    steps = 121  # detections at steps 0, 5, ..., 120
+    g.step(steps), one.step(steps)
+    g.sync()
+    rows = np.unique(np.concatenate([_global_rows(pt, c) for pt, c in zip(parts, ctxs)]), axis=0)
+    a, bb, t, _ = one.contacts()
+    ref = np.unique(np.stack([a.astype(np.int64), bb.astype(np.int64), t.astype(np.int64)], 1), axis=0)
+    assert (ref[:, 2] == 2).sum() > 50 and np.array_equal(rows, ref)  # sphere-triangle pairs included, each on one slab
+    so = one.download_state()
+    sts = [c.download_state() for c in ctxs]
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+    for st, m in zip(sts[1:], mesh_local[1:]):  # the replicas took the same steps
+        assert all(st[k][m] == sts[0][k][mesh_local[0]] for k in keys)
+    m0, mg = mesh_local[0], int(sc.nOwners) - 1
+    assert so["vZ"][mg] != 0.0
+    for k in ("vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ"):
+        assert abs(sts[0][k][m0] - so[k][mg]) <= 2e-4 * max(1.0, abs(so[k][mg])), k
+    Xm = pkg.model.decode_positions(sts[0]["voxelID"], sts[0]["locX"], sts[0]["locY"], sts[0]["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[m0]
+    Xo = pkg.model.decode_positions(so["voxelID"], so["locX"], so["locY"], so["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    assert np.abs(Xm - Xo[mg]).max() < 1e-7
+    X, V = gather_positions(pkg, parts, ctxs, p, sc.nOwnerClumps)
+    assert np.abs(X - Xo[:sc.nOwnerClumps]).max() < 1e-6
+    g.close()
+
+
 def test_neighbour_migration_between_slabs_on_the_gpu(pkg):
     """a sheared bed in three slabs through the library loop: after 150 steps clumps have crossed the cuts; they move to the face
     neighbour with state, template data and contact history (decomp.migrate_neighbours_in_process: the per-rank functions of the

@@ -72,6 +72,26 @@ def host_exchange(pkg, parts):
     return ex
 
 
+def test_free_replicated_owner_is_flagged_not_refused(pkg):
+    """a mesh that moves under contact forces: refused by default (its accelerations need the cross-slab sum), flagged 2 on every
+    slab with shared_free=True (abi.HaloGroup / deme_halo_group_step then all-reduces them); the fixed walls stay unflagged"""
+    from tests.test_mesh import mesh_bed
+    b = mesh_bed(pkg, 600, seed=3, fixed=False)
+    p, sc = b.Initialize()
+    x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+    with pytest.raises(ValueError, match="shared_free=True"):
+        pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035, shared_free=True)
+    for pt in parts:
+        gh, c = pt["arrays"]["ownerGhost"], pt["counts"]
+        assert list(np.nonzero(gh == 2)[0]) == [c["nOwners"] - 1]  # the mesh owner is the last one
+        assert (gh[pt["n_own"]:c["nOwnerClumps"]] == 1).all() and not gh[:pt["n_own"]].any()
+        assert pt["arrays"]["ownerMesh"].min() == c["nOwners"] - 1
+    fixed = mesh_bed(pkg, 600, seed=3, fixed=True)
+    fixed.Initialize()
+    assert not any((pt["arrays"]["ownerGhost"] == 2).any() for pt in pkg.decomp.decompose(fixed.arrays, fixed.counts, x, 2, halo=0.035))
+
+
 def test_two_slabs_equal_single_domain_oracle(pkg, orc):
     b, p, sc, x = build_global(pkg)
     parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
