@@ -176,6 +176,24 @@ def pmc_traffic(n_contacts, kernel):
                               "an upper bound here: the in-pass calibration shows gathers are not half-counted like streams; lower bound beside it)"}
 
 
+def attainable_copy_gbs(torch, gib=1, reps=5):
+    """the attainable HBM rate on this box beside the nominal peak -- a device-to-device copy of `gib` GiB (beyond the
+    256 MiB Infinity Cache), read + written bytes over the best of `reps` timings."""
+    src = torch.empty(gib << 28, dtype=torch.float32, device="cuda").fill_(1.0)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del src, dst
+    return 2.0 * (gib << 30) / (best * 1e-3) / 1e9
+
+
 def pmc_calibration(torch):
     """Known-byte kernels for calibrating FETCH_SIZE / WRITE_SIZE inside a rocprofv3 --pmc pass
     (MI355X_MICROARCH.md, HBM section): a 1 GiB streaming copy and 4 M random 64-byte row gathers out of
@@ -321,8 +339,9 @@ def main():
                          "comes from (DEMdemo_Mixer.cpp:87); the reference's built-in default is 20 (API.h:1509)")
     ap.add_argument("--presettle", type=int, default=30000, help="untimed steps that let the lattice settle")
     ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--order", default="lattice", choices=["lattice", "morton", "random"],
-                    help="order in which the caller hands the clumps over (experiment)")
+    ap.add_argument("--order", default="morton", choices=["lattice", "morton", "random"],
+                    help="numbering of the clumps: morton = along a Z-order curve (what SceneBuilder.ResortClumps gives a running "
+                         "simulation; the default), lattice = the sampler's row-major order (+5 %% step time), random (+30 %%)")
     ap.add_argument("--mesh-triangles", type=int, default=0,
                     help="BASELINE configs[3] flavour: put a wavy, fixed plate of about this many triangles under the bed")
     ap.add_argument("--mesh-update-every", type=int, default=0,
@@ -602,6 +621,12 @@ def main():
     if halo:
         par += (", overlapped with the interior force evaluation on a second stream" if halo.overlap else "")
         par += f", ghost exchange every step over {'gloo via host memory (PLUMBING TEST, not a measurement)' if via_host else 'RCCL'} ({halo.bytes_per_step} B sent per step by rank 0)"
+    copy_gbs = None
+    if rank == 0:
+        try:
+            copy_gbs = attainable_copy_gbs(torch)
+        except Exception as e:  # (a box short of 2 GiB of free HBM)
+            print(f"[bench] attainable-rate probe skipped: {e}", file=sys.stderr)
     out = {
         "metric": "clump*steps/s", "value": value, "unit": "clump*steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -616,6 +641,7 @@ def main():
                    "clumps_total": total_clumps, "owners_this_rank": int(sc.nOwners), "spheres_this_rank": int(sc.nSpheres),
                    "contacts_this_rank": int(c.nContacts), "bin_sphere_touches": int(c.nBinSphereTouches),
                    "triangles": int(sc.nTri), "cd_every": args.cd_freq, "presettle_steps": args.presettle,
+                   "clump_numbering": args.order, "bin_multiple": args.bin_multiple,
                    "force_model": ("user fragment via hipRTC: frictionless Hertz + cohesion, 1 wildcard" if args.config5
                                    else "Hertzian (history, 4 wildcards)"), "integrator": "extended Taylor", "h": p.h,
                    "parallelism": par,
@@ -625,6 +651,7 @@ def main():
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
         "roofline": {"kernel": "deme_custom_forces_ss (hipRTC)" if args.config5 else ("k_forces_fast<0>" if ctx.arith_mode() == "fast" else "k_calc_forces<0, 0>"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "attainable_copy_GBs": copy_gbs, "frac_of_attainable": (achieved / copy_gbs if copy_gbs else None),
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),
                      "launch_sampling": f"every {stride}{'th' if stride > 3 else ('st', 'nd', 'rd')[stride - 1]} launch inside the timed region is bracketed with HIP events"},
         "kernels_ms": {"calc_forces": f_ms, "integrate": i_ms, "detect_update": d_ms, "detect_updates": int(n_det),

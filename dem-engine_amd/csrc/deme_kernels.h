@@ -1088,12 +1088,77 @@ struct PrescArgs {
     const uint32_t* slot;   // per owner: index into rec (only read for owners of a prescribed family)
 };
 
+// The 64 consecutive owner records of a wavefront, read and written as 4 KB of contiguous memory (four fully coalesced 16-byte
+// accesses per lane) and transposed to one record per lane through LDS -- a lane that loads or stores its own 64-byte record
+// piece by piece makes every instruction touch 64 different cache lines (the vector L1 serves one per cycle).
+#ifndef DEME_INT_COOP
+#define DEME_INT_COOP 1
+#endif
+#define DEME_INT_STAGE (64 * 5)  // uint4 per wavefront: records at an 80-byte stride (bank-conflict-free ds_read_b128 per lane)
+__device__ inline void lds_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of one wavefront complete in order: only the
+    __builtin_amdgcn_wave_barrier();                         // compiler has to be kept from reordering
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ inline OwnerRec coop_load_owner(const OwnerRec* owners, uint32_t nOwners, uint32_t waveBase, uint4* stage) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint4* src = reinterpret_cast<const uint4*>(owners) + (size_t)waveBase * 4;
+    const uint32_t lim = (nOwners > waveBase ? min(64u, nOwners - waveBase) : 0u) * 4u;
+    uint4 v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t e = k * 64u + lane;
+        v[k] = (e < lim) ? src[e] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t e = k * 64u + lane;
+        stage[(e >> 2) * 5u + (e & 3u)] = v[k];
+    }
+    lds_wave_fence();
+    OwnerRec r;
+    uint4* q = reinterpret_cast<uint4*>(&r);
+    const uint4* mine = stage + lane * 5u;
+    q[0] = mine[0], q[1] = mine[1], q[2] = mine[2], q[3] = mine[3];
+    return r;
+}
+__device__ inline void coop_store_owner(OwnerRec* owners, uint32_t nOwners, uint32_t waveBase, uint4* stage, const OwnerRec& r) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint4* dst = reinterpret_cast<uint4*>(owners) + (size_t)waveBase * 4;
+    const uint32_t lim = (nOwners > waveBase ? min(64u, nOwners - waveBase) : 0u) * 4u;
+    const uint4* q = reinterpret_cast<const uint4*>(&r);
+    uint4* mine = stage + lane * 5u;
+    lds_wave_fence();
+    mine[0] = q[0], mine[1] = q[1], mine[2] = q[2], mine[3] = q[3];
+    lds_wave_fence();
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t e = k * 64u + lane;
+        if (e < lim)
+            dst[e] = stage[(e >> 2) * 5u + (e & 3u)];
+    }
+}
+
+__device__ inline void integrate_owner(const DevParams& p, OwnerRec& r, float4 a, float4 al, uint32_t o, uint32_t fflags, bool fixed,
+                                       const GatherArgs& g, const PrescArgs& pa);
+
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* __restrict__ owners,
                                                    AccRec* __restrict__ acc, const GatherArgs g, const PrescArgs pa) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = o < p.nOwners;
+    // one LDS area: the record transposes at both ends of the kernel, the gather tiles of the fused path in between
+    __shared__ uint4 smem[FUSED ? sizeof(GatherLds) / 16 : 4 * DEME_INT_STAGE];
+    static_assert(sizeof(GatherLds) / 16 >= 4 * DEME_INT_STAGE, "the gather tile area also holds the four record stages");
+#if DEME_INT_COOP
+    uint4* stage = smem + (threadIdx.x >> 6) * DEME_INT_STAGE;
+    const uint32_t waveBase = o - (threadIdx.x & 63u);
+    OwnerRec r = coop_load_owner(owners, p.nOwners, waveBase, stage);
+    if (FUSED)
+        __syncthreads();  // every wavefront has its records in registers before the gather tiles overwrite the area
+#else
     OwnerRec r = load_owner(owners, valid ? o : 0u);
+#endif
     const uint32_t fflags = p.familyFlags[fam_of(r.family)];
     const bool ghost = ghost_of(r.family);  // its owner rank integrates it; refreshed by deme_halo_unpack
     const bool fixed = (fflags & 1u) != 0;
@@ -1102,25 +1167,36 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         // a fixed owner's a/alpha never feed the integrator (they are reduced on demand); a/alpha are not stored in
         // the stepping loop either (32 B/owner of HBM writes per step saved): a state download re-derives them from
         // the per-contact contributions (launch_full_reduction)
-        __shared__ GatherLds lds;
+        GatherLds& lds = *reinterpret_cast<GatherLds*>(smem);
         const bool hv = valid && g.heavy[o];
         gather_block(g, p.nOwners, o, valid && !ghost && !fixed && !hv, lds, a, al);
-        if (!valid || ghost)
-            return;
-        if (g.world && !fixed && !hv)
-            acc_from_world(p, r, a, al);
-        if (hv) {
-            const float4* ap = reinterpret_cast<const float4*>(acc + o);
-            a = ap[0];
-            al = ap[1];
+        if (valid && !ghost) {
+            if (g.world && !fixed && !hv)
+                acc_from_world(p, r, a, al);
+            if (hv) {
+                const float4* ap = reinterpret_cast<const float4*>(acc + o);
+                a = ap[0];
+                al = ap[1];
+            }
         }
-    } else {
-        if (!valid || ghost)
-            return;
+    } else if (valid && !ghost) {
         const float4* ap = reinterpret_cast<const float4*>(acc + o);
         a = ap[0];
         al = ap[1];
     }
+    if (valid && !ghost)
+        integrate_owner(p, r, a, al, o, fflags, fixed, g, pa);
+#if DEME_INT_COOP
+    coop_store_owner(owners, p.nOwners, waveBase, stage, r);  // a record nobody integrated goes back as it came
+#else
+    if (valid && !ghost)
+        store_owner(owners, o, r);
+#endif
+}
+
+// the explicit update of one owner (DEMIntegrationKernels.cu:100-236); r is updated in place
+__device__ inline void integrate_owner(const DevParams& p, OwnerRec& r, float4 a, float4 al, uint32_t o, uint32_t fflags, bool fixed,
+                                       const GatherArgs& g, const PrescArgs& pa) {
 
     if (g.nextAcc) {  // DEMTracker::AddAcc / AddAngAcc: on top of the contact sums (added last: the sums keep their order)
         const float4* ep = reinterpret_cast<const float4*>(g.nextAcc + o);
@@ -1231,7 +1307,6 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         r.qy = qy / len;
         r.qz = qz / len;
     }
-    store_owner(owners, o, r);
 }
 
 // ---- packing between the C-ABI's SoA view and the device records -------------------------------
