@@ -20,6 +20,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <filesystem>
 #include <fstream>
 #include <iostream>
@@ -129,10 +131,11 @@ struct DEMClumpTemplate {
         }
         nComp = (unsigned)radii.size();
     }
-    void Scale(float s) {  // Structs.h: lengths*s, mass*s^3, MOI*s^5
-        mass *= s * s * s;
-        volume *= s * s * s;
-        const float s5 = s * s * s * s * s;
+    void Scale(float s) {  // Structs.h:682-695: lengths*s, mass*s^3, MOI*s^5 -- with the reference's types (the powers in double)
+        const double ps = (double)std::abs(s);
+        mass *= ps * ps * ps;
+        volume *= ps * ps * ps;
+        const float s5 = (float)(ps * ps * ps * ps * ps);
         MOI = {MOI.x * s5, MOI.y * s5, MOI.z * s5};
         for (auto& r : radii)
             r *= s;
@@ -2167,6 +2170,45 @@ class DEMSolver {
         voxel = 65536.0 * l;
     }
 
+    // records "name\0", element size (u32), element count (u64), raw bytes; the first record is the DemeParams block
+    static void dump_scene(const char* path, const DemeParams& p, const DemeScene& s) {
+        FILE* f = std::fopen(path, "wb");
+        if (!f)
+            throw std::runtime_error(std::string("DEME_DUMP_SCENE: cannot write ") + path);
+        auto rec = [&](const char* name, const void* data, uint32_t esz, uint64_t n) {
+            if (!data)
+                n = 0;
+            std::fwrite(name, 1, std::strlen(name) + 1, f);
+            std::fwrite(&esz, 4, 1, f);
+            std::fwrite(&n, 8, 1, f);
+            if (n)
+                std::fwrite(data, esz, n, f);
+        };
+        rec("DemeParams", &p, (uint32_t)sizeof(DemeParams), 1);
+        const uint64_t nO = s.nOwners, nS = s.nSpheres, nK = s.nComp, nP = s.nMassProps, nA = s.nAnal, nM = s.nMat, nT = s.nTri;
+        const uint32_t cnt[8] = {s.nOwners, s.nOwnerClumps, s.nSpheres, s.nAnal, s.nTri, s.nMat, s.nComp, s.nMassProps};
+        rec("counts", cnt, 4, 8);
+#define DEME_DUMP(field, n) rec(#field, s.field, (uint32_t)sizeof(*s.field), n)
+        DEME_DUMP(voxelID, nO), DEME_DUMP(locX, nO), DEME_DUMP(locY, nO), DEME_DUMP(locZ, nO);
+        DEME_DUMP(oriQw, nO), DEME_DUMP(oriQx, nO), DEME_DUMP(oriQy, nO), DEME_DUMP(oriQz, nO);
+        DEME_DUMP(vX, nO), DEME_DUMP(vY, nO), DEME_DUMP(vZ, nO), DEME_DUMP(omgBarX, nO), DEME_DUMP(omgBarY, nO), DEME_DUMP(omgBarZ, nO);
+        DEME_DUMP(familyID, nO), DEME_DUMP(inertiaPropOffsets, nO);
+        DEME_DUMP(ownerClumpBody, nS), DEME_DUMP(clumpComponentOffset, nS), DEME_DUMP(sphereMaterialOffset, nS);
+        DEME_DUMP(Radii, nK), DEME_DUMP(CDRelPosX, nK), DEME_DUMP(CDRelPosY, nK), DEME_DUMP(CDRelPosZ, nK);
+        DEME_DUMP(MassProperties, nP), DEME_DUMP(moiX, nP), DEME_DUMP(moiY, nP), DEME_DUMP(moiZ, nP);
+        DEME_DUMP(objType, nA), DEME_DUMP(objOwner, nA), DEME_DUMP(objNormal, nA), DEME_DUMP(objMaterial, nA);
+        DEME_DUMP(objRelPosX, nA), DEME_DUMP(objRelPosY, nA), DEME_DUMP(objRelPosZ, nA);
+        DEME_DUMP(objRotX, nA), DEME_DUMP(objRotY, nA), DEME_DUMP(objRotZ, nA);
+        DEME_DUMP(objSize1, nA), DEME_DUMP(objSize2, nA), DEME_DUMP(objSize3, nA), DEME_DUMP(objMass, nA);
+        DEME_DUMP(E, nM), DEME_DUMP(nu, nM), DEME_DUMP(CoR, nM * nM), DEME_DUMP(mu, nM * nM), DEME_DUMP(Crr, nM * nM);
+        DEME_DUMP(familyMasks, (uint64_t)DEME_FAMILY_MASK_ENTRIES), DEME_DUMP(familyExtraMarginSize, (uint64_t)DEME_NUM_FAMILIES);
+        DEME_DUMP(familyFlags, (uint64_t)DEME_NUM_FAMILIES);
+        DEME_DUMP(ownerMesh, nT), DEME_DUMP(triNode1, nT * 3), DEME_DUMP(triNode2, nT * 3), DEME_DUMP(triNode3, nT * 3);
+        DEME_DUMP(triMaterialOffset, nT);
+#undef DEME_DUMP
+        std::fclose(f);
+    }
+
     void initialize_impl() {
         unsigned nv[3];
         double l, voxel;
@@ -2374,6 +2416,8 @@ class DEMSolver {
         s.familyMasks = m_family_masks, s.familyExtraMarginSize = m_family_extra, s.familyFlags = m_family_flags;
         s.ownerMesh = triOwner.data(), s.triNode1 = t1.data(), s.triNode2 = t2.data(), s.triNode3 = t3.data();
         s.triMaterialOffset = triMat.data();
+        if (const char* dump = std::getenv("DEME_DUMP_SCENE"))  // test hook: what this shell hands the engine (tests/test_host_shell.py
+            dump_scene(dump, p, s);                              // compares it field by field with model.py's scene)
         check(deme_set_params(m_ctx, &p));
         check(deme_upload_scene(m_ctx, &s));
         volumes.resize(mass.size(), 0.f);  // analytical / mesh owners: unused, like the reference (dT.cpp:607-618)

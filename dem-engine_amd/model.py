@@ -79,12 +79,16 @@ class ClumpTemplate:
 
     def Scale(self, s):
         """DEMClumpTemplate::Scale (DEM/Structs.h): lengths*s, mass*s^3, MOI*s^5."""
-        s = float(s)
-        self.mass *= s ** 3
-        self.volume *= s ** 3
-        self.moi = tuple(m * s ** 5 for m in self.moi)
-        self.radii = (self.radii * np.float32(s)).astype(np.float32)
-        self.relpos = (self.relpos * np.float32(s)).astype(np.float32)
+        # the reference's types (Structs.h:682-695): s is a float; mass and volume (float) *= a double; MOI (float3) *= that double
+        # converted to float; lengths (float) *= s
+        s32 = np.float32(s)
+        ps = float(abs(s32))
+        self.mass = float(np.float32(float(np.float32(self.mass)) * (ps * ps * ps)))
+        self.volume = float(np.float32(float(np.float32(self.volume)) * (ps * ps * ps)))
+        s5 = np.float32(ps * ps * ps * ps * ps)
+        self.moi = tuple(float(np.float32(m) * s5) for m in self.moi)
+        self.radii = (self.radii * s32).astype(np.float32)
+        self.relpos = (self.relpos * s32).astype(np.float32)
         return self
 
 
@@ -257,7 +261,8 @@ class SceneBuilder:
         r = [rng(x), rng(y), rng(z)]
         self.user_box_min = np.array([a for a, _ in r], np.float32)
         self.user_box_max = np.array([b for _, b in r], np.float32)
-        enlarge = np.array([(b - a) * DEFAULT_BOX_DOMAIN_ENLARGE_RATIO / 2.0 for a, b in r], np.float32)
+        # float arithmetic like the reference's float3 members: |hi - lo| * (0.2f / 2) (APIPublic.cpp:880-885)
+        enlarge = (self.user_box_max - self.user_box_min) * np.float32(np.float32(DEFAULT_BOX_DOMAIN_ENLARGE_RATIO) / np.float32(2.0))
         self.target_box_min = (self.user_box_min - enlarge).astype(np.float32)
         self.target_box_max = (self.user_box_max + enlarge).astype(np.float32)
 

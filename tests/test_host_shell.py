@@ -236,3 +236,115 @@ def test_collide_demo_matches_the_oracle(pkg, orc):
     assert V[0, 0] < -0.2 and V[1, 0] > 0.2 and X[0, 0] < -1.0 and X[1, 0] > 1.0
     assert np.abs(state[:, :3] - X).max() < 2e-6, (state[:, :3], X)   # float3 getters: fp32 of a coordinate of order 1
     assert np.abs(state[:, 3:] - V).max() < 1e-6, (state[:, 3:], V)
+
+
+def _read_scene_dump(path, pkg):
+    """records "name\\0", u32 element size, u64 count, raw bytes (DEMSolver::dump_scene, env DEME_DUMP_SCENE)"""
+    raw = open(path, "rb").read()
+    out, i = {}, 0
+    while i < len(raw):
+        j = raw.index(b"\0", i)
+        name = raw[i:j].decode()
+        esz, n = np.frombuffer(raw, np.uint32, 1, j + 1)[0], np.frombuffer(raw, np.uint64, 1, j + 5)[0]
+        data = raw[j + 13:j + 13 + int(esz) * int(n)]
+        i = j + 13 + int(esz) * int(n)
+        if name == "DemeParams":
+            out[name] = pkg.abi.DemeParams.from_buffer_copy(data)
+        elif name == "counts":
+            out[name] = np.frombuffer(data, np.uint32)
+        else:
+            out[name] = np.frombuffer(data, pkg.abi.SCENE_DTYPES[name])
+    return out
+
+
+def _bed_inputs(n, seed=77):
+    rng = np.random.default_rng(seed)
+    nx, ny = 14, 9
+    k = np.arange(n)
+    xyz = np.stack([0.03 + 0.017 * (k % nx), 0.025 + 0.017 * ((k // nx) % ny), 0.010 + 0.016 * (k // (nx * ny))], 1)
+    xyz = (xyz + rng.uniform(-8e-4, 8e-4, xyz.shape)).astype(np.float32)
+    q = rng.standard_normal((n, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)  # x y z w
+    kind = (rng.random(n) < 0.3).astype(np.float32)  # 1: the single sphere, 0: the three-sphere clump
+    return xyz, q, kind
+
+
+def _bed_scene(pkg, xyz, q, kind):
+    """host/demo_bed.cpp, call for call, through model.py"""
+    b = pkg.model.SceneBuilder()
+    grain = b.LoadMaterial({"E": 1e8, "nu": 0.3, "CoR": 0.6, "mu": 0.2, "Crr": 0.0})
+    wall = b.LoadMaterial({"E": 2e8, "nu": 0.25, "CoR": 0.5, "mu": 0.4, "Crr": 0.0})
+    b.SetMaterialPropertyPair("mu", grain, wall, 0.35)
+    b.InstructBoxDomainDimension((0.0, 0.3), (0.0, 0.2), (0.0, 0.25))
+    b.InstructBoxDomainBoundingBC("top_open", wall)
+    f32 = np.float32
+    clump3 = b.LoadClumpType(f32(2.6e3) * f32(5.5886717), np.array([2.928, 2.6029, 3.9908], f32) * f32(2.6e3), [0.8, 0.8, 0.8],
+                             [(0.5, 0.341729, 0.0), (0.0, -0.658271, 0.0), (-0.5, 0.341729, 0.0)], grain)
+    clump3.Scale(0.005)
+    single = b.LoadSphereType(f32(2.6e3) * f32(4.0) / f32(3.0) * f32(3.14159265) * f32(0.006) * f32(0.006) * f32(0.006), 0.006, grain)
+    batch = b.AddClumps([single if kd > 0.5 else clump3 for kd in kind], xyz)
+    batch.SetOriQ(q)
+    batch.SetVel(np.tile(np.array([0, 0, -0.4], f32), (len(xyz), 1)))
+    batch.SetFamily(np.where(np.arange(len(xyz)) % 3 == 0, 1, 2))
+    plate = b.AddExternalObject()
+    plate.AddPlane((0.0, 0.0, 0.0), (0.6, 0.0, 0.8), wall)
+    plate.SetInitPos((0.02, 0.1, 0.01))
+    plate.SetFamily(10)
+    b.SetFamilyPrescribedLinVel(10, "0.01", "0", "0")
+    b.DisableContactBetweenFamilies(1, 10)
+    b.SetFamilyExtraMargin(2, 2e-4)
+    b.UseFrictionalHertzianModel()
+    b.SetInitTimeStep(5e-6)
+    b.SetGravitationalAcceleration((0, 0, -9.81))
+    b.SetCDUpdateFreq(10)
+    b.SetExpandSafetyMultiplier(1.1)
+    b.SetExpandSafetyAdder(0.05)
+    b.SetMaxVelocity(8.0)
+    b.SetErrorOutVelocity(200.0)
+    b.SetInitBinSizeAsMultipleOfSmallestSphere(3.5)
+    b.SetIntegrator("extended_taylor")
+    return b
+
+
+@pytest.mark.gpu
+def test_shell_and_model_py_hand_the_engine_the_same_scene(pkg, orc, tmp_path):
+    """The C++ shell (host/DEMSolver.h) and model.py implement the set-up logic -- voxel / bin sizing, template order, component
+    and mass tables, position encoding, material pair matrices, family flags / masks / margins, analytical tables -- independently.
+    demo_bed.cpp builds a mixed bed (two clump kinds loaded in the 'wrong' order, two materials with a pair override, box walls,
+    a prescribed plate, a family mask and a family margin) from positions this test supplies and dumps what it hands the engine
+    (DEME_DUMP_SCENE); the same calls through model.py must give the same DemeParams and the same scene arrays, value for value.
+    The program's run (exact arithmetic mode) then lands on the oracle's, which is fed by model.py."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    n, steps = 1100, 7000
+    xyz, q, kind = _bed_inputs(n)
+    np.concatenate([xyz, q, kind[:, None]], 1).astype(np.float32).tofile(tmp_path / "clumps.f32")
+    env = dict(os.environ, DEME_ARITH="exact", DEME_DUMP_SCENE=str(tmp_path / "scene.bin"))
+    out = subprocess.run([os.path.join(HOST, "demo_bed"), str(tmp_path / "clumps.f32"), str(n), str(steps), str(tmp_path)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "DEMO_OK" in out.stdout, out.stdout + out.stderr
+    d = _read_scene_dump(tmp_path / "scene.bin", pkg)
+    b = _bed_scene(pkg, xyz, q, kind)
+    p, sc = b.Initialize()
+    for name, _ in pkg.abi.DemeParams._fields_:
+        assert getattr(d["DemeParams"], name) == getattr(p, name), (name, getattr(d["DemeParams"], name), getattr(p, name))
+    assert list(d["counts"]) == [getattr(sc, k) for k in ("nOwners", "nOwnerClumps", "nSpheres", "nAnal", "nTri", "nMat", "nComp", "nMassProps")]
+    for name in pkg.abi.SCENE_DTYPES:
+        if name == "ownerGhost":
+            continue
+        mine = np.asarray(b.arrays.get(name, np.zeros(0))).ravel()
+        assert len(mine) == len(d[name]), (name, len(mine), len(d[name]))
+        assert np.array_equal(mine, d[name]), (name, np.nonzero(mine != d[name])[0][:5])
+    # and the run: the program's clump file against the oracle on model.py's scene
+    sim = orc.make_sim(pkg, p, sc)
+    c = np.zeros((15, 4), np.float32)
+    c[0] = (0.01, 0, 0, 0)  # the plate's prescription in the oracle's parametric form: vX = 0.01, vY = vZ = 0, all three dictated
+    sim.set_prescription(10, has=0b111, flags=0b111, coef=c)
+    sim.step(steps)
+    st = sim.download_state()
+    rows = np.genfromtxt(tmp_path / "clumps.csv", delimiter=",", names=True)
+    X = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
+    X = X + np.array([p.LBFX, p.LBFY, p.LBFZ])
+    got = np.stack([rows["X"], rows["Y"], rows["Z"]], 1)
+    assert int(out.stdout.split("contacts=")[1].split()[0]) == int(sim.counts().nContacts) > 300
+    assert np.abs(got - X).max() < 3e-8  # the file prints the fp32 of a coordinate below 0.3 m with 10 digits
+    assert np.array_equal(rows["v_z"].astype(np.float32), st["vZ"][:n])
