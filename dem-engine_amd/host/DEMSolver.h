@@ -640,9 +640,10 @@ class DEMSolver {
     void SetInitTimeStep(double h) { m_h = (float)h; }
     void SetGravitationalAcceleration(float3 g) { m_G = g; }
     void SetCDUpdateFreq(int k) { m_cd_freq = k < 0 ? 0 : (unsigned)k; }
-    void SetInitBinSize(double s) { m_bin_size = s; }
+    /// initial bin size (API.h:140-153, 1403-1412): explicit, a multiple of the smallest radius, or -- the default -- whatever gives
+    /// about the target number of bins (1e6), found by the loop of APIPrivate.cpp:525-541 starting from the multiple (8)
+    void SetInitBinSize(double s) { m_bin_size = s, m_bin_num_target = 0; }
     void SetInitBinSizeAsMultipleOfSmallestSphere(float m) { m_bin_multiple = m, m_bin_size = -1, m_bin_num_target = 0; }
-    /// SetInitBinNumTarget (API.h:151): the initial bin size is chosen so that the domain holds about this many bins
     void SetInitBinNumTarget(size_t num) { m_bin_num_target = num, m_bin_size = -1; }
     void SetExpandSafetyMultiplier(float m) { m_safety_multi = m; }
     void SetExpandSafetyAdder(float a) { m_safety_adder = a; }
@@ -1648,7 +1649,7 @@ class DEMSolver {
     float3 m_G{0, 0, -9.81f};
     unsigned m_cd_freq = 20;
     double m_bin_size = -1;
-    size_t m_bin_num_target = 0;
+    size_t m_bin_num_target = 1000000;
     float m_bin_multiple = 8.0f, m_safety_multi = 1.f, m_safety_adder = 0.f, m_max_vel = 1e15f, m_err_vel = 1e15f;
     TIME_INTEGRATOR m_integrator = TIME_INTEGRATOR::EXTENDED_TAYLOR;
     uint8_t m_family_masks[DEME_FAMILY_MASK_ENTRIES] = {0};
@@ -2233,17 +2234,24 @@ class DEMSolver {
         }
         if (Radii.size() > 65535)
             throw std::runtime_error("more than 65535 clump components");
-        double bin = m_bin_size > 0 ? m_bin_size : (double)m_bin_multiple * smallest;
-        if (m_bin_size <= 0 && m_bin_num_target) {  // DEMSolver::decideBinSize (APIPrivate.cpp): cube root of the volume per bin
-            const double vol = (double)(m_target_max.x - m_target_min.x) * (double)(m_target_max.y - m_target_min.y) * (double)(m_target_max.z - m_target_min.z);
-            bin = std::cbrt(vol / (double)m_bin_num_target);
-        }
+        double bin = m_bin_size > 0 ? m_bin_size : (double)(m_bin_multiple * smallest);  // a float product, like the reference's
         auto nbins = [&](uint32_t nb[3]) {
             for (int k = 0; k < 3; k++)
                 nb[k] = (uint32_t)(voxel * (double)(1ull << nv[k]) / bin) + 1;
             return (uint64_t)nb[0] * nb[1] * nb[2];
         };
         uint32_t nb[3];
+        if (m_bin_size <= 0 && m_bin_num_target) {  // DEMSolver::decideBinSize, APIPrivate.cpp:525-541
+            const double tgt = (double)m_bin_num_target;
+            uint64_t num = nbins(nb), prev = num;
+            while ((double)num < 0.67 * tgt || (double)num > 1.5 * tgt) {
+                bin *= (num < m_bin_num_target) ? 0.8 : 1.2;
+                num = nbins(nb);
+                if ((prev < m_bin_num_target && num >= m_bin_num_target) || (prev >= m_bin_num_target && num < m_bin_num_target))
+                    break;
+                prev = num;
+            }
+        }
         while (nbins(nb) > 0xFFFFFFFEull)
             bin *= 1.5;
         // bounding box planes

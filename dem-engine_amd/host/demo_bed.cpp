@@ -2,8 +2,9 @@
 // shell hands the engine can be compared, field by field, with the one the Python set-up path (model.py) builds from the same
 // inputs (tests/test_host_shell.py: the two hosts implement the same sizing / flattening / table logic independently).
 //
-//   DEME_DUMP_SCENE=<file> ./demo_bed <clumps.f32> <n> <steps> <outdir>
-//     clumps.f32: n records of 8 floats (x y z, quaternion x y z w, kind); writes <outdir>/clumps.csv after `steps` steps
+//   DEME_DUMP_SCENE=<file> ./demo_bed <clumps.f32> <n> <steps> <outdir> [mesh.obj]
+//     clumps.f32: n records of 8 floats (x y z, quaternion x y z w, kind); writes <outdir>/clumps.csv after `steps` steps;
+//     with a mesh file the scene also holds that mesh (scaled, turned, fixed), a cylindrical wall, and sizes its bins by number
 #include <DEM/API.h>
 
 #include <cstdio>
@@ -69,6 +70,22 @@ int main(int argc, char** argv) {
     DEMSim.DisableContactBetweenFamilies(1, 10);
     DEMSim.SetFamilyExtraMargin(2, 2e-4f);
 
+    const bool with_mesh = argc > 5;
+    if (with_mesh) {
+        auto ball = DEMSim.AddWavefrontMeshObject(argv[5], mat_wall);
+        ball->Scale(0.02f);
+        ball->SetInitPos(make_float3(0.15f, 0.1f, 0.03f));
+        ball->SetInitQuat(make_float4(0.f, 0.38268343f, 0.f, 0.92387953f));  // 45 degrees about y
+        ball->SetMass(0.2f);
+        ball->SetMOI(make_float3(3e-5f, 3e-5f, 3e-5f));
+        ball->SetFamily(11);
+        DEMSim.SetFamilyFixed(11);
+        auto drum = DEMSim.AddExternalObject();
+        drum->AddCylinder(make_float3(0.15f, 0.1f, 0.f), make_float3(0.f, 0.f, 1.f), 0.16f, mat_wall, ENTITY_NORMAL_INWARD);
+        drum->SetFamily(12);
+        DEMSim.SetFamilyFixed(12);
+    }
+
     DEMSim.UseFrictionalHertzianModel();
     DEMSim.SetInitTimeStep(5e-6);
     DEMSim.SetGravitationalAcceleration(make_float3(0, 0, -9.81f));
@@ -77,7 +94,10 @@ int main(int argc, char** argv) {
     DEMSim.SetExpandSafetyAdder(0.05f);
     DEMSim.SetMaxVelocity(8.f);
     DEMSim.SetErrorOutVelocity(200.f);
-    DEMSim.SetInitBinSizeAsMultipleOfSmallestSphere(3.5f);
+    if (with_mesh)
+        DEMSim.SetInitBinNumTarget(200000);
+    else
+        DEMSim.SetInitBinSizeAsMultipleOfSmallestSphere(3.5f);
     DEMSim.SetIntegrator("extended_taylor");
     DEMSim.Initialize();
 

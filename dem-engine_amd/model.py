@@ -207,9 +207,11 @@ class SceneBuilder:
         self.h = 1e-5
         self.G = (0.0, 0.0, -9.81)
         self.cd_update_freq = 20
+        # initial bin size (API.h:140-153, 1403-1412): explicit, a multiple of the smallest radius, or -- the default -- whatever
+        # gives about m_target_init_bin_num bins, found by the loop of APIPrivate.cpp:525-541 starting from the multiple
         self.bin_size = None
-        self.bin_multiple = 8.0  # API.h:1410 m_binSize_as_multiple
-        self.target_bin_num = None
+        self.bin_multiple = 8.0
+        self.target_bin_num = 1000000
         self.expand_factor = 0.0
         self.safety_multi = 1.0
         self.safety_adder = 0.0
@@ -320,13 +322,16 @@ class SceneBuilder:
 
     def SetInitBinSize(self, s):
         self.bin_size = float(s)
+        self.target_bin_num = None
 
     def SetInitBinSizeAsMultipleOfSmallestSphere(self, m):
-        self.bin_multiple = float(m)
+        self.bin_multiple = float(np.float32(m))
         self.bin_size = None
+        self.target_bin_num = None
 
     def SetInitBinNumTarget(self, n):
         self.target_bin_num = int(n)
+        self.bin_size = None
 
     def SetExpandFactor(self, beta):
         self.expand_factor = float(beta)
@@ -780,7 +785,8 @@ class SceneBuilder:
         tmpl_sorted = [self.templates[i] for i in order]
 
         smallest = float(radii.min()) if len(radii) else 1.0
-        bin_size = self.bin_size if self.bin_size is not None else self.bin_multiple * smallest
+        # the reference multiplies two floats (m_binSize_as_multiple * m_smallest_radius) and stores the product in a double
+        bin_size = self.bin_size if self.bin_size is not None else float(np.float32(self.bin_multiple) * np.float32(smallest))
         nb, nbins = self._calc_bin_num(voxel, bin_size, nv)
         if self.target_bin_num is not None and self.bin_size is None:
             prev = nbins

@@ -68,8 +68,12 @@ def test_voxel_bit_split_and_bins(pkg):
     # the voxel grid covers the (20% enlarged) target box in every direction
     for n, size in ((p.nvXp2, 0.24), (p.nvYp2, 0.24), (p.nvZp2, 2.4)):
         assert p.voxelSize * 2 ** n >= size * 0.999999
-    assert p.binSize == pytest.approx(8 * 0.00125)
+    # default initial bin size: the reference's target of ~1e6 bins (API.h:1403-1412, loop of APIPrivate.cpp:525-541 from 8 radii)
+    assert 0.67e6 <= p.nbX * p.nbY * p.nbZ <= 1.5e6
     assert p.nbX == int(p.voxelSize * 2 ** p.nvXp2 / p.binSize) + 1
+    b.SetInitBinSizeAsMultipleOfSmallestSphere(8)
+    p8, _ = b.Initialize()
+    assert p8.binSize == float(np.float32(8) * np.float32(0.00125))  # a float product stored in a double, like the reference's
     assert sc.nAnal == 5 and sc.nOwners == 2
     # wall planes sit on the USER box faces, normals inward
     a = b.arrays

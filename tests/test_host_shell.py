@@ -269,7 +269,7 @@ def _bed_inputs(n, seed=77):
     return xyz, q, kind
 
 
-def _bed_scene(pkg, xyz, q, kind):
+def _bed_scene(pkg, xyz, q, kind, mesh=None):
     """host/demo_bed.cpp, call for call, through model.py"""
     b = pkg.model.SceneBuilder()
     grain = b.LoadMaterial({"E": 1e8, "nu": 0.3, "CoR": 0.6, "mu": 0.2, "Crr": 0.0})
@@ -293,6 +293,20 @@ def _bed_scene(pkg, xyz, q, kind):
     b.SetFamilyPrescribedLinVel(10, "0.01", "0", "0")
     b.DisableContactBetweenFamilies(1, 10)
     b.SetFamilyExtraMargin(2, 2e-4)
+    if mesh is not None:
+        v, f = pkg.io.read_obj(mesh)
+        ball = b.AddMeshObject(v, f, wall)
+        ball.Scale(0.02)
+        ball.SetInitPos((0.15, 0.1, 0.03))
+        ball.SetInitQuat((0.0, 0.38268343, 0.0, 0.92387953))
+        ball.SetMass(0.2)
+        ball.SetMOI((3e-5, 3e-5, 3e-5))
+        ball.SetFamily(11)
+        b.SetFamilyFixed(11)
+        drum = b.AddExternalObject()
+        drum.AddCylinder((0.15, 0.1, 0.0), (0.0, 0.0, 1.0), 0.16, wall, True)
+        drum.SetFamily(12)
+        b.SetFamilyFixed(12)
     b.UseFrictionalHertzianModel()
     b.SetInitTimeStep(5e-6)
     b.SetGravitationalAcceleration((0, 0, -9.81))
@@ -301,29 +315,35 @@ def _bed_scene(pkg, xyz, q, kind):
     b.SetExpandSafetyAdder(0.05)
     b.SetMaxVelocity(8.0)
     b.SetErrorOutVelocity(200.0)
-    b.SetInitBinSizeAsMultipleOfSmallestSphere(3.5)
+    if mesh is not None:
+        b.SetInitBinNumTarget(200000)
+    else:
+        b.SetInitBinSizeAsMultipleOfSmallestSphere(3.5)
     b.SetIntegrator("extended_taylor")
     return b
 
 
 @pytest.mark.gpu
-def test_shell_and_model_py_hand_the_engine_the_same_scene(pkg, orc, tmp_path):
+@pytest.mark.parametrize("with_mesh", [False, True])
+def test_shell_and_model_py_hand_the_engine_the_same_scene(pkg, orc, tmp_path, with_mesh):
     """The C++ shell (host/DEMSolver.h) and model.py implement the set-up logic -- voxel / bin sizing, template order, component
     and mass tables, position encoding, material pair matrices, family flags / masks / margins, analytical tables -- independently.
     demo_bed.cpp builds a mixed bed (two clump kinds loaded in the 'wrong' order, two materials with a pair override, box walls,
     a prescribed plate, a family mask and a family margin) from positions this test supplies and dumps what it hands the engine
     (DEME_DUMP_SCENE); the same calls through model.py must give the same DemeParams and the same scene arrays, value for value.
-    The program's run (exact arithmetic mode) then lands on the oracle's, which is fed by model.py."""
+    The program's run (exact arithmetic mode) then lands on the oracle's, which is fed by model.py.  with_mesh adds a mesh read
+    from an OBJ file (scaled, turned, fixed), a cylindrical wall, and bins sized by their target number."""
+    mesh = os.path.join(ROOT, "tests", "golden", "ref_data", "sphere.obj") if with_mesh else None
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     n, steps = 1100, 7000
     xyz, q, kind = _bed_inputs(n)
     np.concatenate([xyz, q, kind[:, None]], 1).astype(np.float32).tofile(tmp_path / "clumps.f32")
     env = dict(os.environ, DEME_ARITH="exact", DEME_DUMP_SCENE=str(tmp_path / "scene.bin"))
-    out = subprocess.run([os.path.join(HOST, "demo_bed"), str(tmp_path / "clumps.f32"), str(n), str(steps), str(tmp_path)],
-                         capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([os.path.join(HOST, "demo_bed"), str(tmp_path / "clumps.f32"), str(n), str(steps), str(tmp_path)]
+                         + ([mesh] if with_mesh else []), capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "DEMO_OK" in out.stdout, out.stdout + out.stderr
     d = _read_scene_dump(tmp_path / "scene.bin", pkg)
-    b = _bed_scene(pkg, xyz, q, kind)
+    b = _bed_scene(pkg, xyz, q, kind, mesh)
     p, sc = b.Initialize()
     for name, _ in pkg.abi.DemeParams._fields_:
         assert getattr(d["DemeParams"], name) == getattr(p, name), (name, getattr(d["DemeParams"], name), getattr(p, name))
@@ -345,6 +365,6 @@ def test_shell_and_model_py_hand_the_engine_the_same_scene(pkg, orc, tmp_path):
     X = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
     X = X + np.array([p.LBFX, p.LBFY, p.LBFZ])
     got = np.stack([rows["X"], rows["Y"], rows["Z"]], 1)
-    assert int(out.stdout.split("contacts=")[1].split()[0]) == int(sim.counts().nContacts) > 300
+    assert int(out.stdout.split("contacts=")[1].split()[0]) == int(sim.counts().nContacts) > 150
     assert np.abs(got - X).max() < 3e-8  # the file prints the fp32 of a coordinate below 0.3 m with 10 digits
     assert np.array_equal(rows["v_z"].astype(np.float32), st["vZ"][:n])
