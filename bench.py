@@ -352,6 +352,9 @@ def main():
                     help="BASELINE configs[4] flavour: polydisperse spheres + a user cohesion model compiled at run time")
     ap.add_argument("--bin-multiple", type=float, default=5.0,
                     help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
+    ap.add_argument("--async-detection", type=int, default=0, metavar="D",
+                    help="start each contact detection D steps before its list is due, on a stream of its own beside the steps "
+                         "(deme_set_async_detection; single-domain runs without a mesh).  0 = lock-step")
     ap.add_argument("--adaptive", default="off", choices=["off", "bin", "freq", "both"],
                     help="let the engine tune the bin size / the update frequency on device timers during the pre-settling and "
                          "warm-up (the reference's default mode); frozen before the timed region.  Default: off (fixed K and bin size)")
@@ -437,6 +440,8 @@ def main():
     ctx.set_params(p)
     ctx.upload_scene(sc)
     b.compile_into(ctx)  # user force model / prescriptions, if the scene has any
+    if args.async_detection:
+        ctx.set_async_detection(args.async_detection)
     if args.adaptive != "off":
         ctx.set_adaptive(bin_size=args.adaptive in ("bin", "both"), update_freq=args.adaptive in ("freq", "both"),
                          bin_observe=5, max_update_freq=200, freq_observe=3)
@@ -604,6 +609,13 @@ def main():
     f_ms, f_n = ctx.kernel_time_ms("calc_forces")
     i_ms, _ = ctx.kernel_time_ms("integrate")
     d_ms, d_n = ctx.kernel_time_ms("detect")
+    d_async = None
+    if args.async_detection:  # the two parts of an asynchronous detection: beside the steps on its own stream / at the swap
+        p1, n1 = ctx.kernel_time_ms("detect_async_part1")
+        p2, _ = ctx.kernel_time_ms("detect_async_part2")
+        if n1:
+            d_async = {"part1_beside_the_steps_ms": p1, "part2_at_the_swap_ms": p2, "count": int(n1)}
+            d_ms = (d_ms * d_n + (p1 + p2) * n1) / (d_n + n1)
     c = ctx.counts()
     value = total_clumps * args.steps / dt
     fbytes = force_kernel_bytes(int(sc.nOwners), int(sc.nSpheres), int(c.nContacts), int(p.nContactWildcards))
@@ -641,7 +653,8 @@ def main():
                    "clumps_total": total_clumps, "owners_this_rank": int(sc.nOwners), "spheres_this_rank": int(sc.nSpheres),
                    "contacts_this_rank": int(c.nContacts), "bin_sphere_touches": int(c.nBinSphereTouches),
                    "triangles": int(sc.nTri), "cd_every": args.cd_freq, "presettle_steps": args.presettle,
-                   "clump_numbering": args.order, "bin_multiple": args.bin_multiple,
+                   "clump_numbering": args.order, "bin_multiple": args.bin_multiple, "async_detection_lead": args.async_detection,
+                   "margin_safety": {"multiplier": float(p.expSafetyMulti), "adder_m_per_s": float(p.expSafetyAdder)},
                    "force_model": ("user fragment via hipRTC: frictionless Hertz + cohesion, 1 wildcard" if args.config5
                                    else "Hertzian (history, 4 wildcards)"), "integrator": "extended Taylor", "h": p.h,
                    "parallelism": par,
@@ -658,7 +671,7 @@ def main():
                        # the same step with the detection spread over its K steps (what a run of many K-cycles converges to;
                        # `ms_per_step` above is the measured wall time of exactly `steps` steps, ceil(steps / K) detections included)
                        "amortised_ms_per_step": (f_ms + i_ms + (d_ms / args.cd_freq if args.cd_freq else d_ms)),
-                       "detections_in_timed_region": int(n_det)},
+                       "detections_in_timed_region": int(n_det), "async_detection": d_async},
     }
     assert n_det >= 1 or args.adaptive != "off", "the timed region contains no contact detection: the phase alignment failed"
     out["roofline"].update(pmc_traffic(int(c.nContacts), out["roofline"]["kernel"]))

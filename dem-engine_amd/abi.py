@@ -172,7 +172,7 @@ def load_library():
     lib.deme_ctx_destroy.argtypes = [_P]
     lib.deme_ctx_destroy.restype = None
     for name, args in {
-        "deme_ctx_set_stream": [_P, _P], "deme_sync": [_P], "deme_set_arith_mode": [_P, C.c_int], "deme_get_arith_mode": [_P],
+        "deme_ctx_set_stream": [_P, _P], "deme_sync": [_P], "deme_set_arith_mode": [_P, C.c_int], "deme_set_async_detection": [_P, C.c_uint32], "deme_get_arith_mode": [_P],
         "deme_set_params": [_P, C.POINTER(DemeParams)], "deme_upload_scene": [_P, C.POINTER(DemeScene)],
         "deme_upload_owner_state": [_P, C.POINTER(DemeOwnerState)],
         "deme_download_owner_state": [_P, C.POINTER(DemeOwnerState)],
@@ -405,6 +405,10 @@ class Context:
     def update_tri_nodes(self, n1, n2, n3):
         arrs = [np.ascontiguousarray(x, np.float32).reshape(-1) for x in (n1, n2, n3)]
         self._ck(self.lib.deme_update_tri_nodes(self.h, *[_ptr(x) for x in arrs]), "deme_update_tri_nodes")
+
+    def set_async_detection(self, lead_steps):
+        """deme_set_async_detection: start each detection lead_steps before its list is due, beside the steps (0: lock-step)"""
+        self._ck(self.lib.deme_set_async_detection(self.h, C.c_uint32(int(lead_steps))), "deme_set_async_detection")
 
     def compute_margins(self, drift):
         self._ck(self.lib.deme_compute_margins(self.h, int(drift)), "deme_compute_margins")

@@ -63,7 +63,7 @@ struct deme_ctx {
     DevBuf owners, spheres, acc, comp, massProps, anal, matPair, E, nu, CoR, mu, Crr, famMasks, famExtra, famFlags;
     std::vector<uint8_t> hObjType;  // host copy for contact-type decoding on download
     // detection scratch
-    DevBuf geo, binLo, binN, counts, offsets, incKeys[2], incVals[2], keysRaw, keysSorted[2], mapping, wc[2], ctr,
+    DevBuf geo, binLo, binN, counts, offsets, incKeys[2], incVals[2], keysRaw, keysMid, keysSorted[2], mapping, wc[2], ctr,
         scanTmp, sortTmp, rec[4], stage;
     // per-contact contributions and the per-owner gather lists (built once per detection)
     DevBuf conA4, conA2, conB4, conB2, aSum, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
@@ -101,6 +101,13 @@ struct deme_ctx {
     DevBuf userWc[4][8];  // [kind: owners, spheres, triangles, analytical][index]
     uint32_t nOwnerWc = 0, nGeoWc = 0;
     bool hasGhosts = false;  // a family carries DEME_FAMILY_GHOST: force passes can be split for the halo overlap
+    // asynchronous detection (deme_set_async_detection): part 1 of a detection on its own stream, from a snapshot of the owners,
+    // `asyncLead` steps before the list it builds is swapped in
+    uint32_t asyncLead = 0;
+    DevBuf ownersSnap;
+    hipStream_t detStream = nullptr;
+    hipEvent_t evSnap = nullptr, evP1 = nullptr;
+    uint64_t nAsyncDetections = 0;
     std::vector<uint32_t> hShared;  // replicated free owners (DemeScene.ownerGhost bit 1): their a / alpha are summed across slabs
     DevBuf sharedIds, sharedBuf;
     bool tailFused = true;
@@ -213,7 +220,8 @@ struct ScopedTimer {
     deme_ctx* c;
     TimerSlot* slot = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(deme_ctx* ctx, const char* name, bool always = false) : c(ctx) {
+    hipStream_t st = nullptr;
+    ScopedTimer(deme_ctx* ctx, const char* name, bool always = false, hipStream_t stream = nullptr) : c(ctx), st(stream ? stream : ctx->stream) {
         if (!c->timing)
             return;
         slot = &c->timers[name];
@@ -227,11 +235,11 @@ struct ScopedTimer {
         }
         a = get_event(c);
         b = get_event(c);
-        hipEventRecord(a, c->stream);
+        hipEventRecord(a, st);
     }
     ~ScopedTimer() {
         if (slot) {
-            hipEventRecord(b, c->stream);
+            hipEventRecord(b, st);
             slot->pending.emplace_back(a, b);
         }
     }
@@ -377,39 +385,37 @@ int do_margins(deme_ctx* c, uint32_t drift) {
     return DEME_OK;
 }
 
-// contactDetection() equivalent
+// contactDetection() equivalent, in two parts.  Part 1 -- everything up to the sorted key list of the new contacts -- reads the
+// owners through `ow` and touches detection scratch only, so it can run on its own stream from a snapshot of the owner records
+// while the main stream keeps stepping with the current list (deme_set_async_detection; the reference's kT does the same on its
+// own GPU thread).  Part 2 -- history map and the per-owner gather lists the force and integration kernels read -- runs on the
+// main stream when the list is swapped in.
 int do_migrate(deme_ctx* c);
-int do_detect(deme_ctx* c) {
-    // a history map nobody has applied yet (two detections in a row): apply it now, or the next map would be taken from a
-    // list whose wildcards are still stored against the list before it
-    if (c->mapFresh)
-        if (int rc = do_migrate(c))
-            return rc;
-    ScopedTimer tm(c, "detect", true);  // once per K steps: always timed
+int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t* nCout) {
     const uint32_t nS = c->nSpheres;
     DetectCounters hc{};
     // margins kernel may have left status bits in ctr: fetch them before zeroing
-    HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
+    HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
     if (int rc = status_to_error(c, hc.status))
         return rc;
 
     for (int attempt = 0; attempt < 4; attempt++) {
-        HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->stream));
+        HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), st));
         if (nS) {
-            hipLaunchKernelGGL(k_sphere_prep, dim3(grid_for(nS)), dim3(256), 0, c->stream, c->dp,
-                               c->owners.as<OwnerRec>(), c->spheres.as<SphereRec>(), c->geo.as<GeoRec>(),
+            hipLaunchKernelGGL(k_sphere_prep, dim3(grid_for(nS)), dim3(256), 0, st, c->dp,
+                               ow, c->spheres.as<SphereRec>(), c->geo.as<GeoRec>(),
                                c->binLo.as<uint4>(), c->binN.as<uint2>(), c->counts.as<uint32_t>(),
                                c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap, c->ctr.as<DetectCounters>());
             size_t tmp = c->scanTmp.bytes;
             HIPCK(rocprim::exclusive_scan(c->scanTmp.p, tmp, c->counts.as<uint32_t>(), c->offsets.as<uint32_t>(), 0u,
-                                          (size_t)nS + 1, rocprim::plus<uint32_t>(), c->stream));
+                                          (size_t)nS + 1, rocprim::plus<uint32_t>(), st));
         }
         uint32_t P = 0;
         if (nS) {
-            HIPCK(hipMemcpyAsync(&P, c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-            HIPCK(hipStreamSynchronize(c->stream));
+            HIPCK(hipMemcpyAsync(&P, c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, st));
+            HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+            HIPCK(hipStreamSynchronize(st));
             if (hc.status & DEME_ST_INCIDENCE)
                 return fail(c, DEME_ERR_OVERFLOW,
                             "a sphere touches more than %u bins (margin far larger than the bin size): the incidence list cannot be built",
@@ -419,17 +425,17 @@ int do_detect(deme_ctx* c) {
                                                              [] __host__ __device__(uint32_t v) { return (unsigned long long)v; });
                 unsigned long long* tot = &c->ctr.as<DetectCounters>()->nContactsRaw;  // borrowed: saved and restored around the reduction (k_sphere_prep has already counted its sphere-analytical contacts here)
                 unsigned long long keep = 0, total = 0;
-                HIPCK(hipMemcpyAsync(&keep, tot, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCK(hipMemcpyAsync(&keep, tot, 8, hipMemcpyDeviceToHost, st));
                 size_t need = 0;
-                HIPCK(rocprim::reduce(nullptr, need, in64, tot, 0ull, (size_t)nS, rocprim::plus<unsigned long long>(), c->stream));
+                HIPCK(rocprim::reduce(nullptr, need, in64, tot, 0ull, (size_t)nS, rocprim::plus<unsigned long long>(), st));
                 if (int rc = ensure(c, c->sortTmp, need))
                     return rc;
                 need = c->sortTmp.bytes;
-                HIPCK(rocprim::reduce(c->sortTmp.p, need, in64, tot, 0ull, (size_t)nS, rocprim::plus<unsigned long long>(), c->stream));
-                HIPCK(hipMemcpyAsync(&total, tot, 8, hipMemcpyDeviceToHost, c->stream));
-                HIPCK(hipStreamSynchronize(c->stream));
-                HIPCK(hipMemcpyAsync(tot, &keep, 8, hipMemcpyHostToDevice, c->stream));
-                HIPCK(hipStreamSynchronize(c->stream));
+                HIPCK(rocprim::reduce(c->sortTmp.p, need, in64, tot, 0ull, (size_t)nS, rocprim::plus<unsigned long long>(), st));
+                HIPCK(hipMemcpyAsync(&total, tot, 8, hipMemcpyDeviceToHost, st));
+                HIPCK(hipStreamSynchronize(st));
+                HIPCK(hipMemcpyAsync(tot, &keep, 8, hipMemcpyHostToDevice, st));
+                HIPCK(hipStreamSynchronize(st));
                 if (total > 0xFFFFFFFFull)
                     return fail(c, DEME_ERR_OVERFLOW, "%llu bin-sphere incidences do not fit the 32-bit list offsets (use larger bins)", total);
             }
@@ -441,7 +447,7 @@ int do_detect(deme_ctx* c) {
         c->nInc = P;
         int sortedIdx = 0;
         if (P) {
-            hipLaunchKernelGGL(k_fill_incidence, dim3(grid_for(nS)), dim3(256), 0, c->stream, c->dp,
+            hipLaunchKernelGGL(k_fill_incidence, dim3(grid_for(nS)), dim3(256), 0, st, c->dp,
                                c->binLo.as<uint4>(), c->binN.as<uint2>(), c->offsets.as<uint32_t>(),
                                c->incKeys[0].as<uint32_t>(), c->incVals[0].as<uint32_t>(), (uint64_t)c->incCap);
             const uint64_t nBins = (uint64_t)c->hp.nbX * c->hp.nbY * c->hp.nbZ;
@@ -451,23 +457,23 @@ int do_detect(deme_ctx* c) {
             size_t need = 0;
             HIPCK(rocprim::radix_sort_pairs(nullptr, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
                                             c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
-                                            c->stream));
+                                            st));
             if (int rc = ensure(c, c->sortTmp, need))
                 return rc;
             need = c->sortTmp.bytes;
             HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
                                             c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
-                                            c->stream));
+                                            st));
             sortedIdx = 1;
             const uint32_t nWin = (uint32_t)grid_for(P, SW_T);
             if (int rc = ensure(c, c->binStat, (size_t)nWin * sizeof(uint2)))
                 return rc;
             static_assert(SW_WPB == 1, "k_sweep writes one statistics record per window");
-            hipLaunchKernelGGL(k_sweep, dim3(nWin), dim3(SW_T), 0, c->stream, c->dp,
+            hipLaunchKernelGGL(k_sweep, dim3(nWin), dim3(SW_T), 0, st, c->dp,
                                c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
-                               c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
+                               ow, c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
                                c->ctr.as<DetectCounters>(), c->binStat.as<uint2>());
-            hipLaunchKernelGGL(k_bin_stats_final, dim3((nWin + 2047u) / 2048u), dim3(256), 0, c->stream, c->binStat.as<uint2>(), nWin,
+            hipLaunchKernelGGL(k_bin_stats_final, dim3((nWin + 2047u) / 2048u), dim3(256), 0, st, c->binStat.as<uint2>(), nWin,
                                c->ctr.as<DetectCounters>());
         }
         (void)sortedIdx;
@@ -475,15 +481,15 @@ int do_detect(deme_ctx* c) {
         c->nTriInc = 0;
         if (c->nTri && P) {
             const uint32_t nT = c->nTri;
-            hipLaunchKernelGGL(k_tri_prep, dim3(grid_for(nT)), dim3(256), 0, c->stream, c->dp, nT, c->tris.as<TriRec>(),
-                               c->owners.as<OwnerRec>(), c->triWorld.as<TriWorld>(), c->triLo.as<int4>(),
+            hipLaunchKernelGGL(k_tri_prep, dim3(grid_for(nT)), dim3(256), 0, st, c->dp, nT, c->tris.as<TriRec>(),
+                               ow, c->triWorld.as<TriWorld>(), c->triLo.as<int4>(),
                                c->triHi.as<int4>(), c->triCounts.as<uint32_t>());
             size_t tmp = c->scanTmp.bytes;
             HIPCK(rocprim::exclusive_scan(c->scanTmp.p, tmp, c->triCounts.as<uint32_t>(), c->triOffsets.as<uint32_t>(), 0u,
-                                          (size_t)nT + 1, rocprim::plus<uint32_t>(), c->stream));
+                                          (size_t)nT + 1, rocprim::plus<uint32_t>(), st));
             uint32_t TP = 0;
-            HIPCK(hipMemcpyAsync(&TP, c->triOffsets.as<uint32_t>() + nT, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(hipStreamSynchronize(c->stream));
+            HIPCK(hipMemcpyAsync(&TP, c->triOffsets.as<uint32_t>() + nT, 4, hipMemcpyDeviceToHost, st));
+            HIPCK(hipStreamSynchronize(st));
             if (TP > c->triCap) {
                 const size_t cap = (size_t)TP + TP / 4 + 1024;
                 for (int k = 0; k < 2; k++)
@@ -493,7 +499,7 @@ int do_detect(deme_ctx* c) {
             }
             c->nTriInc = TP;
             if (TP) {
-                hipLaunchKernelGGL(k_tri_fill, dim3(grid_for(nT)), dim3(256), 0, c->stream, c->dp, nT,
+                hipLaunchKernelGGL(k_tri_fill, dim3(grid_for(nT)), dim3(256), 0, st, c->dp, nT,
                                    c->triWorld.as<TriWorld>(), c->triLo.as<int4>(), c->triHi.as<int4>(),
                                    c->triOffsets.as<uint32_t>(), c->triKeys[0].as<uint32_t>(), c->triVals[0].as<uint32_t>(),
                                    (uint64_t)c->triCap);
@@ -504,23 +510,25 @@ int do_detect(deme_ctx* c) {
                 size_t need = 0;
                 HIPCK(rocprim::radix_sort_pairs(nullptr, need, c->triKeys[0].as<uint32_t>(), c->triKeys[1].as<uint32_t>(),
                                                 c->triVals[0].as<uint32_t>(), c->triVals[1].as<uint32_t>(), (size_t)TP, 0, bits,
-                                                c->stream));
+                                                st));
                 if (int rc = ensure(c, c->sortTmp, need))
                     return rc;
                 need = c->sortTmp.bytes;
                 HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, need, c->triKeys[0].as<uint32_t>(), c->triKeys[1].as<uint32_t>(),
                                                 c->triVals[0].as<uint32_t>(), c->triVals[1].as<uint32_t>(), (size_t)TP, 0, bits,
-                                                c->stream));
-                hipLaunchKernelGGL(k_tri_sweep, dim3(grid_for(TP)), dim3(256), 0, c->stream, c->dp, TP,
+                                                st));
+                hipLaunchKernelGGL(k_tri_sweep, dim3(grid_for(TP)), dim3(256), 0, st, c->dp, TP,
                                    c->triKeys[1].as<uint32_t>(), c->triVals[1].as<uint32_t>(), c->triWorld.as<TriWorld>(), P,
                                    c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), c->geo.as<GeoRec>(),
-                                   c->owners.as<OwnerRec>(), c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
+                                   ow, c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
                                    c->ctr.as<DetectCounters>());
             }
         }
-        HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-        HIPCK(hipStreamSynchronize(c->stream));
+        HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
         if (hc.nContactsRaw > c->cntCap) {  // arena too small: grow and redo the emitting kernels
+            if (async)
+                HIPCK(hipStreamSynchronize(c->stream));
             if (int rc = grow_contact_arena(c, (size_t)hc.nContactsRaw + hc.nContactsRaw / 4 + 1024))
                 return rc;
             continue;
@@ -535,11 +543,13 @@ int do_detect(deme_ctx* c) {
         const size_t nPersist = c->hPersist.size();
         if (nPersist) {  // marked contacts join the list whether or not the sweep found them (DEMCubContactDetection.cu:605-802)
             if (nC + nPersist > c->cntCap) {
-                if (int rc = grow_contact_arena(c, (size_t)nC + nPersist + nC / 4 + 1024))
+                if (async)
+                HIPCK(hipStreamSynchronize(c->stream));
+            if (int rc = grow_contact_arena(c, (size_t)nC + nPersist + nC / 4 + 1024))
                     return rc;
                 continue;
             }
-            HIPCK(hipMemcpyAsync(c->keysRaw.as<uint64_t>() + nC, c->persistKeys.p, nPersist * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIPCK(hipMemcpyAsync(c->keysRaw.as<uint64_t>() + nC, c->persistKeys.p, nPersist * 8, hipMemcpyDeviceToDevice, st));
             nC += nPersist;
         }
         const int next = c->keysCur ^ 1;
@@ -554,31 +564,44 @@ int do_detect(deme_ctx* c) {
                 return b;
             };
             const unsigned bitsA = bits_of(c->dp.nSpheres);
-            uint64_t* mid = c->conA4.as<uint64_t>();  // 16 B per contact of scratch: the contribution records are dead until the next force pass
+            if (int rc = ensure(c, c->keysMid, (size_t)c->cntCap * 8))  // (its own scratch: an asynchronous detection runs beside force passes)
+                return rc;
+            uint64_t* mid = c->keysMid.as<uint64_t>();
             size_t needHi = 0;
-            HIPCK(rocprim::radix_sort_keys(nullptr, needHi, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 31, 33 + bitsA, c->stream));
+            HIPCK(rocprim::radix_sort_keys(nullptr, needHi, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 31, 33 + bitsA, st));
             if (int rc = ensure(c, c->sortTmp, needHi))
                 return rc;
             needHi = c->sortTmp.bytes;
-            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, needHi, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 31, 33 + bitsA, c->stream));
-            hipLaunchKernelGGL(k_segment_rank_sort, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC, mid,
+            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, needHi, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 31, 33 + bitsA, st));
+            hipLaunchKernelGGL(k_segment_rank_sort, dim3(grid_for(nC)), dim3(256), 0, st, (uint32_t)nC, mid,
                                c->keysSorted[next].as<uint64_t>());
             if (nPersist) {  // a marked contact the sweep found as well appears once (markDuplicateContacts)
                 unsigned long long* cnt = &c->ctr.as<DetectCounters>()->nContactsRaw;
                 size_t need2 = 0;
                 HIPCK(rocprim::unique(nullptr, need2, c->keysSorted[next].as<uint64_t>(), c->keysRaw.as<uint64_t>(), cnt, (size_t)nC,
-                                      rocprim::equal_to<uint64_t>(), c->stream));
+                                      rocprim::equal_to<uint64_t>(), st));
                 if (int rc = ensure(c, c->scanTmp, need2))
                     return rc;
                 need2 = c->scanTmp.bytes;
                 HIPCK(rocprim::unique(c->scanTmp.p, need2, c->keysSorted[next].as<uint64_t>(), c->keysRaw.as<uint64_t>(), cnt,
-                                      (size_t)nC, rocprim::equal_to<uint64_t>(), c->stream));
+                                      (size_t)nC, rocprim::equal_to<uint64_t>(), st));
                 unsigned long long nU = 0;
-                HIPCK(hipMemcpyAsync(&nU, cnt, 8, hipMemcpyDeviceToHost, c->stream));
-                HIPCK(hipStreamSynchronize(c->stream));
+                HIPCK(hipMemcpyAsync(&nU, cnt, 8, hipMemcpyDeviceToHost, st));
+                HIPCK(hipStreamSynchronize(st));
                 nC = nU;
-                HIPCK(hipMemcpyAsync(c->keysSorted[next].p, c->keysRaw.p, (size_t)nC * 8, hipMemcpyDeviceToDevice, c->stream));
+                HIPCK(hipMemcpyAsync(c->keysSorted[next].p, c->keysRaw.p, (size_t)nC * 8, hipMemcpyDeviceToDevice, st));
             }
+        }
+        *nCout = nC;
+        return DEME_OK;
+    }
+    return fail(c, DEME_ERR_OVERFLOW, "contact arena kept overflowing");
+}
+
+int detect_part2(deme_ctx* c, uint64_t nC) {
+    const int next = c->keysCur ^ 1;
+    {
+        if (nC) {
             const uint64_t nPrev = c->haveList ? c->nContacts : 0;
             hipLaunchKernelGGL(k_history, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC,
                                c->keysSorted[next].as<uint64_t>(), (uint32_t)nPrev,
@@ -655,7 +678,20 @@ int do_detect(deme_ctx* c) {
         c->nDetections++;
         return DEME_OK;
     }
-    return fail(c, DEME_ERR_OVERFLOW, "contact arena kept overflowing");
+}
+
+
+int do_detect(deme_ctx* c) {
+    // a history map nobody has applied yet (two detections in a row): apply it now, or the next map would be taken from a
+    // list whose wildcards are still stored against the list before it
+    if (c->mapFresh)
+        if (int rc = do_migrate(c))
+            return rc;
+    ScopedTimer tm(c, "detect", true);  // once per K steps: always timed
+    uint64_t nC = 0;
+    if (int rc = detect_part1(c, c->stream, c->owners.as<OwnerRec>(), false, &nC))
+        return rc;
+    return detect_part2(c, nC);
 }
 
 int do_migrate(deme_ctx* c) {
@@ -914,12 +950,18 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
+    if (c->detStream) {
+        hipStreamSynchronize(c->detStream);
+        hipEventDestroy(c->evSnap);
+        hipEventDestroy(c->evP1);
+        hipStreamDestroy(c->detStream);
+    }
     DevBuf* all[] = {&c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
                      &c->wc[1], &c->ctr, &c->scanTmp, &c->sortTmp, &c->rec[0], &c->rec[1], &c->rec[2], &c->rec[3],
-                     &c->stage};
+                     &c->stage, &c->sharedIds, &c->sharedBuf, &c->keysMid, &c->ownersSnap};
     for (DevBuf* b : all)
         if (b->p)
             hipFree(b->p);
@@ -1484,12 +1526,86 @@ int deme_get_adaptive_state(deme_ctx* c, double* binSize, uint32_t* cdUpdateFreq
     return DEME_OK;
 }
 
+// ---- asynchronous detection ---------------------------------------------------------------------------------------------------
+// K - D steps after a list was swapped in (D = asyncLead), the owners are copied, the next D steps are enqueued on the main stream
+// with the CURRENT list, and part 1 of the detection runs beside them on its own stream from the copy, with margins for the K + D
+// steps that pass between the copy and the end of the new list's service.  When the D steps are enqueued the main stream waits for
+// part 1, builds the gather lists (part 2), migrates the history, and carries on with the new list.  The host blocks in part 1's
+// two sizing read-backs while the GPU works through the D steps: no second host thread is needed.  Contacts are never missed (the
+// margins cover the whole span); the new list holds a few more near-pairs than a lock-step detection would, whose contributions are
+// zero, so a trajectory in the exact arithmetic mode is the lock-step one.
+static bool async_detection_can_start(deme_ctx* c, uint32_t stepsLeftInCall) {
+    const uint32_t K = c->hp.cdUpdateFreq, D = c->asyncLead;
+    if (!D || K <= D || stepsLeftInCall < D)
+        return false;
+    if (!c->haveList || c->seeded || c->listStale || c->mapFresh || c->hasGhosts || !c->hShared.empty() || c->nTri)
+        return false;
+    if (c->ad.autoBinSize || c->ad.autoUpdateFreq || !c->hPersist.empty())
+        return false;
+    return c->stepsSinceCD == K - D;
+}
+static int async_detection_cycle(deme_ctx* c) {
+    const uint32_t K = c->hp.cdUpdateFreq, D = c->asyncLead;
+    if (!c->detStream) {
+        HIPCK(hipStreamCreateWithFlags(&c->detStream, hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&c->evSnap, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&c->evP1, hipEventDisableTiming));
+    }
+    if (int rc = ensure(c, c->ownersSnap, (size_t)c->nOwners * sizeof(OwnerRec)))
+        return rc;
+    // the copy is ordered on the main stream: after the step just integrated, before the next one
+    HIPCK(hipMemcpyAsync(c->ownersSnap.p, c->owners.p, (size_t)c->nOwners * sizeof(OwnerRec), hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipEventRecord(c->evSnap, c->stream));
+    for (uint32_t d = 0; d < D; d++) {  // D steps with the current list (its margins were sized for them)
+        if (int rc = launch_forces(c))
+            return rc;
+        if (int rc = step_tail(c))
+            return rc;
+    }
+    HIPCK(hipStreamWaitEvent(c->detStream, c->evSnap, 0));
+    uint64_t nC = 0;
+    {
+        ScopedTimer tm(c, "detect_async_part1", true, c->detStream);
+        HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->detStream));
+        hipLaunchKernelGGL(k_margins, dim3(grid_for(c->nOwners)), dim3(256), 0, c->detStream, c->dp, c->ownersSnap.as<OwnerRec>(),
+                           K + D, c->ctr.as<DetectCounters>());
+        if (int rc = detect_part1(c, c->detStream, c->ownersSnap.as<OwnerRec>(), true, &nC))
+            return rc;
+    }
+    HIPCK(hipEventRecord(c->evP1, c->detStream));
+    HIPCK(hipStreamWaitEvent(c->stream, c->evP1, 0));
+    {
+        ScopedTimer tm(c, "detect_async_part2", true);
+        if (int rc = detect_part2(c, nC))
+            return rc;
+        if (int rc = do_migrate(c))
+            return rc;
+    }
+    c->stepsSinceCD = 0;
+    c->listStale = false;
+    c->nAsyncDetections++;
+    return DEME_OK;
+}
+
+int deme_set_async_detection(deme_ctx* c, uint32_t leadSteps) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    c->asyncLead = leadSteps;
+    return DEME_OK;
+}
+
 int deme_step(deme_ctx* c, uint32_t nsteps) {
     if (int rc = check_ready(c))
         return rc;
     if (!c->hShared.empty())
         return fail(c, DEME_ERR_INVALID, "this slab holds replicated free owners: step it through deme_halo_group_step, which adds their accelerations up across the slabs");
     for (uint32_t i = 0; i < nsteps; i++) {
+        if (async_detection_can_start(c, nsteps - i)) {
+            if (int rc = async_detection_cycle(c))
+                return rc;
+            i += c->asyncLead - 1;
+            continue;
+        }
         if (detection_due(c))
             if (int rc = detection_phase(c))
                 return rc;

@@ -1650,7 +1650,7 @@ class DEMSolver {
     unsigned m_cd_freq = 20;
     double m_bin_size = -1;
     size_t m_bin_num_target = 1000000;
-    float m_bin_multiple = 8.0f, m_safety_multi = 1.f, m_safety_adder = 0.f, m_max_vel = 1e15f, m_err_vel = 1e15f;
+    float m_bin_multiple = 8.0f, m_safety_multi = 1.f, m_safety_adder = 3.f /* API.h:1484 m_expand_base_vel */, m_max_vel = 1e15f, m_err_vel = 1e15f;
     TIME_INTEGRATOR m_integrator = TIME_INTEGRATOR::EXTENDED_TAYLOR;
     uint8_t m_family_masks[DEME_FAMILY_MASK_ENTRIES] = {0};
     float m_family_extra[DEME_NUM_FAMILIES] = {0};

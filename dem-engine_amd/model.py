@@ -213,8 +213,8 @@ class SceneBuilder:
         self.bin_multiple = 8.0
         self.target_bin_num = 1000000
         self.expand_factor = 0.0
-        self.safety_multi = 1.0
-        self.safety_adder = 0.0
+        self.safety_multi = 1.0   # API.h:1481 m_expand_safety_multi
+        self.safety_adder = 3.0   # API.h:1484 m_expand_base_vel: 3 m/s on top of every owner's speed when sizing the margins
         self.approx_max_vel = 1e15
         self.err_out_vel = 1e15
         self.err_out_bin_sph = 32768
@@ -1127,6 +1127,7 @@ def packed_bed(n_target, seed=2024, scale=0.005, spacing_mult=3.0, jitter=0.05, 
     b.SetGravitationalAcceleration((0, 0, -9.81))
     b.SetCDUpdateFreq(cd_freq)
     b.SetInitBinSizeAsMultipleOfSmallestSphere(bin_multiple)
+    b.SetExpandSafetyAdder(0.0)  # margins from the owners' own speeds alone (the reference's default adds 3 m/s: far too wide for a bed)
     b.force_model = force_model
     b.SetMaxVelocity(5.0)
     b.SetErrorOutVelocity(1e3)

@@ -218,6 +218,14 @@ int deme_calc_forces(deme_ctx* ctx);
 int deme_integrate(deme_ctx* ctx);
 /* DoDynamics inner loop (dT.cpp:2401-2467): nsteps of {detect every K, forces, integrate}. */
 int deme_step(deme_ctx* ctx, uint32_t nsteps);
+/* The reference runs its contact detection (kT) beside the dynamics (dT) with bounded staleness (kT.cpp:100-216, dT.cpp:1955-2038,
+ * 2276-2299).  Here, opt-in: leadSteps = D > 0 makes deme_step start a detection D steps before the list is due -- from a copy of
+ * the owner records, on a stream of its own, with margins for the K + D steps between the copy and the end of the new list's
+ * service -- while the main stream works through those D steps with the current list; the new list is swapped in when they are
+ * enqueued.  No contact is missed; the list holds a few more near-pairs (zero contributions) than a lock-step detection's, so an
+ * exact-mode trajectory is the lock-step one.  Needs K > D and a deme_step call of at least D steps at the right moment; scenes
+ * with a mesh, ghosts, persistent contacts or the adaptive controllers keep the lock-step detection.  0 switches it off. */
+int deme_set_async_detection(deme_ctx* ctx, uint32_t leadSteps);
 
 int deme_get_counts(deme_ctx* ctx, DemeCounts* out);
 
