@@ -34,9 +34,10 @@ README_CLUMP_STEPS_PER_S = 1e6 * 1e6 / 3600.0  # reference README.md:48, two RTX
 HALO = 0.03  # ghost layer thickness [m]: two lattice spacings (clump reach 7.3 mm)
 
 
-def build_bed(pkg, n_clumps, seed, cd_freq, x_mult=1, order="lattice", bin_multiple=5.0):
+def build_bed(pkg, n_clumps, seed, cd_freq, x_mult=1, order="lattice", bin_multiple=5.0, slab=None):
+    """slab = (rank, n_ranks, halo): only that x-slab of the bed (own clumps + ghosts) is flattened into a scene"""
     b = pkg.model.packed_bed(n_clumps * x_mult, seed=seed, cd_freq=cd_freq, aspect=(1.0 * x_mult, 1.0, 0.05),
-                             spacing_mult=3.0, jitter=0.05, bin_multiple=bin_multiple, init_vz=-1.0, order=order)
+                             spacing_mult=3.0, jitter=0.05, bin_multiple=bin_multiple, init_vz=-1.0, order=order, slab=slab)
     b.SetExpandSafetyMultiplier(1.2)
     b.SetExpandSafetyAdder(0.02)
     return b
@@ -405,7 +406,9 @@ def main():
     if args.config5:
         b = build_config5(pkg, args.clumps * world, args.seed, args.cd_freq)
     else:
-        b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order, bin_multiple=args.bin_multiple)
+        # N > 1: every rank builds its own slab of the N-times-longer bed (its clumps and their ghosts), not the whole bed
+        b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order, bin_multiple=args.bin_multiple,
+                      slab=(rank, world, HALO) if (world > 1 and not args.mesh_triangles) else None)
     mesh_obj = None
     if args.mesh_triangles:
         lo, hi = b.user_box_min, b.user_box_max
@@ -418,8 +421,11 @@ def main():
     halo, part = None, None
     group, extra_ctx, slab_parts = None, [], None
     if world > 1:
-        x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
-        part = pkg.decomp.decompose(b.arrays, b.counts, x, world, HALO)[rank]
+        if getattr(b, "slab_edges", None) is not None:
+            part = pkg.decomp.decompose(b.arrays, b.counts, b.slab_x, world, HALO, edges=b.slab_edges, only_rank=rank)[rank]
+        else:
+            x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+            part = pkg.decomp.decompose(b.arrays, b.counts, x, world, HALO)[rank]
         sc = part["scene"]
         n_own = part["n_own"]
     elif args.slabs > 1:

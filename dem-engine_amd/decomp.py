@@ -42,11 +42,14 @@ def _ranges(starts, counts):
     return np.repeat(starts - first, counts) + np.arange(total, dtype=np.int64)
 
 
-def decompose(arrays, counts, clump_x, n_ranks, halo, shared_free=False):
+def decompose(arrays, counts, clump_x, n_ranks, halo, shared_free=False, edges=None, only_rank=None):
     """Split a global scene.  clump_x: x of every clump centre (world frame).  Returns one dict per rank:
     arrays, counts, n_own, global_ids (own clumps' global owner ids), send/recv id lists (local owner ids).
     shared_free: allow replicated owners that move under contact forces (see below); the slabs must then be stepped by
-    abi.HaloGroup (deme_halo_group_step), which adds their accelerations up across the slabs every step."""
+    abi.HaloGroup (deme_halo_group_step), which adds their accelerations up across the slabs every step.
+    edges / only_rank: the scene holds ONE slab of a larger bed (that rank's clumps and its ghosts, in the larger bed's order --
+    model.packed_bed(slab=...)): the boundaries of the whole bed are given, only that rank's part is built (the others are None),
+    and `global_ids` / ghost ids are indices into the scene given, not into the larger bed."""
     n_clumps = int(counts["nOwnerClumps"])
     n_owners = int(counts["nOwners"])
     # Analytical owners and meshes are replicated on every rank.  That is exact as it stands when the owner's motion does not
@@ -62,7 +65,9 @@ def decompose(arrays, counts, clump_x, n_ranks, halo, shared_free=False):
         raise ValueError(f"replicated owner(s) {free} (meshes / analytical bodies) move under contact forces: decompose(..., "
                          "shared_free=True) and step the slabs with abi.HaloGroup, which all-reduces their accelerations every step")
     x = np.asarray(clump_x, np.float64)[:n_clumps]
-    edges = slab_edges(x, n_ranks)
+    if edges is None:
+        edges = slab_edges(x, n_ranks)
+    edges = np.asarray(edges, np.float64)
     # ghosts are taken from the face neighbours only: an interior slab thinner than the halo would leave clumps of the slab
     # after next within reach of the face without a ghost copy (equal-count slabs get thin where the bed is dense)
     widths = np.diff(edges)[1:-1]
@@ -75,6 +80,9 @@ def decompose(arrays, counts, clump_x, n_ranks, halo, shared_free=False):
     extra_owners = np.arange(n_clumps, n_owners)  # analytical and mesh owners, kept on every rank
     out = []
     for r in range(n_ranks):
+        if only_rank is not None and r != only_rank:
+            out.append(None)
+            continue
         own = np.nonzero(rank_of == r)[0]
         gl = np.nonzero((rank_of == r - 1) & (x >= edges[r] - halo))[0] if r > 0 else np.zeros(0, np.int64)
         gr = np.nonzero((rank_of == r + 1) & (x < edges[r + 1] + halo))[0] if r < n_ranks - 1 else np.zeros(0, np.int64)
@@ -105,14 +113,25 @@ def decompose(arrays, counts, clump_x, n_ranks, halo, shared_free=False):
     # send lists: what my neighbour holds as ghosts, in the neighbour's slot order (ascending global id on both sides)
     for r in range(n_ranks):
         me = out[r]
+        if me is None:
+            continue
         me["recv_left"] = np.arange(me["n_own"], me["n_own"] + len(me["ghost_left_g"]), dtype=np.uint32)
         me["recv_right"] = np.arange(me["n_own"] + len(me["ghost_left_g"]),
                                      me["n_own"] + len(me["ghost_left_g"]) + len(me["ghost_right_g"]), dtype=np.uint32)
-        me["send_left"] = me["new_id"][out[r - 1]["ghost_right_g"]].astype(np.uint32) if r > 0 else np.zeros(0, np.uint32)
-        me["send_right"] = me["new_id"][out[r + 1]["ghost_left_g"]].astype(np.uint32) if r < n_ranks - 1 \
-            else np.zeros(0, np.uint32)
+        # what the neighbour holds as ghosts from me: my own clumps within the halo of the shared face (the neighbour's rule,
+        # evaluated here so that a rank needs nobody else's part)
+        to_left = np.nonzero((rank_of == r) & (x < edges[r] + halo))[0] if r > 0 else np.zeros(0, np.int64)
+        to_right = np.nonzero((rank_of == r) & (x >= edges[r + 1] - halo))[0] if r < n_ranks - 1 else np.zeros(0, np.int64)
+        me["send_left"] = me["new_id"][to_left].astype(np.uint32)
+        me["send_right"] = me["new_id"][to_right].astype(np.uint32)
         assert (me["send_left"] < me["n_own"]).all() and (me["send_right"] < me["n_own"]).all()
+        if r > 0 and out[r - 1] is not None:
+            assert np.array_equal(to_left, out[r - 1]["ghost_right_g"])
+        if r < n_ranks - 1 and out[r + 1] is not None:
+            assert np.array_equal(to_right, out[r + 1]["ghost_left_g"])
     for me in out:
+        if me is None:
+            continue
         me["scene"] = abi.make_scene_struct(me["arrays"], me["counts"])
         del me["new_id"]
     return out

@@ -1088,9 +1088,14 @@ def morton_codes(pts, cell):
 
 def packed_bed(n_target, seed=2024, scale=0.005, spacing_mult=3.0, jitter=0.05, aspect=(1.0, 1.0, 0.45),
                three_sphere=True, cd_freq=0, E=1e8, nu=0.3, CoR=0.6, mu=0.2, Crr=0.0, h=5e-6, bin_multiple=4.0,
-               radii_poly=None, force_model=abi.FORCE_HERTZIAN, init_vz=0.0, order="lattice"):
+               radii_poly=None, force_model=abi.FORCE_HERTZIAN, init_vz=0.0, order="lattice", slab=None):
     """BASELINE.md config-2 recipe: three-sphere clumps (3_clump.csv * scale) on an HCP lattice of
-    spacing 3*scale with seeded jitter and random orientations inside a box with 5 wall planes."""
+    spacing 3*scale with seeded jitter and random orientations inside a box with 5 wall planes.
+    slab = (rank, n_ranks, halo): the scene of ONE x-slab of that bed -- the clumps rank owns plus those within `halo` of its faces,
+    with the positions, orientations and kinds the whole bed would give them (the cheap per-clump random draws are made for the
+    whole bed, the expensive flattening only for the slab).  The builder then carries slab_edges (equal-count boundaries of the whole
+    bed), slab_global_ids (global clump index of every local clump) and slab_x (their x); decomp.decompose(..., edges=, only_rank=)
+    turns it into rank's part without any rank ever holding the whole bed's scene."""
     rng = np.random.default_rng(seed)
     sep = spacing_mult * scale
     vol_per = sep ** 3 / math.sqrt(2.0)
@@ -1112,17 +1117,27 @@ def packed_bed(n_target, seed=2024, scale=0.005, spacing_mult=3.0, jitter=0.05, 
     elif order == "morton":
         pts = pts[np.argsort(morton_codes(pts, 2.0 * sep), kind="stable")]
     pts = pts + ((rng.random(pts.shape) * 2 - 1) * (jitter * sep)).astype(np.float32)
+    keep = None
+    if slab is not None:
+        from .decomp import slab_edges
+        rank, n_ranks, halo = slab
+        x = pts[:, 0].astype(np.float64)
+        edges = slab_edges(x, n_ranks)
+        keep = np.nonzero((x >= edges[rank] - halo) & (x < edges[rank + 1] + halo))[0]
+        b.slab_edges, b.slab_global_ids, b.slab_x, b.slab_total = edges, keep, pts[keep, 0].copy(), len(pts)
+    sub = (lambda v: v) if keep is None else (lambda v: v[keep])
     if three_sphere:
         tmpl = b.LoadThreeSphereClump(scale, 2.6e3, mat)
-        batch = b.AddClumps(tmpl, pts)
+        batch = b.AddClumps(tmpl, sub(pts))
     else:
         radii_poly = radii_poly or [scale]
         tmpls = [b.LoadSphereType(2.6e3 * 4.0 / 3.0 * math.pi * r ** 3, r, mat) for r in radii_poly]
         pick = rng.integers(0, len(tmpls), len(pts))
-        batch = b.AddClumps([tmpls[i] for i in pick], pts)
-    batch.SetOriQ(random_unit_quaternions(len(pts), rng))
+        batch = b.AddClumps([tmpls[i] for i in sub(pick)], sub(pts))
+    batch.SetOriQ(sub(random_unit_quaternions(len(pts), rng)))
+    n_local = len(pts) if keep is None else len(keep)
     if init_vz:
-        batch.SetVel(np.tile(np.array([0, 0, init_vz], np.float32), (len(pts), 1)))
+        batch.SetVel(np.tile(np.array([0, 0, init_vz], np.float32), (n_local, 1)))
     b.SetInitTimeStep(h)
     b.SetGravitationalAcceleration((0, 0, -9.81))
     b.SetCDUpdateFreq(cd_freq)

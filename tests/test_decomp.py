@@ -92,6 +92,33 @@ def test_free_replicated_owner_is_flagged_not_refused(pkg):
     assert not any((pt["arrays"]["ownerGhost"] == 2).any() for pt in pkg.decomp.decompose(fixed.arrays, fixed.counts, x, 2, halo=0.035))
 
 
+def test_slab_local_construction_equals_the_cut_of_the_whole_bed(pkg):
+    """model.packed_bed(slab=(rank, n, halo)) + decompose(edges=, only_rank=): a rank builds its own slab of the bed (own clumps
+    and ghosts) without ever holding the whole bed's scene -- same parameters, same arrays, same exchange lists as cutting the
+    whole bed (what bench.py --gpus N does per rank)"""
+    kw = dict(seed=4, cd_freq=5, spacing_mult=2.5, init_vz=-0.4, aspect=(3.0, 1.0, 0.4), order="morton")
+    n, world, halo = 2400, 3, 0.035
+    whole = pkg.model.packed_bed(n, **kw)
+    p, sc = whole.Initialize()
+    x = np.concatenate([bb.xyz for bb in whole.batches])[:, 0]
+    parts = pkg.decomp.decompose(whole.arrays, whole.counts, x, world, halo)
+    for r in range(world):
+        b = pkg.model.packed_bed(n, slab=(r, world, halo), **kw)
+        pr, scr = b.Initialize()
+        for name, _ in pkg.abi.DemeParams._fields_:
+            assert getattr(pr, name) == getattr(p, name), name
+        assert b.slab_total == int(sc.nOwnerClumps) and np.array_equal(b.slab_edges, parts[r]["all_edges"])
+        mine = pkg.decomp.decompose(b.arrays, b.counts, b.slab_x, world, halo, edges=b.slab_edges, only_rank=r)[r]
+        ref = parts[r]
+        assert mine["n_own"] == ref["n_own"]
+        assert np.array_equal(b.slab_global_ids[mine["global_ids"]], ref["global_ids"])
+        for k in ("send_left", "send_right", "recv_left", "recv_right"):
+            assert np.array_equal(mine[k], ref[k]), k
+        for k, v in ref["arrays"].items():
+            assert np.array_equal(np.asarray(mine["arrays"][k]), np.asarray(v)), k
+        assert mine["counts"] == ref["counts"]
+
+
 def test_two_slabs_equal_single_domain_oracle(pkg, orc):
     b, p, sc, x = build_global(pkg)
     parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
