@@ -371,6 +371,9 @@ def main():
                     help="profiling aid (1 GPU): file that keeps the pre-settled bed (owner state, contact list, wildcards) so "
                          "that repeated rocprofv3 passes of the same command skip the 30 000 untimed steps; created when absent")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--watchdog", type=float, default=1500.0,
+                    help="seconds after which the process gives up with exit code 3 (a rank stuck in a collective must not hold "
+                         "the others, and the launcher, for ever); 0 = none")
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout: RCCL prints a version banner there when a communicator is created.  The real stdout
@@ -378,6 +381,15 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.watchdog > 0:
+        import threading
+
+        def _give_up():
+            print(f"[bench] rank {os.environ.get('RANK', '0')}: not done after {args.watchdog:.0f} s -- giving up", file=sys.stderr, flush=True)
+            os._exit(3)
+        wd = threading.Timer(args.watchdog, _give_up)
+        wd.daemon = True
+        wd.start()
 
     import torch
     import torch.distributed as dist
