@@ -329,12 +329,34 @@ class Halo:
             c.halo_unpack(self.ids[r].data_ptr(), self.n[r], self.buf[r].data_ptr())
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: run the same command line as N ranks of ONE node under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and pass its exit code on.  A scaling run can then not
+    silently measure one rank."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n_gpus} without a launcher: re-executing as {n_gpus} ranks under torch.distributed.run", file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--clumps", type=int, default=1_000_000, help="clumps per GPU")
+    ap.add_argument("--clumps", type=int, default=1_000_000, help="clumps per GPU (weak scaling)")
+    ap.add_argument("--clumps-total", type=int, default=0,
+                    help="STRONG scaling: this many clumps in the whole job, cut into --gpus slabs (BASELINE configs[2] as written: "
+                         "--clumps-total 10000000 at 2 and 8 GPUs); overrides --clumps")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="plumbing check of the launch path only: rendezvous, count the ranks, print a one-line JSON and exit "
+                         "(no GPU work; what tests/test_bench_launch.py runs on a CPU box)")
     ap.add_argument("--cd-freq", type=int, default=40,
                     help="contact detection every K steps (0: every step); 40 = the setting of the demo the config-2 recipe "
                          "comes from (DEMdemo_Mixer.cpp:87); the reference's built-in default is 20 (API.h:1509)")
@@ -375,6 +397,10 @@ def main():
                     help="seconds after which the process gives up with exit code 3 (a rank stuck in a collective must not hold "
                          "the others, and the launcher, for ever); 0 = none")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    if args.clumps_total:
+        args.clumps = max(1, args.clumps_total // max(1, args.gpus))
 
     # Only the JSON line may reach stdout: RCCL prints a version banner there when a communicator is created.  The real stdout
     # is kept aside and file descriptor 1 points at stderr for everything else this process (and its C libraries) writes.
@@ -397,6 +423,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started as {world} rank(s): launch it plainly (it spawns its own ranks) or with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.launch_check:  # no GPU work: the rendezvous and the rank count only
+        seen = 1
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t_ = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t_)
+            seen = int(t_.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen,
+                                           "clumps_per_gpu": args.clumps, "scaling": "strong" if args.clumps_total else "weak"}) + "\n").encode())
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # DEME_BENCH_VIA_HOST=1: plumbing test of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs,
@@ -412,7 +454,6 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     red_dev = "cpu" if via_host else "cuda"
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     pkg = entry.load_package()
     if args.config5:
@@ -657,13 +698,23 @@ def main():
             copy_gbs = attainable_copy_gbs(torch)
         except Exception as e:  # (a box short of 2 GiB of free HBM)
             print(f"[bench] attainable-rate probe skipped: {e}", file=sys.stderr)
+    halo_loop = "library" if group is not None else ("python" if halo is not None else None)
+    rccl_ranks = None
+    if group is not None:
+        rccl_ranks = group.comm_count()
+    elif halo is not None and not via_host:
+        rccl_ranks = dist.get_world_size()
     out = {
         "metric": "clump*steps/s", "value": value, "unit": "clump*steps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if args.clumps_total else "weak",
+        # who moved the ghosts, and how many ranks the communicator that moved them spans (ncclCommCount of the library's own
+        # communicator; the world size of torch's for the Python loop): a run whose count differs from --gpus exits non-zero
+        "halo_loop": halo_loop, "rccl_ranks": rccl_ranks,
         "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "arith_mode": ctx.arith_mode(), "data": "synthetic",
         "config": {"workload": ("BASELINE configs[4] flavour: polydisperse spheres (8 templates, r..3r) with a run-time compiled "
                                 "cohesion model" if args.config5 else
-                                f"BASELINE configs[1]: {args.clumps} three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling"
+                                f"BASELINE configs[{2 if args.clumps_total else 1}]: {args.clumps} three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling"
                                 + (f"; one bed {world} times as long cut into {world} x-slabs (configs[2] flavour)" if world > 1 else ""))
                                + (f" + {int(sc.nTri)}-triangle plate (configs[3] flavour)" if int(sc.nTri) else "")
                                + (f", a deformable mesh: nodes rewritten every {args.mesh_update_every} steps ({mesh_state['updates']} updates so far)"
@@ -701,6 +752,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if world > 1 and not via_host and rccl_ranks != world:
+        raise SystemExit(f"[bench] the ghost exchange ran on a communicator of {rccl_ranks} rank(s), not {world}: this is not a {world}-GPU measurement")
 
 
 if __name__ == "__main__":

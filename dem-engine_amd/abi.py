@@ -297,6 +297,13 @@ class HaloGroup:
         self._ck(self.lib.deme_halo_group_stats(self.h, C.byref(a), C.byref(b)), "deme_halo_group_stats")
         return int(a.value), int(b.value)
 
+    def comm_count(self):
+        """ranks of the group's RCCL communicator, as RCCL reports it (ncclCommCount)"""
+        n = C.c_int(0)
+        self.lib.deme_halo_group_comm_count.argtypes = [_P, C.POINTER(C.c_int)]
+        self._ck(self.lib.deme_halo_group_comm_count(self.h, C.byref(n)), "deme_halo_group_comm_count")
+        return int(n.value)
+
     def host_time(self, reset=False):
         """host microseconds spent enqueuing: (interior passes, packs, RCCL group, unpack + boundary pass + integration)"""
         us = (C.c_double * 4)()

@@ -26,6 +26,7 @@
 #include "deme_force_fast.h"
 #include "deme_jit.h"
 #include "deme_kernels.h"
+#include "deme_tile.h"
 #include "deme_mesh_kernels.h"
 
 using namespace deme_dev;
@@ -69,6 +70,12 @@ struct deme_ctx {
     DevBuf conA4, conA2, conB4, conB2, aSum, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
+    // owner-tile form of the force pass (deme_tile.h), rebuilt per detection
+    DevBuf tInfo, hList, hCount, tileMode, rIdx, rStart, rFlag, rPos;
+    bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
+    bool conTile = false;     // the contributions in memory were written by the tile kernel
+    int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
+    uint32_t tileMaxHalo = 0;
     // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
     DevBuf persistKeys, binStat;
     // acceleration the script adds for the next step only (deme_add_owner_acc): device records + host mirror
@@ -342,6 +349,10 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
         rc |= ensure(c, c->bIdx[k], cap * 4);
     }
     rc |= ensure(c, c->info, cap * 16);
+    rc |= ensure(c, c->tInfo, cap * 8);
+    rc |= ensure(c, c->rIdx, cap * 4);
+    rc |= ensure(c, c->rFlag, (cap + 1) * 4);
+    rc |= ensure(c, c->rPos, (cap + 1) * 4);
     if (c->hasGhosts) {
         rc |= ensure(c, c->cDefer, cap);
         rc |= ensure(c, c->blockMode, (cap / DEME_FORCE_BLOCK + 2) * 4);
@@ -659,9 +670,33 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                            c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(), (uint32_t)(c->heavyList.bytes / 4),
                            c->rangeCtr.as<RangeCounters>(), c->info.as<uint4>(),
                            c->hasGhosts ? c->cDefer.as<uint8_t>() : (uint8_t*)nullptr, c->blockMode.as<uint32_t>());
+        const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM &&
+                                  c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 8192 && c->nComp <= 8192;
+        if (tileEligible) {
+            const uint32_t nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
+            hipLaunchKernelGGL(k_tile_rflag, dim3(grid_for(nC + 1)), dim3(256), 0, c->stream, (uint32_t)nC, c->bIdx[1].as<uint32_t>(),
+                               c->info.as<uint4>(), c->rFlag.as<uint32_t>());
+            size_t need = 0;
+            HIPCK(rocprim::exclusive_scan(nullptr, need, c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(), 0u, (size_t)nC + 1,
+                                          rocprim::plus<uint32_t>(), c->stream));
+            if (int rc = ensure(c, c->scanTmp, need))
+                return rc;
+            need = c->scanTmp.bytes;
+            HIPCK(rocprim::exclusive_scan(c->scanTmp.p, need, c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(), 0u, (size_t)nC + 1,
+                                          rocprim::plus<uint32_t>(), c->stream));
+            hipLaunchKernelGGL(k_tile_rfill, dim3(grid_for(std::max<size_t>(nC, (size_t)c->nOwners + 1))), dim3(256), 0, c->stream,
+                               (uint32_t)nC, c->nOwners, c->bIdx[1].as<uint32_t>(), c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(),
+                               c->bStart.as<uint32_t>(), c->rIdx.as<uint32_t>(), c->rStart.as<uint32_t>());
+            hipLaunchKernelGGL(k_tile_build, dim3(nTiles), dim3(256), 0, c->stream, c->dp, c->nOwners, c->info.as<uint4>(),
+                               c->aStart.as<uint32_t>(), c->owners.as<OwnerRec>(), c->tInfo.as<uint2>(), c->hList.as<uint32_t>(),
+                               c->hCount.as<uint32_t>(), c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr,
+                               c->rangeCtr.as<RangeCounters>());
+        }
         RangeCounters hr{};
         HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
+        c->tileActive = tileEligible && !hr.tileOverflow;
+        c->tileMaxHalo = hr.tileMaxHalo;
         if (hr.nHeavy > c->heavyList.bytes / 4)
             return fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", hr.nHeavy);
         c->nHeavy = hr.nHeavy;
@@ -722,6 +757,10 @@ GatherArgs gather_args(deme_ctx* c) {
     g.aSum = c->aSum.as<float4>();
     g.nextAcc = c->nextAccPending ? c->nextAcc.as<AccRec>() : nullptr;
     g.world = c->arith == DEME_ARITH_FAST ? 1u : 0u;
+    if (c->conTile) {  // the tile kernel's sums and its records of tile-crossing contacts
+        g.bStart = c->rStart.as<uint32_t>(), g.bIdx = c->rIdx.as<uint32_t>();
+        g.tile = 1u;
+    }
     return g;
 }
 
@@ -738,6 +777,7 @@ void launch_reduce_heavy(deme_ctx* c, bool skipFixed) {
 int launch_forces(deme_ctx* c, int pass = -1) {
     if (c->nContacts == 0) {
         c->conValid = true;
+        c->conTile = false;
         return DEME_OK;
     }
     if (c->hp.forceModel == DEME_FORCE_CUSTOM && !c->customFn[0])
@@ -773,6 +813,35 @@ int launch_forces(deme_ctx* c, int pass = -1) {
     // the fast kernel covers the built-in models' hot classes; contact recording (body-frame contact points) and user
     // fragments (the reference's body-frame vocabulary) run the general kernel, with world-frame contributions in fast mode
     const bool fastKernel = fastMode && !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM;
+    if (fastKernel && c->tileActive && c->tileEnable) {  // owner tiles: deme_tile.h
+        TileArgs ta{};
+        ta.owners = a.owners;
+        ta.tInfo = c->tInfo.as<uint2>();
+        ta.aStart = a.aStart;
+        ta.hList = c->hList.as<uint32_t>(), ta.hCount = c->hCount.as<uint32_t>();
+        ta.wc = a.wc;
+        ta.tSum = a.aSum;
+        ta.conB4 = a.conB4, ta.conB2 = a.conB2;
+        ta.nOwners = c->nOwners;
+        ta.nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
+        ta.xcdGroup = c->xcdGroup;
+        if (pass >= 0 && c->hasGhosts) {
+            ta.tileMode = c->tileMode.as<uint32_t>();
+            ta.pass = (uint32_t)pass;
+        }
+        unsigned nBlk = ta.nTiles;
+        if (ta.xcdGroup)
+            nBlk = (nBlk + 8u * ta.xcdGroup - 1u) / (8u * ta.xcdGroup) * (8u * ta.xcdGroup);
+        ScopedTimer tm(c, "calc_forces");
+        if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
+            hipLaunchKernelGGL((k_tile_forces<0>), dim3(nBlk), dim3(DEME_TILE_T), 0, c->stream, c->dp, ta);
+        else
+            hipLaunchKernelGGL((k_tile_forces<1>), dim3(nBlk), dim3(DEME_TILE_T), 0, c->stream, c->dp, ta);
+        c->conValid = true;
+        c->conTile = true;
+        return DEME_OK;
+    }
+    c->conTile = false;
 
     if (c->record) {
         a.recForce = c->rec[0].as<float>(), a.recTorque = c->rec[1].as<float>(), a.recCPA = c->rec[2].as<float>(),
@@ -923,6 +992,8 @@ int deme_ctx_create(int device, deme_ctx** out) {
         c->arith = (strcmp(e, "exact") == 0) ? DEME_ARITH_EXACT : DEME_ARITH_FAST;
     if (const char* e = getenv("DEME_XCD_GROUP"))  // tuning knob (profiles/): see force_block_id
         c->xcdGroup = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("DEME_TILE"))  // 0: keep the per-contact-block force kernel (A/B measurements)
+        c->tileEnable = atoi(e);
     *out = c;
     return DEME_OK;
 }
@@ -956,7 +1027,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->rIdx, &c->rStart, &c->rFlag, &c->rPos, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1067,6 +1138,14 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->aSum, (nO + 1) * 32) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
         ensure(c, c->fixedFlag, nO + 1) || ensure(c, c->heavyList, 4096 * 4) || ensure(c, c->rangeCtr, sizeof(RangeCounters)))
         return c->lastStatus;
+    {
+        const size_t nTiles = (nO + DEME_TILE_NB - 1) / DEME_TILE_NB + 1;
+        if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) ||
+            ensure(c, c->rStart, (nO + 1) * 4))
+            return c->lastStatus;
+        HIPCK(hipMemsetAsync(c->hCount.p, 0, c->hCount.bytes, c->stream));
+        c->tileActive = c->conTile = false;
+    }
     HIPCK(hipMemsetAsync(c->aStart.p, 0, c->aStart.bytes, c->stream));
     HIPCK(hipMemsetAsync(c->bStart.p, 0, c->bStart.bytes, c->stream));
     HIPCK(hipMemsetAsync(c->heavy.p, 0, c->heavy.bytes, c->stream));
@@ -1778,6 +1857,7 @@ struct RcclApi {
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(ncclComm_t, int*) = nullptr;
     std::string err;
 };
 RcclApi* rccl_api() {
@@ -1810,6 +1890,7 @@ RcclApi* rccl_api() {
     api.Recv = (decltype(api.Recv))sym("ncclRecv");
     api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
     if (!ok) {
         api.err = "librccl.so lacks one of the entry points (send / recv / all-reduce)";
         return &api;
@@ -2024,44 +2105,59 @@ static int halo_exchange(deme_halo_group* g) {
                 return &s;
         return nullptr;
     };
+    for (auto& s : g->slabs) {  // every check that can fail comes BEFORE the group opens: an RCCL group left open hangs what follows
+        HaloSide& r = s.side[1];
+        if (r.peerRank >= 0 && r.peerLocal) {
+            HaloSlab* nb = find(r.peerLocal);
+            if (!nb)
+                return gfail(g, DEME_ERR_INVALID, "a local neighbour context is not attached to the group");
+            HaloSide& l = nb->side[0];
+            if (l.nRecv != r.nSend || l.nSend != r.nRecv)
+                return gfail(g, DEME_ERR_INVALID, "ghost lists of two neighbouring slabs do not match (%u/%u vs %u/%u)", r.nSend, r.nRecv, l.nRecv, l.nSend);
+        }
+    }
     const double t1 = now_us();
     g->hostUs[1] += t1 - t0;
     GNCCL(g->api->GroupStart());
+#define GNCCL_IN_GROUP(call)                                                                                                     \
+    do {                                                                                                                         \
+        int _r = (call);                                                                                                         \
+        if (_r != 0) {                                                                                                           \
+            g->api->GroupEnd();                                                                                                  \
+            return gfail(g, DEME_ERR_HIP, "%s failed: %s (%s:%d)", #call, g->api->GetErrorString(_r), __FILE__, __LINE__);        \
+        }                                                                                                                        \
+    } while (0)
     for (auto& s : g->slabs) {
         // the right-hand edge of every slab (each edge once).  A neighbour in this process: the two transfers go to self, and
         // sends to self meet receives from self in posting order -- so each send is posted right before the receive it feeds
         HaloSide& r = s.side[1];
         if (r.peerRank >= 0) {
             if (r.peerLocal) {
-                HaloSlab* nb = find(r.peerLocal);
-                if (!nb)
-                    return gfail(g, DEME_ERR_INVALID, "a local neighbour context is not attached to the group");
-                HaloSide& l = nb->side[0];
-                if (l.nRecv != r.nSend || l.nSend != r.nRecv)
-                    return gfail(g, DEME_ERR_INVALID, "ghost lists of two neighbouring slabs do not match (%u/%u vs %u/%u)", r.nSend, r.nRecv, l.nRecv, l.nSend);
+                HaloSide& l = find(r.peerLocal)->side[0];  // (checked above)
                 if (r.nSend) {
-                    GNCCL(g->api->Send(r.sendBuf, (size_t)r.nSend * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
-                    GNCCL(g->api->Recv(l.recvBuf, (size_t)l.nRecv * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
+                    GNCCL_IN_GROUP(g->api->Send(r.sendBuf, (size_t)r.nSend * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
+                    GNCCL_IN_GROUP(g->api->Recv(l.recvBuf, (size_t)l.nRecv * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
                 }
                 if (l.nSend) {
-                    GNCCL(g->api->Send(l.sendBuf, (size_t)l.nSend * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
-                    GNCCL(g->api->Recv(r.recvBuf, (size_t)r.nRecv * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
+                    GNCCL_IN_GROUP(g->api->Send(l.sendBuf, (size_t)l.nSend * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
+                    GNCCL_IN_GROUP(g->api->Recv(r.recvBuf, (size_t)r.nRecv * sizeof(GhostRec), kNcclUint8, g->rank, g->comm, g->xstream));
                 }
             } else {
                 if (r.nSend)
-                    GNCCL(g->api->Send(r.sendBuf, (size_t)r.nSend * sizeof(GhostRec), kNcclUint8, r.peerRank, g->comm, g->xstream));
+                    GNCCL_IN_GROUP(g->api->Send(r.sendBuf, (size_t)r.nSend * sizeof(GhostRec), kNcclUint8, r.peerRank, g->comm, g->xstream));
                 if (r.nRecv)
-                    GNCCL(g->api->Recv(r.recvBuf, (size_t)r.nRecv * sizeof(GhostRec), kNcclUint8, r.peerRank, g->comm, g->xstream));
+                    GNCCL_IN_GROUP(g->api->Recv(r.recvBuf, (size_t)r.nRecv * sizeof(GhostRec), kNcclUint8, r.peerRank, g->comm, g->xstream));
             }
         }
         HaloSide& l = s.side[0];
         if (l.peerRank >= 0 && !l.peerLocal) {  // a left neighbour on another rank (a local one was served as its right edge)
             if (l.nSend)
-                GNCCL(g->api->Send(l.sendBuf, (size_t)l.nSend * sizeof(GhostRec), kNcclUint8, l.peerRank, g->comm, g->xstream));
+                GNCCL_IN_GROUP(g->api->Send(l.sendBuf, (size_t)l.nSend * sizeof(GhostRec), kNcclUint8, l.peerRank, g->comm, g->xstream));
             if (l.nRecv)
-                GNCCL(g->api->Recv(l.recvBuf, (size_t)l.nRecv * sizeof(GhostRec), kNcclUint8, l.peerRank, g->comm, g->xstream));
+                GNCCL_IN_GROUP(g->api->Recv(l.recvBuf, (size_t)l.nRecv * sizeof(GhostRec), kNcclUint8, l.peerRank, g->comm, g->xstream));
         }
     }
+#undef GNCCL_IN_GROUP
     GNCCL(g->api->GroupEnd());
     GHIP(hipEventRecord(g->evExchanged, g->xstream));
     const double t2 = now_us();
@@ -2086,6 +2182,9 @@ static int halo_exchange(deme_halo_group* g) {
 // and every slab integrates its replica with the same total.  (the only all-reduce of the path.)
 static int shared_tail(deme_halo_group* g) {
     const uint32_t n = g->nShared, n4 = 2 * n;
+    for (auto& s : g->slabs)  // the rules would see each slab's PARTIAL acceleration of a replicated owner and could decide differently per slab
+        if (s.ctx->rulesFn && s.ctx->rulesNeedAcc)
+            return gfail(g, DEME_ERR_INVALID, "family-change rules that read accelerations cannot be combined with replicated free owners under decomposition");
     for (auto& s : g->slabs) {
         deme_ctx* c = s.ctx;
         if (int rc = overlap_forces(c))
@@ -2192,6 +2291,12 @@ int deme_halo_group_stats(const deme_halo_group* g, uint64_t* exchanges, uint64_
     if (bytesSentPerStep)
         *bytesSentPerStep = g->bytesPerStep;
     return DEME_OK;
+}
+
+int deme_halo_group_comm_count(const deme_halo_group* g, int* ranks) {
+    if (!g || !g->comm || !ranks)
+        return DEME_ERR_INVALID;
+    return g->api->CommCount(g->comm, ranks) == 0 ? DEME_OK : DEME_ERR_HIP;
 }
 
 int deme_get_counts(deme_ctx* c, DemeCounts* out) {

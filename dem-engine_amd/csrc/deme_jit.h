@@ -330,7 +330,7 @@ extern "C" __global__ __launch_bounds__(256) void deme_family_changes(const deme
 )DEMEFAM" << rules << R"DEMEFAM(
     }
     if (deme_new_family != family_code)
-        owners[myOwner].family = (r.family & 0x100u) | (uint32_t)deme_new_family;
+        owners[myOwner].family = (r.family & OWNER_FLAG_BITS) | (uint32_t)deme_new_family;  // ghost / replicated-owner bits stay
 }
 )DEMEFAM";
     out = o.str();

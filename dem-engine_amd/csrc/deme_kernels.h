@@ -750,6 +750,9 @@ struct GatherArgs {
     // fast arithmetic mode: the contributions are world-frame forces and torques (ForceArgs::world); their per-owner sums
     // become a and alpha through acc_from_world
     uint32_t world;
+    // owner-tile form of the force pass (deme_tile.h): aSum holds, for EVERY owner, the sum over the contacts its tile evaluated
+    // (A and B sides); bStart / bIdx list only the contacts whose B owner lives in another tile than A's, with records in conB
+    uint32_t tile;
 };
 
 // per-owner conversion of the fast mode: a = F / m, alpha = R^T tau / I (body frame, like the reference's alpha)
@@ -766,7 +769,7 @@ __device__ inline void acc_from_world(const DevParams& p, const OwnerRec& r, flo
 // same in-order sum over the per-contact records (loads issued four at a time).
 __device__ inline void a_side_sum(const GatherArgs& g, uint32_t o, uint32_t s, uint32_t e, float& ax, float& ay, float& az,
                                   float& lx, float& ly, float& lz) {
-    if (a_run_in_one_block(s, e)) {
+    if (g.tile || a_run_in_one_block(s, e)) {
         const float4 v = g.aSum[2 * (size_t)o], w = g.aSum[2 * (size_t)o + 1];
         ax = v.x, ay = v.y, az = v.z, lx = w.x, ly = w.y, lz = w.z;
         return;
@@ -910,7 +913,7 @@ __global__ __launch_bounds__(256) void k_reduce_heavy(const DevParams p, const G
             continue;
         float s[6] = {0, 0, 0, 0, 0, 0};
         const uint32_t a0 = g.aStart[o], a1 = g.aStart[o + 1];
-        if (a_run_in_one_block(a0, a1)) {
+        if (g.tile || a_run_in_one_block(a0, a1)) {
             if (threadIdx.x == 0) {
                 const float4 v = g.aSum[2 * (size_t)o], w = g.aSum[2 * (size_t)o + 1];
                 s[0] = v.x, s[1] = v.y, s[2] = v.z, s[3] = w.x, s[4] = w.y, s[5] = w.z;
@@ -1023,7 +1026,9 @@ struct RangeCounters {
     unsigned int nHeavy;
     unsigned int nHeavyFree;  // heavy owners that are not fixed (they must be reduced every step)
     unsigned int nSA, nSM;    // sphere-analytical / sphere-mesh contacts in the list
-    unsigned int pad[12];
+    unsigned int tileOverflow;  // a tile's halo did not fit (deme_tile.h): the list is evaluated without tiles
+    unsigned int tileMaxHalo;
+    unsigned int pad[10];
 };
 
 // start[o] = first index i with owner[i] >= o, for o = 0 .. nOwners (owner[] ascending): every element fills the owners that

@@ -193,6 +193,11 @@ def owned_payload(part, state, contacts, wildcards, flip_sign_wildcards=(0, 1, 2
             Wm[fm, k] = -Wm[fm, k]
     out = {"global_ids": np.asarray(part["global_ids"], np.int64), "state": own_state, "gA": gA[mine], "gB": gB[mine],
            "type": ctype[mine], "wc": Wm}
+    # replicated owners (walls, meshes, analytical bodies; the same on every rank): their CURRENT state travels too, or a moving
+    # one would jump back to its pose at the previous decomposition
+    n_cl_here = int(part["counts"]["nOwnerClumps"])
+    out["replicated_global"] = np.asarray(part["owner_global"], np.int64)[n_cl_here:].copy()
+    out["replicated_state"] = {k: np.asarray(state[k])[n_cl_here:].copy() for k in GHOST_STATE_KEYS}
     if persistent is not None:
         pA, pB, pT = (np.asarray(x) for x in persistent[:3])
         pm, pgA, pgB, _ = _globalise_pairs(part, pA, pB, pT)
@@ -232,7 +237,7 @@ def _localise_pairs(part, n_sph_global, gA, gB, ty):
     return keep, la, lb, flip
 
 
-def redecompose(global_arrays, counts, payloads, n_ranks, halo, decode_x, flip_sign_wildcards=(0, 1, 2)):
+def redecompose(global_arrays, counts, payloads, n_ranks, halo, decode_x, flip_sign_wildcards=(0, 1, 2), shared_free=False, edges=None):
     """payloads: owned_payload() of every rank (in-process list, or the result of an all_gather_object).
     decode_x(arrays) -> world x of every clump centre.  Returns (global_arrays_now, new_parts, seeds) where
     seeds[r] = (idA, idB, type, wildcards) in rank r's new local sphere ids, ready for seed_contacts().
@@ -247,7 +252,10 @@ def redecompose(global_arrays, counts, payloads, n_ranks, halo, decode_x, flip_s
     for pl in payloads:
         for k in GHOST_STATE_KEYS:
             g[k][pl["global_ids"]] = pl["state"][k]
-    parts = decompose(g, counts, decode_x(g), n_ranks, halo)
+    if payloads and "replicated_state" in payloads[0]:  # every rank holds the same replicas: rank 0's copy speaks for all
+        for k in GHOST_STATE_KEYS:
+            g[k][payloads[0]["replicated_global"]] = payloads[0]["replicated_state"][k]
+    parts = decompose(g, counts, decode_x(g), n_ranks, halo, shared_free=shared_free, edges=edges)
     gA = np.concatenate([pl["gA"] for pl in payloads])
     gB = np.concatenate([pl["gB"] for pl in payloads])
     ty = np.concatenate([pl["type"] for pl in payloads])
@@ -394,10 +402,12 @@ def ghost_packets(own_packet, edges, rank, n_ranks, halo, x_own):
     return sel_l, sub(sel_l), sel_r, sub(sel_r)
 
 
-def assemble_part(old_part, own_packet, send_l, send_r, ghosts_l, ghosts_r, rows_list, flip_sign_wildcards=(0, 1, 2)):
+def assemble_part(old_part, own_packet, send_l, send_r, ghosts_l, ghosts_r, rows_list, flip_sign_wildcards=(0, 1, 2), state=None):
     """New local scene of a rank: [own | ghosts from the left | ghosts from the right | replicated owners (walls, meshes)], its
     exchange lists, and the contact history to seed: every known row (own history first, then what arrived) whose spheres are
-    present and that involves an own clump.  Returns (part, seed = (idA, idB, type, wildcards))."""
+    present and that involves an own clump.  `state`: the old part's CURRENT per-owner state; the replicated owners take their
+    rows from it (without it they would return to their pose at the previous decomposition).
+    Returns (part, seed = (idA, idB, type, wildcards))."""
     a_old, c_old = old_part["arrays"], old_part["counts"]
     n_cl_old, n_ow_old = int(c_old["nOwnerClumps"]), int(c_old["nOwners"])
     packs = [own_packet, ghosts_l, ghosts_r]
@@ -405,8 +415,9 @@ def assemble_part(old_part, own_packet, send_l, send_r, ghosts_l, ghosts_r, rows
     n_cl = n_own + n_gl + n_gr
     extras = np.arange(n_cl_old, n_ow_old)
     a = dict(a_old)
+    rep_src = state if state is not None else a_old
     for k in GHOST_STATE_KEYS:
-        a[k] = np.concatenate([q["state"][k] for q in packs] + [np.asarray(a_old[k])[extras]]).astype(np.asarray(a_old[k]).dtype)
+        a[k] = np.concatenate([q["state"][k] for q in packs] + [np.asarray(rep_src[k])[extras]]).astype(np.asarray(a_old[k]).dtype)
     a["inertiaPropOffsets"] = np.concatenate([q["inertia"] for q in packs] + [np.asarray(a_old["inertiaPropOffsets"])[extras]]).astype(
         np.asarray(a_old["inertiaPropOffsets"]).dtype)
     ghost = np.zeros(n_cl + len(extras), np.uint8)
@@ -487,7 +498,8 @@ def migrate_neighbours(rank, n_ranks, part, state, contacts, wildcards, edges, h
     sel_l, gp_l, sel_r, gp_r = ghost_packets(own, edges, rank, n_ranks, halo, x_own)
     gh_l, gh_r = transport("ghosts", gp_l if rank > 0 else None, gp_r if rank + 1 < n_ranks else None)
     rows_list = [rows] + [q["rows"] for q in (from_l, from_r) if q is not None]
-    return assemble_part(part, own, sel_l, sel_r, gh_l or _empty_packet(part), gh_r or _empty_packet(part), rows_list, flip_sign_wildcards)
+    return assemble_part(part, own, sel_l, sel_r, gh_l or _empty_packet(part), gh_r or _empty_packet(part), rows_list, flip_sign_wildcards,
+                         state=state)
 
 
 def torch_transport(dist, rank, n_ranks):
@@ -538,5 +550,5 @@ def migrate_neighbours_in_process(parts, states, contacts, wildcards, edges, hal
         gh_l = gp[r - 1][3] if r > 0 else _empty_packet(parts[r])
         gh_r = gp[r + 1][1] if r + 1 < n else _empty_packet(parts[r])
         rows_list = [phase1[r][3]] + [q["rows"] for q in (from_l, from_r) if q is not None]
-        out.append(assemble_part(parts[r], own, gp[r][0], gp[r][2], gh_l, gh_r, rows_list, flip_sign_wildcards))
+        out.append(assemble_part(parts[r], own, gp[r][0], gp[r][2], gh_l, gh_r, rows_list, flip_sign_wildcards, state=states[r]))
     return [o[0] for o in out], [o[1] for o in out]

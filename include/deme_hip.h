@@ -439,6 +439,9 @@ int deme_halo_group_stats(const deme_halo_group* g, uint64_t* exchanges, uint64_
 /* host microseconds spent enqueuing since creation / the last reset: [0] interior force passes, [1] packs, [2] the RCCL group,
  * [3] unpacks + boundary passes + integration */
 int deme_halo_group_host_time(deme_halo_group* g, double us[4], int reset);
+/* how many ranks the group's RCCL communicator spans, as RCCL itself reports it (ncclCommCount): a scaling run checks this
+ * against the number of processes it believes it launched */
+int deme_halo_group_comm_count(const deme_halo_group* g, int* ranks);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ def main():
     start = 0
     if last_n:
         # the hot variant of the contact-force kernel: built-in models, or the run-time compiled user model
-        idx = [i for i, r in enumerate(rows) if ("k_calc_forces" in r[2] and "1>" not in short(r[2])) or "deme_custom_forces_ss" in r[2] or "k_forces_fast" in r[2]]
+        idx = [i for i, r in enumerate(rows) if ("k_calc_forces" in r[2] and "1>" not in short(r[2])) or "deme_custom_forces_ss" in r[2] or "k_forces_fast" in r[2] or "k_tile_forces" in r[2] or "k_tile_step" in r[2]]
         if len(idx) >= last_n:
             start = idx[-last_n]
     agg = defaultdict(lambda: [0, 0, 10 ** 18, 0, "", ""])

@@ -28,7 +28,7 @@ def main():
         disp[d][r["Counter_Name"]] = float(r["Counter_Value"])
         names[d] = r["Kernel_Name"]
     ids = sorted(disp)
-    f_ids = [d for d in ids if ("k_calc_forces" in names[d] or "k_forces_fast" in names[d] or "deme_custom_forces" in names[d])]
+    f_ids = [d for d in ids if ("k_calc_forces" in names[d] or "k_forces_fast" in names[d] or "k_tile_forces" in names[d] or "k_tile_step" in names[d] or "deme_custom_forces" in names[d])]
     start = f_ids[-last_n] if len(f_ids) >= last_n else ids[0]
     agg = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(int)

@@ -15,6 +15,7 @@ PMC[fetch]="FETCH_SIZE GRBM_GUI_ACTIVE"
 PMC[write]="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 PMC[tcp]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
 PMC[ta]="TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum"
+PMC[lds]="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_LEVEL_LDS"
 PMC[ea]="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
 cd /tmp
 for P in $PASSES; do
@@ -29,6 +30,6 @@ for P in $PASSES; do
     rocprofv3 --kernel-trace --pmc ${PMC[$P]} --output-format csv -d /tmp/prof_$P -o p -- python $ROOT/bench.py $ARGS > /tmp/prof_$P.json 2> /tmp/prof_$P.err
     f=$(find /tmp/prof_$P -name 'p_counter_collection.csv' | head -1)
     if [ -z "$f" ]; then echo "pass $P produced no counters"; tail -5 /tmp/prof_$P.err; continue; fi
-    python $ROOT/profiles/summarize_pmc.py $f $OUT/${TAG}_${P}_pmc.txt 60 | grep -E "^kernel|forces|integrate|copyBuffer|index|elementwise" | cut -c1-260
+    python $ROOT/profiles/summarize_pmc.py $f $OUT/${TAG}_${P}_pmc.txt 60 | grep -E "^kernel|forces|tile|integrate|copyBuffer|index|elementwise" | cut -c1-260
   fi
 done
