@@ -71,11 +71,11 @@ struct deme_ctx {
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
     // owner-tile form of the force pass (deme_tile.h), rebuilt per detection
-    DevBuf tInfo, hList, hCount, tileMode, rIdx, rStart, rFlag, rPos;
+    DevBuf tInfo, hList, hCount, tileMode, rIdx, rStart, rFlag, rPos, lPos, lStart;
     bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
     bool conTile = false;     // the contributions in memory were written by the tile kernel
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
-    uint32_t tileMaxHalo = 0;
+    uint32_t tileMaxHalo = 0, tileMaxList = 0;
     // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
     DevBuf persistKeys, binStat;
     // acceleration the script adds for the next step only (deme_add_owner_acc): device records + host mirror
@@ -351,6 +351,7 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
     rc |= ensure(c, c->info, cap * 16);
     rc |= ensure(c, c->tInfo, cap * 8);
     rc |= ensure(c, c->rIdx, cap * 4);
+    rc |= ensure(c, c->lPos, cap * 2);
     rc |= ensure(c, c->rFlag, (cap + 1) * 4);
     rc |= ensure(c, c->rPos, (cap + 1) * 4);
     if (c->hasGhosts) {
@@ -671,7 +672,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                            c->rangeCtr.as<RangeCounters>(), c->info.as<uint4>(),
                            c->hasGhosts ? c->cDefer.as<uint8_t>() : (uint8_t*)nullptr, c->blockMode.as<uint32_t>());
         const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM &&
-                                  c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 8192 && c->nComp <= 8192;
+                                  c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535;
         if (tileEligible) {
             const uint32_t nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
             hipLaunchKernelGGL(k_tile_rflag, dim3(grid_for(nC + 1)), dim3(256), 0, c->stream, (uint32_t)nC, c->bIdx[1].as<uint32_t>(),
@@ -686,17 +687,18 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                                           rocprim::plus<uint32_t>(), c->stream));
             hipLaunchKernelGGL(k_tile_rfill, dim3(grid_for(std::max<size_t>(nC, (size_t)c->nOwners + 1))), dim3(256), 0, c->stream,
                                (uint32_t)nC, c->nOwners, c->bIdx[1].as<uint32_t>(), c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(),
-                               c->bStart.as<uint32_t>(), c->rIdx.as<uint32_t>(), c->rStart.as<uint32_t>());
+                               c->bStart.as<uint32_t>(), c->aStart.as<uint32_t>(), c->info.as<uint4>(), c->rIdx.as<uint32_t>(),
+                               c->rStart.as<uint32_t>(), c->lPos.as<uint16_t>(), c->lStart.as<uint32_t>());
             hipLaunchKernelGGL(k_tile_build, dim3(nTiles), dim3(256), 0, c->stream, c->dp, c->nOwners, c->info.as<uint4>(),
                                c->aStart.as<uint32_t>(), c->owners.as<OwnerRec>(), c->tInfo.as<uint2>(), c->hList.as<uint32_t>(),
                                c->hCount.as<uint32_t>(), c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr,
-                               c->rangeCtr.as<RangeCounters>());
+                               c->lStart.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
         }
         RangeCounters hr{};
         HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
         c->tileActive = tileEligible && !hr.tileOverflow;
-        c->tileMaxHalo = hr.tileMaxHalo;
+        c->tileMaxHalo = hr.tileMaxHalo, c->tileMaxList = hr.tileMaxList;
         if (hr.nHeavy > c->heavyList.bytes / 4)
             return fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", hr.nHeavy);
         c->nHeavy = hr.nHeavy;
@@ -819,6 +821,7 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         ta.tInfo = c->tInfo.as<uint2>();
         ta.aStart = a.aStart;
         ta.hList = c->hList.as<uint32_t>(), ta.hCount = c->hCount.as<uint32_t>();
+        ta.lStart = c->lStart.as<uint32_t>(), ta.lPos = c->lPos.as<uint16_t>();
         ta.wc = a.wc;
         ta.tSum = a.aSum;
         ta.conB4 = a.conB4, ta.conB2 = a.conB2;
@@ -832,11 +835,15 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         unsigned nBlk = ta.nTiles;
         if (ta.xcdGroup)
             nBlk = (nBlk + 8u * ta.xcdGroup - 1u) / (8u * ta.xcdGroup) * (8u * ta.xcdGroup);
+        // LDS sized from this list's largest tile (rounded up so that a launch configuration serves many detections)
+        ta.hCap = std::min<uint32_t>(DEME_TILE_HMAX, (c->tileMaxHalo + 15u) & ~15u);
+        ta.lCap = std::min<uint32_t>(DEME_TILE_LMAX, (c->tileMaxList + 63u) & ~63u);
+        const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap);
         ScopedTimer tm(c, "calc_forces");
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
-            hipLaunchKernelGGL((k_tile_forces<0>), dim3(nBlk), dim3(DEME_TILE_T), 0, c->stream, c->dp, ta);
+            hipLaunchKernelGGL((k_tile_forces<0>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, c->stream, c->dp, ta);
         else
-            hipLaunchKernelGGL((k_tile_forces<1>), dim3(nBlk), dim3(DEME_TILE_T), 0, c->stream, c->dp, ta);
+            hipLaunchKernelGGL((k_tile_forces<1>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, c->stream, c->dp, ta);
         c->conValid = true;
         c->conTile = true;
         return DEME_OK;
@@ -1027,7 +1034,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->rIdx, &c->rStart, &c->rFlag, &c->rPos, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->rIdx, &c->rStart, &c->rFlag, &c->rPos, &c->lPos, &c->lStart, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1141,7 +1148,7 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     {
         const size_t nTiles = (nO + DEME_TILE_NB - 1) / DEME_TILE_NB + 1;
         if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) ||
-            ensure(c, c->rStart, (nO + 1) * 4))
+            ensure(c, c->rStart, (nO + 1) * 4) || ensure(c, c->lStart, (nO + 1) * 4))
             return c->lastStatus;
         HIPCK(hipMemsetAsync(c->hCount.p, 0, c->hCount.bytes, c->stream));
         c->tileActive = c->conTile = false;

@@ -1027,8 +1027,8 @@ struct RangeCounters {
     unsigned int nHeavyFree;  // heavy owners that are not fixed (they must be reduced every step)
     unsigned int nSA, nSM;    // sphere-analytical / sphere-mesh contacts in the list
     unsigned int tileOverflow;  // a tile's halo did not fit (deme_tile.h): the list is evaluated without tiles
-    unsigned int tileMaxHalo;
-    unsigned int pad[10];
+    unsigned int tileMaxHalo, tileMaxList;  // the largest tile's foreign owners / local-B list entries: they size the kernel's LDS
+    unsigned int pad[9];
 };
 
 // start[o] = first index i with owner[i] >= o, for o = 0 .. nOwners (owner[] ascending): every element fills the owners that

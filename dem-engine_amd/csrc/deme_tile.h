@@ -10,14 +10,15 @@
 //     integer difference of the encoded positions times l, world-frame angular velocity, mass) and staged in LDS; a contact then
 //     reads its two owners from LDS through two 10-bit slot numbers -- the per-contact gather record shrinks from 16 to 8 bytes
 //     and the force pass issues no scattered global loads at all;
-//   * both sides' contributions are summed inside the wavefront -- the 64 contacts of a chunk are sorted by A's slot as the
-//     list comes, and by B's slot through a 6-bit rank the builder leaves in the gather record (one scatter through LDS), so
-//     either side is a sequence of runs: a segmented DPP scan (row_shr 1, 2, 4, 8, row_bcast 15 / 31) leaves each run's sum in
-//     its last lane, which adds it to the wavefront's own copy of the tile's sums with a plain LDS read-modify-write (no two
-//     lanes of one instruction share a slot; LDS float atomics were measured at ~2 cycles PER LANE on gfx950: 12 of them per
-//     contact made the first version of this kernel 2.6 times slower than k_forces_fast) -- fixed order, reproducible run to run.
-//     The four copies leave the workgroup as ONE 32-byte sum per owner; only a contact whose B owner lives in another tile
-//     writes a 24-byte record, which the integrator gathers through the per-owner list of such contacts (deme_kernels.h:
+//   * the sums are PULLED by the owners: the tile's contacts are evaluated in rounds of 256 (one per thread); a round leaves
+//     every contact's two contributions in LDS, and after a barrier thread o (of 128) adds the round's part of owner o's A run
+//     -- a contiguous range of the list -- to its registers while thread 128 + o adds the round's part of owner o's list of
+//     contacts that hold it as B (tile-local positions the builder left behind), both in ascending order: no atomics, no
+//     ordering between wavefronts, a fixed summation order, reproducible run to run.  (LDS float atomics were measured at ~2 cycles
+//     PER LANE on gfx950 -- 12 of them per contact made the first version of this kernel 2.6 times slower than k_forces_fast -- and
+//     in-wavefront segmented DPP scans of the six sums cost 230 instructions per 64 contacts, a third of the kernel.)
+//     The sums leave the workgroup as ONE 32-byte record per owner; only a contact whose B owner lives in another tile writes a
+//     24-byte record, which the integrator gathers through the per-owner list of such contacts (deme_kernels.h:
 //     k_integrate<true> with GatherArgs::tile).
 // What the per-detection builder below leaves behind: tInfo (8 B per contact), the halo list of every tile, the per-owner lists
 // of tile-crossing contacts.  A tile whose halo does not fit the LDS area switches the whole context back to k_forces_fast for
@@ -31,10 +32,15 @@
 #ifndef DEME_TILE_HMAX
 #define DEME_TILE_HMAX 192  // foreign owners a tile can stage (measured at 1e6 packed clumps: mean 93, largest 147)
 #endif
-#define DEME_TILE_T 256
+#ifndef DEME_TILE_T
+#define DEME_TILE_T 256  // threads per tile (a round = DEME_TILE_T contacts); the first 2 * DEME_TILE_NB of them pull the sums
+#endif
 #define DEME_TILE_HP2 256  // DEME_TILE_HMAX rounded up to a power of two (bitonic sort of the halo list)
+static_assert(DEME_TILE_T >= 2 * DEME_TILE_NB, "one pulling thread per owner and side");
 #define DEME_TILE_HASH 1024u
-#define DEME_TILE_REC 5  // uint4 per staged owner (80 bytes)
+#define DEME_TILE_REC 6    // uint4 per staged owner (96 bytes)
+#define DEME_TILE_CMAX 8192   // contacts of one tile (their tile-local positions are 16-bit)
+#define DEME_TILE_LMAX 2048   // entries of a tile's local-B lists staged in LDS
 static_assert(DEME_TILE_NB + DEME_TILE_HMAX <= 1024, "slot numbers are 10 bits");
 static_assert(DEME_TILE_HMAX <= DEME_TILE_HP2, "halo list sort size");
 
@@ -43,8 +49,7 @@ static_assert(DEME_TILE_HMAX <= DEME_TILE_HP2, "halo list sort size");
 namespace deme_dev {
 
 // tInfo.x: slot of A (10) | slot of B (10) | class (2) | B lives in another tile: write a record (1) | 1 spare | material of A (4) |
-//          material of B (4);  tInfo.y: component of A (13) | component of B or analytical-object index (13) | rank of the
-//          contact among the 64 of its chunk when they are ordered by B's slot, B's in other tiles last (6)
+//          material of B (4);  tInfo.y: component of A (16) | component of B or analytical-object index (16)
 __host__ __device__ inline uint32_t tile_info_x(uint32_t slotA, uint32_t slotB, uint32_t cls, uint32_t rec, uint32_t matA, uint32_t matB) {
     return slotA | (slotB << 10) | (cls << 20) | (rec << 22) | (matA << 24) | (matB << 28);
 }
@@ -56,11 +61,14 @@ struct TileArgs {
     const uint32_t* hList;     // DEME_TILE_HMAX entries per tile
     const uint32_t* hCount;
     const uint32_t* tileMode;  // halo overlap: bit p = the tile is evaluated in pass p (1: reads no ghost owner, 2: does); null: no split
+    const uint32_t* lStart;    // nOwners + 1: first entry of each owner's list of contacts that hold it as B with A in the same tile
+    const uint16_t* lPos;      // those contacts as positions in their tile's range of the list, ascending per owner
     float* wc;
     float4* tSum;              // two float4 per owner: the sum of the contributions of contacts evaluated by the owner's tile
     float4* conB4;             // per-contact records of the B sides that live in another tile
     float2* conB2;
     uint32_t nOwners, nTiles, pass, xcdGroup;
+    uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
 };
 
 // one staged owner, as the contact loop reads it back from LDS
@@ -68,7 +76,7 @@ struct TileOwner {
     double px, py, pz;  // position relative to the tile's origin [m]
     float mass;
     uint32_t family;
-    float qw, qx, qy, qz;
+    RotM R;            // rotation coefficients of the orientation (reference rounding: rot_coeffs of deme_device.h)
     float vx, vy, vz;
     float wx, wy, wz;  // angular velocity in the WORLD frame
 };
@@ -84,22 +92,24 @@ __device__ inline void tile_stage_owner(const DevParams& p, const OwnerRec& r, i
     __builtin_memcpy(&bx, &px, 8), __builtin_memcpy(&by, &py, 8), __builtin_memcpy(&bz, &pz, 8);
     dst[0] = make_uint4(bx.x, bx.y, by.x, by.y);
     dst[1] = make_uint4(bz.x, bz.y, __float_as_uint(mass), r.family);
-    dst[2] = make_uint4(__float_as_uint(r.qw), __float_as_uint(r.qx), __float_as_uint(r.qy), __float_as_uint(r.qz));
-    dst[3] = make_uint4(__float_as_uint(r.vx), __float_as_uint(r.vy), __float_as_uint(r.vz), __float_as_uint(w.x));
-    dst[4] = make_uint4(__float_as_uint(w.y), __float_as_uint(w.z), 0u, 0u);
+    dst[2] = make_uint4(__float_as_uint(R.xx), __float_as_uint(R.xy), __float_as_uint(R.xz), __float_as_uint(R.yx));
+    dst[3] = make_uint4(__float_as_uint(R.yy), __float_as_uint(R.yz), __float_as_uint(R.zx), __float_as_uint(R.zy));
+    dst[4] = make_uint4(__float_as_uint(R.zz), __float_as_uint(r.vx), __float_as_uint(r.vy), __float_as_uint(r.vz));
+    dst[5] = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), 0u);
 }
 __device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t slot) {
     const uint4* q = sOwn + slot * DEME_TILE_REC;
-    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
     TileOwner o;
     uint2 t;
     t = make_uint2(a.x, a.y), __builtin_memcpy(&o.px, &t, 8);
     t = make_uint2(a.z, a.w), __builtin_memcpy(&o.py, &t, 8);
     t = make_uint2(b.x, b.y), __builtin_memcpy(&o.pz, &t, 8);
     o.mass = __uint_as_float(b.z), o.family = b.w;
-    o.qw = __uint_as_float(c.x), o.qx = __uint_as_float(c.y), o.qy = __uint_as_float(c.z), o.qz = __uint_as_float(c.w);
-    o.vx = __uint_as_float(d.x), o.vy = __uint_as_float(d.y), o.vz = __uint_as_float(d.z), o.wx = __uint_as_float(d.w);
-    o.wy = __uint_as_float(e.x), o.wz = __uint_as_float(e.y);
+    o.R.xx = __uint_as_float(c.x), o.R.xy = __uint_as_float(c.y), o.R.xz = __uint_as_float(c.z), o.R.yx = __uint_as_float(c.w);
+    o.R.yy = __uint_as_float(d.x), o.R.yz = __uint_as_float(d.y), o.R.zx = __uint_as_float(d.z), o.R.zy = __uint_as_float(d.w);
+    o.R.zz = __uint_as_float(e.x), o.vx = __uint_as_float(e.y), o.vy = __uint_as_float(e.z), o.vz = __uint_as_float(e.w);
+    o.wx = __uint_as_float(f.x), o.wy = __uint_as_float(f.y), o.wz = __uint_as_float(f.z);
     return o;
 }
 
@@ -110,11 +120,10 @@ template <int MODEL>
 __device__ inline void tile_contact(const DevParams& p, const uint2 inf, const TileOwner& A, const TileOwner& B, float4& hist, f3& force,
                                     f3& tA, f3& tB) {
     const uint32_t cls = (inf.x >> 20) & 3u;
-    const float4 cA = p.comp[inf.y & 0x1FFFu];
+    const float4 cA = p.comp[inf.y & 0xFFFFu];
     const uint32_t matA = (inf.x >> 24) & 15u;
     // sphere offsets with the reference's own rounding (no contraction: deme_device.h), see forces_fast_body
-    const RotM RA = rot_coeffs(A.qw, A.qx, A.qy, A.qz);
-    const RotM RB = rot_coeffs(B.qw, B.qx, B.qy, B.qz);
+    const RotM &RA = A.R, &RB = B.R;
     const f3 relA = rot_apply(RA, mk3(cA.x, cA.y, cA.z));
     const float rA = cA.w;
     float extraMargin = 0.f;
@@ -129,7 +138,7 @@ __device__ inline void tile_contact(const DevParams& p, const uint2 inf, const T
     uint32_t matB;
     bool touching;
     if (cls == DEME_KEY_CLASS_SS) {
-        const float4 cB = p.comp[(inf.y >> 13) & 0x1FFFu];
+        const float4 cB = p.comp[inf.y >> 16];
         matB = inf.x >> 28;
         rB = cB.w;
         massB = B.mass;
@@ -150,7 +159,7 @@ __device__ inline void tile_contact(const DevParams& p, const uint2 inf, const T
         rBv = mk3(relB.x + s * n.x, relB.y + s * n.y, relB.z + s * n.z);
         rAv = fsub(rBv, dO);
     } else {  // sphere-analytical: the reference's arithmetic in the tile's frame (only differences of positions enter)
-        const AnalObj ob = p.anal[(inf.y >> 13) & 0x1FFFu];
+        const AnalObj ob = p.anal[inf.y >> 16];
         matB = ob.mat;
         rB = 1e15f;  // DEME_HUGE_FLOAT
         massB = ob.mass;
@@ -245,96 +254,58 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
     return ((j / G) * 8u + xcd) * G + (j % G);
 }
 
-// Segmented sum of six values over the wavefront + accumulation into the wavefront's own LDS sums.  `slot` ascends along the
-// lanes (runs of equal slots; DEME_TILE_NONE = nothing to add, sorted last).  After the scan the last lane of every run holds
-// the run's total and adds it to acc[slot]: distinct slots within the instruction, and the wavefront's LDS operations complete
-// in program order, so the read-modify-write needs no atomic.
-#define DEME_TILE_NONE 0x3FFu
-#define DEME_TILE_ACC 8  // floats per slot of a wavefront's sums (two float4)
-__device__ inline float tile_dpp(float v, const int ctrl, const int rowMask) {
-    // (ctrl / rowMask are compile-time constants at every call site; the builtin needs literals, hence the switch)
-    const int i = __builtin_bit_cast(int, v);
-    int r;
-    switch (ctrl) {
-        case 0x111: r = __builtin_amdgcn_update_dpp(0, i, 0x111, 0xF, 0xF, true); break;  // row_shr:1
-        case 0x112: r = __builtin_amdgcn_update_dpp(0, i, 0x112, 0xF, 0xF, true); break;
-        case 0x114: r = __builtin_amdgcn_update_dpp(0, i, 0x114, 0xF, 0xF, true); break;
-        case 0x118: r = __builtin_amdgcn_update_dpp(0, i, 0x118, 0xF, 0xF, true); break;
-        case 0x142: r = __builtin_amdgcn_update_dpp(0, i, 0x142, 0xA, 0xF, true); break;  // row_bcast:15 into rows 1 and 3
-        default: r = __builtin_amdgcn_update_dpp(0, i, 0x143, 0xC, 0xF, true); break;      // row_bcast:31 into rows 2 and 3
-    }
-    (void)rowMask;
-    return __builtin_bit_cast(float, r);
-}
-__device__ inline void tile_seg_accumulate(float* acc, const uint32_t lane, const uint32_t slot, float v[6]) {
-    // run structure: head = first lane of a run; dist = lanes back to the head of my run
-    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)slot, 0x138, 0xF, 0xF, false);  // wave_shr:1
-    const bool head = lane == 0u || prev != slot;
-    const uint64_t heads = __ballot(head);
-    const uint64_t upto = heads & (~0ull >> (63u - lane));
-    const uint32_t headLane = 63u - (uint32_t)__clzll((long long)upto);
-    const uint32_t dist = lane - headLane;
-    const bool tail = lane == 63u || ((heads >> (lane + 1u)) & 1ull);
-    const uint32_t row = lane & 48u;
-    const float f1 = dist >= 1u ? 1.f : 0.f, f2 = dist >= 2u ? 1.f : 0.f, f4 = dist >= 4u ? 1.f : 0.f, f8 = dist >= 8u ? 1.f : 0.f;
-    const float f15 = headLane < row ? 1.f : 0.f;   // my run began in an earlier row (rows 1, 3 take lane 15 / 47 of the row before)
-    const float f31 = headLane < 32u ? 1.f : 0.f;   // rows 2, 3: my run began in the lower half
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        v[k] = __builtin_fmaf(tile_dpp(v[k], 0x111, 0xF), f1, v[k]);
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        v[k] = __builtin_fmaf(tile_dpp(v[k], 0x112, 0xF), f2, v[k]);
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        v[k] = __builtin_fmaf(tile_dpp(v[k], 0x114, 0xF), f4, v[k]);
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        v[k] = __builtin_fmaf(tile_dpp(v[k], 0x118, 0xF), f8, v[k]);
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        v[k] = __builtin_fmaf(tile_dpp(v[k], 0x142, 0xA), f15, v[k]);
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        v[k] = __builtin_fmaf(tile_dpp(v[k], 0x143, 0xC), f31, v[k]);
-    if (tail && slot < DEME_TILE_NB) {
-        float4* a = reinterpret_cast<float4*>(acc + slot * DEME_TILE_ACC);
-        float4 x = a[0], y = a[1];
-        x.x += v[0], x.y += v[1], x.z += v[2];
-        y.x += v[3], y.y += v[4], y.z += v[5];
-        a[0] = x, a[1] = y;
-    }
-}
-
 #ifndef DEME_TILE_OCC
 #define DEME_TILE_OCC 1
 #endif
+#define DEME_TILE_DEPTH 3  // rounds whose streams are in flight (tInfo + history: 24 bytes per thread and round)
+// LDS of one tile, laid out at launch from the list's own extremes (TileArgs::hCap, lCap): occupancy is bound by LDS here, and
+// the compile-time capacities (DEME_TILE_HMAX foreign owners, DEME_TILE_LMAX list entries) are twice what a packed bed needs
+//   own   [(NB + hCap) x 96 B]   staged owners
+//   recA4 [T x 16 B]  recT [T x 16 B]  recA2 [T x 8 B]   a round's contributions: (F.x F.y F.z tA.x) (tB.x tB.y tB.z -) (tA.y tA.z);
+//                                                        B's side is -F and tB
+//   aLo, lLo [(NB + 1) x 4 B each]   owner o's A run = positions [aLo[o], aLo[o + 1]) of the tile's range, its local-B list =
+//                                    lPos[lLo[o] .. lLo[o + 1])
+//   lPos  [lCap x 2 B]
+__host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap) {
+    return (DEME_TILE_NB + hCap) * DEME_TILE_REC * 16u + DEME_TILE_T * 40u + 2u * (DEME_TILE_NB + 1u) * 4u + ((lCap * 2u + 15u) & ~15u) + 16u;
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(const DevParams p, const TileArgs a) {
-    __shared__ uint4 sOwn[(DEME_TILE_NB + DEME_TILE_HMAX) * DEME_TILE_REC];
-    __shared__ float4 sAcc[DEME_TILE_T / 64][DEME_TILE_NB * DEME_TILE_ACC / 4];
-    __shared__ float4 sScat[DEME_TILE_T / 64][64 * 2];  // per wavefront: the chunk's B-side contributions in B-slot order
+    extern __shared__ uint4 tileLds[];
+    uint4* const sOwn = tileLds;
+    float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * DEME_TILE_REC);
+    float4* const recT = recA4 + DEME_TILE_T;
+    float2* const recA2 = reinterpret_cast<float2*>(recT + DEME_TILE_T);
+    uint32_t* const sALo = reinterpret_cast<uint32_t*>(recA2 + DEME_TILE_T);
+    uint32_t* const sLLo = sALo + (DEME_TILE_NB + 1);
+    uint16_t* const sLPos = reinterpret_cast<uint16_t*>(sLLo + (DEME_TILE_NB + 1) + ((DEME_TILE_NB + 1) & 1u) * 0u);
     const uint32_t t = tile_block_id(a.xcdGroup);
     if (t >= a.nTiles)
         return;
     if (a.tileMode && !(a.tileMode[t] & (1u << a.pass)))
         return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     const uint32_t o0 = t * DEME_TILE_NB;
     const uint32_t nLoc = min((uint32_t)DEME_TILE_NB, a.nOwners - o0);
     const uint32_t nH = a.hCount[t];
     const uint32_t c0 = a.aStart[o0], c1 = a.aStart[o0 + nLoc];
-    // the first chunk's streams do not depend on the staging: issue them first
+    // the streams of the first rounds do not depend on the staging: issue them first, all of them (a tile is ~2 rounds; memory
+    // latency under load is longer than a round takes)
     const float4* wc4 = reinterpret_cast<const float4*>(a.wc);
-    uint32_t c = c0 + wave * 64u + lane;
-    uint2 inf = make_uint2(0, 0);
-    float4 hist = make_float4(0, 0, 0, 0);
-    if (c < c1) {
-        inf = stream_load(a.tInfo + c);
-        if (MODEL == 0)
-            hist = stream_load(wc4 + c);
+    uint2 inf[DEME_TILE_DEPTH];
+    float4 hist[DEME_TILE_DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEME_TILE_DEPTH; d++) {
+        const uint32_t cd = c0 + tid + d * DEME_TILE_T;
+        inf[d] = make_uint2(0, 0), hist[d] = make_float4(0, 0, 0, 0);
+        if (cd < c1) {
+            inf[d] = stream_load(a.tInfo + cd);
+            if (MODEL == 0)
+                hist[d] = stream_load(wc4 + cd);
+        }
     }
-    {   // stage the tile's owners and its halo
+    {   // stage the tile's owners, its halo, the owners' run bounds and local-B lists
         int64_t u0x, u0y, u0z;
         {
             const OwnerRec f = load_owner(a.owners, o0);  // (one address for the whole workgroup)
@@ -346,65 +317,113 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             const OwnerRec r = load_owner(a.owners, id);
             tile_stage_owner(p, r, u0x, u0y, u0z, sOwn + (loc ? s : DEME_TILE_NB + (s - nLoc)) * DEME_TILE_REC);
         }
-        float4* z = &sAcc[0][0];
-        for (uint32_t i = tid; i < (DEME_TILE_T / 64) * DEME_TILE_NB * DEME_TILE_ACC / 4; i += DEME_TILE_T)
-            z[i] = make_float4(0, 0, 0, 0);
+        const uint32_t l0 = a.lStart[o0], l1 = a.lStart[o0 + nLoc];
+        if (tid <= DEME_TILE_NB) {
+            const uint32_t o = min(tid, nLoc);
+            sALo[tid] = a.aStart[o0 + o] - c0;
+            sLLo[tid] = a.lStart[o0 + o] - l0;
+        }
+        for (uint32_t i = tid; i < l1 - l0; i += DEME_TILE_T)
+            sLPos[i] = a.lPos[l0 + i];
     }
     __syncthreads();
-    float* acc = reinterpret_cast<float*>(sAcc[wave]);
-    float4* scat = sScat[wave];
-    for (uint32_t base = c0 + wave * 64u; base < c1; base += DEME_TILE_T) {
-        const bool valid = c < c1;
-        // the next chunk's streams, before this chunk's arithmetic
-        const uint32_t cn = c + DEME_TILE_T;
-        uint2 infN = make_uint2(0, 0);
-        float4 histN = make_float4(0, 0, 0, 0);
-        if (cn < c1) {
-            infN = stream_load(a.tInfo + cn);
-            if (MODEL == 0)
-                histN = stream_load(wc4 + cn);
-        }
-        uint32_t slotA = DEME_TILE_NONE, slotB = DEME_TILE_NONE;
-        float va[6] = {0, 0, 0, 0, 0, 0};
-        float4 bF = make_float4(0, 0, 0, __uint_as_float(DEME_TILE_NONE)), bT = make_float4(0, 0, 0, 0);
-        if (valid) {
-            slotA = inf.x & 1023u, slotB = (inf.x >> 10) & 1023u;
+    // the pulling side of this thread: threads 0 .. NB - 1 take the A runs, NB .. 2 NB - 1 the local-B lists
+    const uint32_t po = tid % DEME_TILE_NB;
+    const bool sideA = tid < DEME_TILE_NB, sideB = !sideA && tid < 2 * DEME_TILE_NB;
+    uint32_t plo = sideB ? sLLo[po] : sALo[po];
+    const uint32_t phi = (sideA || sideB) ? (sideB ? sLLo[po + 1] : sALo[po + 1]) : plo;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
+    uint32_t c = c0 + tid;
+    for (uint32_t rlo = 0; rlo < c1 - c0; rlo += DEME_TILE_T) {
+        if (c < c1) {
+            const uint2 ci = inf[0];
+            float4 h = hist[0];
+            const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
             const TileOwner A = tile_read_owner(sOwn, slotA), B = tile_read_owner(sOwn, slotB);
             f3 force, tA, tB;
-            tile_contact<MODEL>(p, inf, A, B, hist, force, tA, tB);
+            tile_contact<MODEL>(p, ci, A, B, h, force, tA, tB);
             if (MODEL == 0)
-                stream_store(reinterpret_cast<float4*>(a.wc) + c, hist);
-            va[0] = force.x, va[1] = force.y, va[2] = force.z, va[3] = tA.x, va[4] = tA.y, va[5] = tA.z;
+                stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
+            recA4[tid] = make_float4(force.x, force.y, force.z, tA.x);
+            recA2[tid] = make_float2(tA.y, tA.z);
             if (slotB < DEME_TILE_NB) {
-                bF = make_float4(-force.x, -force.y, -force.z, __uint_as_float(slotB));
-                bT = make_float4(tB.x, tB.y, tB.z, 0.f);
-            } else if (inf.x & (1u << 22)) {
+                recT[tid] = make_float4(tB.x, tB.y, tB.z, 0.f);
+            } else if (ci.x & (1u << 22)) {
                 stream_store(a.conB4 + c, make_float4(-force.x, -force.y, -force.z, tB.x));
                 stream_store(a.conB2 + c, make_float2(tB.y, tB.z));
             }
         }
-        // A side: the lanes come sorted by A's slot (lanes past the end of the tile's range carry DEME_TILE_NONE)
-        tile_seg_accumulate(acc, lane, slotA, va);
-        // B side: through LDS into B-slot order (the builder's rank; lanes past the end keep their own position: the ranks of the
-        // valid lanes of a chunk are 0 .. nValid - 1)
+        // rotate the stream registers and refill the last stage
+#pragma unroll
+        for (int d = 0; d + 1 < DEME_TILE_DEPTH; d++)
+            inf[d] = inf[d + 1], hist[d] = hist[d + 1];
         {
-            const uint32_t rank = valid ? (inf.y >> 26) : lane;
-            wave_lds_fence();
-            scat[2 * rank] = bF, scat[2 * rank + 1] = bT;
-            wave_lds_fence();
-            const float4 gF = scat[2 * lane], gT = scat[2 * lane + 1];
-            float vb[6] = {gF.x, gF.y, gF.z, gT.x, gT.y, gT.z};
-            tile_seg_accumulate(acc, lane, __float_as_uint(gF.w), vb);
+            const uint32_t cd = c + DEME_TILE_DEPTH * DEME_TILE_T;
+            inf[DEME_TILE_DEPTH - 1] = make_uint2(0, 0), hist[DEME_TILE_DEPTH - 1] = make_float4(0, 0, 0, 0);
+            if (cd < c1) {
+                inf[DEME_TILE_DEPTH - 1] = stream_load(a.tInfo + cd);
+                if (MODEL == 0)
+                    hist[DEME_TILE_DEPTH - 1] = stream_load(wc4 + cd);
+            }
         }
-        c = cn, inf = infN, hist = histN;
+        __syncthreads();
+        const uint32_t rhi = rlo + DEME_TILE_T;
+        if (sideA) {  // my A run's part of this round: positions [plo, min(phi, rhi))
+            const uint32_t e = min(phi, rhi);
+            while (plo < e) {
+                float4 v4[4];
+                float2 v2[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = min(plo + k, e - 1u) - rlo;
+                    v4[k] = recA4[i], v2[k] = recA2[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (plo + k < e)
+                        s0 += v4[k].x, s1 += v4[k].y, s2 += v4[k].z, s3 += v4[k].w, s4 += v2[k].x, s5 += v2[k].y;
+                plo = min(plo + 4u, e);
+            }
+        } else if (sideB) {  // my local-B list's entries that fall into this round: -F and tB of those contacts
+            while (plo < phi) {
+                uint32_t pos[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    pos[k] = (plo + k < phi) ? (uint32_t)sLPos[plo + k] : 0xFFFFFFFFu;
+                if (pos[0] >= rhi)
+                    break;
+                float4 v4[4], vt[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = (pos[k] < rhi ? pos[k] : pos[0]) - rlo;
+                    v4[k] = recA4[i], vt[k] = recT[i];
+                }
+                uint32_t used = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (pos[k] < rhi) {
+                        s0 -= v4[k].x, s1 -= v4[k].y, s2 -= v4[k].z, s3 += vt[k].x, s4 += vt[k].y, s5 += vt[k].z;
+                        used++;
+                    }
+                plo += used;
+                if (used < 4u)
+                    break;
+            }
+        }
+        __syncthreads();
+        c += DEME_TILE_T;
+    }
+    // A-side sum + B-side sum, through LDS (the contribution arrays are free now)
+    if (sideB) {
+        recA4[po] = make_float4(s0, s1, s2, s3);
+        recA2[po] = make_float2(s4, s5);
     }
     __syncthreads();
-    if (tid < 2u * nLoc) {  // the four wavefronts' copies in a fixed order; thread = (owner, half of its record)
-        const float4 w0 = sAcc[0][tid], w1 = sAcc[1][tid], w2 = sAcc[2][tid], w3 = sAcc[3][tid];
-        float4 r;
-        r.x = ((w0.x + w1.x) + w2.x) + w3.x, r.y = ((w0.y + w1.y) + w2.y) + w3.y;
-        r.z = ((w0.z + w1.z) + w2.z) + w3.z, r.w = ((w0.w + w1.w) + w2.w) + w3.w;
-        a.tSum[2 * (size_t)o0 + tid] = r;  // (F.x F.y F.z 0 | t.x t.y t.z 0): the layout of aSum
+    if (sideA && po < nLoc) {
+        const float4 b4 = recA4[po];
+        const float2 b2 = recA2[po];
+        a.tSum[2 * (size_t)(o0 + po)] = make_float4(s0 + b4.x, s1 + b4.y, s2 + b4.z, 0.f);
+        a.tSum[2 * (size_t)(o0 + po) + 1] = make_float4(s3 + b4.w, s4 + b2.x, s5 + b2.y, 0.f);
     }
 }
 
@@ -423,16 +442,30 @@ __global__ __launch_bounds__(256) void k_tile_rflag(uint32_t nC, const uint32_t*
     }
     flag[j] = f;
 }
-// rIdx: the crossing contacts in B-owner order; rStart[o] = first of owner o's (o = 0 .. nOwners)
+// rIdx: the crossing contacts in B-owner order; rStart[o] = first of owner o's (o = 0 .. nOwners).  The others -- B's owner in
+// A's tile -- go to lPos as positions in that tile's range of the list (what the tile's pulling threads walk), lStart likewise;
+// the number of non-crossing entries before j is j - rPos[j], so one scan serves both lists.
 __global__ __launch_bounds__(256) void k_tile_rfill(uint32_t nC, uint32_t nOwners, const uint32_t* __restrict__ bIdx,
                                                     const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rPos,
-                                                    const uint32_t* __restrict__ bStart, uint32_t* __restrict__ rIdx,
-                                                    uint32_t* __restrict__ rStart) {
+                                                    const uint32_t* __restrict__ bStart, const uint32_t* __restrict__ aStart,
+                                                    const uint4* __restrict__ info, uint32_t* __restrict__ rIdx,
+                                                    uint32_t* __restrict__ rStart, uint16_t* __restrict__ lPos,
+                                                    uint32_t* __restrict__ lStart) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < nC && flag[j])
-        rIdx[rPos[j]] = bIdx[j];
-    if (j <= nOwners)
-        rStart[j] = rPos[bStart[j]];
+    if (j < nC) {
+        const uint32_t c = bIdx[j];
+        if (flag[j]) {
+            rIdx[rPos[j]] = c;
+        } else {
+            const uint32_t tile0 = (info[c].y / DEME_TILE_NB) * DEME_TILE_NB;
+            lPos[j - rPos[j]] = (uint16_t)min(c - aStart[tile0], 0xFFFFu);  // (a tile beyond DEME_TILE_CMAX contacts is refused by k_tile_build)
+        }
+    }
+    if (j <= nOwners) {
+        const uint32_t b = bStart[j], r = rPos[b];
+        rStart[j] = r;
+        lStart[j] = b - r;
+    }
 }
 
 // one workgroup per tile: the sorted list of the foreign owners its contacts touch, the 8-byte gather records, the pass of the
@@ -441,7 +474,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
                                                     const uint32_t* __restrict__ aStart, const OwnerRec* __restrict__ owners,
                                                     uint2* __restrict__ tInfo, uint32_t* __restrict__ hList,
                                                     uint32_t* __restrict__ hCount, uint32_t* __restrict__ tileMode,
-                                                    RangeCounters* rc) {
+                                                    const uint32_t* __restrict__ lStart, RangeCounters* rc) {
     __shared__ uint32_t table[DEME_TILE_HASH];
     __shared__ uint32_t list[DEME_TILE_HP2];
     __shared__ uint32_t nU, nL, anyGhost;
@@ -473,7 +506,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
     }
     __syncthreads();
     const uint32_t n = nU;
-    if (n > DEME_TILE_HMAX) {  // the halo does not fit the LDS area of k_tile_forces: this list is evaluated by k_forces_fast
+    if (n > DEME_TILE_HMAX || c1 - c0 > DEME_TILE_CMAX || lStart[o1] - lStart[o0] > DEME_TILE_LMAX) {  // the halo does not fit the LDS area of k_tile_forces: this list is evaluated by k_forces_fast
         if (tid == 0) {
             atomicOr(&rc->tileOverflow, 1u);
             hCount[t] = 0;
@@ -505,6 +538,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
     if (tid == 0) {
         hCount[t] = n;
         atomicMax(&rc->tileMaxHalo, n);
+        atomicMax(&rc->tileMaxList, lStart[o1] - lStart[o0]);
     }
     if (tileMode) {  // a tile that stages a ghost's record waits for the ghosts of this step (pass 1)
         bool g = false;
@@ -516,45 +550,28 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         if (tid == 0)
             tileMode[t] = anyGhost ? 2u : 1u;
     }
-    const uint32_t lane = tid & 63u;
-    for (uint32_t base = c0 + (tid & ~63u); base < c1; base += 256) {  // a wavefront = one 64-contact chunk of k_tile_forces
-        const uint32_t c = base + lane;
-        const bool valid = c < c1;
-        uint4 ci = make_uint4(0, 0, 0, 0);
-        if (valid)
-            ci = info[c];
+    for (uint32_t c = c0 + tid; c < c1; c += 256) {
+        const uint4 ci = info[c];
         const uint32_t oa = ci.x & 0x3FFFFFFFu, cls = ci.x >> 30, ob = ci.y;
-        uint32_t slotB = DEME_TILE_NONE, rec = 0;
-        if (valid) {
-            if (ob >= o0 && ob < o1) {
-                slotB = ob - o0;
-            } else {
-                uint32_t lo = 0, hi = n;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (list[mid] < ob)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                slotB = DEME_TILE_NB + lo;
-                rec = 1;
+        uint32_t slotB, rec = 0;
+        if (ob >= o0 && ob < o1) {
+            slotB = ob - o0;
+        } else {
+            uint32_t lo = 0, hi = n;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (list[mid] < ob)
+                    lo = mid + 1;
+                else
+                    hi = mid;
             }
+            slotB = DEME_TILE_NB + lo;
+            rec = 1;
         }
-        // rank among the chunk's valid lanes by (B's slot if it lives in this tile, else last; lane)
-        const uint32_t key = ((slotB < DEME_TILE_NB ? slotB : DEME_TILE_NONE) << 6) | lane;
-        uint32_t rank = 0;
-        for (int j = 0; j < 64; j++) {
-            const uint32_t kj = (uint32_t)__shfl((int)key, j);
-            const int vj = __shfl((int)valid, j);
-            rank += (vj && kj < key) ? 1u : 0u;
-        }
-        if (valid) {
-            const uint32_t matA = ci.z >> 16, compA = ci.z & 0xFFFFu;
-            const uint32_t matB = (cls == DEME_KEY_CLASS_SS) ? (ci.w >> 16) : 0u;  // (an analytical object's material is in its record)
-            const uint32_t wB = (cls == DEME_KEY_CLASS_SS) ? (ci.w & 0xFFFFu) : ci.w;
-            tInfo[c] = make_uint2(tile_info_x(oa - o0, slotB, cls, rec, matA, matB), compA | (wB << 13) | (rank << 26));
-        }
+        const uint32_t matA = ci.z >> 16, compA = ci.z & 0xFFFFu;
+        const uint32_t matB = (cls == DEME_KEY_CLASS_SS) ? (ci.w >> 16) : 0u;  // (an analytical object's material is in its record)
+        const uint32_t wB = (cls == DEME_KEY_CLASS_SS) ? (ci.w & 0xFFFFu) : ci.w;
+        tInfo[c] = make_uint2(tile_info_x(oa - o0, slotB, cls, rec, matA, matB), compA | (wB << 16));
     }
 }
 

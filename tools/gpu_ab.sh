@@ -1,11 +1,12 @@
 #!/bin/bash
-# A/B: the default build against every libdeme_v_*.so, three interleaved rounds (box-to-box spread is ~5 %, run-to-run ~1 %)
-mkdir -p gpurun_out/ab
-for r in 1 2 3; do
-  DEME_BMERGE=0 python bench.py --no-cpu-baseline --state-cache /tmp/bed.npz > gpurun_out/ab/cur_$r.json 2>/dev/null
+# A/B: the default build against every libdeme_v_*.so, interleaved rounds (box-to-box spread is ~5 %, run-to-run ~1 %)
+mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/*.json
+R=${ROUNDS:-2}
+for r in $(seq 1 $R); do
+  python bench.py --no-cpu-baseline --state-cache /tmp/bed.npz > gpurun_out/ab/cur_$r.json 2>/dev/null
   for f in dem-engine_amd/csrc/libdeme_v_*.so; do
     n=$(basename $f .so); n=${n#libdeme_v_}
-    DEME_BMERGE=0 DEME_HIP_LIB=$PWD/$f python bench.py --no-cpu-baseline --state-cache /tmp/bed.npz > gpurun_out/ab/${n}_$r.json 2>/dev/null
+    DEME_HIP_LIB=$PWD/$f python bench.py --no-cpu-baseline --state-cache /tmp/bed.npz > gpurun_out/ab/${n}_$r.json 2>gpurun_out/ab/${n}_$r.err
   done
 done
 python - <<'PY'
