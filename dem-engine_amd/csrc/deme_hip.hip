@@ -71,7 +71,7 @@ struct deme_ctx {
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
     // owner-tile form of the force pass (deme_tile.h), rebuilt per detection
-    DevBuf tInfo, hList, hCount, tileMode, rIdx, rStart, rFlag, rPos, lPos, lStart;
+    DevBuf tInfo, hList, hCount, tileMode, rIdx, rStart, rFlag, rPos, lPos, lStart, rFlagC, rankC, rec32;
     bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
     bool conTile = false;     // the contributions in memory were written by the tile kernel
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
@@ -352,6 +352,9 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
     rc |= ensure(c, c->tInfo, cap * 8);
     rc |= ensure(c, c->rIdx, cap * 4);
     rc |= ensure(c, c->lPos, cap * 2);
+    rc |= ensure(c, c->rFlagC, (cap + 1) * 4);
+    rc |= ensure(c, c->rankC, (cap + 1) * 4);
+    rc |= ensure(c, c->rec32, cap * 32);
     rc |= ensure(c, c->rFlag, (cap + 1) * 4);
     rc |= ensure(c, c->rPos, (cap + 1) * 4);
     if (c->hasGhosts) {
@@ -672,11 +675,12 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                            c->rangeCtr.as<RangeCounters>(), c->info.as<uint4>(),
                            c->hasGhosts ? c->cDefer.as<uint8_t>() : (uint8_t*)nullptr, c->blockMode.as<uint32_t>());
         const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM &&
-                                  c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535;
+                                  c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535 &&
+                                  tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial) <= DEME_TILE_TABLE_MAX;
         if (tileEligible) {
             const uint32_t nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
             hipLaunchKernelGGL(k_tile_rflag, dim3(grid_for(nC + 1)), dim3(256), 0, c->stream, (uint32_t)nC, c->bIdx[1].as<uint32_t>(),
-                               c->info.as<uint4>(), c->rFlag.as<uint32_t>());
+                               c->info.as<uint4>(), c->rFlag.as<uint32_t>(), c->rFlagC.as<uint32_t>());
             size_t need = 0;
             HIPCK(rocprim::exclusive_scan(nullptr, need, c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(), 0u, (size_t)nC + 1,
                                           rocprim::plus<uint32_t>(), c->stream));
@@ -685,9 +689,13 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
             need = c->scanTmp.bytes;
             HIPCK(rocprim::exclusive_scan(c->scanTmp.p, need, c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(), 0u, (size_t)nC + 1,
                                           rocprim::plus<uint32_t>(), c->stream));
+            need = c->scanTmp.bytes;
+            HIPCK(rocprim::exclusive_scan(c->scanTmp.p, need, c->rFlagC.as<uint32_t>(), c->rankC.as<uint32_t>(), 0u, (size_t)nC + 1,
+                                          rocprim::plus<uint32_t>(), c->stream));
             hipLaunchKernelGGL(k_tile_rfill, dim3(grid_for(std::max<size_t>(nC, (size_t)c->nOwners + 1))), dim3(256), 0, c->stream,
                                (uint32_t)nC, c->nOwners, c->bIdx[1].as<uint32_t>(), c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(),
-                               c->bStart.as<uint32_t>(), c->aStart.as<uint32_t>(), c->info.as<uint4>(), c->rIdx.as<uint32_t>(),
+                               c->bStart.as<uint32_t>(), c->aStart.as<uint32_t>(), c->info.as<uint4>(), c->rankC.as<uint32_t>(),
+                               c->rIdx.as<uint32_t>(),
                                c->rStart.as<uint32_t>(), c->lPos.as<uint16_t>(), c->lStart.as<uint32_t>());
             hipLaunchKernelGGL(k_tile_build, dim3(nTiles), dim3(256), 0, c->stream, c->dp, c->nOwners, c->info.as<uint4>(),
                                c->aStart.as<uint32_t>(), c->owners.as<OwnerRec>(), c->tInfo.as<uint2>(), c->hList.as<uint32_t>(),
@@ -761,6 +769,7 @@ GatherArgs gather_args(deme_ctx* c) {
     g.world = c->arith == DEME_ARITH_FAST ? 1u : 0u;
     if (c->conTile) {  // the tile kernel's sums and its records of tile-crossing contacts
         g.bStart = c->rStart.as<uint32_t>(), g.bIdx = c->rIdx.as<uint32_t>();
+        g.rec32 = c->rec32.as<float4>();
         g.tile = 1u;
     }
     return g;
@@ -824,7 +833,7 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         ta.lStart = c->lStart.as<uint32_t>(), ta.lPos = c->lPos.as<uint16_t>();
         ta.wc = a.wc;
         ta.tSum = a.aSum;
-        ta.conB4 = a.conB4, ta.conB2 = a.conB2;
+        ta.rec32 = c->rec32.as<float4>(), ta.rankC = c->rankC.as<uint32_t>();
         ta.nOwners = c->nOwners;
         ta.nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
         ta.xcdGroup = c->xcdGroup;
@@ -838,7 +847,9 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         // LDS sized from this list's largest tile (rounded up so that a launch configuration serves many detections)
         ta.hCap = std::min<uint32_t>(DEME_TILE_HMAX, (c->tileMaxHalo + 15u) & ~15u);
         ta.lCap = std::min<uint32_t>(DEME_TILE_LMAX, (c->tileMaxList + 63u) & ~63u);
-        const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap);
+        ta.nComp = c->nComp, ta.nAnal = c->nAnal, ta.nMass = c->nMassProps;
+        static const uint32_t ldsPad = getenv("DEME_TILE_LDS_PAD") ? (uint32_t)atoi(getenv("DEME_TILE_LDS_PAD")) : 0u;  // occupancy experiments
+        const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial)) + ldsPad;
         ScopedTimer tm(c, "calc_forces");
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
             hipLaunchKernelGGL((k_tile_forces<0>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, c->stream, c->dp, ta);
@@ -1034,7 +1045,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->rIdx, &c->rStart, &c->rFlag, &c->rPos, &c->lPos, &c->lStart, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->rIdx, &c->rStart, &c->rFlag, &c->rPos, &c->lPos, &c->lStart, &c->rFlagC, &c->rankC, &c->rec32, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],

@@ -753,7 +753,18 @@ struct GatherArgs {
     // owner-tile form of the force pass (deme_tile.h): aSum holds, for EVERY owner, the sum over the contacts its tile evaluated
     // (A and B sides); bStart / bIdx list only the contacts whose B owner lives in another tile than A's, with records in conB
     uint32_t tile;
+    const float4* rec32;     // tile form: the crossing contacts' B-side records, 32 bytes each, dense; bIdx holds record numbers
 };
+
+// one B-side record for the per-owner gather: by contact index from the two per-contact arrays, or (tile form) by record number
+__device__ inline void gather_b_load(const GatherArgs& g, uint32_t idx, float4& c4, float2& c2) {
+    if (g.tile) {
+        const float4 r0 = g.rec32[2 * (size_t)idx], r1 = g.rec32[2 * (size_t)idx + 1];
+        c4 = r0, c2 = make_float2(r1.x, r1.y);
+    } else {
+        conb_load(g.conB4, g.conB2, idx, c4, c2);
+    }
+}
 
 // per-owner conversion of the fast mode: a = F / m, alpha = R^T tau / I (body frame, like the reference's alpha)
 __device__ inline void acc_from_world(const DevParams& p, const OwnerRec& r, float4& a, float4& al) {
@@ -811,7 +822,7 @@ __device__ inline void gather_owner(const GatherArgs& g, uint32_t o, float4& a, 
             c4[k] = make_float4(0, 0, 0, 0);
             c2[k] = make_float2(0, 0);
             if (ok)
-                conb_load(g.conB4, g.conB2, idx[k], c4[k], c2[k]);
+                gather_b_load(g, idx[k], c4[k], c2[k]);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -867,7 +878,7 @@ __device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint3
 #pragma unroll
         for (int k = 0; k < DEME_GATHER_TILE / 256; k++)
             if (idx[k] != 0xFFFFFFFFu) {
-                conb_load(g.conB4, g.conB2, idx[k], L.c4[k * 256 + t], L.c2[k * 256 + t]);
+                gather_b_load(g, idx[k], L.c4[k * 256 + t], L.c2[k * 256 + t]);
             }
         __syncthreads();
         const uint32_t s = (sB > base) ? sB : base;
@@ -929,7 +940,7 @@ __global__ __launch_bounds__(256) void k_reduce_heavy(const DevParams p, const G
             const uint32_t c = g.bIdx[i];
             float4 c4;
             float2 c2;
-            conb_load(g.conB4, g.conB2, c, c4, c2);
+            gather_b_load(g, c, c4, c2);
             s[0] += c4.x, s[1] += c4.y, s[2] += c4.z, s[3] += c4.w, s[4] += c2.x, s[5] += c2.y;
         }
         for (int k = 0; k < 6; k++)

@@ -65,10 +65,12 @@ struct TileArgs {
     const uint16_t* lPos;      // those contacts as positions in their tile's range of the list, ascending per owner
     float* wc;
     float4* tSum;              // two float4 per owner: the sum of the contributions of contacts evaluated by the owner's tile
-    float4* conB4;             // per-contact records of the B sides that live in another tile
-    float2* conB2;
+    float4* rec32;             // the B-side records of the contacts whose B owner lives in another tile: 32 bytes each, dense, in
+                               // list order (the k-th such contact writes record k: full cache lines instead of scattered pieces)
+    const uint32_t* rankC;     // per contact: the number of such contacts before it
     uint32_t nOwners, nTiles, pass, xcdGroup;
     uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
+    uint32_t nComp, nAnal, nMass;  // table sizes (tile_table_bytes)
 };
 
 // one staged owner, as the contact loop reads it back from LDS
@@ -81,13 +83,14 @@ struct TileOwner {
     float wx, wy, wz;  // angular velocity in the WORLD frame
 };
 
-__device__ inline void tile_stage_owner(const DevParams& p, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z, uint4* dst) {
+__device__ inline void tile_stage_owner(const DevParams& p, const float* massTable, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z,
+                                        uint4* dst) {
     int64_t ux, uy, uz;
     pos_units(r, p, ux, uy, uz);
     const double px = (double)(ux - u0x) * p.l, py = (double)(uy - u0y) * p.l, pz = (double)(uz - u0z) * p.l;
     const RotM R = rot_coeffs(r.qw, r.qx, r.qy, r.qz);
     const f3 w = frot_apply(R, mk3(r.wx, r.wy, r.wz));
-    const float mass = p.massProps[r.inertiaOff].x;
+    const float mass = massTable[r.inertiaOff];
     uint2 bx, by, bz;
     __builtin_memcpy(&bx, &px, 8), __builtin_memcpy(&by, &py, 8), __builtin_memcpy(&bz, &pz, 8);
     dst[0] = make_uint4(bx.x, bx.y, by.x, by.y);
@@ -116,11 +119,21 @@ __device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t slot) {
 // One contact of the hot classes between two staged owners.  Arithmetic: forces_fast_body (deme_force_fast.h), with the
 // owner-level quantities taken from the staged records.  Returns the world-frame force on A, the torques about A's and B's
 // centres, and the updated history.
+// The small tables a contact indexes per lane (components, material pairs, analytical objects, family margins) are copied to LDS
+// by every workgroup: a global load in the contact loop makes its wait drain everything that was issued before it -- the vector
+// memory counter retires in order -- and that is where the streams of the next rounds are in flight.
+struct TileTables {
+    const float4* comp;
+    const MatPair* mat;
+    const AnalObj* anal;
+    const float* fam;   // family extra margins (read only when the scene has any)
+    const float* mass;  // per mass-property entry
+};
 template <int MODEL>
-__device__ inline void tile_contact(const DevParams& p, const uint2 inf, const TileOwner& A, const TileOwner& B, float4& hist, f3& force,
-                                    f3& tA, f3& tB) {
+__device__ inline void tile_contact(const DevParams& p, const TileTables& T, const uint2 inf, const TileOwner& A, const TileOwner& B,
+                                    float4& hist, f3& force, f3& tA, f3& tB) {
     const uint32_t cls = (inf.x >> 20) & 3u;
-    const float4 cA = p.comp[inf.y & 0xFFFFu];
+    const float4 cA = T.comp[inf.y & 0xFFFFu];
     const uint32_t matA = (inf.x >> 24) & 15u;
     // sphere offsets with the reference's own rounding (no contraction: deme_device.h), see forces_fast_body
     const RotM &RA = A.R, &RB = B.R;
@@ -128,7 +141,7 @@ __device__ inline void tile_contact(const DevParams& p, const uint2 inf, const T
     const float rA = cA.w;
     float extraMargin = 0.f;
     if (!p.familyTrivial) {
-        const float eA = p.familyExtra[A.family & 0xFFu], eB = p.familyExtra[B.family & 0xFFu];
+        const float eA = T.fam[A.family & 0xFFu], eB = T.fam[B.family & 0xFFu];
         extraMargin = fmaxf(eA, eB);
     }
     const double dOx = A.px - B.px, dOy = A.py - B.py, dOz = A.pz - B.pz;
@@ -138,7 +151,7 @@ __device__ inline void tile_contact(const DevParams& p, const uint2 inf, const T
     uint32_t matB;
     bool touching;
     if (cls == DEME_KEY_CLASS_SS) {
-        const float4 cB = p.comp[inf.y >> 16];
+        const float4 cB = T.comp[inf.y >> 16];
         matB = inf.x >> 28;
         rB = cB.w;
         massB = B.mass;
@@ -159,7 +172,7 @@ __device__ inline void tile_contact(const DevParams& p, const uint2 inf, const T
         rBv = mk3(relB.x + s * n.x, relB.y + s * n.y, relB.z + s * n.z);
         rAv = fsub(rBv, dO);
     } else {  // sphere-analytical: the reference's arithmetic in the tile's frame (only differences of positions enter)
-        const AnalObj ob = p.anal[inf.y >> 16];
+        const AnalObj ob = T.anal[inf.y >> 16];
         matB = ob.mat;
         rB = 1e15f;  // DEME_HUGE_FLOAT
         massB = ob.mass;
@@ -181,7 +194,7 @@ __device__ inline void tile_contact(const DevParams& p, const uint2 inf, const T
     if (touching) {
         if (depth > 0.f) {
             const float massA = A.mass;
-            const MatPair mp = p.matPair[matA * p.nMat + matB];
+            const MatPair mp = T.mat[matA * p.nMat + matB];
             const f3 rotVelA = fcross(mk3(A.wx, A.wy, A.wz), rAv), rotVelB = fcross(mk3(B.wx, B.wy, B.wz), rBv);
             const f3 velB2A = fsub(fadd(mk3(A.vx, A.vy, A.vz), rotVelA), fadd(mk3(B.vx, B.vy, B.vz), rotVelB));
             const float projection = fdot(velB2A, n);
@@ -266,8 +279,15 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
 //   aLo, lLo [(NB + 1) x 4 B each]   owner o's A run = positions [aLo[o], aLo[o + 1]) of the tile's range, its local-B list =
 //                                    lPos[lLo[o] .. lLo[o + 1])
 //   lPos  [lCap x 2 B]
-__host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap) {
-    return (DEME_TILE_NB + hCap) * DEME_TILE_REC * 16u + DEME_TILE_T * 40u + 2u * (DEME_TILE_NB + 1u) * 4u + ((lCap * 2u + 15u) & ~15u) + 16u;
+//   tables: components [nComp x 16 B], material pairs [nMat^2 x 32 B], analytical objects [nAnal x 64 B], masses [nMass x 4 B],
+//           family margins [256 x 4 B, only when a family has one]
+#define DEME_TILE_TABLE_MAX 4096u  // bytes of tables a scene may have and still take the tile path
+__host__ __device__ inline uint32_t tile_table_bytes(uint32_t nComp, uint32_t nMat, uint32_t nAnal, uint32_t nMass, uint32_t famTrivial) {
+    return nComp * 16u + nMat * nMat * 32u + nAnal * 64u + ((nMass * 4u + 15u) & ~15u) + (famTrivial ? 0u : 1024u);
+}
+__host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap, uint32_t tableBytes) {
+    return (DEME_TILE_NB + hCap) * DEME_TILE_REC * 16u + DEME_TILE_T * 40u + 2u * (DEME_TILE_NB + 1u) * 4u + 8u + ((lCap * 2u + 15u) & ~15u) +
+           tableBytes + 16u;
 }
 
 template <int MODEL>
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     float2* const recA2 = reinterpret_cast<float2*>(recT + DEME_TILE_T);
     uint32_t* const sALo = reinterpret_cast<uint32_t*>(recA2 + DEME_TILE_T);
     uint32_t* const sLLo = sALo + (DEME_TILE_NB + 1);
-    uint16_t* const sLPos = reinterpret_cast<uint16_t*>(sLLo + (DEME_TILE_NB + 1) + ((DEME_TILE_NB + 1) & 1u) * 0u);
+    uint16_t* const sLPos = reinterpret_cast<uint16_t*>(sLLo + (DEME_TILE_NB + 1) + 2);  // (16-byte aligned: 2 x 129 + 2 words)
     const uint32_t t = tile_block_id(a.xcdGroup);
     if (t >= a.nTiles)
         return;
@@ -295,15 +315,39 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const float4* wc4 = reinterpret_cast<const float4*>(a.wc);
     uint2 inf[DEME_TILE_DEPTH];
     float4 hist[DEME_TILE_DEPTH];
+    uint32_t rbase[DEME_TILE_DEPTH];  // record number of the first crossing contact of this wavefront's 64 contacts
 #pragma unroll
     for (int d = 0; d < DEME_TILE_DEPTH; d++) {
         const uint32_t cd = c0 + tid + d * DEME_TILE_T;
-        inf[d] = make_uint2(0, 0), hist[d] = make_float4(0, 0, 0, 0);
+        inf[d] = make_uint2(0, 0), hist[d] = make_float4(0, 0, 0, 0), rbase[d] = 0u;
         if (cd < c1) {
             inf[d] = stream_load(a.tInfo + cd);
             if (MODEL == 0)
                 hist[d] = stream_load(wc4 + cd);
+            rbase[d] = a.rankC[cd - (tid & 63u)];
         }
+    }
+    TileTables T;
+    {
+        uint4* base = reinterpret_cast<uint4*>(reinterpret_cast<char*>(sLPos) + ((a.lCap * 2u + 15u) & ~15u));
+        float4* sComp = reinterpret_cast<float4*>(base);
+        MatPair* sMat = reinterpret_cast<MatPair*>(sComp + a.nComp);
+        AnalObj* sAnal = reinterpret_cast<AnalObj*>(sMat + p.nMat * p.nMat);
+        float* sMass = reinterpret_cast<float*>(sAnal + a.nAnal);
+        float* sFam = sMass + ((a.nMass + 3u) & ~3u);
+        T.comp = sComp, T.mat = sMat, T.anal = sAnal, T.mass = sMass, T.fam = sFam;
+        for (uint32_t i = tid; i < a.nMass; i += DEME_TILE_T)  // (the staging below reads the masses: their own barrier)
+            sMass[i] = p.massProps[i].x;
+        __syncthreads();
+        for (uint32_t i = tid; i < a.nComp; i += DEME_TILE_T)
+            sComp[i] = p.comp[i];
+        for (uint32_t i = tid; i < p.nMat * p.nMat * 2u; i += DEME_TILE_T)
+            reinterpret_cast<uint4*>(sMat)[i] = reinterpret_cast<const uint4*>(p.matPair)[i];
+        for (uint32_t i = tid; i < a.nAnal * 4u; i += DEME_TILE_T)
+            reinterpret_cast<uint4*>(sAnal)[i] = reinterpret_cast<const uint4*>(p.anal)[i];
+        if (!p.familyTrivial)
+            for (uint32_t i = tid; i < 256u; i += DEME_TILE_T)
+                sFam[i] = p.familyExtra[i];
     }
     {   // stage the tile's owners, its halo, the owners' run bounds and local-B lists
         int64_t u0x, u0y, u0z;
@@ -315,7 +359,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             const bool loc = s < nLoc;
             const uint32_t id = loc ? o0 + s : a.hList[(size_t)t * DEME_TILE_HMAX + (s - nLoc)];
             const OwnerRec r = load_owner(a.owners, id);
-            tile_stage_owner(p, r, u0x, u0y, u0z, sOwn + (loc ? s : DEME_TILE_NB + (s - nLoc)) * DEME_TILE_REC);
+            tile_stage_owner(p, T.mass, r, u0x, u0y, u0z, sOwn + (loc ? s : DEME_TILE_NB + (s - nLoc)) * DEME_TILE_REC);
         }
         const uint32_t l0 = a.lStart[o0], l1 = a.lStart[o0 + nLoc];
         if (tid <= DEME_TILE_NB) {
@@ -335,13 +379,15 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
     uint32_t c = c0 + tid;
     for (uint32_t rlo = 0; rlo < c1 - c0; rlo += DEME_TILE_T) {
+        bool crossing = false;
+        float4 x4 = make_float4(0, 0, 0, 0), x2 = x4;
         if (c < c1) {
             const uint2 ci = inf[0];
             float4 h = hist[0];
             const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
             const TileOwner A = tile_read_owner(sOwn, slotA), B = tile_read_owner(sOwn, slotB);
             f3 force, tA, tB;
-            tile_contact<MODEL>(p, ci, A, B, h, force, tA, tB);
+            tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
             if (MODEL == 0)
                 stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
             recA4[tid] = make_float4(force.x, force.y, force.z, tA.x);
@@ -349,21 +395,30 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             if (slotB < DEME_TILE_NB) {
                 recT[tid] = make_float4(tB.x, tB.y, tB.z, 0.f);
             } else if (ci.x & (1u << 22)) {
-                stream_store(a.conB4 + c, make_float4(-force.x, -force.y, -force.z, tB.x));
-                stream_store(a.conB2 + c, make_float2(tB.y, tB.z));
+                crossing = true;
+                x4 = make_float4(-force.x, -force.y, -force.z, tB.x), x2 = make_float4(tB.y, tB.z, 0.f, 0.f);
+            }
+        }
+        {   // the wavefront's crossing contacts write consecutive records
+            const uint64_t m = __ballot(crossing);
+            if (crossing) {
+                const uint32_t k = rbase[0] + (uint32_t)__popcll(m & ((1ull << (tid & 63u)) - 1ull));
+                stream_store(a.rec32 + 2 * (size_t)k, x4);
+                stream_store(a.rec32 + 2 * (size_t)k + 1, x2);
             }
         }
         // rotate the stream registers and refill the last stage
 #pragma unroll
         for (int d = 0; d + 1 < DEME_TILE_DEPTH; d++)
-            inf[d] = inf[d + 1], hist[d] = hist[d + 1];
+            inf[d] = inf[d + 1], hist[d] = hist[d + 1], rbase[d] = rbase[d + 1];
         {
             const uint32_t cd = c + DEME_TILE_DEPTH * DEME_TILE_T;
-            inf[DEME_TILE_DEPTH - 1] = make_uint2(0, 0), hist[DEME_TILE_DEPTH - 1] = make_float4(0, 0, 0, 0);
+            inf[DEME_TILE_DEPTH - 1] = make_uint2(0, 0), hist[DEME_TILE_DEPTH - 1] = make_float4(0, 0, 0, 0), rbase[DEME_TILE_DEPTH - 1] = 0u;
             if (cd < c1) {
                 inf[DEME_TILE_DEPTH - 1] = stream_load(a.tInfo + cd);
                 if (MODEL == 0)
                     hist[DEME_TILE_DEPTH - 1] = stream_load(wc4 + cd);
+                rbase[DEME_TILE_DEPTH - 1] = a.rankC[cd - (tid & 63u)];
             }
         }
         __syncthreads();
@@ -430,17 +485,21 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
 // ---- per-detection builder ------------------------------------------------------------------------------------------------------
 // flag[j] = 1 iff the j-th entry of the B-sorted contact list crosses a tile boundary (its B owner's sum needs a record);
 // flag[nC] = 0 closes the scan
+// flagC[c]: the same for contact c in list order (scanned into rankC, the crossing contacts' record numbers)
 __global__ __launch_bounds__(256) void k_tile_rflag(uint32_t nC, const uint32_t* __restrict__ bIdx, const uint4* __restrict__ info,
-                                                    uint32_t* __restrict__ flag) {
+                                                    uint32_t* __restrict__ flag, uint32_t* __restrict__ flagC) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > nC)
         return;
-    uint32_t f = 0;
+    uint32_t f = 0, fc = 0;
     if (j < nC) {
         const uint4 ci = info[bIdx[j]];
         f = ((ci.x & 0x3FFFFFFFu) / DEME_TILE_NB != ci.y / DEME_TILE_NB) ? 1u : 0u;
+        const uint4 cj = info[j];
+        fc = ((cj.x & 0x3FFFFFFFu) / DEME_TILE_NB != cj.y / DEME_TILE_NB) ? 1u : 0u;
     }
     flag[j] = f;
+    flagC[j] = fc;
 }
 // rIdx: the crossing contacts in B-owner order; rStart[o] = first of owner o's (o = 0 .. nOwners).  The others -- B's owner in
 // A's tile -- go to lPos as positions in that tile's range of the list (what the tile's pulling threads walk), lStart likewise;
@@ -448,14 +507,14 @@ __global__ __launch_bounds__(256) void k_tile_rflag(uint32_t nC, const uint32_t*
 __global__ __launch_bounds__(256) void k_tile_rfill(uint32_t nC, uint32_t nOwners, const uint32_t* __restrict__ bIdx,
                                                     const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rPos,
                                                     const uint32_t* __restrict__ bStart, const uint32_t* __restrict__ aStart,
-                                                    const uint4* __restrict__ info, uint32_t* __restrict__ rIdx,
-                                                    uint32_t* __restrict__ rStart, uint16_t* __restrict__ lPos,
-                                                    uint32_t* __restrict__ lStart) {
+                                                    const uint4* __restrict__ info, const uint32_t* __restrict__ rankC,
+                                                    uint32_t* __restrict__ rIdx, uint32_t* __restrict__ rStart,
+                                                    uint16_t* __restrict__ lPos, uint32_t* __restrict__ lStart) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < nC) {
         const uint32_t c = bIdx[j];
         if (flag[j]) {
-            rIdx[rPos[j]] = c;
+            rIdx[rPos[j]] = rankC[c];  // the record the crossing contact writes (k_tile_forces), not its contact index
         } else {
             const uint32_t tile0 = (info[c].y / DEME_TILE_NB) * DEME_TILE_NB;
             lPos[j - rPos[j]] = (uint16_t)min(c - aStart[tile0], 0xFFFFu);  // (a tile beyond DEME_TILE_CMAX contacts is refused by k_tile_build)
