@@ -385,8 +385,26 @@ inline int compile(const std::string& src, std::vector<char>& code, std::string&
         log = "hiprtcCreateProgram failed";
         return 1;
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    // user kernel includes (DEMSolver::AddKernelInclude, DEM/API.h:1362-1367) resolve against the ROCm installation and against the
+    // directories of DEME_KERNEL_INCLUDE_PATH (':'-separated), like the reference's jitify include path
+    std::vector<std::string> optStr = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I/opt/rocm/include"};
+    if (const char* e = getenv("DEME_KERNEL_INCLUDE_PATH")) {
+        std::string all = e;
+        size_t pos = 0;
+        while (pos <= all.size()) {
+            const size_t end = all.find(':', pos);
+            const std::string dir = all.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+            if (!dir.empty())
+                optStr.push_back("-I" + dir);
+            if (end == std::string::npos)
+                break;
+            pos = end + 1;
+        }
+    }
+    std::vector<const char*> opts;
+    for (auto& o : optStr)
+        opts.push_back(o.c_str());
+    const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
     if (ls > 1) {

@@ -465,9 +465,14 @@ class DEMSolver {
     void EnsureKernelErrMsgLineNum(bool = true) {}
     std::vector<std::string> GetJitifyOptions() const { return {"--offload-arch=gfx950", "-O3", "-std=c++17"}; }  // what hipRTC is given
     void SetJitifyOptions(const std::vector<std::string>&) {}
-    void AddKernelInclude(const std::string&) {}
-    void SetKernelInclude(const std::string&) {}
-    void RemoveKernelInclude() {}
+    // DEM/API.h:1362-1367, APIPublic.cpp:1638: text put in front of every run-time compiled force model (the reference's
+    // _kernelIncludes_).  Its default there is CUDA's <curand_kernel.h>, which has nothing to name here: the default is empty, and a
+    // script that adds that header by name gets hipRAND's device header, its counterpart in this toolchain.
+    void AddKernelInclude(const std::string& lib_name) {
+        m_kernel_includes += "#include <" + std::string(lib_name == "curand_kernel.h" ? "hiprand/hiprand_kernel.h" : lib_name) + ">\n";
+    }
+    void SetKernelInclude(const std::string& includes) { m_kernel_includes = includes; }
+    void RemoveKernelInclude() { m_kernel_includes = " "; }
     void PrintKinematicScratchSpaceUsage() const {}
     void SetCDNumStepsMaxDriftAheadOfAvg(float) {}
     void SetCDNumStepsMaxDriftMultipleOfAvg(float) {}
@@ -1364,7 +1369,10 @@ class DEMSolver {
     void ClearTimingStats() { deme_kernel_time_reset(m_ctx); }
     void ClearThreadCollaborationStats() {}
     void UseCubForceCollection(bool = true) {}  // accumulation is atomics-free here: nothing to choose
-    void SetExpandSafetyType(const std::string&) {}
+    void SetExpandSafetyType(const std::string& insp_type) {  // DEM/APIPublic.cpp:836-843: only "auto" exists
+        if (insp_type != "auto")
+            throw std::runtime_error("Unknown string input \"" + insp_type + "\" for SetExpandSafetyType.");
+    }
 
     // ---- inspectors and trackers (API.h:652-679, AuxClasses.h:26-420)
     std::shared_ptr<class DEMInspector> CreateInspector(const std::string& quantity = "clump_max_z");
@@ -1642,6 +1650,7 @@ class DEMSolver {
     std::vector<std::shared_ptr<DEMExternObj>> m_ext;
     std::vector<std::shared_ptr<DEMMeshConnected>> m_meshes;
     std::shared_ptr<DEMForceModel> m_force_model;
+    std::string m_kernel_includes;
     float3 m_user_min{-10, -10, -10}, m_user_max{10, 10, 10}, m_target_min{-12, -12, -12}, m_target_max{12, 12, 12};
     std::string m_bounding = "none";
     std::shared_ptr<DEMMaterial> m_bounding_mat;
@@ -2440,6 +2449,7 @@ class DEMSolver {
                         extra.insert(kv.first);
             std::ostringstream pre;
             pre.precision(9);
+            pre << m_kernel_includes << "\n";  // AddKernelInclude / SetKernelInclude: in front of everything the model declares
             for (auto& name : extra) {
                 if (m_force_model->pairwise_props.count(name)) {
                     const std::vector<float> M = pair(name);

@@ -15,7 +15,7 @@ using namespace deme;
 static const char* MODEL = R"MODEL(
 {
     const float qq = charge_A[AGeo] * charge_B[BGeo];
-    force += (float)(2.5e-3 * qq) * B2A;
+    force += demo_charge_force(qq) * B2A;  // from the user's header (AddKernelInclude)
     if (overlapDepth > 0) {
         float E_cnt;
         matProxy2ContactParam<float>(E_cnt, E[bodyAMatType], nu[bodyAMatType], E[bodyBMatType], nu[bodyBMatType]);
@@ -50,6 +50,18 @@ int main(int argc, char** argv) {
     batch->SetFamilies(fam);
     batch->SetVel(make_float3(0.f, 0.f, -0.3f));
 
+    {   // SetExpandSafetyType (DEM/APIPublic.cpp:836-843): "auto" is the one type there is, anything else is an error
+        bool threw = false;
+        DEMSim.SetExpandSafetyType("auto");
+        try {
+            DEMSim.SetExpandSafetyType("manual");
+        } catch (const std::runtime_error&) {
+            threw = true;
+        }
+        std::printf("CHECK safety_type_throws %d\n", (int)threw);
+    }
+    // a header of the user's, found through DEME_KERNEL_INCLUDE_PATH (the test puts demo_helpers.h there)
+    DEMSim.AddKernelInclude("demo_helpers.h");
     auto model = DEMSim.DefineContactForceModel(MODEL);
     model->SetPerContactWildcards({"contact_age"});
     model->SetPerOwnerWildcards({"n_touch"});

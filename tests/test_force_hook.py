@@ -41,6 +41,20 @@ def test_fragment_compiles_for_gfx950_without_a_gpu(pkg):
     assert ok, log
 
 
+def test_user_kernel_includes_reach_the_runtime_compiler(pkg, tmp_path, monkeypatch):
+    """DEMSolver::AddKernelInclude / SetKernelInclude (DEM/API.h:1362-1367; the reference's _kernelIncludes_): a model that needs
+    a header of the user's compiles once the header's directory is on DEME_KERNEL_INCLUDE_PATH, and fails to without it"""
+    (tmp_path / "my_contact_helpers.h").write_text("__device__ inline float my_softening(float d) { return 0.5f * d; }\n")
+    body = PLAIN.replace("force += (k_n * overlapDepth", "force += my_softening(1.0f) * (k_n * overlapDepth")
+    pre = "#include <my_contact_helpers.h>\n"
+    monkeypatch.delenv("DEME_KERNEL_INCLUDE_PATH", raising=False)
+    ok, log = pkg.abi.jit_probe(body, [], pre)
+    assert not ok and "my_contact_helpers.h" in log
+    monkeypatch.setenv("DEME_KERNEL_INCLUDE_PATH", str(tmp_path))
+    ok, log = pkg.abi.jit_probe(body, [], pre)
+    assert ok, log
+
+
 def test_name_clash_and_syntax_errors_are_reported(pkg):
     ok, log = pkg.abi.jit_probe(PLAIN, ["force"], "")  # APIPrivate.cpp:1425-1465: wildcard clashes with an ingredient
     assert not ok and "force" in log

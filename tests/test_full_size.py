@@ -151,6 +151,54 @@ def test_full_size_update_frequency_and_margins(pkg, big):
 
 
 @pytest.mark.gpu
+def test_full_size_fast_mode_matches_oracle(pkg, orc, big):
+    """The mode and the policy bench.py times -- the library's default FAST arithmetic (owner-tile force pass), detection every
+    K = 40 steps with the bench's margins (1.2 x own speed + 0.02 m/s) -- at the headline size against the oracle: 1e6 clumps from
+    a packed, still moving state with its contact history, N = 100 steps (three detections).  STATED BOUNDS, the ones of
+    tests/test_fast_mode.py at 3e3 clumps: positions within 5e-8 m, velocities within 2e-4 m/s, contact lists identical (a pair
+    whose margin-inflated spheres touch to within the position difference itself may fall on either side: at most 3 of 4e6)."""
+    import copy
+    import os
+    b, p, sc, ctx = big
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+    st = ctx.download_state()
+    ctx.compute_margins(0), ctx.detect(), ctx.migrate()
+    a, bb, t, _ = ctx.contacts()
+    W = np.stack([ctx.wildcard(w) for w in range(4)], 1)
+    q = copy.copy(p)
+    q.cdUpdateFreq = 40
+    fast = pkg.Context(0)
+    fast.set_arith_mode("fast")
+    assert fast.arith_mode() == "fast"
+    fast.set_params(q), fast.upload_scene(sc)
+    fast.upload_state({k: st[k] for k in keys})
+    fast.seed_contacts(a, bb, t, W)
+    orc.set_num_threads(min(64, os.cpu_count() or 1))
+    try:
+        sim = orc.make_sim(pkg, q, sc)
+        sim.upload_state({k: st[k] for k in keys})
+        sim.seed_contacts(a, bb, t, W)
+        fast.step(100), sim.step(100)
+        assert int(fast.counts().nDetections) == int(sim.counts().nDetections) == 3
+        g, o = fast.download_state(), sim.download_state()
+        X = pkg.model.decode_positions(g["voxelID"], g["locX"], g["locY"], g["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+        Y = pkg.model.decode_positions(o["voxelID"], o["locX"], o["locY"], o["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+        dx = float(np.abs(X - Y).max())
+        dv = max(float(np.abs(g[k] - o[k]).max()) for k in ("vX", "vY", "vZ"))
+        assert dx <= 5e-8, f"fast mode at 1e6 clumps: positions differ by {dx} m from the oracle after 100 steps"
+        assert dv <= 2e-4, f"fast mode at 1e6 clumps: velocities differ by {dv} m/s"
+        ga, gb, gt, _ = fast.contacts()
+        oa, ob, ot, _ = sim.contacts()
+        kg = (ga.astype(np.uint64) << np.uint64(34)) | (gt.astype(np.uint64) << np.uint64(31)) | gb.astype(np.uint64)
+        ko = (oa.astype(np.uint64) << np.uint64(34)) | (ot.astype(np.uint64) << np.uint64(31)) | ob.astype(np.uint64)
+        diff = np.setxor1d(kg, ko)
+        assert len(ga) > 3_000_000 and len(diff) <= 3, f"{len(diff)} pairs are in one list only"
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+        fast.close()
+
+
+@pytest.mark.gpu
 def test_mesh_flavour_at_scale_matches_oracle(pkg, orc):
     """BASELINE configs[3] flavour at scale: 3e5 clumps settled on a wavy 30k-triangle plate (1e5 sphere-triangle contacts among
     8e5): contact list and 15 further steps bit-identical to the oracle.  (A one-off run of the same check at 1e6 clumps + 50k

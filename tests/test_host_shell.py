@@ -124,9 +124,14 @@ def test_custom_model_demo_wildcards_from_the_script(tmp_path):
     (SetSphereWildcardValue, SetOwnerWildcardValue, SetFamilyOwnerWildcardValue, Get*, SetFamilyContactWildcardValueBoth) and
     the OWNER_WILDCARD / GEO_WILDCARD / CNT_WILDCARD output columns"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
-    out = subprocess.run([os.path.join(HOST, "demo_custom"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    # the model calls a function of a user header: DEMSolver::AddKernelInclude + DEME_KERNEL_INCLUDE_PATH (the reference's
+    # _kernelIncludes_ / jitify include path, DEM/API.h:1362-1367)
+    (tmp_path / "demo_helpers.h").write_text("__device__ inline float demo_charge_force(float qq) { return (float)(2.5e-3 * qq); }\n")
+    out = subprocess.run([os.path.join(HOST, "demo_custom"), str(tmp_path)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, DEME_KERNEL_INCLUDE_PATH=str(tmp_path)))
     assert out.returncode == 0 and "DEMO_OK" in out.stdout, out.stdout + out.stderr
     chk = {l.split()[1]: l.split()[2:] for l in out.stdout.splitlines() if l.startswith("CHECK")}
+    assert chk["safety_type_throws"] == ["1"]
     assert chk["charge"] == ["1.0", "-1.0", "1.0", "-1.0"]
     assert chk["n_touch_before"] == ["1000.0", "100.0", "1000.0", "0.0"]  # owners 2..5: family 2 = even owners, 3 set by id
     total = float(chk["n_touch_total"][0])
@@ -168,18 +173,30 @@ NAMED = ["BallDrop", "Mixer", "SingleSphereCollide", "FlexibleMesh", "TestPack"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_DEMOS), reason="the reference tree is only present in the build container")
-def test_reference_demo_scripts_compile_unchanged_against_the_shell():
-    """`g++ -fsyntax-only` on the reference's own demo sources, read where they lie (never copied), against the include tree
-    dem-engine_amd/host/include (DEM/API.h, DEM/HostSideHelpers.hpp, DEM/utils/Samplers.hpp, core/ApiVersion.h,
-    core/utils/ThreadManager.h): the scripting surface they use exists with the reference's signatures."""
+def test_reference_demo_scripts_compile_and_link_unchanged_against_the_shell(tmp_path):
+    """The reference's own demo sources, read where they lie (never copied), COMPILED AND LINKED into executables against the include
+    tree dem-engine_amd/host/include (DEM/API.h, DEM/HostSideHelpers.hpp, DEM/utils/Samplers.hpp, core/ApiVersion.h,
+    core/utils/ThreadManager.h) and libdeme_hip.so: every symbol of the scripting surface they use exists with the reference's
+    signature and a definition.  (Running them needs a GPU and the reference's data directory: host/demo_*.cpp are the programs
+    that run, tests/test_host_shell.py above.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    lib_dir = os.path.join(ROOT, "dem-engine_amd", "csrc")
+    assert os.path.exists(os.path.join(lib_dir, "libdeme_hip.so")), "build() first"
     inc = ["-I", os.path.join(HOST, "include"), "-I", os.path.join(ROOT, "include")]
     others = sorted(f[len("DEMdemo_"):-4] for f in os.listdir(REF_DEMOS) if f.startswith("DEMdemo_") and f.endswith(".cpp"))
-    failed = {}
-    for name in NAMED + [o for o in others if o not in NAMED]:
-        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", *inc, os.path.join(REF_DEMOS, f"DEMdemo_{name}.cpp")],
+    names = NAMED + [o for o in others if o not in NAMED]
+
+    def build(name):
+        exe = str(tmp_path / f"demo_{name}")
+        r = subprocess.run(["g++", "-std=c++17", "-O0", *inc, os.path.join(REF_DEMOS, f"DEMdemo_{name}.cpp"), "-o", exe,
+                            "-L", lib_dir, "-ldeme_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined", "-lpthread"],
                            capture_output=True, text=True)
-        if r.returncode != 0:
-            failed[name] = [ln for ln in r.stderr.splitlines() if "error" in ln][:3]
+        ok = r.returncode == 0 and os.path.exists(exe)
+        return name, ok, [ln for ln in r.stderr.splitlines() if "error" in ln or "undefined" in ln][:3]
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(build, names))
+    failed = {n: err for n, ok, err in results if not ok}
     assert not failed, failed
     assert len(others) >= 27
 
