@@ -35,6 +35,18 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+// ORC_PERF (oracle/Makefile: libdeme_oracle_perf.so, -O3 -march=native): the build bench.py TIMES as its cpu_baseline.  Same
+// algorithmic steps, with the list building, the sorts, the history map and the accumulation spread over the OpenMP team
+// ("OpenMP over owners / contacts / bins").  The parity build (no ORC_PERF, -O2 -ffp-contract=off) is what the tests
+// compare the HIP path with; tests/test_oracle_perf_build.py holds the two builds to each other.
+#ifdef ORC_PERF
+#include <parallel/algorithm>
+#define ORC_SORT __gnu_parallel::sort
+#define ORC_STABLE_SORT __gnu_parallel::stable_sort
+#else
+#define ORC_SORT std::sort
+#define ORC_STABLE_SORT std::stable_sort
+#endif
 #endif
 
 namespace {
@@ -739,6 +751,38 @@ int detect(Sim& s) {
 
     // (bin, sphere) incidences in sphere order, z-y-x loop nest: DEMBinSphereKernels.cu:181-203
     std::vector<uint32_t> ub, us;
+#ifdef ORC_PERF
+    {   // count per sphere, prefix, fill: the same list in the same order, built by the whole team
+        std::vector<size_t> first((size_t)nS + 1, 0);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)nS; i++) {
+            uint32_t lx, hx, ly, hy, lz, hz;
+            bin_range(s.sphX[i], rBin[i], s.p.binSize, s.p.nbX, lx, hx);
+            bin_range(s.sphY[i], rBin[i], s.p.binSize, s.p.nbY, ly, hy);
+            bin_range(s.sphZ[i], rBin[i], s.p.binSize, s.p.nbZ, lz, hz);
+            hx = std::min(hx, s.p.nbX - 1), hy = std::min(hy, s.p.nbY - 1), hz = std::min(hz, s.p.nbZ - 1);
+            first[i + 1] = (lx <= hx && ly <= hy && lz <= hz) ? (size_t)(hx - lx + 1) * (hy - ly + 1) * (hz - lz + 1) : 0;
+        }
+        for (size_t i = 0; i < nS; i++)
+            first[i + 1] += first[i];
+        ub.resize(first[nS]);
+        us.resize(first[nS]);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)nS; i++) {
+            uint32_t lx, hx, ly, hy, lz, hz;
+            bin_range(s.sphX[i], rBin[i], s.p.binSize, s.p.nbX, lx, hx);
+            bin_range(s.sphY[i], rBin[i], s.p.binSize, s.p.nbY, ly, hy);
+            bin_range(s.sphZ[i], rBin[i], s.p.binSize, s.p.nbZ, lz, hz);
+            size_t w = first[i];
+            for (uint32_t k = lz; k <= hz && k < s.p.nbZ; k++)
+                for (uint32_t j = ly; j <= hy && j < s.p.nbY; j++)
+                    for (uint32_t ii = lx; ii <= hx && ii < s.p.nbX; ii++) {
+                        ub[w] = ii + j * s.p.nbX + k * s.p.nbX * s.p.nbY;
+                        us[w++] = (uint32_t)i;
+                    }
+        }
+    }
+#else
     ub.reserve((size_t)nS * 4);
     us.reserve((size_t)nS * 4);
     for (uint32_t i = 0; i < nS; i++) {
@@ -753,15 +797,19 @@ int detect(Sim& s) {
                     us.push_back(i);
                 }
     }
+#endif
     // stable sort by bin: DEMCubContactDetection.cu:181 (radix sort => stable)
     const size_t P = ub.size();
     std::vector<uint32_t> perm(P);
     for (size_t i = 0; i < P; i++)
         perm[i] = (uint32_t)i;
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return ub[x] < ub[y]; });
+    ORC_STABLE_SORT(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return ub[x] < ub[y]; });
     s.incBin.resize(P);
     s.incSph.resize(P);
-    for (size_t i = 0; i < P; i++) {
+#ifdef ORC_PERF
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)P; i++) {
         s.incBin[i] = ub[perm[i]];
         s.incSph[i] = us[perm[i]];
     }
@@ -948,7 +996,7 @@ int detect(Sim& s) {
     for (auto& v : perThread)
         keys.insert(keys.end(), v.begin(), v.end());
     keys.insert(keys.end(), s.persist.begin(), s.persist.end());
-    std::sort(keys.begin(), keys.end(), key_less);
+    ORC_SORT(keys.begin(), keys.end(), key_less);
     if (!s.persist.empty())  // a marked contact the sweep found as well appears once (markDuplicateContacts)
         keys.erase(std::unique(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.a == y.a && x.b == y.b && x.t == y.t; }),
                    keys.end());
@@ -962,6 +1010,27 @@ int detect(Sim& s) {
     s.cB.resize(nC);
     s.cType.resize(nC);
     s.cMap.assign(nC, DEME_NULL_MAPPING_PARTNER);
+#ifdef ORC_PERF
+#pragma omp parallel for schedule(static)
+    for (int64_t ii = 0; ii < (int64_t)nC; ii++) {  // every new key looks itself up in the previous (sorted) list
+        const size_t i = (size_t)ii;
+        s.cA[i] = keys[i].a;
+        s.cB[i] = keys[i].b;
+        s.cType[i] = keys[i].t;
+        if (!s.haveList)
+            continue;
+        size_t lo = 0, hi = nP;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if (key_less({s.pA[mid], s.pB[mid], s.pType[mid]}, keys[i]))
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        if (lo < nP && s.pA[lo] == keys[i].a && s.pB[lo] == keys[i].b && s.pType[lo] == keys[i].t)
+            s.cMap[i] = (uint32_t)lo;
+    }
+#else
     size_t j = 0;
     for (size_t i = 0; i < nC; i++) {
         s.cA[i] = keys[i].a;
@@ -974,6 +1043,7 @@ int detect(Sim& s) {
         if (j < nP && s.pA[j] == keys[i].a && s.pB[j] == keys[i].b && s.pType[j] == keys[i].t)
             s.cMap[i] = (uint32_t)j;
     }
+#endif
     s.haveList = true;
     s.seeded = false;
     s.nDetections++;
@@ -985,7 +1055,10 @@ void migrate(Sim& s) {
     const size_t nC = s.cA.size();
     for (uint32_t w = 0; w < s.p.nContactWildcards; w++) {
         std::vector<float> nw(nC, 0.f);
-        for (size_t i = 0; i < nC; i++)
+#ifdef ORC_PERF
+#pragma omp parallel for schedule(static)
+#endif
+        for (int64_t i = 0; i < (int64_t)nC; i++)
             if (s.cMap[i] != DEME_NULL_MAPPING_PARTNER && s.cMap[i] < s.wc[w].size())
                 nw[i] = s.wc[w][s.cMap[i]];
         s.wc[w].swap(nw);
@@ -1173,6 +1246,52 @@ void calc_forces(Sim& s, bool record) {
     // accumulation (the reference uses float atomics: order-nondeterministic).  Fixed order of this build: for every owner
     // first the contacts in which it is the A side, in list order, then those in which it is the B side, in list order --
     // the order of the HIP path's atomics-free gather, so that a / alpha can be compared bit for bit.
+#ifdef ORC_PERF
+    // per owner, by its own thread: its A run (the list is sorted by sphere A, so by A's owner) and then the contacts that hold
+    // it as B, both ascending -- the order of the loop below, so the sums are the same bit for bit
+    {
+        const size_t nO = s.nOwners;
+        std::vector<uint32_t> aStart(nO + 1, 0), bStart(nO + 1, 0);
+        for (size_t c = 0; c < nC; c++)
+            aStart[ownA[c] + 1]++, bStart[ownB[c] + 1]++;
+        for (size_t o = 0; o < nO; o++)
+            aStart[o + 1] += aStart[o], bStart[o + 1] += bStart[o];
+        std::vector<uint32_t> bIdx(nC), fill(bStart.begin(), bStart.end() - 1);
+        for (size_t c = 0; c < nC; c++)
+            bIdx[fill[ownB[c]]++] = (uint32_t)c;
+#pragma omp parallel for schedule(dynamic, 512)
+        for (int64_t oo = 0; oo < (int64_t)nO; oo++) {
+            const uint32_t o = (uint32_t)oo;
+            const Q4 q{s.oriQw[o], s.oriQx[o], s.oriQy[o], s.oriQz[o]};
+            const V3f moi{s.moiX[s.inertiaOff[o]], s.moiY[s.inertiaOff[o]], s.moiZ[s.inertiaOff[o]]};
+            float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
+            for (int side = 0; side < 2; side++) {
+                const uint32_t i0 = side ? bStart[o] : aStart[o], i1 = side ? bStart[o + 1] : aStart[o + 1];
+                for (uint32_t i = i0; i < i1; i++) {
+                    const size_t c = side ? bIdx[i] : i;
+                    if (!live[c])
+                        continue;
+                    const V3f force{F[c * 3], F[c * 3 + 1], F[c * 3 + 2]};
+                    const V3f tq{T[c * 3], T[c * 3 + 1], T[c * 3 + 2]};
+                    const float m = (side && s.cType[c] > 10) ? s.objMass[s.cB[c]] : s.mass[s.inertiaOff[o]];
+                    const V3f cp = side ? V3f{PB[c * 3], PB[c * 3 + 1], PB[c * 3 + 2]} : V3f{PA[c * 3], PA[c * 3 + 1], PA[c * 3 + 2]};
+                    V3f myF;
+                    if (side == 0) {
+                        ax += force.x / m, ay += force.y / m, az += force.z / m;
+                        myF = force + tq;
+                    } else {
+                        ax += -force.x / m, ay += -force.y / m, az += -force.z / m;
+                        myF = -1.f * (force + tq);
+                    }
+                    myF = rotate_q_inv(q, myF);
+                    const V3f cr = crossf(cp, myF);
+                    lx += cr.x / moi.x, ly += cr.y / moi.y, lz += cr.z / moi.z;
+                }
+            }
+            s.aX[o] = ax, s.aY[o] = ay, s.aZ[o] = az, s.alX[o] = lx, s.alY[o] = ly, s.alZ[o] = lz;
+        }
+    }
+#else
     for (int side = 0; side < 2; side++) {
         for (size_t c = 0; c < nC; c++) {
             if (!live[c])
@@ -1203,6 +1322,7 @@ void calc_forces(Sim& s, bool record) {
             s.alZ[o] += cr.z / moi.z;
         }
     }
+#endif
     if (record) {
         s.recF.swap(F);
         s.recT.swap(T);

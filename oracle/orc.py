@@ -16,6 +16,25 @@ FORCE_NF = 39
 
 _orc = None
 _ref = None
+_variant = ""  # "" = the parity build; "_perf" = libdeme_oracle_perf.so, the build bench.py times (oracle/Makefile)
+_libs = {}
+
+
+def set_variant(perf):
+    """Which build new simulations use: the parity build (default; what the tests compare the HIP path with) or the -O3 build
+    with its list building, sorts and accumulation spread over the OpenMP team (bench.py's cpu_baseline only)."""
+    global _variant, _orc
+    _variant = "_perf" if perf else ""
+    _orc = _libs.get(_variant)
+
+
+def build_perf_native():
+    """rebuild the timed variant with -march=native on THIS host (the shipped file is generic AVX2); False if there is no compiler"""
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "perf-native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return True
+    except Exception:  # noqa: BLE001
+        return False
 
 
 def build(force=False):
@@ -35,7 +54,9 @@ def lib():
     global _orc
     if _orc is None:
         build()
-        _orc = C.CDLL(os.path.join(_HERE, "libdeme_oracle.so"))
+        if _variant and not os.path.exists(os.path.join(_HERE, f"libdeme_oracle{_variant}.so")):
+            subprocess.check_call(["make", "-C", _HERE, f"libdeme_oracle{_variant}.so"], stdout=subprocess.DEVNULL)
+        _orc = _libs[_variant] = C.CDLL(os.path.join(_HERE, f"libdeme_oracle{_variant}.so"))
         _orc.orc_sim_create.restype = _P
         _orc.orc_sim_create.argtypes = [_P, _P]
         for n in ("orc_sim_destroy", "orc_sim_set_params", "orc_sim_set_margins", "orc_sim_compute_margins",
