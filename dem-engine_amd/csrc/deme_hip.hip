@@ -71,7 +71,7 @@ struct deme_ctx {
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
     // owner-tile form of the force pass (deme_tile.h), rebuilt per detection
-    DevBuf tInfo, hList, hCount, tileMode, rIdx, rStart, rFlag, rPos, lPos, lStart, rFlagC, rankC, rec32;
+    DevBuf tInfo, hList, hCount, tileMode, tileOrg, rIdx, rStart, rFlag, rPos, lPos, lStart, rFlagC, rankC, rec32;
     bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
     bool conTile = false;     // the contributions in memory were written by the tile kernel
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
@@ -676,7 +676,8 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                            c->hasGhosts ? c->cDefer.as<uint8_t>() : (uint8_t*)nullptr, c->blockMode.as<uint32_t>());
         const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM &&
                                   c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535 &&
-                                  tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial) <= DEME_TILE_TABLE_MAX;
+                                  tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial) <= DEME_TILE_TABLE_MAX &&
+                                  c->nComp + c->nMat * c->nMat * 2u + c->nAnal * 4u <= DEME_TILE_T && c->nMassProps <= DEME_TILE_T;
         if (tileEligible) {
             const uint32_t nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
             hipLaunchKernelGGL(k_tile_rflag, dim3(grid_for(nC + 1)), dim3(256), 0, c->stream, (uint32_t)nC, c->bIdx[1].as<uint32_t>(),
@@ -700,7 +701,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
             hipLaunchKernelGGL(k_tile_build, dim3(nTiles), dim3(256), 0, c->stream, c->dp, c->nOwners, c->info.as<uint4>(),
                                c->aStart.as<uint32_t>(), c->owners.as<OwnerRec>(), c->tInfo.as<uint2>(), c->hList.as<uint32_t>(),
                                c->hCount.as<uint32_t>(), c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr,
-                               c->lStart.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
+                               c->lStart.as<uint32_t>(), c->tileOrg.as<int64_t>(), c->rangeCtr.as<RangeCounters>());
         }
         RangeCounters hr{};
         HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
@@ -829,7 +830,7 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         ta.owners = a.owners;
         ta.tInfo = c->tInfo.as<uint2>();
         ta.aStart = a.aStart;
-        ta.hList = c->hList.as<uint32_t>(), ta.hCount = c->hCount.as<uint32_t>();
+        ta.hList = c->hList.as<uint32_t>(), ta.hCount = c->hCount.as<uint32_t>(), ta.org = c->tileOrg.as<int64_t>();
         ta.lStart = c->lStart.as<uint32_t>(), ta.lPos = c->lPos.as<uint16_t>();
         ta.wc = a.wc;
         ta.tSum = a.aSum;
@@ -1045,7 +1046,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->rIdx, &c->rStart, &c->rFlag, &c->rPos, &c->lPos, &c->lStart, &c->rFlagC, &c->rankC, &c->rec32, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->rFlag, &c->rPos, &c->lPos, &c->lStart, &c->rFlagC, &c->rankC, &c->rec32, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1158,7 +1159,7 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         return c->lastStatus;
     {
         const size_t nTiles = (nO + DEME_TILE_NB - 1) / DEME_TILE_NB + 1;
-        if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) ||
+        if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) || ensure(c, c->tileOrg, nTiles * 24) ||
             ensure(c, c->rStart, (nO + 1) * 4) || ensure(c, c->lStart, (nO + 1) * 4))
             return c->lastStatus;
         HIPCK(hipMemsetAsync(c->hCount.p, 0, c->hCount.bytes, c->stream));

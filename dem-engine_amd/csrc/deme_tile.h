@@ -36,11 +36,14 @@
 #define DEME_TILE_T 256  // threads per tile (a round = DEME_TILE_T contacts); the first 2 * DEME_TILE_NB of them pull the sums
 #endif
 #define DEME_TILE_HP2 256  // DEME_TILE_HMAX rounded up to a power of two (bitonic sort of the halo list)
+#define DEME_TILE_LREG 4      // entries of a tile's local-B lists a thread carries from its load to the staging
+#define DEME_TILE_LMAX (DEME_TILE_LREG * DEME_TILE_T)   // entries of a tile's local-B lists staged in LDS
 static_assert(DEME_TILE_T >= 2 * DEME_TILE_NB, "one pulling thread per owner and side");
+static_assert(DEME_TILE_NB + DEME_TILE_HMAX <= 2 * DEME_TILE_T, "a thread stages at most two owner records");
+static_assert(DEME_TILE_LMAX == DEME_TILE_LREG * DEME_TILE_T, "list entries per thread");
 #define DEME_TILE_HASH 1024u
 #define DEME_TILE_REC 6    // uint4 per staged owner (96 bytes)
 #define DEME_TILE_CMAX 8192   // contacts of one tile (their tile-local positions are 16-bit)
-#define DEME_TILE_LMAX 2048   // entries of a tile's local-B lists staged in LDS
 static_assert(DEME_TILE_NB + DEME_TILE_HMAX <= 1024, "slot numbers are 10 bits");
 static_assert(DEME_TILE_HMAX <= DEME_TILE_HP2, "halo list sort size");
 
@@ -60,6 +63,9 @@ struct TileArgs {
     const uint32_t* aStart;
     const uint32_t* hList;     // DEME_TILE_HMAX entries per tile
     const uint32_t* hCount;
+    // per tile: the origin of its frame in sub-voxel units (x, y, z) -- its first owner's position when the list was built; any
+    // fixed point near the tile serves, and one that does not move between detections is not another load behind the records
+    const int64_t* org;
     const uint32_t* tileMode;  // halo overlap: bit p = the tile is evaluated in pass p (1: reads no ghost owner, 2: does); null: no split
     const uint32_t* lStart;    // nOwners + 1: first entry of each owner's list of contacts that hold it as B with A in the same tile
     const uint16_t* lPos;      // those contacts as positions in their tile's range of the list, ascending per owner
@@ -308,10 +314,46 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const uint32_t tid = threadIdx.x;
     const uint32_t o0 = t * DEME_TILE_NB;
     const uint32_t nLoc = min((uint32_t)DEME_TILE_NB, a.nOwners - o0);
+    // ---- every load that needs nothing but the tile number goes out first: the ids of the foreign owners behind my staging slots
+    // (the list is padded to DEME_TILE_HMAX per tile: reading past the tile's own count is harmless), my local owner's record,
+    // my entries of the small tables.  A tile's lifetime is a chain of memory latencies; this makes it two deep
+    // (ids -> foreign records), with the scalars -> streams chain beside it.
+    const uint32_t* hl = a.hList + (size_t)t * DEME_TILE_HMAX;
+    const uint32_t h0 = tid - nLoc, h1 = tid + DEME_TILE_T - nLoc;  // my foreign slots (meaningful when < nH)
+    uint32_t id0 = (tid >= nLoc && h0 < DEME_TILE_HMAX) ? hl[h0] : 0u;
+    uint32_t id1 = (h1 < DEME_TILE_HMAX) ? hl[h1] : 0u;
+    OwnerRec rec0;
+    if (tid < nLoc)
+        rec0 = load_owner(a.owners, o0 + tid);
+    TileTables T;
+    uint4* const tabBase = reinterpret_cast<uint4*>(reinterpret_cast<char*>(sLPos) + ((a.lCap * 2u + 15u) & ~15u));
+    const uint32_t nTab16 = a.nComp + p.nMat * p.nMat * 2u + a.nAnal * 4u;  // 16-byte pieces of the first three tables
+    {
+        float4* sComp = reinterpret_cast<float4*>(tabBase);
+        MatPair* sMat = reinterpret_cast<MatPair*>(sComp + a.nComp);
+        AnalObj* sAnal = reinterpret_cast<AnalObj*>(sMat + p.nMat * p.nMat);
+        float* sMass = reinterpret_cast<float*>(sAnal + a.nAnal);
+        float* sFam = sMass + ((a.nMass + 3u) & ~3u);
+        T.comp = sComp, T.mat = sMat, T.anal = sAnal, T.mass = sMass, T.fam = sFam;
+    }
+    uint4 tab16 = make_uint4(0, 0, 0, 0);
+    float tabMass = 0.f, tabFam = 0.f;
+    if (tid < nTab16) {
+        const uint32_t k = tid;
+        tab16 = k < a.nComp ? reinterpret_cast<const uint4*>(p.comp)[k]
+                : (k < a.nComp + p.nMat * p.nMat * 2u ? reinterpret_cast<const uint4*>(p.matPair)[k - a.nComp]
+                                                       : reinterpret_cast<const uint4*>(p.anal)[k - a.nComp - p.nMat * p.nMat * 2u]);
+    }
+    if (tid < a.nMass)
+        tabMass = p.massProps[tid].x;
+    if (!p.familyTrivial)
+        tabFam = p.familyExtra[tid & 255u];
+    // ---- the scalars of the tile, then what hangs on them: the streams of the first rounds (a tile is ~2 rounds; memory latency
+    // under load is longer than a round takes), the run bounds, the local-B lists
     const uint32_t nH = a.hCount[t];
     const uint32_t c0 = a.aStart[o0], c1 = a.aStart[o0 + nLoc];
-    // the streams of the first rounds do not depend on the staging: issue them first, all of them (a tile is ~2 rounds; memory
-    // latency under load is longer than a round takes)
+    const uint32_t l0 = a.lStart[o0], l1 = a.lStart[o0 + nLoc];
+    const int64_t u0x = a.org[3 * (size_t)t], u0y = a.org[3 * (size_t)t + 1], u0z = a.org[3 * (size_t)t + 2];
     const float4* wc4 = reinterpret_cast<const float4*>(a.wc);
     uint2 inf[DEME_TILE_DEPTH];
     float4 hist[DEME_TILE_DEPTH];
@@ -327,48 +369,41 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             rbase[d] = a.rankC[cd - (tid & 63u)];
         }
     }
-    TileTables T;
-    {
-        uint4* base = reinterpret_cast<uint4*>(reinterpret_cast<char*>(sLPos) + ((a.lCap * 2u + 15u) & ~15u));
-        float4* sComp = reinterpret_cast<float4*>(base);
-        MatPair* sMat = reinterpret_cast<MatPair*>(sComp + a.nComp);
-        AnalObj* sAnal = reinterpret_cast<AnalObj*>(sMat + p.nMat * p.nMat);
-        float* sMass = reinterpret_cast<float*>(sAnal + a.nAnal);
-        float* sFam = sMass + ((a.nMass + 3u) & ~3u);
-        T.comp = sComp, T.mat = sMat, T.anal = sAnal, T.mass = sMass, T.fam = sFam;
-        for (uint32_t i = tid; i < a.nMass; i += DEME_TILE_T)  // (the staging below reads the masses: their own barrier)
-            sMass[i] = p.massProps[i].x;
-        __syncthreads();
-        for (uint32_t i = tid; i < a.nComp; i += DEME_TILE_T)
-            sComp[i] = p.comp[i];
-        for (uint32_t i = tid; i < p.nMat * p.nMat * 2u; i += DEME_TILE_T)
-            reinterpret_cast<uint4*>(sMat)[i] = reinterpret_cast<const uint4*>(p.matPair)[i];
-        for (uint32_t i = tid; i < a.nAnal * 4u; i += DEME_TILE_T)
-            reinterpret_cast<uint4*>(sAnal)[i] = reinterpret_cast<const uint4*>(p.anal)[i];
-        if (!p.familyTrivial)
-            for (uint32_t i = tid; i < 256u; i += DEME_TILE_T)
-                sFam[i] = p.familyExtra[i];
+    uint32_t bA = 0, bL = 0;
+    if (tid <= DEME_TILE_NB) {
+        const uint32_t o = min(tid, nLoc);
+        bA = a.aStart[o0 + o], bL = a.lStart[o0 + o];
     }
+    uint32_t lp[DEME_TILE_LREG];
+#pragma unroll
+    for (int k = 0; k < DEME_TILE_LREG; k++) {
+        const uint32_t i = tid + k * DEME_TILE_T;
+        lp[k] = (i < l1 - l0) ? (uint32_t)a.lPos[l0 + i] : 0u;
+    }
+    // ---- the foreign owners' records (their ids have arrived by now), the tables into LDS
+    OwnerRec rec1;
+    if (tid >= nLoc && h0 < nH)
+        rec0 = load_owner(a.owners, id0);
+    if (h1 < nH)
+        rec1 = load_owner(a.owners, id1);
+    if (tid < nTab16)
+        tabBase[tid] = tab16;
+    if (tid < a.nMass)
+        const_cast<float*>(T.mass)[tid] = tabMass;
+    if (!p.familyTrivial)
+        const_cast<float*>(T.fam)[tid & 255u] = tabFam;
+    __syncthreads();  // (the staging below reads the masses)
     {   // stage the tile's owners, its halo, the owners' run bounds and local-B lists
-        int64_t u0x, u0y, u0z;
-        {
-            const OwnerRec f = load_owner(a.owners, o0);  // (one address for the whole workgroup)
-            pos_units(f, p, u0x, u0y, u0z);
-        }
-        for (uint32_t s = tid; s < nLoc + nH; s += DEME_TILE_T) {
-            const bool loc = s < nLoc;
-            const uint32_t id = loc ? o0 + s : a.hList[(size_t)t * DEME_TILE_HMAX + (s - nLoc)];
-            const OwnerRec r = load_owner(a.owners, id);
-            tile_stage_owner(p, T.mass, r, u0x, u0y, u0z, sOwn + (loc ? s : DEME_TILE_NB + (s - nLoc)) * DEME_TILE_REC);
-        }
-        const uint32_t l0 = a.lStart[o0], l1 = a.lStart[o0 + nLoc];
-        if (tid <= DEME_TILE_NB) {
-            const uint32_t o = min(tid, nLoc);
-            sALo[tid] = a.aStart[o0 + o] - c0;
-            sLLo[tid] = a.lStart[o0 + o] - l0;
-        }
-        for (uint32_t i = tid; i < l1 - l0; i += DEME_TILE_T)
-            sLPos[i] = a.lPos[l0 + i];
+        if (tid < nLoc + nH)
+            tile_stage_owner(p, T.mass, rec0, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * DEME_TILE_REC);
+        if (h1 < nH)
+            tile_stage_owner(p, T.mass, rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * DEME_TILE_REC);
+        if (tid <= DEME_TILE_NB)
+            sALo[tid] = bA - c0, sLLo[tid] = bL - l0;
+#pragma unroll
+        for (int k = 0; k < DEME_TILE_LREG; k++)
+            if (tid + k * DEME_TILE_T < l1 - l0)
+                sLPos[tid + k * DEME_TILE_T] = (uint16_t)lp[k];
     }
     __syncthreads();
     // the pulling side of this thread: threads 0 .. NB - 1 take the A runs, NB .. 2 NB - 1 the local-B lists
@@ -533,7 +568,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
                                                     const uint32_t* __restrict__ aStart, const OwnerRec* __restrict__ owners,
                                                     uint2* __restrict__ tInfo, uint32_t* __restrict__ hList,
                                                     uint32_t* __restrict__ hCount, uint32_t* __restrict__ tileMode,
-                                                    const uint32_t* __restrict__ lStart, RangeCounters* rc) {
+                                                    const uint32_t* __restrict__ lStart, int64_t* __restrict__ org, RangeCounters* rc) {
     __shared__ uint32_t table[DEME_TILE_HASH];
     __shared__ uint32_t list[DEME_TILE_HP2];
     __shared__ uint32_t nU, nL, anyGhost;
@@ -596,6 +631,9 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         hList[(size_t)t * DEME_TILE_HMAX + i] = list[i];
     if (tid == 0) {
         hCount[t] = n;
+        int64_t ux, uy, uz;
+        pos_units(load_owner(owners, o0), p, ux, uy, uz);
+        org[3 * (size_t)t] = ux, org[3 * (size_t)t + 1] = uy, org[3 * (size_t)t + 2] = uz;
         atomicMax(&rc->tileMaxHalo, n);
         atomicMax(&rc->tileMaxList, lStart[o1] - lStart[o0]);
     }
