@@ -184,16 +184,31 @@ __device__ inline void tile_contact(const DevParams& p, const TileTables& T, con
         massB = ob.mass;
         const f3 relB = rot_apply(RB, mk3(ob.relx, ob.rely, ob.relz));
         const f3 dir = rot_apply(RB, mk3(ob.rotx, ob.roty, ob.rotz));
-        const d3 PA{A.px, A.py, A.pz}, PB{B.px, B.py, B.pz};
-        const d3 bodyA{PA.x + (double)relA.x, PA.y + (double)relA.y, PA.z + (double)relA.z};
-        const d3 bodyB{PB.x + (double)relB.x, PB.y + (double)relB.y, PB.z + (double)relB.z};
-        d3 cp;
-        double dd;
-        sphere_entity(bodyA, rA, ob.type, bodyB, dir, ob.size1, ob.normal, 0.0f, cp, n, dd);
-        depth = (float)dd;
-        touching = !(dd < -(double)extraMargin);
-        rAv = mk3((float)(cp.x - PA.x), (float)(cp.y - PA.y), (float)(cp.z - PA.z));
-        rBv = mk3((float)(cp.x - PB.x), (float)(cp.y - PB.y), (float)(cp.z - PB.z));
+        if (ob.type == 0u) {  // a plane -- the walls of every box -- in a few lines (checkSphereEntityOverlap's plane branch,
+            // DEMHelperKernels.cuh:459-478): half of a packed bed's tiles touch the floor, and the general branch below is 150
+            // instructions that every wavefront with one wall contact among its 64 would execute
+            const double px = (dOx + (double)relA.x) - (double)relB.x, py = (dOy + (double)relA.y) - (double)relB.y,
+                         pz = (dOz + (double)relA.z) - (double)relB.z;
+            const float dist = (float)(px * (double)dir.x + py * (double)dir.y + pz * (double)dir.z);
+            const double dd = (double)rA - (double)dist;
+            depth = (float)dd;
+            touching = !(dd < -(double)extraMargin);
+            const float sOff = (float)((double)dist + dd / 2.0);
+            n = dir;
+            rAv = mk3(relA.x - dir.x * sOff, relA.y - dir.y * sOff, relA.z - dir.z * sOff);  // contact point = sphere centre - s n
+            rBv = fadd(rAv, dO);
+        } else {
+            const d3 PA{A.px, A.py, A.pz}, PB{B.px, B.py, B.pz};
+            const d3 bodyA{PA.x + (double)relA.x, PA.y + (double)relA.y, PA.z + (double)relA.z};
+            const d3 bodyB{PB.x + (double)relB.x, PB.y + (double)relB.y, PB.z + (double)relB.z};
+            d3 cp;
+            double dd;
+            sphere_entity(bodyA, rA, ob.type, bodyB, dir, ob.size1, ob.normal, 0.0f, cp, n, dd);
+            depth = (float)dd;
+            touching = !(dd < -(double)extraMargin);
+            rAv = mk3((float)(cp.x - PA.x), (float)(cp.y - PA.y), (float)(cp.z - PA.z));
+            rBv = mk3((float)(cp.x - PB.x), (float)(cp.y - PB.y), (float)(cp.z - PB.z));
+        }
     }
     force = mk3(0, 0, 0);
     f3 torque_only = mk3(0, 0, 0);
