@@ -702,6 +702,8 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                                c->aStart.as<uint32_t>(), c->owners.as<OwnerRec>(), c->tInfo.as<uint2>(), c->hList.as<uint32_t>(),
                                c->hCount.as<uint32_t>(), c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr,
                                c->lStart.as<uint32_t>(), c->tileOrg.as<int64_t>(), c->rangeCtr.as<RangeCounters>());
+            hipLaunchKernelGGL(k_tile_stats, dim3(1), dim3(256), 0, c->stream, nTiles, c->nOwners, c->hCount.as<uint32_t>(),
+                               c->lStart.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
         }
         RangeCounters hr{};
         HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));

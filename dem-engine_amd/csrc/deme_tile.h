@@ -45,7 +45,7 @@ static_assert(DEME_TILE_LMAX == DEME_TILE_LREG * DEME_TILE_T, "list entries per 
 #define DEME_TILE_REC 6    // uint4 per staged owner (96 bytes)
 #define DEME_TILE_CMAX 8192   // contacts of one tile (their tile-local positions are 16-bit)
 static_assert(DEME_TILE_NB + DEME_TILE_HMAX <= 1024, "slot numbers are 10 bits");
-static_assert(DEME_TILE_HMAX <= DEME_TILE_HP2, "halo list sort size");
+static_assert(DEME_TILE_HMAX <= DEME_TILE_HP2 && DEME_TILE_HMAX <= 256, "halo list: one entry per builder thread");
 
 #pragma clang fp contract(fast)
 
@@ -627,20 +627,18 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         if (v != 0xFFFFFFFFu)
             list[atomicAdd(&nL, 1u)] = v;
     }
-    // bitonic sort (ascending; the padding sorts to the end)
-    for (uint32_t k = 2; k <= DEME_TILE_HP2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            for (uint32_t i = tid; i < DEME_TILE_HP2; i += 256) {
-                const uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t x = list[i], y = list[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up)
-                        list[i] = y, list[ixj] = x;
-                }
-            }
-        }
+    // sort by rank: the n <= DEME_TILE_HMAX entries are distinct, so an entry's place is the number of smaller ones -- every
+    // thread counts for its own entry (broadcast reads, no barrier inside; a bitonic network spent 36 barriers here)
+    __syncthreads();
+    uint32_t mine = 0xFFFFFFFFu, rank = 0;
+    if (tid < n) {
+        mine = list[tid];
+        for (uint32_t j = 0; j < n; j++)
+            rank += list[j] < mine ? 1u : 0u;
+    }
+    __syncthreads();
+    if (tid < n)
+        list[rank] = mine;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 256)
         hList[(size_t)t * DEME_TILE_HMAX + i] = list[i];
@@ -649,8 +647,6 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         int64_t ux, uy, uz;
         pos_units(load_owner(owners, o0), p, ux, uy, uz);
         org[3 * (size_t)t] = ux, org[3 * (size_t)t + 1] = uy, org[3 * (size_t)t + 2] = uz;
-        atomicMax(&rc->tileMaxHalo, n);
-        atomicMax(&rc->tileMaxList, lStart[o1] - lStart[o0]);
     }
     if (tileMode) {  // a tile that stages a ghost's record waits for the ghosts of this step (pass 1)
         bool g = false;
@@ -685,6 +681,30 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         const uint32_t wB = (cls == DEME_KEY_CLASS_SS) ? (ci.w & 0xFFFFu) : ci.w;
         tInfo[c] = make_uint2(tile_info_x(oa - o0, slotB, cls, rec, matA, matB), compA | (wB << 16));
     }
+}
+
+// the largest tile's foreign-owner count and local-B list length (they size the LDS of k_tile_forces): one workgroup over the
+// per-tile values -- 8 000 atomicMax on one address from k_tile_build cost 190 us (same-address atomics serialise at ~12 ns)
+__global__ __launch_bounds__(256) void k_tile_stats(uint32_t nTiles, uint32_t nOwners, const uint32_t* __restrict__ hCount,
+                                                    const uint32_t* __restrict__ lStart, RangeCounters* rc) {
+    __shared__ uint32_t mh[256], ml[256];
+    uint32_t a = 0, b = 0;
+    for (uint32_t t = threadIdx.x; t < nTiles; t += 256) {
+        const uint32_t o0 = t * DEME_TILE_NB, o1 = min(o0 + (uint32_t)DEME_TILE_NB, nOwners);
+        a = max(a, hCount[t]);
+        b = max(b, lStart[o1] - lStart[o0]);
+    }
+    mh[threadIdx.x] = a, ml[threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            mh[threadIdx.x] = max(mh[threadIdx.x], mh[threadIdx.x + off]);
+            ml[threadIdx.x] = max(ml[threadIdx.x], ml[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        rc->tileMaxHalo = mh[0], rc->tileMaxList = ml[0];
 }
 
 }  // namespace deme_dev

@@ -1,4 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out/r3c
-bash tools/prof.sh t1 r3c trace sqA sqB lds > gpurun_out/r3c/log.txt 2>&1
-grep -E "k_tile_forces|k_integrate|^kernel" gpurun_out/r3c/log.txt | cut -c1-250
+bash tools/prof.sh t3 r3c trace > gpurun_out/r3c/log3.txt 2>&1
+cat gpurun_out/r3c/t3_kernels.txt | cut -c1-150
