@@ -685,6 +685,7 @@ def main():
     c = ctx.counts()
     value = total_clumps * args.steps / dt
     fbytes = force_kernel_bytes(int(sc.nOwners), int(sc.nSpheres), int(c.nContacts), int(p.nContactWildcards))
+    fk_name, tile_halo, tile_list = ctx.force_kernel()
     achieved = fbytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
     par = f"{world} x-slab(s)"
     if group is not None:
@@ -738,10 +739,12 @@ def main():
                                 {"mode": args.adaptive, "bin_size": adaptive_state[0], "cd_every": adaptive_state[1],
                                  "bin_size_changes": adaptive_state[2], "update_freq_changes": adaptive_state[3]}),
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
-        "roofline": {"kernel": "deme_custom_forces_ss (hipRTC)" if args.config5 else ("k_forces_fast<0>" if ctx.arith_mode() == "fast" else "k_calc_forces<0, 0>"), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": fk_name + (" (hipRTC)" if args.config5 else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "attainable_copy_GBs": copy_gbs, "frac_of_attainable": (achieved / copy_gbs if copy_gbs else None),
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),
+                     "tile": ({"owners_per_tile": 128, "largest_tile_foreign_owners": tile_halo, "largest_tile_local_list": tile_list}
+                              if fk_name.startswith("k_tile") else None),
                      "launch_sampling": f"every {stride}{'th' if stride > 3 else ('st', 'nd', 'rd')[stride - 1]} launch inside the timed region is bracketed with HIP events"},
         "kernels_ms": {"calc_forces": f_ms, "integrate": i_ms, "detect_update": d_ms, "detect_updates": int(n_det),
                        # the same step with the detection spread over its K steps (what a run of many K-cycles converges to;

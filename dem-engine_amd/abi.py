@@ -280,6 +280,7 @@ class HaloGroup:
         lr, lc, ls, lrv = side(left, part["send_left"], part["recv_left"])
         rr, rc_, rs, rrv = side(right, part["send_right"], part["recv_right"])
         self._keep = getattr(self, "_keep", []) + [(ls, lrv, rs, rrv)]
+        self._ctxs = getattr(self, "_ctxs", []) + [ctx]
         self._ck(self.lib.deme_halo_group_attach(self.h, ctx.h, lr, lc, _ptr(ls), ls.size, _ptr(lrv), lrv.size, rr, rc_, _ptr(rs),
                                                   rs.size, _ptr(rrv), rrv.size), "deme_halo_group_attach")
 
@@ -296,6 +297,44 @@ class HaloGroup:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._ck(self.lib.deme_halo_group_stats(self.h, C.byref(a), C.byref(b)), "deme_halo_group_stats")
         return int(a.value), int(b.value)
+
+    def set_slab(self, ctx, part, halo, flip_mask=7):
+        """what deme_halo_group_migrate has to know about a slab: global ids of its owners and spheres (part = an entry of
+        decomp.decompose / the result of a migration), its x range and the halo thickness; flip_mask: contact wildcards that are
+        B -> A vectors (bit w)"""
+        og = np.ascontiguousarray(part["owner_global"], np.uint32)
+        sg = np.ascontiguousarray(part["sphere_global"], np.uint32)
+        lo, hi = (float(v) for v in part["edges"])
+        self.lib.deme_halo_group_set_slab.argtypes = [_P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double,
+                                                      C.c_uint32]
+        self._ck(self.lib.deme_halo_group_set_slab(self.h, ctx.h, _ptr(og), _ptr(sg), int(part["n_own"]), len(part["ghost_left_g"]),
+                                                   len(part["ghost_right_g"]), lo, hi, float(halo), int(flip_mask)), "deme_halo_group_set_slab")
+
+    def migrate(self):
+        """deme_halo_group_migrate: clumps that crossed a face move to the face neighbour (state, template ids, contact history), ghost
+        sets and exchange lists are renewed -- on the device, over RCCL between ranks.  Returns the clumps this process sent away."""
+        n = C.c_uint32(0)
+        self.lib.deme_halo_group_migrate.argtypes = [_P, C.POINTER(C.c_uint32)]
+        self._ck(self.lib.deme_halo_group_migrate(self.h, C.byref(n)), "deme_halo_group_migrate")
+        for c in getattr(self, "_ctxs", []):  # the slabs have new owner / sphere counts
+            cnt = self.slab_counts(c)
+            c.n_owners, c.n_spheres = cnt[3], cnt[4]
+        return int(n.value)
+
+    def slab_counts(self, ctx):
+        """(own clumps, ghosts from the left, ghosts from the right, owners, spheres, seeded contacts) of a slab"""
+        v = (C.c_uint32 * 6)()
+        self.lib.deme_halo_group_slab_counts.argtypes = [_P, _P, C.POINTER(C.c_uint32)]
+        self._ck(self.lib.deme_halo_group_slab_counts(self.h, ctx.h, v), "deme_halo_group_slab_counts")
+        return tuple(int(x) for x in v)
+
+    def slab_ids(self, ctx):
+        """(global clump id per owner, global sphere id per sphere, owner per sphere, component per sphere) in the slab's current numbering"""
+        n_own, n_gl, n_gr, n_o, n_s, _ = self.slab_counts(ctx)
+        og, sg, so, sc = np.zeros(n_o, np.uint32), np.zeros(n_s, np.uint32), np.zeros(n_s, np.uint32), np.zeros(n_s, np.uint16)
+        self.lib.deme_halo_group_download_ids.argtypes = [_P, _P, _P, _P, _P, _P]
+        self._ck(self.lib.deme_halo_group_download_ids(self.h, ctx.h, _ptr(og), _ptr(sg), _ptr(so), _ptr(sc)), "deme_halo_group_download_ids")
+        return og, sg, so, sc
 
     def comm_count(self):
         """ranks of the group's RCCL communicator, as RCCL reports it (ncclCommCount)"""
@@ -403,6 +442,14 @@ class Context:
     def upload_state(self, arrays):
         st, _ = make_state_struct(self.n_owners, arrays)
         self._ck(self.lib.deme_upload_owner_state(self.h, C.byref(st)), "deme_upload_owner_state")
+
+    def force_kernel(self):
+        """(name of the kernel that evaluates the contact forces of the current list, largest tile's foreign owners, local list)"""
+        buf = C.create_string_buffer(64)
+        h, l = C.c_uint32(0), C.c_uint32(0)
+        self.lib.deme_force_kernel_name.argtypes = [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        self._ck(self.lib.deme_force_kernel_name(self.h, buf, 64, C.byref(h), C.byref(l)), "deme_force_kernel_name")
+        return buf.value.decode(), int(h.value), int(l.value)
 
     def download_state(self):
         st, out = make_state_struct(self.n_owners)

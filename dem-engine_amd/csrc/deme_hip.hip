@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include <iterator>
+#include <limits>
 
 #include "../../include/deme_hip.h"
 #include "deme_device.h"
@@ -27,6 +28,7 @@
 #include "deme_jit.h"
 #include "deme_kernels.h"
 #include "deme_tile.h"
+#include "deme_migrate.h"
 #include "deme_mesh_kernels.h"
 
 using namespace deme_dev;
@@ -1096,6 +1098,26 @@ int deme_set_arith_mode(deme_ctx* c, int mode) {
 }
 int deme_get_arith_mode(const deme_ctx* c) { return c ? c->arith : -1; }
 
+int deme_force_kernel_name(const deme_ctx* c, char* name, size_t cap, uint32_t* tileMaxHalo, uint32_t* tileMaxList) {
+    if (!c || !name || !cap)
+        return DEME_ERR_INVALID;
+    const int m = c->hp.forceModel == DEME_FORCE_HERTZIAN ? 0 : 1;
+    const bool fastKernel = c->arith == DEME_ARITH_FAST && !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM;
+    if (c->hp.forceModel == DEME_FORCE_CUSTOM)
+        snprintf(name, cap, "deme_custom_forces_ss");
+    else if (fastKernel && c->tileActive && c->tileEnable)
+        snprintf(name, cap, "k_tile_forces<%d>", m);
+    else if (fastKernel)
+        snprintf(name, cap, "k_forces_fast<%d>", m);
+    else
+        snprintf(name, cap, "k_calc_forces<%d, 0>", m);
+    if (tileMaxHalo)
+        *tileMaxHalo = c->tileMaxHalo;
+    if (tileMaxList)
+        *tileMaxList = c->tileMaxList;
+    return DEME_OK;
+}
+
 int deme_sync(deme_ctx* c) {
     if (!c)
         return DEME_ERR_INVALID;
@@ -1928,8 +1950,21 @@ struct HaloSide {
     void *sendIds = nullptr, *recvIds = nullptr, *sendBuf = nullptr, *recvBuf = nullptr;
     uint32_t nSend = 0, nRecv = 0;
 };
+struct MigBuf {  // one direction of a migration exchange: clumps, their spheres, history rows (device buffers, counts on the host)
+    void *clumps = nullptr, *spheres = nullptr, *rowH = nullptr, *rowW = nullptr, *counts = nullptr;
+    uint32_t nC = 0, nS = 0, nR = 0;
+    bool borrowed = false;  // the buffers belong to a neighbour slab of this process
+};
+struct SlabGeom {  // what deme_halo_group_migrate needs to know about a slab (deme_halo_group_set_slab)
+    bool set = false;
+    void *ownerGid = nullptr, *sphereGid = nullptr;
+    size_t gidCapO = 0, gidCapS = 0;
+    double xLo = 0, xHi = 0, halo = 0;
+    uint32_t nOwn = 0, nGL = 0, nGR = 0, flipMask = 7u;
+};
 struct HaloSlab {
     deme_ctx* ctx = nullptr;
+    SlabGeom geo;
     HaloSide side[2];  // 0 left, 1 right
     hipEvent_t evPacked = nullptr;
     hipEvent_t evAcc = nullptr;  // this slab's share of the replicated owners' a / alpha is in its buffer
@@ -2319,6 +2354,8 @@ int deme_halo_group_comm_count(const deme_halo_group* g, int* ranks) {
         return DEME_ERR_INVALID;
     return g->api->CommCount(g->comm, ranks) == 0 ? DEME_OK : DEME_ERR_HIP;
 }
+
+#include "deme_migrate_host.inc"
 
 int deme_get_counts(deme_ctx* c, DemeCounts* out) {
     if (!c || !out)

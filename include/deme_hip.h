@@ -188,6 +188,12 @@ int deme_sync(deme_ctx* ctx);
 #define DEME_ARITH_EXACT 0
 int deme_set_arith_mode(deme_ctx* ctx, int mode);
 int deme_get_arith_mode(const deme_ctx* ctx);
+/* Which kernel evaluates the contact forces of the current list (what a profile of the stepping loop shows as its dominant
+ * kernel): "k_tile_forces<M>" -- the owner-tile pass of the fast mode, csrc/deme_tile.h -- , "k_forces_fast<M>" (fast mode, a
+ * list or scene the tile pass does not take: a mesh, replicated free owners, a tile whose foreign owners do not fit LDS),
+ * "k_calc_forces<M, 0>" (exact mode, contact recording) or "deme_custom_forces_ss" (a run-time compiled model); M = 0 Hertzian
+ * with history, 1 frictionless.  Also the largest tile's foreign-owner count and local list length of the current list. */
+int deme_force_kernel_name(const deme_ctx* ctx, char* name, size_t cap, uint32_t* tileMaxHalo, uint32_t* tileMaxList);
 
 /* setSimParams / UpdateSimParams (APIPrivate.cpp:1121, dT.cpp:2463-2466) */
 int deme_set_params(deme_ctx* ctx, const DemeParams* p);
@@ -439,6 +445,25 @@ int deme_halo_group_stats(const deme_halo_group* g, uint64_t* exchanges, uint64_
 /* host microseconds spent enqueuing since creation / the last reset: [0] interior force passes, [1] packs, [2] the RCCL group,
  * [3] unpacks + boundary passes + integration */
 int deme_halo_group_host_time(deme_halo_group* g, double us[4], int reset);
+/* Migration inside the library (SURVEY 8e "migration at re-bin time"; the algorithm of decomp.migrate_neighbours, on the device).
+ *   deme_halo_group_set_slab     what the group has to know about a slab beyond its exchange lists: global clump / sphere ids of
+ *                                its owners and spheres (scene order: own clumps, ghosts from the left, ghosts from the right,
+ *                                replicated owners), the slab's x range [xLo, xHi) and the halo thickness; flipMask: the contact
+ *                                wildcards that are B->A vectors (bit w; 7 = delta_tan_x/y/z of the Hertzian model)
+ *   deme_halo_group_migrate      collective over the group: every own clump whose centre crossed a face moves to that face
+ *                                neighbour with its state, template ids and the history rows of its contacts (global sphere
+ *                                ids; ncclSend / ncclRecv between ranks, buffer hand-over between slabs of one process), ghost
+ *                                sets are renewed from the neighbours' current clumps, every slab is re-assembled and re-seeded on
+ *                                the device and its exchange lists rebuilt.  Only counts pass through the host.  The next step of
+ *                                every slab starts with a contact detection.
+ *   deme_halo_group_slab_counts  own / ghost-left / ghost-right clumps, owners, spheres, seeded contacts of a slab
+ *   deme_halo_group_download_ids global ids (and sphere -> owner / component) of a slab's current numbering, for the caller's books */
+int deme_halo_group_set_slab(deme_halo_group* g, deme_ctx* ctx, const uint32_t* ownerGlobal, const uint32_t* sphereGlobal, uint32_t nOwn,
+                             uint32_t nGhostLeft, uint32_t nGhostRight, double xLo, double xHi, double halo, uint32_t flipMask);
+int deme_halo_group_migrate(deme_halo_group* g, uint32_t* clumpsMoved);
+int deme_halo_group_slab_counts(const deme_halo_group* g, const deme_ctx* ctx, uint32_t counts[6]);
+int deme_halo_group_download_ids(deme_halo_group* g, deme_ctx* ctx, uint32_t* ownerGlobal, uint32_t* sphereGlobal, uint32_t* sphereOwner,
+                                 uint16_t* sphereComp);
 /* how many ranks the group's RCCL communicator spans, as RCCL itself reports it (ncclCommCount): a scaling run checks this
  * against the number of processes it believes it launched */
 int deme_halo_group_comm_count(const deme_halo_group* g, int* ranks);

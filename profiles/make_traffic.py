@@ -40,16 +40,16 @@ def main():
     bench = json.load(open(f"{d}/{tag}_bench.json"))
     nc = bench["config"]["contacts_this_rank"]
     out = {"contacts": nc, "source": [f"{tag}_fetch_pmc.txt", f"{tag}_write_pmc.txt"], "unit": "bytes per launch", "kernels": {}}
-    force = "k_forces_fast<0>" if "k_forces_fast<0>" in fetch else "k_calc_forces<0, 0>"
+    force = next(k for k in ("k_tile_forces<0>", "k_forces_fast<0>", "k_calc_forces<0, 0>") if k in fetch)
     out["force_kernel"] = force
     for k in (force, "k_integrate<true>", "k_sweep"):
         if k not in fetch or k not in write:
             continue
         f_kib, w_kib = fetch[k][1], write[k][1]
         out["kernels"][k] = {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "traffic_prescribed": int((2 * f_kib + w_kib) * 1024)}
-    # force kernel: coalesced 16 B/lane streams read per contact = gather record (16) + wildcards (16)
+    # force kernel: coalesced streams read per contact = gather record (16; 8 in the tile pass) + wildcards (16)
     fk = out["kernels"][force]
-    stream_read = nc * 32
+    stream_read = nc * (24 if force.startswith("k_tile") else 32)
     raw = fk["FETCH_SIZE_KiB"] * 1024
     fk["traffic_lower_bound"] = int(stream_read + max(0.0, raw - stream_read / 2) + fk["WRITE_SIZE_KiB"] * 1024)
     out["traffic_bytes_per_launch"] = fk["traffic_prescribed"]

@@ -179,6 +179,65 @@ def test_neighbour_migration_between_slabs_on_the_gpu(pkg):
     g.close(), g2.close()
 
 
+def test_library_migration_equals_the_numpy_statement(pkg):
+    """deme_halo_group_migrate (device kernels + buffer hand-over / RCCL inside the library) against decomp.migrate_neighbours (the
+    numpy statement of the same algorithm): a sheared bed in three slabs, 150 steps, clumps have crossed the cuts.  Both leave the
+    same slabs behind -- own clumps, ghosts, numbering, seeded history (pairs and wildcards) -- and 20 steps later the two sets of
+    slabs are in the SAME state bit for bit (same numbering, same summation order), which is also the state of the old slabs
+    simply continuing to fp32 summation order (1e-9 m)."""
+    b, p, sc, x = _sheared_bed(pkg, 3000, 6)
+    halo = 0.035
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=halo)
+    runs = []
+    for _ in range(3):  # old slabs continuing / numpy migration / library migration: three identical starts
+        ctxs = [_make(pkg, p, pt["scene"]) for pt in parts]
+        g = _group(pkg, ctxs, parts)
+        g.step(150)
+        g.sync()
+        runs.append((ctxs, g))
+    (c0, g0), (c1, g1), (c2, g2) = runs
+    # numpy statement
+    states = [c.download_state() for c in c1]
+    cnts = [c.contacts() for c in c1]
+    Ws = [np.stack([c.wildcard(w) for w in range(4)], 1) for c in c1]
+    partsP, seeds = pkg.decomp.migrate_neighbours_in_process(parts, states, cnts, Ws, parts[0]["all_edges"], halo, _state_x(pkg, p))
+    ctxsP = [_make(pkg, p, pt["scene"]) for pt in partsP]
+    for c, sd in zip(ctxsP, seeds):
+        c.seed_contacts(*sd)
+    gP = _group(pkg, ctxsP, partsP)
+    # library
+    for c, pt in zip(c2, parts):
+        g2.set_slab(c, pt, halo)
+    moved = g2.migrate()
+    assert moved >= 3 and moved == sum(len(np.setdiff1d(a["global_ids"], b_["global_ids"])) for a, b_ in zip(parts, partsP))
+    for c, pt, sd in zip(c2, partsP, seeds):
+        n_own, n_gl, n_gr, n_o, n_s, n_seed = g2.slab_counts(c)
+        assert (n_own, n_gl, n_gr) == (pt["n_own"], len(pt["ghost_left_g"]), len(pt["ghost_right_g"]))
+        og, sg, so, scmp = g2.slab_ids(c)
+        assert np.array_equal(og, np.asarray(pt["owner_global"], np.uint32))
+        assert np.array_equal(sg, np.asarray(pt["sphere_global"], np.uint32))
+        assert np.array_equal(so, np.asarray(pt["arrays"]["ownerClumpBody"], np.uint32))
+        assert np.array_equal(scmp, np.asarray(pt["arrays"]["clumpComponentOffset"], np.uint16))
+        a, bb, t, _ = c.contacts()  # the seeded list
+        key = lambda A, B, T: np.lexsort((B, T, A))
+        ka, ks = key(a, bb, t), key(sd[0], sd[1], sd[2])
+        assert n_seed == len(sd[0]) == len(a)
+        assert np.array_equal(a[ka], sd[0][ks]) and np.array_equal(bb[ka], sd[1][ks]) and np.array_equal(t[ka], sd[2][ks])
+        Wl = np.stack([c.wildcard(w) for w in range(4)], 1)
+        assert np.array_equal(Wl[ka], np.asarray(sd[3], np.float32)[ks])
+    g0.step(20), gP.step(20), g2.step(20)
+    g0.sync(), gP.sync(), g2.sync()
+    for cl, cp in zip(c2, ctxsP):  # library == numpy statement, bit for bit
+        sl, sp = cl.download_state(), cp.download_state()
+        for k in GKEYS:
+            assert np.array_equal(sl[k], sp[k]), k
+    X, V = gather_positions(pkg, partsP, c2, p, sc.nOwnerClumps)
+    X0, V0 = gather_positions(pkg, parts, c0, p, sc.nOwnerClumps)
+    assert np.abs(X - X0).max() < 1e-9 and np.abs(V - V0).max() < 1e-5, (np.abs(X - X0).max(), np.abs(V - V0).max())
+    for g in (g0, g1, gP, g2):
+        g.close()
+
+
 @pytest.fixture(scope="module")
 def packed_million(pkg):
     """configs[1] bed, settled on one GPU context (exact mode): params, scene, builder, state, contact list + history"""
