@@ -238,6 +238,83 @@ def test_library_migration_equals_the_numpy_statement(pkg):
         g.close()
 
 
+def test_drifting_bed_with_repeated_library_migrations_against_single_domain_oracle(pkg, orc):
+    """1e5 clumps with a lateral drift (neighbouring clumps fly at 0.6 and 0.3 m/s in x: the bed shears, hundreds of clumps cross
+    the two cuts) in three slabs on one GPU, deme_halo_group_migrate every 50 steps, 200 steps -- against the ORACLE's
+    single-domain run of the same bed and against the same three slabs simply continuing (valid for these 200 steps: nobody
+    leaves a halo yet).  STATED TOLERANCE: after the last step the union of the slabs' contact lists is the oracle's list; the
+    migrated slabs are within 1e-7 m / 1e-3 m/s of the continuing ones (measured 1.3e-8 m / 2e-4 m/s: the migrations carry every
+    history row, the two differ by local numbering = fp32 summation order, which this colliding bed amplifies; 20 steps after ONE
+    migration the difference is < 1e-9 m and the numpy statement is met bit for bit -- the test above); against the single-domain oracle both sets of slabs sit at the SAME distance --
+    this bed of clumps colliding at 0.3 m/s amplifies a summation-order ulp to ~1e-5 m in 200 steps, slabs or no slabs -- bound
+    1e-4 m, and the two distances must agree to 1e-7 m."""
+    b, p, sc, x = _sheared_bed(pkg, 100_000, 6)
+    nc = int(sc.nOwnerClumps)
+    halo = 0.035
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=halo)
+    ctxs = [_make(pkg, p, pt["scene"]) for pt in parts]
+    grp = _group(pkg, ctxs, parts)
+    for c, pt in zip(ctxs, parts):
+        grp.set_slab(c, pt, halo)
+    still = [_make(pkg, p, pt["scene"]) for pt in parts]  # the same slabs, never migrated
+    gst = _group(pkg, still, parts)
+    gst.step(201)
+    gst.sync()
+    Xs, Vs = gather_positions(pkg, parts, still, p, nc)
+    gst.close()
+    for c in still:
+        c.close()
+    sim = orc.make_sim(pkg, p, sc)
+    orc.set_num_threads(min(32, os.cpu_count() or 1))
+    moved = 0
+    try:
+        for _ in range(4):
+            grp.step(50), sim.step(50)
+            grp.sync()
+            moved += grp.migrate()
+        grp.step(1), sim.step(1)  # (a migration leaves the slabs due for a detection: compare lists of the same state)
+        grp.sync()
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+    assert moved > 100, moved
+    # the slabs' current books from the library
+    pos = np.zeros((nc, 3)), np.zeros((nc, 3))
+    seen = np.zeros(nc, bool)
+    rows = []
+    for c in ctxs:
+        n_own, n_gl, n_gr, n_o, n_s, _ = grp.slab_counts(c)
+        og, sg, so, _ = grp.slab_ids(c)
+        st = c.download_state()
+        X = pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+        gid = og[:n_own].astype(np.int64)
+        assert not seen[gid].any()
+        seen[gid] = True
+        pos[0][gid] = X[:n_own]
+        pos[1][gid] = np.stack([st["vX"], st["vY"], st["vZ"]], 1)[:n_own]
+        a, bb, t, _ = c.contacts()
+        ss = t == 1
+        gA = sg[a].astype(np.int64)
+        gB = np.where(ss, sg[np.where(ss, bb, 0)].astype(np.int64), bb.astype(np.int64))
+        flip = ss & (gA > gB)
+        rows.append(np.stack([np.where(flip, gB, gA), np.where(flip, gA, gB), t.astype(np.int64)], 1))
+    assert seen.all()  # every clump owned exactly once
+    ref = sim.contacts()
+    ref_rows = np.unique(np.stack([ref[0].astype(np.int64), ref[1].astype(np.int64), ref[2].astype(np.int64)], 1), axis=0)
+    got = np.unique(np.concatenate(rows), axis=0)
+    assert got.shape == ref_rows.shape and np.array_equal(got, ref_rows), (got.shape, ref_rows.shape)
+    so = sim.download_state()
+    Xo = pkg.model.decode_positions(so["voxelID"], so["locX"], so["locY"], so["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:nc]
+    Vo = np.stack([so["vX"], so["vY"], so["vZ"]], 1)[:nc]
+    dx, dv = np.abs(pos[0] - Xo).max(), np.abs(pos[1] - Vo).max()
+    dxs, dvs = np.abs(pos[0] - Xs).max(), np.abs(pos[1] - Vs).max()
+    dx0 = np.abs(Xs - Xo).max()
+    print(f"drifting bed, 3 slabs, 4 library migrations ({moved} clumps moved): |dx| {dxs:.3e} m, |dv| {dvs:.3e} m/s vs the slabs continuing; "
+          f"{dx:.3e} m vs the single-domain oracle (the continuing slabs: {dx0:.3e} m)")
+    assert dxs < 1e-7 and dvs < 1e-3
+    assert dx < 1e-4 and abs(dx - dx0) < 1e-7
+    grp.close()
+
+
 @pytest.fixture(scope="module")
 def packed_million(pkg):
     """configs[1] bed, settled on one GPU context (exact mode): params, scene, builder, state, contact list + history"""
