@@ -352,6 +352,25 @@ def self_launch(n_gpus):
     return subprocess.call(cmd)
 
 
+def globalise_part(part, b):
+    """A rank that built only its own slab of the bed (model.packed_bed(slab=...)) numbers clumps and spheres by position in that
+    scene; the library's migration needs ids that mean the same on every rank: the clump's index in the whole bed
+    (b.slab_global_ids), 3 g + k for its spheres (the bench bed: three spheres per clump), replicated owners behind all clumps."""
+    if getattr(b, "slab_global_ids", None) is None:
+        return part
+    q = dict(part)
+    og = np.asarray(part["owner_global"], np.int64)
+    n_cl = int(part["counts"]["nOwnerClumps"])
+    gids = np.asarray(b.slab_global_ids, np.int64)
+    glob = np.concatenate([gids[og[:n_cl]], int(b.slab_total) + np.arange(len(og) - n_cl)])
+    sg = np.asarray(part["sphere_global"], np.int64)
+    scene_owner = np.asarray(b.arrays["ownerClumpBody"], np.int64)[sg]
+    first = np.searchsorted(np.asarray(b.arrays["ownerClumpBody"], np.int64), scene_owner)
+    q["owner_global"] = glob
+    q["sphere_global"] = 3 * gids[scene_owner] + (sg - first)
+    return q
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -395,6 +414,12 @@ def main():
     ap.add_argument("--slabs", type=int, default=1,
                     help="1-GPU harness of the N > 1 path: cut this rank's bed into S x-slabs held by this one process, exchanged "
                          "through RCCL sends to self by the library loop (measures the loop's host cost; not a scaling number)")
+    ap.add_argument("--migrate-every", type=int, default=0, metavar="M",
+                    help="slab runs with the library loop: every M steps the slabs hand over the clumps that crossed a cut "
+                         "(deme_halo_group_migrate: device-side, RCCL between ranks) INSIDE the timed loop; 0 = never")
+    ap.add_argument("--drift", type=float, default=0.0, metavar="VX",
+                    help="give every clump this lateral velocity [m/s] after the pre-settling, so that clumps really cross the cuts "
+                         "(with --migrate-every)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--state-cache", default="",
                     help="profiling aid (1 GPU): file that keeps the pre-settled bed (owner state, contact list, wildcards) so "
@@ -528,6 +553,8 @@ def main():
             try:
                 group = pkg.abi.HaloGroup(rank=rank, world=world, device=local_rank, unique_id=uid[0])
                 group.attach(ctx, part, left=rank - 1 if rank > 0 else None, right=rank + 1 if rank + 1 < world else None)
+                if args.migrate_every:
+                    group.set_slab(ctx, globalise_part(part, b), HALO)
             except Exception as e:  # noqa: BLE001
                 print(f"[bench] rank {rank}: library halo loop unavailable ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
                 ok = 0
@@ -552,8 +579,11 @@ def main():
         group = pkg.abi.HaloGroup(rank=0, world=1, device=local_rank)
         for i, (c_, pt) in enumerate(zip(all_ctx, slab_parts)):
             group.attach(c_, pt, left=all_ctx[i - 1] if i else None, right=all_ctx[i + 1] if i + 1 < len(all_ctx) else None)
+            if args.migrate_every:
+                group.set_slab(c_, pt, HALO)
 
     host_enqueue = {"s": 0.0, "steps": 0}
+    migration = {"calls": 0, "moved": 0, "since": 0, "s": 0.0}
     mesh_state = {"since": 0, "updates": 0, "t": 0.0}
 
     def deform_mesh():
@@ -579,10 +609,21 @@ def main():
                     mesh_state["since"] = 0
             return
         if group is not None:
-            t_ = time.perf_counter()
-            group.step(n)
-            host_enqueue["s"] += time.perf_counter() - t_
-            host_enqueue["steps"] += n
+            left = n
+            while left > 0:
+                k = min(left, args.migrate_every - migration["since"]) if args.migrate_every else left
+                t_ = time.perf_counter()
+                group.step(k)
+                host_enqueue["s"] += time.perf_counter() - t_
+                host_enqueue["steps"] += k
+                left -= k
+                migration["since"] += k
+                if args.migrate_every and migration["since"] >= args.migrate_every:
+                    t_ = time.perf_counter()
+                    migration["moved"] += group.migrate()
+                    migration["s"] += time.perf_counter() - t_
+                    migration["calls"] += 1
+                    migration["since"] = 0
         elif halo is None:
             ctx.step(n)
         else:
@@ -642,7 +683,15 @@ def main():
                 break
         # stepsSinceCD == 1 now; the first timed step detects when it equals K there
         run((K - 1 - args.warmup) % K)
+    if args.drift:
+        for c_ in [ctx] + extra_ctx:
+            st_ = c_.download_state()
+            st_["vX"] = st_["vX"] + np.float32(args.drift)  # (fixed owners are held at rest by the integrator, ghosts are refreshed below)
+            c_.upload_state({k: st_[k] for k in st_ if k not in ("aX", "aY", "aZ", "alphaX", "alphaY", "alphaZ")})
+        if group is not None:
+            group.exchange()
     run(args.warmup)
+    migration.update(calls=0, moved=0, s=0.0)
     adaptive_state = None
     if args.adaptive != "off":  # what the controllers settled on; frozen for the timed region
         adaptive_state = ctx.adaptive_state()
@@ -719,6 +768,8 @@ def main():
         # who moved the ghosts, and how many ranks the communicator that moved them spans (ncclCommCount of the library's own
         # communicator; the world size of torch's for the Python loop): a run whose count differs from --gpus exits non-zero
         "halo_loop": halo_loop, "rccl_ranks": rccl_ranks,
+        "migration": ({"every_steps": args.migrate_every, "calls_in_timed_region": migration["calls"], "clumps_moved": migration["moved"],
+                       "host_seconds": migration["s"], "drift_m_per_s": args.drift} if args.migrate_every else None),
         "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "arith_mode": ctx.arith_mode(), "data": "synthetic",
         "config": {"workload": ("BASELINE configs[4] flavour: polydisperse spheres (8 templates, r..3r) with a run-time compiled "
                                 "cohesion model" if args.config5 else
