@@ -291,7 +291,9 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
 #ifndef DEME_TILE_OCC
 #define DEME_TILE_OCC 1
 #endif
+#ifndef DEME_TILE_DEPTH
 #define DEME_TILE_DEPTH 3  // rounds whose streams are in flight (tInfo + history: 24 bytes per thread and round)
+#endif
 // LDS of one tile, laid out at launch from the list's own extremes (TileArgs::hCap, lCap): occupancy is bound by LDS here, and
 // the compile-time capacities (DEME_TILE_HMAX foreign owners, DEME_TILE_LMAX list entries) are twice what a packed bed needs
 //   own   [(NB + hCap) x 96 B]   staged owners
