@@ -66,7 +66,7 @@ struct deme_ctx {
     DevBuf owners, spheres, acc, comp, massProps, anal, matPair, E, nu, CoR, mu, Crr, famMasks, famExtra, famFlags;
     std::vector<uint8_t> hObjType;  // host copy for contact-type decoding on download
     // detection scratch
-    DevBuf geo, binLo, binN, counts, offsets, incKeys[2], incVals[2], keysRaw, keysMid, keysSorted[2], mapping, wc[2], ctr,
+    DevBuf geo, binLo, binN, counts, offsets, incKeys[2], incVals[2], keysRaw, keysMid, keysSorted[2], mapping, wc[2], ctr, segCtr,
         scanTmp, sortTmp, rec[4], stage;
     // per-contact contributions and the per-owner gather lists (built once per detection)
     DevBuf conA4, conA2, conB4, conB2, aSum, ownerA, ownerB[2], bIdx[2], aStart, bStart, heavy, fixedFlag, heavyList, rangeCtr;
@@ -77,6 +77,7 @@ struct deme_ctx {
     bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
     bool conTile = false;     // the contributions in memory were written by the tile kernel
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
+    size_t keySegMin = (size_t)1 << 20;  // arenas from this many slots on are cut into DEME_KEY_SEGS segments (DEME_KEY_SEG_MIN; 0: never)
     uint32_t tileMaxHalo = 0, tileMaxList = 0;
     // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
     DevBuf persistKeys, binStat;
@@ -417,13 +418,25 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
     if (int rc = status_to_error(c, hc.status))
         return rc;
 
+    if (int rc = ensure(c, c->segCtr, DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE * 8))
+        return rc;
     for (int attempt = 0; attempt < 4; attempt++) {
         HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), st));
+        // the raw key arena: 64 segments with a counter each once it is large enough for every segment to hold a fair share of any
+        // list (see KeyArena); one segment, counted in DetectCounters::nContactsRaw, below that
+        const bool segmented = c->keySegMin && c->cntCap >= c->keySegMin && c->cntCap >= DEME_KEY_SEGS * 64u;
+        KeyArena ar;
+        ar.keys = c->keysRaw.as<uint64_t>();
+        ar.segMask = segmented ? DEME_KEY_SEGS - 1u : 0u;
+        ar.segCap = segmented ? (uint64_t)c->cntCap / DEME_KEY_SEGS : (uint64_t)c->cntCap;
+        ar.ctr = segmented ? c->segCtr.as<unsigned long long>() : &c->ctr.as<DetectCounters>()->nContactsRaw;
+        if (segmented)
+            HIPCK(hipMemsetAsync(c->segCtr.p, 0, DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE * 8, st));
         if (nS) {
             hipLaunchKernelGGL(k_sphere_prep, dim3(grid_for(nS)), dim3(256), 0, st, c->dp,
                                ow, c->spheres.as<SphereRec>(), c->geo.as<GeoRec>(),
                                c->binLo.as<uint4>(), c->binN.as<uint2>(), c->counts.as<uint32_t>(),
-                               c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap, c->ctr.as<DetectCounters>());
+                               ar, c->ctr.as<DetectCounters>());
             size_t tmp = c->scanTmp.bytes;
             HIPCK(rocprim::exclusive_scan(c->scanTmp.p, tmp, c->counts.as<uint32_t>(), c->offsets.as<uint32_t>(), 0u,
                                           (size_t)nS + 1, rocprim::plus<uint32_t>(), st));
@@ -488,8 +501,7 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             static_assert(SW_WPB == 1, "k_sweep writes one statistics record per window");
             hipLaunchKernelGGL(k_sweep, dim3(nWin), dim3(SW_T), 0, st, c->dp,
                                c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
-                               ow, c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
-                               c->ctr.as<DetectCounters>(), c->binStat.as<uint2>());
+                               ow, ar, c->binStat.as<uint2>());
             hipLaunchKernelGGL(k_bin_stats_final, dim3((nWin + 2047u) / 2048u), dim3(256), 0, st, c->binStat.as<uint2>(), nWin,
                                c->ctr.as<DetectCounters>());
         }
@@ -537,16 +549,29 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
                 hipLaunchKernelGGL(k_tri_sweep, dim3(grid_for(TP)), dim3(256), 0, st, c->dp, TP,
                                    c->triKeys[1].as<uint32_t>(), c->triVals[1].as<uint32_t>(), c->triWorld.as<TriWorld>(), P,
                                    c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), c->geo.as<GeoRec>(),
-                                   ow, c->keysRaw.as<uint64_t>(), (uint64_t)c->cntCap,
-                                   c->ctr.as<DetectCounters>());
+                                   ow, ar);
             }
         }
         HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+        unsigned long long hseg[DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE];
+        if (segmented)
+            HIPCK(hipMemcpyAsync(hseg, c->segCtr.p, sizeof(hseg), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
-        if (hc.nContactsRaw > c->cntCap) {  // arena too small: grow and redo the emitting kernels
+        KeySegOffsets so{};
+        unsigned long long segMax = 0;
+        if (segmented) {
+            hc.nContactsRaw = 0;
+            for (uint32_t g = 0; g < DEME_KEY_SEGS; g++) {
+                so.count[g] = hseg[g * DEME_KEY_SEG_STRIDE], so.start[g] = hc.nContactsRaw;
+                hc.nContactsRaw += so.count[g];
+                segMax = std::max(segMax, so.count[g]);
+            }
+        }
+        if (hc.nContactsRaw > c->cntCap || segMax > ar.segCap) {  // arena (or one segment of it) too small: grow and redo the emitting kernels
             if (async)
                 HIPCK(hipStreamSynchronize(c->stream));
-            if (int rc = grow_contact_arena(c, (size_t)hc.nContactsRaw + hc.nContactsRaw / 4 + 1024))
+            const size_t want = std::max<size_t>(hc.nContactsRaw, (size_t)segMax * DEME_KEY_SEGS);
+            if (int rc = grow_contact_arena(c, want + want / 4 + 1024))
                 return rc;
             continue;
         }
@@ -566,10 +591,17 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
                     return rc;
                 continue;
             }
-            HIPCK(hipMemcpyAsync(c->keysRaw.as<uint64_t>() + nC, c->persistKeys.p, nPersist * 8, hipMemcpyDeviceToDevice, st));
             nC += nPersist;
         }
         const int next = c->keysCur ^ 1;
+        uint64_t* rawKeys = c->keysRaw.as<uint64_t>();
+        if (segmented && hc.nContactsRaw) {  // close the gaps between the segments (the next list's buffer is free until the rank sort fills it)
+            hipLaunchKernelGGL(k_compact_keys, dim3((unsigned)grid_for(segMax), DEME_KEY_SEGS), dim3(256), 0, st, c->keysRaw.as<uint64_t>(),
+                               ar.segCap, so, c->keysSorted[next].as<uint64_t>());
+            rawKeys = c->keysSorted[next].as<uint64_t>();
+        }
+        if (nPersist)
+            HIPCK(hipMemcpyAsync(rawKeys + hc.nContactsRaw, c->persistKeys.p, nPersist * 8, hipMemcpyDeviceToDevice, st));
         if (nC) {
             // key = A << 33 | class << 31 | B.  One radix sort over the occupied upper bits [31, 33 + bits(A)) groups the keys by
             // (sphere A, class) -- 3 passes at 3e6 spheres, where a full 64-bit order took 6 to 8 -- and k_segment_rank_sort puts each
@@ -585,11 +617,11 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
                 return rc;
             uint64_t* mid = c->keysMid.as<uint64_t>();
             size_t needHi = 0;
-            HIPCK(rocprim::radix_sort_keys(nullptr, needHi, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 31, 33 + bitsA, st));
+            HIPCK(rocprim::radix_sort_keys(nullptr, needHi, rawKeys, mid, (size_t)nC, 31, 33 + bitsA, st));
             if (int rc = ensure(c, c->sortTmp, needHi))
                 return rc;
             needHi = c->sortTmp.bytes;
-            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, needHi, c->keysRaw.as<uint64_t>(), mid, (size_t)nC, 31, 33 + bitsA, st));
+            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, needHi, rawKeys, mid, (size_t)nC, 31, 33 + bitsA, st));
             hipLaunchKernelGGL(k_segment_rank_sort, dim3(grid_for(nC)), dim3(256), 0, st, (uint32_t)nC, mid,
                                c->keysSorted[next].as<uint64_t>());
             if (nPersist) {  // a marked contact the sweep found as well appears once (markDuplicateContacts)
@@ -1017,6 +1049,8 @@ int deme_ctx_create(int device, deme_ctx** out) {
         c->xcdGroup = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("DEME_TILE"))  // 0: keep the per-contact-block force kernel (A/B measurements)
         c->tileEnable = atoi(e);
+    if (const char* e = getenv("DEME_KEY_SEG_MIN"))  // tests lower it to put small scenes through the segmented arena; 0 = one segment always
+        c->keySegMin = (size_t)std::max(0ll, atoll(e));
     *out = c;
     return DEME_OK;
 }

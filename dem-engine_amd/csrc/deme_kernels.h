@@ -32,6 +32,42 @@ struct DetectCounters {  // one 64-byte block of device counters, zeroed per det
     unsigned int pad[10];
 };
 
+// Where the emitting kernels (k_sphere_prep, k_sweep, k_tri_sweep) append their raw contact keys.  A reservation is an atomic add
+// on a counter, and atomics on ONE address retire at ~12 ns each whoever issues them (tools/probes/atomic_probe.hip: 32 768
+// workgroups with one reservation each take 400 us on one counter, 67 us on 8, 19 us on 64): with one counter the 32 000 windows
+// of k_sweep could not finish in less than 0.4 ms whatever else they did.  So a large arena is cut into DEME_KEY_SEGS equal
+// segments with a counter each (128 bytes apart), a workgroup appends to segment blockIdx & segMask, and k_compact_keys closes the
+// gaps afterwards (the host has read the counters by then: it needs the total anyway).  Small arenas keep one segment.
+#define DEME_KEY_SEGS 64u
+#define DEME_KEY_SEG_STRIDE 16u  // in counters (8 bytes each)
+struct KeyArena {
+    uint64_t* keys;
+    unsigned long long* ctr;  // segment g counts at ctr[g * DEME_KEY_SEG_STRIDE]
+    uint64_t segCap;          // slots per segment
+    uint32_t segMask;         // number of segments - 1 (0: the whole arena is one segment)
+};
+__device__ inline uint32_t arena_seg(const KeyArena& a) {
+    return blockIdx.x & a.segMask;
+}
+__device__ inline unsigned long long arena_reserve(const KeyArena& a, uint32_t seg, unsigned long long n) {
+    return atomicAdd(&a.ctr[seg * DEME_KEY_SEG_STRIDE], n);
+}
+__device__ inline void arena_store(const KeyArena& a, uint32_t seg, unsigned long long slot, uint64_t key) {
+    if (slot < a.segCap)  // (a full segment drops the key; its counter keeps counting and the host grows the arena and repeats)
+        a.keys[(uint64_t)seg * a.segCap + slot] = key;
+}
+struct KeySegOffsets {
+    unsigned long long count[DEME_KEY_SEGS], start[DEME_KEY_SEGS];
+};
+// one thread per slot of the segmented arena: the occupied slots move to their place in the contiguous list
+__global__ __launch_bounds__(256) void k_compact_keys(const uint64_t* __restrict__ in, uint64_t segCap, const KeySegOffsets so,
+                                                      uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t seg = blockIdx.y;
+    if (i < so.count[seg])
+        out[so.start[seg] + i] = in[(uint64_t)seg * segCap + i];
+}
+
 // ---------------------------------------------------------------------------
 // kernel/DEMMiscKernels.cu:37-61 (computeMarginFromAbsv) with the "absv" inspector
 // (DEM/AuxClasses.cpp:54-61) and the max-velocity check of DEM/kT.cpp:136-149.
@@ -75,8 +111,7 @@ struct ObjWorld {
 __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const OwnerRec* __restrict__ owners,
                                                      const SphereRec* __restrict__ spheres, GeoRec* __restrict__ geo,
                                                      uint4* __restrict__ binLo, uint2* __restrict__ binN,
-                                                     uint32_t* __restrict__ counts, uint64_t* __restrict__ outKeys,
-                                                     uint64_t cap, DetectCounters* ctr) {
+                                                     uint32_t* __restrict__ counts, const KeyArena ar, DetectCounters* ctr) {
     __shared__ ObjWorld sObj[64];
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = s < p.nSpheres;
@@ -135,26 +170,40 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
             sObj[threadIdx.x] = w;
         }
         __syncthreads();
-        if (valid) {
+        {
+            // every lane of the wavefront runs the loop (an idle one never hits): the hits of one object are appended with ONE
+            // reservation per wavefront -- the spheres along a wall are neighbours in the list, and same-address atomics serialise
+            // at ~10 ns each (one per sphere-wall contact made this kernel three times as long as its memory traffic)
             const uint32_t nHere = min(64u, p.nAnal - ob0);
+            const uint32_t lane = threadIdx.x & 63u;
             for (uint32_t k = 0; k < nHere; k++) {
                 const ObjWorld w = sObj[k];
+                bool hit = valid;
                 float thres = 0.f;
-                if (!p.familyTrivial) {
+                if (hit && !p.familyTrivial) {
                     if (p.familyMasks[mask_pair(fam, w.family)] != 0)
-                        continue;
+                        hit = false;
                     const float ea = p.familyExtra[fam], eb = p.familyExtra[w.family];
                     thres = (ea < eb) ? ea : eb;
                 }
-                d3 cp;
-                f3 nr;
-                double depth;
-                const uint32_t t = sphere_entity(pos, (float)rBin, w.type, {w.x, w.y, w.z}, mk3(w.dx, w.dy, w.dz),
-                                                 w.size1, w.nsign, w.margin, cp, nr, depth);
-                if (t && depth > (double)thres) {
-                    const unsigned long long slot = atomicAdd(&ctr->nContactsRaw, 1ull);
-                    if (slot < cap)
-                        outKeys[slot] = make_key(DEME_KEY_CLASS_SA, s, ob0 + k);
+                if (hit) {
+                    d3 cp;
+                    f3 nr;
+                    double depth;
+                    const uint32_t t = sphere_entity(pos, (float)rBin, w.type, {w.x, w.y, w.z}, mk3(w.dx, w.dy, w.dz),
+                                                     w.size1, w.nsign, w.margin, cp, nr, depth);
+                    hit = t && depth > (double)thres;
+                }
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    unsigned long long slot0 = 0;
+                    if ((int)lane == leader)
+                        slot0 = arena_reserve(ar, arena_seg(ar), (unsigned long long)__popcll(m));
+                    slot0 = __shfl(slot0, leader);
+                    const unsigned long long slot = slot0 + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                    if (hit)
+                        arena_store(ar, arena_seg(ar), slot, make_key(DEME_KEY_CLASS_SA, s, ob0 + k));
                 }
             }
         }
@@ -219,6 +268,8 @@ struct SweepLDS {
     uint32_t nOut;
     uint32_t start, endIdx, giant;
     uint32_t pop;  // largest bin population this workgroup has seen
+    uint32_t nBins, nextBin;
+    uint16_t binStart[SW_W + 2];  // first entry of the b-th bin of the range; binStart[nBins] = end of the range
 };
 
 // The cheap half of pair_test: different owners and centres closer than the sum of the inflated radii.
@@ -275,8 +326,7 @@ __device__ inline bool pair_test(const DevParams& p, double ax, double ay, doubl
 }
 
 // wave-wide append of `key` for lanes with `hit` (all lanes of the wave must call this together)
-__device__ inline void sweep_emit(SweepLDS& L, bool hit, uint64_t key, uint32_t lane, uint64_t* outKeys, uint64_t cap,
-                                  DetectCounters* ctr) {
+__device__ inline void sweep_emit(SweepLDS& L, bool hit, uint64_t key, uint32_t lane, const KeyArena& ar) {
     const unsigned long long m = __ballot(hit);
     if (!m)
         return;
@@ -290,9 +340,7 @@ __device__ inline void sweep_emit(SweepLDS& L, bool hit, uint64_t key, uint32_t 
         if (pos < SW_OUT) {
             L.out[pos] = key;
         } else {  // LDS buffer full: spill straight to global
-            const unsigned long long slot = atomicAdd(&ctr->nContactsRaw, 1ull);
-            if (slot < cap)
-                outKeys[slot] = key;
+            arena_store(ar, arena_seg(ar), arena_reserve(ar, arena_seg(ar), 1ull), key);
         }
     }
 }
@@ -303,7 +351,7 @@ __device__ inline uint64_t ss_key(uint32_t a, uint32_t b) {
 
 // all lanes of one wavefront: exact test of the first `cnt` queued pairs (entry i | entry q << 16) and emission of the hits
 __device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const GeoRec* __restrict__ geo, const uint32_t* wq, uint32_t cnt,
-                                     uint32_t lane, uint64_t* outKeys, uint64_t cap, DetectCounters* ctr) {
+                                     uint32_t lane, const KeyArena& ar) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of one wavefront complete in order: only the
     __builtin_amdgcn_wave_barrier();                         // compiler has to be kept from reordering
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -322,20 +370,18 @@ __device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const GeoR
         if (hit)
             key = ss_key(L.sph[i], L.sph[q]);
     }
-    sweep_emit(L, hit, key, lane, outKeys, cap, ctr);
+    sweep_emit(L, hit, key, lane, ar);
 }
 
 // block-wide flush of the LDS output buffer (call from uniform control flow)
-__device__ inline void sweep_flush(SweepLDS& L, uint32_t t, uint64_t* outKeys, uint64_t cap, DetectCounters* ctr) {
+__device__ inline void sweep_flush(SweepLDS& L, uint32_t t, const KeyArena& ar) {
     const uint32_t nOut = min(L.nOut, (uint32_t)SW_OUT);
+    const uint32_t seg = arena_seg(ar);
     if (t == 0)
-        L.gBase = nOut ? atomicAdd(&ctr->nContactsRaw, (unsigned long long)nOut) : 0ull;
+        L.gBase = nOut ? arena_reserve(ar, seg, (unsigned long long)nOut) : 0ull;
     __syncthreads();
-    for (uint32_t q = t; q < nOut; q += SW_T) {
-        const unsigned long long slot = L.gBase + q;
-        if (slot < cap)
-            outKeys[slot] = L.out[q];
-    }
+    for (uint32_t q = t; q < nOut; q += SW_T)
+        arena_store(ar, seg, L.gBase + q, L.out[q]);
     __syncthreads();
     if (t == 0)
         L.nOut = 0;
@@ -345,8 +391,7 @@ __device__ inline void sweep_flush(SweepLDS& L, uint32_t t, uint64_t* outKeys, u
 __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_t* __restrict__ keys,
                                                 const uint32_t* __restrict__ sphIds, uint32_t P,
                                                 const GeoRec* __restrict__ geo, const OwnerRec* __restrict__ owners,
-                                                uint64_t* __restrict__ outKeys, uint64_t cap, DetectCounters* ctr,
-                                                uint2* __restrict__ winStats) {
+                                                const KeyArena ar, uint2* __restrict__ winStats) {
     __shared__ SweepLDS L;
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & 63u;
@@ -435,85 +480,95 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                 L.headMask[q >> 6] = hm;
         }
         __syncthreads();
-        // ---- balanced cyclic pairing, entries q = t and q = t + SW_T
+        // ---- list of the range's bins: the b-th head begins bin b
+        for (uint32_t q = t; q < SW_W; q += SW_T) {
+            const unsigned long long hm = L.headMask[q >> 6];
+            if ((hm >> lane) & 1ull) {
+                uint32_t idx = (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                for (uint32_t ch = 0; ch < (q >> 6); ch++)
+                    idx += (uint32_t)__popcll(L.headMask[ch]);
+                L.binStart[idx] = (uint16_t)q;
+            }
+        }
+        if (t == 0) {
+            uint32_t nb = 0;
+            for (uint32_t ch = 0; ch < SW_W / 64; ch++)
+                nb += (uint32_t)__popcll(L.headMask[ch]);
+            L.binStart[nb] = (uint16_t)n_rng;
+            L.nBins = nb;
+            L.nextBin = 0;
+        }
+        __syncthreads();
+        // ---- a wavefront per bin, a lane per PAIR.  The n(n-1)/2 pairs of a bin of n entries are numbered f = (m-1) n + k: entry k
+        // with the entry m places further on (cyclically), m = 1 .. (n-1)/2, and for even n the first n/2 entries once more with
+        // m = n/2 -- every unordered pair exactly once.  Lane l takes f = l, l + 64, ...; k and m advance by 64 mod n and 64 div n.
+        // (The first version gave every ENTRY a lane and ran the wavefront for the trips of its largest bin: with four or five
+        // bins of different sizes per wavefront two thirds of the lane-trips were idle, and the kernel is bound by instruction issue.)
+        // Bins are handed out through an LDS counter: their work goes with n^2.
         uint32_t* wq = L.queue[t >> 6];
         uint32_t qn = 0;  // entries in my wavefront's queue (wave-uniform)
         uint32_t popMine = 0;
-        for (uint32_t q = t; q < SW_W; q += SW_T) {
-            const bool valid = q < n_rng;
-            uint32_t s = 0, n = 1, k = 0;
-            if (valid) {
-                // my bin = [s, e): s the last head at or before q, e the first head after q (or the end of the range)
-                int ch = (int)(q >> 6);
-                unsigned long long mm = L.headMask[ch] & ((2ull << lane) - 1ull);
-                while (!mm)
-                    mm = L.headMask[--ch];  // entry 0 of the range is a head: terminates
-                s = (uint32_t)ch * 64u + (63u - (uint32_t)__clzll((long long)mm));
-                ch = (int)(q >> 6);
-                mm = (lane < 63u) ? (L.headMask[ch] & ~((2ull << lane) - 1ull)) : 0ull;
-                while (!mm && ++ch < (int)(SW_W / 64))
-                    mm = L.headMask[ch];
-                const uint32_t e = mm ? min((uint32_t)ch * 64u + (uint32_t)__ffsll((long long)mm) - 1u, n_rng) : n_rng;
-                n = e - s;
-                k = q - s;
-                popMine = max(popMine, n);
-            }
-            const uint32_t half = valid ? (n - 1) / 2 : 0;
-            const uint32_t trips = half + ((valid && (n & 1u) == 0 && k < n / 2) ? 1u : 0u);
-            float4 mf4 = make_float4(0, 0, 0, 0);
-            uint32_t mo = 0;
-            if (valid)
-                mf4 = L.f[q], mo = L.owner[q];
-            // Two phases (only ~3 % of the pairs of a bin pass the distance test, but with 64 lanes almost every loop
-            // iteration had at least one survivor and paid for the exact test -- sqrt, divisions, contact-point bin): the
-            // loop only runs the distance test and queues the survivors per wavefront; the exact test then runs on full
-            // wavefronts of survivors.
-            // Two partners per trip of the loop, their four LDS reads issued together; the trip count is the wavefront's largest.
-            uint32_t tripsMax = trips;
-            for (int off = 32; off > 0; off >>= 1)
-                tripsMax = max(tripsMax, (uint32_t)__shfl_xor((int)tripsMax, off));
-            const uint32_t qSelf = valid ? q : 0u;  // an idle lane reads its own entry: same owner, never near
-            const uint32_t qTag = q << 16;
-            auto partner = [&](uint32_t m) {
-                const uint32_t qq = k + ((m <= half) ? m : n / 2);
-                return s + min(qq, qq - n);  // qq - n wraps to a huge value when qq < n
-            };
-            auto enqueue = [&](bool near, uint32_t packed) {
-                const unsigned long long nm = __ballot(near);
-                if (nm) {
-                    if (near)
-                        wq[qn + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = packed;
-                    qn += (uint32_t)__popcll(nm);  // wave-uniform
-                    if (qn >= 64u) {
-                        sweep_confirm(p, L, geo, wq, 64u, lane, outKeys, cap, ctr);
-                        const uint32_t rest = qn - 64u;
-                        uint32_t carry = 0;
-                        if (lane < rest)
-                            carry = wq[64u + lane];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane < rest)
-                            wq[lane] = carry;
-                        qn = rest;
-                    }
+        const uint32_t nBinsHere = L.nBins;
+        // Two phases (only ~3 % of the pairs of a bin pass the distance test, but with 64 lanes almost every trip has a survivor):
+        // the loop runs the fp32 distance test and queues the survivors per wavefront; the exact test -- sqrt, divisions,
+        // contact-point bin -- then runs on full wavefronts of survivors.
+        auto enqueue = [&](bool near, uint32_t packed) {
+            const unsigned long long nm = __ballot(near);
+            if (nm) {
+                if (near)
+                    wq[qn + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull))] = packed;
+                qn += (uint32_t)__popcll(nm);  // wave-uniform
+                if (qn >= 64u) {
+                    sweep_confirm(p, L, geo, wq, 64u, lane, ar);
+                    const uint32_t rest = qn - 64u;
+                    uint32_t carry = 0;
+                    if (lane < rest)
+                        carry = wq[64u + lane];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rest)
+                        wq[lane] = carry;
+                    qn = rest;
                 }
-            };
-            for (uint32_t m = 1; m <= tripsMax; m += 2) {
-                const bool act0 = m <= trips, act1 = m + 1 <= trips;
-                const uint32_t i0 = act0 ? partner(m) : qSelf, i1 = act1 ? partner(m + 1) : qSelf;
-                const float4 f0 = L.f[i0], f1 = L.f[i1];
-                const uint32_t o0 = L.owner[i0], o1 = L.owner[i1];
-                // fp32, conservative; the exact fp64 test follows in phase 2
-                enqueue(act0 & pair_near_f(f0, o0, mf4, mo), i0 | qTag);
-                enqueue(act1 & pair_near_f(f1, o1, mf4, mo), i1 | qTag);
+            }
+        };
+        for (;;) {
+            uint32_t b = 0;
+            if (lane == 0)
+                b = atomicAdd(&L.nextBin, 1u);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (b >= nBinsHere)
+                break;
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.binStart[b]);
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.binStart[b + 1]) - s;
+            popMine = max(popMine, n);
+            if (n < 2u)
+                continue;
+            const uint32_t total = n * (n - 1u) / 2u;
+            // lane / n and 64 / n through the reciprocal: (x + 0.5) / n is at least 0.5 / n away from an integer, far outside the
+            // rounding of the product for x <= 64, n < 2 SW_T
+            const float rn = __builtin_amdgcn_rcpf((float)n);  // (1 ulp)
+            uint32_t m = (uint32_t)(((float)lane + 0.5f) * rn);
+            uint32_t k = lane - m * n;
+            m += 1u;
+            const uint32_t c2 = (uint32_t)(64.5f * rn), c1 = 64u - c2 * n;
+            for (uint32_t f = lane, f0 = 0; f0 < total; f0 += 64u, f += 64u) {
+                const bool act = f < total;
+                uint32_t j = k + m;
+                j = min(j, j - n);  // (j - n wraps to a huge value when j < n)
+                const uint32_t ia = s + k, ib = act ? s + j : s + k;  // an idle lane pairs an entry with itself: same owner, never near
+                const float4 fa = L.f[ia], fb = L.f[ib];
+                const uint32_t oa = L.owner[ia], ob = L.owner[ib];
+                enqueue(act & pair_near_f(fa, oa, fb, ob), ia | (ib << 16));  // fp32, conservative; the exact fp64 test follows in phase 2
+                k += c1, m += c2;
+                if (k >= n)
+                    k -= n, m += 1u;
             }
         }
         if (qn) {
-            sweep_confirm(p, L, geo, wq, qn, lane, outKeys, cap, ctr);
+            sweep_confirm(p, L, geo, wq, qn, lane, ar);
             qn = 0;
         }
-        for (int off = 32; off > 0; off >>= 1)
-            popMine = max(popMine, (uint32_t)__shfl_xor((int)popMine, off));
         if (lane == 0 && popMine)
             atomicMax(&L.pop, popMine);
         uint32_t giantPop = 0;
@@ -563,11 +618,11 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                             if (hit)
                                 key = ss_key(L.sph[i], ms);
                         }
-                        sweep_emit(L, hit, key, lane, outKeys, cap, ctr);
+                        sweep_emit(L, hit, key, lane, ar);
                     }
                     __syncthreads();
                     if (L.nOut >= SW_FLUSH)
-                        sweep_flush(L, t, outKeys, cap, ctr);
+                        sweep_flush(L, t, ar);
                 }
             }
         }
@@ -579,10 +634,10 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             winStats[win] = make_uint2(heads, max(L.pop, giantPop));
         }
         if (L.nOut >= SW_FLUSH)  // uniform: read after the barrier
-            sweep_flush(L, t, outKeys, cap, ctr);
+            sweep_flush(L, t, ar);
     }
     __syncthreads();
-    sweep_flush(L, t, outKeys, cap, ctr);
+    sweep_flush(L, t, ar);
 }
 
 // Active-bin count and the largest bin population (numSpheresBinTouches statistics of DEMCubContactDetection.cu:195-230; the

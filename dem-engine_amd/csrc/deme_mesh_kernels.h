@@ -101,18 +101,16 @@ __global__ __launch_bounds__(256) void k_tri_fill(const DevParams p, uint32_t nT
 
 #define TRI_WBUF 256u
 // all lanes of one wavefront: append wbuf[0..n) to the global key list (LDS operations of one wavefront complete in order)
-__device__ inline void tri_flush(const uint64_t* wbuf, uint32_t n, uint32_t lane, uint64_t* __restrict__ outKeys, uint64_t cap,
-                                 DetectCounters* ctr) {
+__device__ inline void tri_flush(const uint64_t* wbuf, uint32_t n, uint32_t lane, const KeyArena& ar) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     unsigned long long base = 0;
     if (lane == 0)
-        base = atomicAdd(&ctr->nContactsRaw, (unsigned long long)n);
+        base = arena_reserve(ar, arena_seg(ar), (unsigned long long)n);
     base = __shfl(base, 0);
     for (uint32_t i = lane; i < n; i += 64u)
-        if (base + i < cap)
-            outKeys[base + i] = wbuf[i];
+        arena_store(ar, arena_seg(ar), base + i, wbuf[i]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
@@ -123,8 +121,7 @@ __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t T
                                                    const uint32_t* __restrict__ triIds, const TriWorld* __restrict__ tw,
                                                    uint32_t P, const uint32_t* __restrict__ sphKeys,
                                                    const uint32_t* __restrict__ sphIds, const GeoRec* __restrict__ geo,
-                                                   const OwnerRec* __restrict__ owners, uint64_t* __restrict__ outKeys,
-                                                   uint64_t cap, DetectCounters* ctr) {
+                                                   const OwnerRec* __restrict__ owners, const KeyArena ar) {
     __shared__ uint64_t wbufAll[4][TRI_WBUF];
     uint64_t* wbuf = wbufAll[threadIdx.x >> 6];
     uint32_t nBuf = 0;
@@ -199,12 +196,12 @@ __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t T
             nBuf += (uint32_t)__popcll(m);  // wave-uniform
         }
         if (nBuf > TRI_WBUF - 64u) {
-            tri_flush(wbuf, nBuf, lane, outKeys, cap, ctr);
+            tri_flush(wbuf, nBuf, lane, ar);
             nBuf = 0;
         }
     }
     if (nBuf)
-        tri_flush(wbuf, nBuf, lane, outKeys, cap, ctr);
+        tri_flush(wbuf, nBuf, lane, ar);
 }
 
 __global__ __launch_bounds__(256) void k_pack_tris(uint32_t nTri, TriRec* tris, const float* n1, const float* n2, const float* n3) {
