@@ -73,7 +73,10 @@ struct deme_ctx {
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
     // owner-tile form of the force pass (deme_tile.h), rebuilt per detection
-    DevBuf tInfo, hList, hCount, tileMode, tileOrg, rIdx, rStart, rFlag, rPos, lPos, lStart, rFlagC, rankC, rec32;
+    DevBuf tInfo, hList, hCount, tileMode, tileOrg, rIdx, rStart, remKey[2], remVal, lPos, lOff, lCount, tileRem, tileBase, rankC, rec32;
+    uint64_t nListed = 0;      // contacts of the list the owner arrays (ownerA, ownerB[0], info ...) were built for
+    int listKeys = 0;
+    bool legacyLists = false;  // the B-sorted list of the round-2 kernels exists for the current contact list (built on demand when the list has tile structures)
     bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
     bool conTile = false;     // the contributions in memory were written by the tile kernel
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
@@ -355,11 +358,11 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
     rc |= ensure(c, c->tInfo, cap * 8);
     rc |= ensure(c, c->rIdx, cap * 4);
     rc |= ensure(c, c->lPos, cap * 2);
-    rc |= ensure(c, c->rFlagC, (cap + 1) * 4);
+    rc |= ensure(c, c->remVal, (cap + 1) * 4);
     rc |= ensure(c, c->rankC, (cap + 1) * 4);
     rc |= ensure(c, c->rec32, cap * 32);
-    rc |= ensure(c, c->rFlag, (cap + 1) * 4);
-    rc |= ensure(c, c->rPos, (cap + 1) * 4);
+    rc |= ensure(c, c->remKey[0], (cap + 1) * 4);
+    rc |= ensure(c, c->remKey[1], (cap + 1) * 4);
     if (c->hasGhosts) {
         rc |= ensure(c, c->cDefer, cap);
         rc |= ensure(c, c->blockMode, (cap / DEME_FORCE_BLOCK + 2) * 4);
@@ -647,6 +650,60 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
     return fail(c, DEME_ERR_OVERFLOW, "contact arena kept overflowing");
 }
 
+// The B-sorted contact list of the round-2 kernels (k_forces_fast / k_calc_forces + the integrator's gather): owner-B sort, run
+// starts, heavy / fixed flags, the deferral flags of the halo overlap.  Enqueued on the main stream; the caller reads rangeCtr.
+int build_legacy_lists(deme_ctx* c) {
+    const uint64_t nC = c->nListed;
+    if (nC) {
+        unsigned obits = 1;
+        while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
+            obits++;
+        size_t need = 0;
+        HIPCK(rocprim::radix_sort_pairs(nullptr, need, c->ownerB[0].as<uint32_t>(), c->ownerB[1].as<uint32_t>(),
+                                        c->bIdx[0].as<uint32_t>(), c->bIdx[1].as<uint32_t>(), (size_t)nC, 0, obits, c->stream));
+        if (int rc = ensure(c, c->sortTmp, need))
+            return rc;
+        need = c->sortTmp.bytes;
+        HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, need, c->ownerB[0].as<uint32_t>(), c->ownerB[1].as<uint32_t>(),
+                                        c->bIdx[0].as<uint32_t>(), c->bIdx[1].as<uint32_t>(), (size_t)nC, 0, obits, c->stream));
+    }
+    if (c->hasGhosts) {  // (the arena may have been sized before the scene's family flags were known)
+        if (ensure(c, c->cDefer, c->cntCap) || ensure(c, c->blockMode, (c->cntCap / DEME_FORCE_BLOCK + 2) * 4))
+            return c->lastStatus;
+        HIPCK(hipMemsetAsync(c->blockMode.p, 0, c->blockMode.bytes, c->stream));
+    }
+    if (nC)
+        hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC, c->ownerB[1].as<uint32_t>(),
+                           c->nOwners, c->bStart.as<uint32_t>());
+    else
+        HIPCK(hipMemsetAsync(c->bStart.p, 0, ((size_t)c->nOwners + 1) * 4, c->stream));
+    // (the counters may hold the tile builders' count of the same owners)
+    HIPCK(hipMemsetAsync(&c->rangeCtr.as<RangeCounters>()->nHeavy, 0, 2 * sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(k_owner_ranges, dim3(grid_for((size_t)c->nOwners + 1)), dim3(256), 0, c->stream, c->dp, (uint32_t)nC,
+                       c->ownerA.as<uint32_t>(), c->ownerB[1].as<uint32_t>(), c->owners.as<OwnerRec>(), c->aStart.as<uint32_t>(),
+                       c->bStart.as<uint32_t>(), c->heavy.as<uint8_t>(), c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(),
+                       (uint32_t)(c->heavyList.bytes / 4), c->rangeCtr.as<RangeCounters>(), c->info.as<uint4>(),
+                       c->hasGhosts ? c->cDefer.as<uint8_t>() : (uint8_t*)nullptr, c->blockMode.as<uint32_t>());
+    c->legacyLists = true;
+    return DEME_OK;
+}
+
+// a list built with tile structures that the round-2 kernels evaluate after all (contact recording switched on, the arithmetic
+// mode changed, DEME_TILE=0 set between detections ...): its B-sorted form is built now
+int ensure_legacy_lists(deme_ctx* c) {
+    if (c->legacyLists || !c->haveList)
+        return DEME_OK;
+    if (int rc = build_legacy_lists(c))
+        return rc;
+    RangeCounters hr{};
+    HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    if (hr.nHeavy > c->heavyList.bytes / 4)
+        return fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", hr.nHeavy);
+    c->nHeavy = hr.nHeavy, c->nHeavyFree = hr.nHeavyFree;
+    return DEME_OK;
+}
+
 int detect_part2(deme_ctx* c, uint64_t nC) {
     const int next = c->keysCur ^ 1;
     {
@@ -658,11 +715,19 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
         }
         // per-owner gather lists for the atomics-free accumulation
         HIPCK(hipMemsetAsync(c->rangeCtr.p, 0, sizeof(RangeCounters), c->stream));
+        const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM &&
+                                  c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535 &&
+                                  tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial) <= DEME_TILE_TABLE_MAX &&
+                                  c->nComp + c->nMat * c->nMat * 2u + c->nAnal * 4u <= DEME_TILE_T && c->nMassProps <= DEME_TILE_T;
+        const uint32_t nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
+        if (tileEligible)
+            HIPCK(hipMemsetAsync(c->tileRem.p, 0, ((size_t)nTiles + 1) * 4, c->stream));
         if (nC) {
             hipLaunchKernelGGL(k_contact_owners, dim3(grid_for(nC)), dim3(256), 0, c->stream, c->dp, (uint32_t)nC,
                                c->keysSorted[next].as<uint64_t>(), c->spheres.as<SphereRec>(), c->ownerA.as<uint32_t>(),
                                c->ownerB[0].as<uint32_t>(), c->bIdx[0].as<uint32_t>(), c->info.as<uint4>(),
-                               c->nTri ? c->smFlag.as<uint8_t>() : (uint8_t*)nullptr);
+                               c->nTri ? c->smFlag.as<uint8_t>() : (uint8_t*)nullptr,
+                               tileEligible ? c->tileRem.as<uint32_t>() : (uint32_t*)nullptr, (uint32_t)DEME_TILE_NB);
             if (c->nTri) {  // work list of the mesh-variant force kernel; its length lands in RangeCounters::nSM
                 unsigned int* cnt = &c->rangeCtr.as<RangeCounters>()->nSM;
                 size_t need2 = 0;
@@ -674,75 +739,67 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                 HIPCK(rocprim::select(c->scanTmp.p, need2, rocprim::counting_iterator<uint32_t>(0), c->smFlag.as<uint8_t>(),
                                       c->smList.as<uint32_t>(), cnt, (size_t)nC, c->stream));
             }
-            unsigned obits = 1;
-            while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
-                obits++;
-            size_t need = 0;
-            HIPCK(rocprim::radix_sort_pairs(nullptr, need, c->ownerB[0].as<uint32_t>(), c->ownerB[1].as<uint32_t>(),
-                                            c->bIdx[0].as<uint32_t>(), c->bIdx[1].as<uint32_t>(), (size_t)nC, 0, obits,
-                                            c->stream));
-            if (int rc = ensure(c, c->sortTmp, need))
-                return rc;
-            need = c->sortTmp.bytes;
-            HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, need, c->ownerB[0].as<uint32_t>(), c->ownerB[1].as<uint32_t>(),
-                                            c->bIdx[0].as<uint32_t>(), c->bIdx[1].as<uint32_t>(), (size_t)nC, 0, obits,
-                                            c->stream));
-        }
-        if (c->hasGhosts) {  // (the arena may have been sized before the scene's family flags were known)
-            if (ensure(c, c->cDefer, c->cntCap) || ensure(c, c->blockMode, (c->cntCap / DEME_FORCE_BLOCK + 2) * 4))
-                return c->lastStatus;
-            HIPCK(hipMemsetAsync(c->blockMode.p, 0, c->blockMode.bytes, c->stream));
-        }
-        if (nC) {
             hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC, c->ownerA.as<uint32_t>(),
                                c->nOwners, c->aStart.as<uint32_t>());
-            hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nC)), dim3(256), 0, c->stream, (uint32_t)nC, c->ownerB[1].as<uint32_t>(),
-                               c->nOwners, c->bStart.as<uint32_t>());
         } else {
             HIPCK(hipMemsetAsync(c->aStart.p, 0, ((size_t)c->nOwners + 1) * 4, c->stream));
-            HIPCK(hipMemsetAsync(c->bStart.p, 0, ((size_t)c->nOwners + 1) * 4, c->stream));
         }
-        hipLaunchKernelGGL(k_owner_ranges, dim3(grid_for((size_t)c->nOwners + 1)), dim3(256), 0, c->stream, c->dp,
-                           (uint32_t)nC, c->ownerA.as<uint32_t>(), c->ownerB[1].as<uint32_t>(), c->owners.as<OwnerRec>(),
-                           c->aStart.as<uint32_t>(), c->bStart.as<uint32_t>(), c->heavy.as<uint8_t>(),
-                           c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(), (uint32_t)(c->heavyList.bytes / 4),
-                           c->rangeCtr.as<RangeCounters>(), c->info.as<uint4>(),
-                           c->hasGhosts ? c->cDefer.as<uint8_t>() : (uint8_t*)nullptr, c->blockMode.as<uint32_t>());
-        const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM &&
-                                  c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535 &&
-                                  tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial) <= DEME_TILE_TABLE_MAX &&
-                                  c->nComp + c->nMat * c->nMat * 2u + c->nAnal * 4u <= DEME_TILE_T && c->nMassProps <= DEME_TILE_T;
-        if (tileEligible) {
-            const uint32_t nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
-            hipLaunchKernelGGL(k_tile_rflag, dim3(grid_for(nC + 1)), dim3(256), 0, c->stream, (uint32_t)nC, c->bIdx[1].as<uint32_t>(),
-                               c->info.as<uint4>(), c->rFlag.as<uint32_t>(), c->rFlagC.as<uint32_t>());
+        c->legacyLists = false;
+        c->nListed = nC, c->listKeys = next;
+        bool tiled = false;
+        RangeCounters hr{};
+        if (tileEligible) {  // owner tiles (deme_tile.h): the builders of the list structures k_tile_forces and the integrator read
             size_t need = 0;
-            HIPCK(rocprim::exclusive_scan(nullptr, need, c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(), 0u, (size_t)nC + 1,
+            HIPCK(rocprim::exclusive_scan(nullptr, need, c->tileRem.as<uint32_t>(), c->tileBase.as<uint32_t>(), 0u, (size_t)nTiles + 1,
                                           rocprim::plus<uint32_t>(), c->stream));
             if (int rc = ensure(c, c->scanTmp, need))
                 return rc;
             need = c->scanTmp.bytes;
-            HIPCK(rocprim::exclusive_scan(c->scanTmp.p, need, c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(), 0u, (size_t)nC + 1,
+            HIPCK(rocprim::exclusive_scan(c->scanTmp.p, need, c->tileRem.as<uint32_t>(), c->tileBase.as<uint32_t>(), 0u, (size_t)nTiles + 1,
                                           rocprim::plus<uint32_t>(), c->stream));
-            need = c->scanTmp.bytes;
-            HIPCK(rocprim::exclusive_scan(c->scanTmp.p, need, c->rFlagC.as<uint32_t>(), c->rankC.as<uint32_t>(), 0u, (size_t)nC + 1,
-                                          rocprim::plus<uint32_t>(), c->stream));
-            hipLaunchKernelGGL(k_tile_rfill, dim3(grid_for(std::max<size_t>(nC, (size_t)c->nOwners + 1))), dim3(256), 0, c->stream,
-                               (uint32_t)nC, c->nOwners, c->bIdx[1].as<uint32_t>(), c->rFlag.as<uint32_t>(), c->rPos.as<uint32_t>(),
-                               c->bStart.as<uint32_t>(), c->aStart.as<uint32_t>(), c->info.as<uint4>(), c->rankC.as<uint32_t>(),
-                               c->rIdx.as<uint32_t>(),
-                               c->rStart.as<uint32_t>(), c->lPos.as<uint16_t>(), c->lStart.as<uint32_t>());
             hipLaunchKernelGGL(k_tile_build, dim3(nTiles), dim3(256), 0, c->stream, c->dp, c->nOwners, c->info.as<uint4>(),
-                               c->aStart.as<uint32_t>(), c->owners.as<OwnerRec>(), c->tInfo.as<uint2>(), c->hList.as<uint32_t>(),
-                               c->hCount.as<uint32_t>(), c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr,
-                               c->lStart.as<uint32_t>(), c->tileOrg.as<int64_t>(), c->rangeCtr.as<RangeCounters>());
-            hipLaunchKernelGGL(k_tile_stats, dim3(1), dim3(256), 0, c->stream, nTiles, c->nOwners, c->hCount.as<uint32_t>(),
-                               c->lStart.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
+                               c->aStart.as<uint32_t>(), c->owners.as<OwnerRec>(), c->tileBase.as<uint32_t>(), c->tInfo.as<uint2>(),
+                               c->hList.as<uint32_t>(), c->hCount.as<uint32_t>(),
+                               c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr, c->lOff.as<uint16_t>(),
+                               c->lPos.as<uint16_t>(), c->lCount.as<uint32_t>(), c->rankC.as<uint32_t>(), c->remKey[0].as<uint32_t>(),
+                               c->remVal.as<uint32_t>(), c->tileOrg.as<int64_t>(), c->rangeCtr.as<RangeCounters>());
+            hipLaunchKernelGGL(k_tile_stats, dim3((nTiles + 1023u) / 1024u), dim3(256), 0, c->stream, nTiles, c->hCount.as<uint32_t>(),
+                               c->lCount.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
+            uint32_t nR = 0;  // crossing contacts = records = entries of the sort below: the one size the host has to know
+            HIPCK(hipMemcpyAsync(&nR, c->tileBase.as<uint32_t>() + nTiles, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipStreamSynchronize(c->stream));
+            if (!hr.tileOverflow) {
+                unsigned obits = 1;
+                while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
+                    obits++;
+                if (nR) {
+                    size_t needS = 0;
+                    HIPCK(rocprim::radix_sort_pairs(nullptr, needS, c->remKey[0].as<uint32_t>(), c->remKey[1].as<uint32_t>(),
+                                                    c->remVal.as<uint32_t>(), c->rIdx.as<uint32_t>(), (size_t)nR, 0, obits, c->stream));
+                    if (int rc = ensure(c, c->sortTmp, needS))
+                        return rc;
+                    needS = c->sortTmp.bytes;
+                    HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, needS, c->remKey[0].as<uint32_t>(), c->remKey[1].as<uint32_t>(),
+                                                    c->remVal.as<uint32_t>(), c->rIdx.as<uint32_t>(), (size_t)nR, 0, obits, c->stream));
+                    hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nR)), dim3(256), 0, c->stream, nR, c->remKey[1].as<uint32_t>(),
+                                       c->nOwners, c->rStart.as<uint32_t>());
+                } else {
+                    HIPCK(hipMemsetAsync(c->rStart.p, 0, ((size_t)c->nOwners + 1) * 4, c->stream));
+                }
+                hipLaunchKernelGGL(k_owner_ranges_tile, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
+                                   c->aStart.as<uint32_t>(), c->lOff.as<uint16_t>(), c->rStart.as<uint32_t>(), c->heavy.as<uint8_t>(),
+                                   c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(), (uint32_t)(c->heavyList.bytes / 4),
+                                   c->rangeCtr.as<RangeCounters>());
+                tiled = true;
+            }
         }
-        RangeCounters hr{};
+        if (!tiled)
+            if (int rc = build_legacy_lists(c))
+                return rc;
         HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
-        c->tileActive = tileEligible && !hr.tileOverflow;
+        c->tileActive = tiled;
         c->tileMaxHalo = hr.tileMaxHalo, c->tileMaxList = hr.tileMaxList;
         if (hr.nHeavy > c->heavyList.bytes / 4)
             return fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", hr.nHeavy);
@@ -867,7 +924,7 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         ta.tInfo = c->tInfo.as<uint2>();
         ta.aStart = a.aStart;
         ta.hList = c->hList.as<uint32_t>(), ta.hCount = c->hCount.as<uint32_t>(), ta.org = c->tileOrg.as<int64_t>();
-        ta.lStart = c->lStart.as<uint32_t>(), ta.lPos = c->lPos.as<uint16_t>();
+        ta.lOff = c->lOff.as<uint16_t>(), ta.lPos = c->lPos.as<uint16_t>();
         ta.wc = a.wc;
         ta.tSum = a.aSum;
         ta.rec32 = c->rec32.as<float4>(), ta.rankC = c->rankC.as<uint32_t>();
@@ -897,6 +954,8 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         return DEME_OK;
     }
     c->conTile = false;
+    if (int rc = ensure_legacy_lists(c))  // (a list with tile structures that is evaluated by the other kernels after all: recording switched on, ...)
+        return rc;
 
     if (c->record) {
         a.recForce = c->rec[0].as<float>(), a.recTorque = c->rec[1].as<float>(), a.recCPA = c->rec[2].as<float>(),
@@ -1084,7 +1143,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->rFlag, &c->rPos, &c->lPos, &c->lStart, &c->rFlagC, &c->rankC, &c->rec32, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1218,7 +1277,8 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     {
         const size_t nTiles = (nO + DEME_TILE_NB - 1) / DEME_TILE_NB + 1;
         if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) || ensure(c, c->tileOrg, nTiles * 24) ||
-            ensure(c, c->rStart, (nO + 1) * 4) || ensure(c, c->lStart, (nO + 1) * 4))
+            ensure(c, c->rStart, (nO + 1) * 4) || ensure(c, c->lOff, nTiles * (DEME_TILE_NB + 1) * 2) || ensure(c, c->lCount, nTiles * 4) ||
+            ensure(c, c->tileRem, (nTiles + 1) * 4) || ensure(c, c->tileBase, (nTiles + 1) * 4))
             return c->lastStatus;
         HIPCK(hipMemsetAsync(c->hCount.p, 0, c->hCount.bytes, c->stream));
         c->tileActive = c->conTile = false;

@@ -1026,8 +1026,32 @@ __global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint3
                                                         const SphereRec* __restrict__ spheres,
                                                         uint32_t* __restrict__ ownerA, uint32_t* __restrict__ ownerB,
                                                         uint32_t* __restrict__ idx, uint4* __restrict__ info,
-                                                        uint8_t* __restrict__ smFlag) {
+                                                        uint8_t* __restrict__ smFlag, uint32_t* __restrict__ tileRem,
+                                                        uint32_t tileNB) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tileRem) {  // per tile of tileNB owners: how many of its contacts (by A) have their B owner in another tile (deme_tile.h)
+        // one atomic per wavefront and tile: the lanes of a wavefront sit in one tile, or in two neighbouring ones
+        uint32_t tA = 0xFFFFFFFFu;
+        bool remote = false;
+        if (c < nC) {
+            const uint64_t k = keys[c];
+            const uint32_t oa = load_sphere(spheres, key_a(k)).owner, cls = key_class(k);
+            const uint32_t ob = (cls == DEME_KEY_CLASS_SS) ? load_sphere(spheres, key_b(k)).owner
+                                : (cls == DEME_KEY_CLASS_SA) ? p.anal[key_b(k)].owner
+                                                             : reinterpret_cast<const uint32_t*>(p.tris)[12 * (size_t)key_b(k) + 9];
+            tA = oa / tileNB;
+            remote = tA != ob / tileNB;
+        }
+        unsigned long long todo = __ballot(remote);
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const uint32_t t0 = (uint32_t)__shfl((int)tA, first);
+            const unsigned long long m = __ballot(remote && tA == t0);
+            if ((int)(threadIdx.x & 63u) == first)
+                atomicAdd(&tileRem[t0], (uint32_t)__popcll(m));
+            todo &= ~m;
+        }
+    }
     if (c >= nC)
         return;
     const uint64_t k = keys[c];

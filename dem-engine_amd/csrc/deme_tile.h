@@ -67,8 +67,9 @@ struct TileArgs {
     // fixed point near the tile serves, and one that does not move between detections is not another load behind the records
     const int64_t* org;
     const uint32_t* tileMode;  // halo overlap: bit p = the tile is evaluated in pass p (1: reads no ghost owner, 2: does); null: no split
-    const uint32_t* lStart;    // nOwners + 1: first entry of each owner's list of contacts that hold it as B with A in the same tile
-    const uint16_t* lPos;      // those contacts as positions in their tile's range of the list, ascending per owner
+    const uint16_t* lOff;      // per tile NB + 1 entries: where each owner's list of contacts that hold it as B with A in the same tile begins
+    const uint16_t* lPos;      // those contacts as positions in their tile's range of the list, ascending per owner; a tile's lists start
+                               // at the index of the tile's first contact (there are never more of them than the tile has contacts)
     float* wc;
     float4* tSum;              // two float4 per owner: the sum of the contributions of contacts evaluated by the owner's tile
     float4* rec32;             // the B-side records of the contacts whose B owner lives in another tile: 32 bytes each, dense, in
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     // under load is longer than a round takes), the run bounds, the local-B lists
     const uint32_t nH = a.hCount[t];
     const uint32_t c0 = a.aStart[o0], c1 = a.aStart[o0 + nLoc];
-    const uint32_t l0 = a.lStart[o0], l1 = a.lStart[o0 + nLoc];
+    const uint16_t* const lOffT = a.lOff + (size_t)t * (DEME_TILE_NB + 1);
+    const uint32_t nL = lOffT[nLoc];
     const int64_t u0x = a.org[3 * (size_t)t], u0y = a.org[3 * (size_t)t + 1], u0z = a.org[3 * (size_t)t + 2];
     const float4* wc4 = reinterpret_cast<const float4*>(a.wc);
     uint2 inf[DEME_TILE_DEPTH];
@@ -389,13 +391,13 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     uint32_t bA = 0, bL = 0;
     if (tid <= DEME_TILE_NB) {
         const uint32_t o = min(tid, nLoc);
-        bA = a.aStart[o0 + o], bL = a.lStart[o0 + o];
+        bA = a.aStart[o0 + o], bL = lOffT[o];
     }
     uint32_t lp[DEME_TILE_LREG];
 #pragma unroll
     for (int k = 0; k < DEME_TILE_LREG; k++) {
         const uint32_t i = tid + k * DEME_TILE_T;
-        lp[k] = (i < l1 - l0) ? (uint32_t)a.lPos[l0 + i] : 0u;
+        lp[k] = (i < nL) ? (uint32_t)a.lPos[c0 + i] : 0u;
     }
     // ---- the foreign owners' records (their ids have arrived by now), the tables into LDS
     OwnerRec rec1;
@@ -416,10 +418,10 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         if (h1 < nH)
             tile_stage_owner(p, T.mass, rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * DEME_TILE_REC);
         if (tid <= DEME_TILE_NB)
-            sALo[tid] = bA - c0, sLLo[tid] = bL - l0;
+            sALo[tid] = bA - c0, sLLo[tid] = bL;
 #pragma unroll
         for (int k = 0; k < DEME_TILE_LREG; k++)
-            if (tid + k * DEME_TILE_T < l1 - l0)
+            if (tid + k * DEME_TILE_T < nL)
                 sLPos[tid + k * DEME_TILE_T] = (uint16_t)lp[k];
     }
     __syncthreads();
@@ -534,75 +536,46 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     }
 }
 
-// ---- per-detection builder ------------------------------------------------------------------------------------------------------
-// flag[j] = 1 iff the j-th entry of the B-sorted contact list crosses a tile boundary (its B owner's sum needs a record);
-// flag[nC] = 0 closes the scan
-// flagC[c]: the same for contact c in list order (scanned into rankC, the crossing contacts' record numbers)
-__global__ __launch_bounds__(256) void k_tile_rflag(uint32_t nC, const uint32_t* __restrict__ bIdx, const uint4* __restrict__ info,
-                                                    uint32_t* __restrict__ flag, uint32_t* __restrict__ flagC) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > nC)
-        return;
-    uint32_t f = 0, fc = 0;
-    if (j < nC) {
-        const uint4 ci = info[bIdx[j]];
-        f = ((ci.x & 0x3FFFFFFFu) / DEME_TILE_NB != ci.y / DEME_TILE_NB) ? 1u : 0u;
-        const uint4 cj = info[j];
-        fc = ((cj.x & 0x3FFFFFFFu) / DEME_TILE_NB != cj.y / DEME_TILE_NB) ? 1u : 0u;
-    }
-    flag[j] = f;
-    flagC[j] = fc;
-}
-// rIdx: the crossing contacts in B-owner order; rStart[o] = first of owner o's (o = 0 .. nOwners).  The others -- B's owner in
-// A's tile -- go to lPos as positions in that tile's range of the list (what the tile's pulling threads walk), lStart likewise;
-// the number of non-crossing entries before j is j - rPos[j], so one scan serves both lists.
-__global__ __launch_bounds__(256) void k_tile_rfill(uint32_t nC, uint32_t nOwners, const uint32_t* __restrict__ bIdx,
-                                                    const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rPos,
-                                                    const uint32_t* __restrict__ bStart, const uint32_t* __restrict__ aStart,
-                                                    const uint4* __restrict__ info, const uint32_t* __restrict__ rankC,
-                                                    uint32_t* __restrict__ rIdx, uint32_t* __restrict__ rStart,
-                                                    uint16_t* __restrict__ lPos, uint32_t* __restrict__ lStart) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < nC) {
-        const uint32_t c = bIdx[j];
-        if (flag[j]) {
-            rIdx[rPos[j]] = rankC[c];  // the record the crossing contact writes (k_tile_forces), not its contact index
-        } else {
-            const uint32_t tile0 = (info[c].y / DEME_TILE_NB) * DEME_TILE_NB;
-            lPos[j - rPos[j]] = (uint16_t)min(c - aStart[tile0], 0xFFFFu);  // (a tile beyond DEME_TILE_CMAX contacts is refused by k_tile_build)
-        }
-    }
-    if (j <= nOwners) {
-        const uint32_t b = bStart[j], r = rPos[b];
-        rStart[j] = r;
-        lStart[j] = b - r;
-    }
-}
-
-// one workgroup per tile: the sorted list of the foreign owners its contacts touch, the 8-byte gather records, the pass of the
-// halo overlap the tile belongs to
+// ---- per-detection builders ----------------------------------------------------------------------------------------------------
+// (1) k_contact_owners counts, per tile, the contacts whose B owner lives in another tile (tileRem; deme_kernels.h); an exclusive
+//     scan gives every tile the number of its first record (tileBase).
+// (2) k_tile_build, one workgroup per tile: the sorted list of the foreign owners the tile's contacts touch, the 8-byte gather
+//     records, the tile's origin, the pass of the halo overlap it belongs to; the per-owner lists of contacts that hold an owner as
+//     B from inside the tile (LDS counting sort, each list put in ascending order afterwards: the summation order is fixed); for
+//     every contact the number of crossing contacts before it (rankC) and for the crossing ones the pair (B owner, record number).
+// (3) a radix sort of those pairs by owner -- 41 % of the contacts of a packed bed; the round-2 pipeline sorted all of them -- gives
+//     the integrator its per-owner lists of records (rIdx, rStart).
 __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t nOwners, const uint4* __restrict__ info,
                                                     const uint32_t* __restrict__ aStart, const OwnerRec* __restrict__ owners,
-                                                    uint2* __restrict__ tInfo, uint32_t* __restrict__ hList,
-                                                    uint32_t* __restrict__ hCount, uint32_t* __restrict__ tileMode,
-                                                    const uint32_t* __restrict__ lStart, int64_t* __restrict__ org, RangeCounters* rc) {
+                                                    const uint32_t* __restrict__ tileBase, uint2* __restrict__ tInfo,
+                                                    uint32_t* __restrict__ hList, uint32_t* __restrict__ hCount,
+                                                    uint32_t* __restrict__ tileMode, uint16_t* __restrict__ lOff,
+                                                    uint16_t* __restrict__ lPos, uint32_t* __restrict__ lCount,
+                                                    uint32_t* __restrict__ rankC, uint32_t* __restrict__ remKey,
+                                                    uint32_t* __restrict__ remVal, int64_t* __restrict__ org, RangeCounters* rc) {
     __shared__ uint32_t table[DEME_TILE_HASH];
     __shared__ uint32_t list[DEME_TILE_HP2];
+    __shared__ uint32_t cnt[DEME_TILE_NB], off[DEME_TILE_NB + 1], wsum[4];
+    __shared__ uint16_t lp[DEME_TILE_LMAX];
     __shared__ uint32_t nU, nL, anyGhost;
-    const uint32_t t = blockIdx.x, tid = threadIdx.x;
+    const uint32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t o0 = t * DEME_TILE_NB, o1 = min(o0 + (uint32_t)DEME_TILE_NB, nOwners);
     const uint32_t c0 = aStart[o0], c1 = aStart[o1];
     for (uint32_t i = tid; i < DEME_TILE_HASH; i += 256)
         table[i] = 0xFFFFFFFFu;
     for (uint32_t i = tid; i < DEME_TILE_HP2; i += 256)
         list[i] = 0xFFFFFFFFu;
+    if (tid < DEME_TILE_NB)
+        cnt[tid] = 0;
     if (tid == 0)
         nU = 0, nL = 0, anyGhost = 0;
     __syncthreads();
     for (uint32_t c = c0 + tid; c < c1; c += 256) {
         const uint32_t ob = info[c].y;
-        if (ob >= o0 && ob < o1)
+        if (ob >= o0 && ob < o1) {
+            atomicAdd(&cnt[ob - o0], 1u);
             continue;
+        }
         uint32_t h = (ob * 2654435761u) >> 22;  // 10 bits
         while (*(volatile uint32_t*)&nU <= DEME_TILE_HMAX) {
             const uint32_t old = atomicCAS(&table[h], 0xFFFFFFFFu, ob);
@@ -616,11 +589,31 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         }
     }
     __syncthreads();
-    const uint32_t n = nU;
-    if (n > DEME_TILE_HMAX || c1 - c0 > DEME_TILE_CMAX || lStart[o1] - lStart[o0] > DEME_TILE_LMAX) {  // the halo does not fit the LDS area of k_tile_forces: this list is evaluated by k_forces_fast
+    // exclusive scan of the owners' local-B counts (two wavefronts of 64)
+    {
+        uint32_t v = (tid < DEME_TILE_NB) ? cnt[tid] : 0u, inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)inc, d);
+            if ((int)lane >= d)
+                inc += u;
+        }
+        if (lane == 63u)
+            wsum[wave] = inc;
+        __syncthreads();
+        if (tid < DEME_TILE_NB) {
+            const uint32_t base = (wave == 1u) ? wsum[0] : 0u;
+            off[tid] = base + inc - v;
+            if (tid == DEME_TILE_NB - 1u)
+                off[DEME_TILE_NB] = base + inc;
+        }
+        __syncthreads();
+    }
+    const uint32_t n = nU, nLoc = off[DEME_TILE_NB];
+    if (n > DEME_TILE_HMAX || c1 - c0 > DEME_TILE_CMAX || nLoc > DEME_TILE_LMAX) {  // the tile does not fit the LDS area of k_tile_forces: this list is evaluated by k_forces_fast
         if (tid == 0) {
             atomicOr(&rc->tileOverflow, 1u);
             hCount[t] = 0;
+            lCount[t] = 0;
         }
         return;
     }
@@ -641,11 +634,14 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
     __syncthreads();
     if (tid < n)
         list[rank] = mine;
+    if (tid < DEME_TILE_NB)
+        cnt[tid] = 0;  // (from here on: entries already placed in an owner's list)
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 256)
         hList[(size_t)t * DEME_TILE_HMAX + i] = list[i];
     if (tid == 0) {
         hCount[t] = n;
+        lCount[t] = nLoc;
         int64_t ux, uy, uz;
         pos_units(load_owner(owners, o0), p, ux, uy, uz);
         org[3 * (size_t)t] = ux, org[3 * (size_t)t + 1] = uy, org[3 * (size_t)t + 2] = uz;
@@ -660,53 +656,126 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         if (tid == 0)
             tileMode[t] = anyGhost ? 2u : 1u;
     }
-    for (uint32_t c = c0 + tid; c < c1; c += 256) {
-        const uint4 ci = info[c];
-        const uint32_t oa = ci.x & 0x3FFFFFFFu, cls = ci.x >> 30, ob = ci.y;
-        uint32_t slotB, rec = 0;
-        if (ob >= o0 && ob < o1) {
-            slotB = ob - o0;
-        } else {
-            uint32_t lo = 0, hi = n;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (list[mid] < ob)
-                    lo = mid + 1;
-                else
-                    hi = mid;
+    // the contacts in list order, 256 at a time: gather records, local-B lists, record numbers of the crossing ones
+    uint32_t run = tileBase[t];
+    for (uint32_t cb = c0; cb < c1; cb += 256) {
+        const uint32_t c = cb + tid;
+        bool remote = false;
+        uint32_t ob = 0;
+        if (c < c1) {
+            const uint4 ci = info[c];
+            const uint32_t oa = ci.x & 0x3FFFFFFFu, cls = ci.x >> 30;
+            ob = ci.y;
+            uint32_t slotB;
+            if (ob >= o0 && ob < o1) {
+                slotB = ob - o0;
+                lp[off[slotB] + atomicAdd(&cnt[slotB], 1u)] = (uint16_t)(c - c0);
+            } else {
+                uint32_t lo = 0, hi = n;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (list[mid] < ob)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                slotB = DEME_TILE_NB + lo;
+                remote = true;
             }
-            slotB = DEME_TILE_NB + lo;
-            rec = 1;
+            const uint32_t matA = ci.z >> 16, compA = ci.z & 0xFFFFu;
+            const uint32_t matB = (cls == DEME_KEY_CLASS_SS) ? (ci.w >> 16) : 0u;  // (an analytical object's material is in its record)
+            const uint32_t wB = (cls == DEME_KEY_CLASS_SS) ? (ci.w & 0xFFFFu) : ci.w;
+            tInfo[c] = make_uint2(tile_info_x(oa - o0, slotB, cls, remote ? 1u : 0u, matA, matB), compA | (wB << 16));
         }
-        const uint32_t matA = ci.z >> 16, compA = ci.z & 0xFFFFu;
-        const uint32_t matB = (cls == DEME_KEY_CLASS_SS) ? (ci.w >> 16) : 0u;  // (an analytical object's material is in its record)
-        const uint32_t wB = (cls == DEME_KEY_CLASS_SS) ? (ci.w & 0xFFFFu) : ci.w;
-        tInfo[c] = make_uint2(tile_info_x(oa - o0, slotB, cls, rec, matA, matB), compA | (wB << 16));
+        const unsigned long long m = __ballot(remote);
+        if (lane == 0)
+            wsum[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 4; w++) {
+            const uint32_t v = wsum[w];
+            before += (w < wave) ? v : 0u;
+            total += v;
+        }
+        const uint32_t r = run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (c < c1) {
+            rankC[c] = r;
+            if (remote)
+                remKey[r] = ob, remVal[r] = r;
+        }
+        run += total;
+        __syncthreads();
+    }
+    // every owner's list in ascending order (a few entries each)
+    if (tid < DEME_TILE_NB) {
+        const uint32_t b = off[tid], e = off[tid + 1];
+        for (uint32_t i = b + 1; i < e; i++) {
+            const uint16_t v = lp[i];
+            uint32_t j = i;
+            while (j > b && lp[j - 1] > v) {
+                lp[j] = lp[j - 1];
+                j--;
+            }
+            lp[j] = v;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nLoc; i += 256)
+        lPos[c0 + i] = lp[i];
+    if (tid <= DEME_TILE_NB)
+        lOff[(size_t)t * (DEME_TILE_NB + 1) + tid] = (uint16_t)off[tid];
+}
+
+// the largest tile's foreign-owner count and local-B list length (they size the LDS of k_tile_forces): a reduction over the
+// per-tile values with one pair of atomics per workgroup -- 8 000 atomicMax on one address from k_tile_build cost 190 us
+// (same-address atomics serialise at ~12 ns)
+__global__ __launch_bounds__(256) void k_tile_stats(uint32_t nTiles, const uint32_t* __restrict__ hCount,
+                                                    const uint32_t* __restrict__ lCount, RangeCounters* rc) {
+    __shared__ uint32_t mh[4], ml[4];
+    uint32_t a = 0, b = 0;
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t t = (blockIdx.x * 4u + k) * 256u + threadIdx.x;
+        if (t < nTiles)
+            a = max(a, hCount[t]), b = max(b, lCount[t]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a = max(a, (uint32_t)__shfl_xor((int)a, o));
+        b = max(b, (uint32_t)__shfl_xor((int)b, o));
+    }
+    if ((threadIdx.x & 63u) == 0)
+        mh[threadIdx.x >> 6] = a, ml[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&rc->tileMaxHalo, max(max(mh[0], mh[1]), max(mh[2], mh[3])));
+        atomicMax(&rc->tileMaxList, max(max(ml[0], ml[1]), max(ml[2], ml[3])));
     }
 }
 
-// the largest tile's foreign-owner count and local-B list length (they size the LDS of k_tile_forces): one workgroup over the
-// per-tile values -- 8 000 atomicMax on one address from k_tile_build cost 190 us (same-address atomics serialise at ~12 ns)
-__global__ __launch_bounds__(256) void k_tile_stats(uint32_t nTiles, uint32_t nOwners, const uint32_t* __restrict__ hCount,
-                                                    const uint32_t* __restrict__ lStart, RangeCounters* rc) {
-    __shared__ uint32_t mh[256], ml[256];
-    uint32_t a = 0, b = 0;
-    for (uint32_t t = threadIdx.x; t < nTiles; t += 256) {
-        const uint32_t o0 = t * DEME_TILE_NB, o1 = min(o0 + (uint32_t)DEME_TILE_NB, nOwners);
-        a = max(a, hCount[t]);
-        b = max(b, lStart[o1] - lStart[o0]);
+// heavy / fixed flags of the owners when the list has tile structures: an owner's B-side entries are its tile-local list plus its
+// records (k_owner_ranges, deme_kernels.h, reads the B-sorted list of the round-2 pipeline instead)
+__global__ __launch_bounds__(256) void k_owner_ranges_tile(const DevParams p, const OwnerRec* __restrict__ owners,
+                                                           const uint32_t* __restrict__ aStart, const uint16_t* __restrict__ lOff,
+                                                           const uint32_t* __restrict__ rStart, uint8_t* __restrict__ heavy,
+                                                           uint8_t* __restrict__ fixedFlag, uint32_t* __restrict__ heavyList,
+                                                           uint32_t heavyCap, RangeCounters* rc) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= p.nOwners)
+        return;
+    const uint32_t t = o / DEME_TILE_NB, k = o - t * DEME_TILE_NB;
+    const uint16_t* lo = lOff + (size_t)t * (DEME_TILE_NB + 1);
+    const uint32_t nA = aStart[o + 1] - aStart[o], nB = (uint32_t)(lo[k + 1] - lo[k]) + (rStart[o + 1] - rStart[o]);
+    const uint32_t fw = owners[o].family;
+    const bool isFixed = (p.familyFlags[fam_of(fw)] & 1u) != 0 || ghost_of(fw);
+    fixedFlag[o] = isFixed ? 1 : 0;
+    const bool hv = nA + nB > DEME_HEAVY_THRESHOLD || shared_of(fw);
+    heavy[o] = hv ? 1 : 0;
+    if (hv) {
+        const unsigned int slot = atomicAdd(&rc->nHeavy, 1u);
+        if (slot < heavyCap)
+            heavyList[slot] = o;
+        if (!isFixed)
+            atomicAdd(&rc->nHeavyFree, 1u);
     }
-    mh[threadIdx.x] = a, ml[threadIdx.x] = b;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            mh[threadIdx.x] = max(mh[threadIdx.x], mh[threadIdx.x + off]);
-            ml[threadIdx.x] = max(ml[threadIdx.x], ml[threadIdx.x + off]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        rc->tileMaxHalo = mh[0], rc->tileMaxList = ml[0];
 }
 
 }  // namespace deme_dev
