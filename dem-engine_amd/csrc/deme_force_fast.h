@@ -68,7 +68,7 @@ __device__ inline T stream_load(const T* p) {
 #if DEME_FAST_NT
     static_assert(sizeof(T) == 16 || sizeof(T) == 8, "16- or 8-byte records");
     T out;
-    if (sizeof(T) == 16) {
+    if constexpr (sizeof(T) == 16) {
         const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p));
         __builtin_memcpy(&out, &v, 16);
     } else {
@@ -83,7 +83,7 @@ __device__ inline T stream_load(const T* p) {
 template <typename T>
 __device__ inline void stream_store(T* p, T v) {
 #if DEME_FAST_NT
-    if (sizeof(T) == 16) {
+    if constexpr (sizeof(T) == 16) {
         nt_u4 w;
         __builtin_memcpy(&w, &v, 16);
         __builtin_nontemporal_store(w, reinterpret_cast<nt_u4*>(p));

@@ -74,6 +74,12 @@ struct deme_ctx {
     DevBuf info;
     // owner-tile form of the force pass (deme_tile.h), rebuilt per detection
     DevBuf tInfo, hList, hCount, tileMode, tileOrg, rIdx, rStart, remKey[2], remVal, lPos, lOff, lCount, tileRem, tileBase, rankC, rec32;
+    // the heavy-owner counts of a tiled list are fetched without stopping the stream: the copy lands in pinned memory, the first
+    // reader (launch_reduce_heavy, one force launch later) waits for its event
+    RangeCounters* hrPinned = nullptr;
+    hipEvent_t hrEvent = nullptr;
+    bool hrPending = false, heavyOverflow = false;
+    bool ctrFresh = false;  // DetectCounters were zeroed by the margins kernel's launch and nothing has counted in them since
     uint64_t nListed = 0;      // contacts of the list the owner arrays (ownerA, ownerB[0], info ...) were built for
     int listKeys = 0;
     bool legacyLists = false;  // the B-sorted list of the round-2 kernels exists for the current contact list (built on demand when the list has tile structures)
@@ -401,6 +407,7 @@ int status_to_error(deme_ctx* c, uint32_t st) {
 
 int do_margins(deme_ctx* c, uint32_t drift) {
     HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->stream));
+    c->ctrFresh = true;
     hipLaunchKernelGGL(k_margins, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
                        drift, c->ctr.as<DetectCounters>());
     return DEME_OK;
@@ -415,16 +422,17 @@ int do_migrate(deme_ctx* c);
 int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t* nCout) {
     const uint32_t nS = c->nSpheres;
     DetectCounters hc{};
-    // margins kernel may have left status bits in ctr: fetch them before zeroing
-    HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-    if (int rc = status_to_error(c, hc.status))
-        return rc;
+    // The margins kernel zeroes the counters and may leave status bits (velocity limit, non-finite state): when it has just run the
+    // block is not zeroed again and its status comes back with the first sizing read-back below (no read-back of its own).
+    const bool countersFresh = c->ctrFresh;
+    c->ctrFresh = false;
+    bool statusSeen = false;
 
     if (int rc = ensure(c, c->segCtr, DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE * 8))
         return rc;
     for (int attempt = 0; attempt < 4; attempt++) {
-        HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), st));
+        if (attempt > 0 || !countersFresh)
+            HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), st));
         // the raw key arena: 64 segments with a counter each once it is large enough for every segment to hold a fair share of any
         // list (see KeyArena); one segment, counted in DetectCounters::nContactsRaw, below that
         const bool segmented = c->keySegMin && c->cntCap >= c->keySegMin && c->cntCap >= DEME_KEY_SEGS * 64u;
@@ -449,6 +457,11 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             HIPCK(hipMemcpyAsync(&P, c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, st));
             HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
             HIPCK(hipStreamSynchronize(st));
+            if (!statusSeen) {
+                statusSeen = true;
+                if (int rc = status_to_error(c, hc.status & ~DEME_ST_INCIDENCE))
+                    return rc;
+            }
             if (hc.status & DEME_ST_INCIDENCE)
                 return fail(c, DEME_ERR_OVERFLOW,
                             "a sphere touches more than %u bins (margin far larger than the bin size): the incidence list cannot be built",
@@ -560,6 +573,11 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
         if (segmented)
             HIPCK(hipMemcpyAsync(hseg, c->segCtr.p, sizeof(hseg), hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
+        if (!statusSeen) {
+            statusSeen = true;
+            if (int rc = status_to_error(c, hc.status & ~DEME_ST_INCIDENCE))
+                return rc;
+        }
         KeySegOffsets so{};
         unsigned long long segMax = 0;
         if (segmented) {
@@ -688,11 +706,13 @@ int build_legacy_lists(deme_ctx* c) {
     return DEME_OK;
 }
 
+void resolve_heavy_counts(deme_ctx* c);
 // a list built with tile structures that the round-2 kernels evaluate after all (contact recording switched on, the arithmetic
 // mode changed, DEME_TILE=0 set between detections ...): its B-sorted form is built now
 int ensure_legacy_lists(deme_ctx* c) {
     if (c->legacyLists || !c->haveList)
         return DEME_OK;
+    resolve_heavy_counts(c);
     if (int rc = build_legacy_lists(c))
         return rc;
     RangeCounters hr{};
@@ -794,17 +814,28 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                 tiled = true;
             }
         }
-        if (!tiled)
+        c->hrPending = c->heavyOverflow = false;
+        if (tiled) {  // (hr holds the tile extremes already; nSA / nSM are not used by the tile path)
+            if (!c->hrPinned) {
+                HIPCK(hipHostMalloc((void**)&c->hrPinned, sizeof(RangeCounters), hipHostMallocDefault));
+                HIPCK(hipEventCreateWithFlags(&c->hrEvent, hipEventDisableTiming));
+            }
+            HIPCK(hipMemcpyAsync(c->hrPinned, c->rangeCtr.p, sizeof(RangeCounters), hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipEventRecord(c->hrEvent, c->stream));
+            c->hrPending = true;
+            c->nHeavy = c->nHeavyFree = 0;
+        } else {
             if (int rc = build_legacy_lists(c))
                 return rc;
-        HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
-        HIPCK(hipStreamSynchronize(c->stream));
+            HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipStreamSynchronize(c->stream));
+            if (hr.nHeavy > c->heavyList.bytes / 4)
+                return fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", hr.nHeavy);
+            c->nHeavy = hr.nHeavy;
+            c->nHeavyFree = hr.nHeavyFree;
+        }
         c->tileActive = tiled;
         c->tileMaxHalo = hr.tileMaxHalo, c->tileMaxList = hr.tileMaxList;
-        if (hr.nHeavy > c->heavyList.bytes / 4)
-            return fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", hr.nHeavy);
-        c->nHeavy = hr.nHeavy;
-        c->nHeavyFree = hr.nHeavyFree;
         c->nSA = hr.nSA;
         c->nSM = hr.nSM;
         c->conValid = false;
@@ -870,7 +901,23 @@ GatherArgs gather_args(deme_ctx* c) {
 }
 
 // heavy owners: skipFixed=true in the stepping loop (a fixed owner's a/alpha are only needed by queries)
+void resolve_heavy_counts(deme_ctx* c) {
+    if (!c->hrPending)
+        return;
+    c->hrPending = false;
+    if (hipEventSynchronize(c->hrEvent) != hipSuccess)
+        return;
+    const size_t cap = c->heavyList.bytes / 4;
+    c->nHeavy = c->hrPinned->nHeavy, c->nHeavyFree = c->hrPinned->nHeavyFree;
+    if (c->nHeavy > cap) {
+        fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", c->nHeavy);
+        c->nHeavy = (uint32_t)cap;
+        c->heavyOverflow = true;  // (the stepping loop returns the error)
+    }
+}
+
 void launch_reduce_heavy(deme_ctx* c, bool skipFixed) {
+    resolve_heavy_counts(c);
     if (c->nHeavy == 0 || (skipFixed && c->nHeavyFree == 0))
         return;
     hipLaunchKernelGGL(k_reduce_heavy, dim3(std::min<uint32_t>(c->nHeavy, 1024)), dim3(256), 0, c->stream, c->dp, gather_args(c),
@@ -924,7 +971,7 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         ta.tInfo = c->tInfo.as<uint2>();
         ta.aStart = a.aStart;
         ta.hList = c->hList.as<uint32_t>(), ta.hCount = c->hCount.as<uint32_t>(), ta.org = c->tileOrg.as<int64_t>();
-        ta.lOff = c->lOff.as<uint16_t>(), ta.lPos = c->lPos.as<uint16_t>();
+        ta.lOff = c->lOff.as<uint16_t>(), ta.lPos = c->lPos.as<uint16_t>(), ta.lCount = c->lCount.as<uint32_t>();
         ta.wc = a.wc;
         ta.tSum = a.aSum;
         ta.rec32 = c->rec32.as<float4>(), ta.rankC = c->rankC.as<uint32_t>();
@@ -1054,6 +1101,8 @@ int launch_integrate(deme_ctx* c, bool fused, bool heavyDone = false) {
     if (fused) {
         if (!heavyDone)
             launch_reduce_heavy(c, true);
+        if (c->heavyOverflow)
+            return c->lastStatus;
         hipLaunchKernelGGL(k_integrate<true>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
                            c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c), pa);
     } else {
@@ -1136,6 +1185,10 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evStepDone);
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
+    }
+    if (c->hrPinned) {
+        hipHostFree(c->hrPinned);
+        hipEventDestroy(c->hrEvent);
     }
     if (c->detStream) {
         hipStreamSynchronize(c->detStream);
@@ -1289,6 +1342,7 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     HIPCK(hipMemsetAsync(c->fixedFlag.p, 0, c->fixedFlag.bytes, c->stream));
     HIPCK(hipMemsetAsync(c->rangeCtr.p, 0, sizeof(RangeCounters), c->stream));
     c->nHeavy = c->nHeavyFree = 0;
+    c->hrPending = false;
     c->conValid = false;
     // spheres
     std::vector<SphereRec> hs(nS);
@@ -1785,6 +1839,7 @@ static int async_detection_cycle(deme_ctx* c) {
         HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->detStream));
         hipLaunchKernelGGL(k_margins, dim3(grid_for(c->nOwners)), dim3(256), 0, c->detStream, c->dp, c->ownersSnap.as<OwnerRec>(),
                            K + D, c->ctr.as<DetectCounters>());
+        c->ctrFresh = true;
         if (int rc = detect_part1(c, c->detStream, c->ownersSnap.as<OwnerRec>(), true, &nC))
             return rc;
     }
@@ -1860,6 +1915,8 @@ static int step_tail_pre(deme_ctx* c) {
     c->tailFused = fused;
     if (fused)
         launch_reduce_heavy(c, true);
+    if (c->heavyOverflow)
+        return c->lastStatus;
     return DEME_OK;
 }
 static int step_tail_post(deme_ctx* c) {

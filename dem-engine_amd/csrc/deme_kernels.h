@@ -1029,19 +1029,35 @@ __global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint3
                                                         uint8_t* __restrict__ smFlag, uint32_t* __restrict__ tileRem,
                                                         uint32_t tileNB) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tileRem) {  // per tile of tileNB owners: how many of its contacts (by A) have their B owner in another tile (deme_tile.h)
-        // one atomic per wavefront and tile: the lanes of a wavefront sit in one tile, or in two neighbouring ones
-        uint32_t tA = 0xFFFFFFFFu;
-        bool remote = false;
-        if (c < nC) {
-            const uint64_t k = keys[c];
-            const uint32_t oa = load_sphere(spheres, key_a(k)).owner, cls = key_class(k);
-            const uint32_t ob = (cls == DEME_KEY_CLASS_SS) ? load_sphere(spheres, key_b(k)).owner
-                                : (cls == DEME_KEY_CLASS_SA) ? p.anal[key_b(k)].owner
-                                                             : reinterpret_cast<const uint32_t*>(p.tris)[12 * (size_t)key_b(k) + 9];
-            tA = oa / tileNB;
+    uint32_t tA = 0xFFFFFFFFu;
+    bool remote = false;
+    if (c < nC) {
+        const uint64_t k = keys[c];
+        const SphereRec sa = load_sphere(spheres, key_a(k));
+        const uint32_t cls = key_class(k);
+        uint32_t ob = 0, w = key_b(k);
+        if (cls == DEME_KEY_CLASS_SS) {
+            const SphereRec sb = load_sphere(spheres, key_b(k));
+            ob = sb.owner;
+            w = (uint32_t)sb.comp | ((uint32_t)sb.mat << 16);
+        } else if (cls == DEME_KEY_CLASS_SA) {
+            ob = p.anal[key_b(k)].owner;
+        } else {  // sphere-mesh: TriRec is 48 bytes with the owner id at byte 36 (deme_mesh.h)
+            ob = reinterpret_cast<const uint32_t*>(p.tris)[12 * (size_t)key_b(k) + 9];
+        }
+        ownerA[c] = sa.owner;
+        ownerB[c] = ob;
+        idx[c] = c;
+        info[c] = make_uint4(sa.owner | (cls << 30), ob, (uint32_t)sa.comp | ((uint32_t)sa.mat << 16), w);
+        if (smFlag)
+            smFlag[c] = (cls == DEME_KEY_CLASS_SM) ? 1 : 0;
+        if (tileRem) {
+            tA = sa.owner / tileNB;
             remote = tA != ob / tileNB;
         }
+    }
+    if (tileRem) {  // per tile of tileNB owners: how many of its contacts (by A) have their B owner in another tile (deme_tile.h)
+        // one atomic per wavefront and tile: the lanes of a wavefront sit in one tile, or in two neighbouring ones
         unsigned long long todo = __ballot(remote);
         while (todo) {
             const int first = __ffsll((long long)todo) - 1;
@@ -1052,27 +1068,6 @@ __global__ __launch_bounds__(256) void k_contact_owners(const DevParams p, uint3
             todo &= ~m;
         }
     }
-    if (c >= nC)
-        return;
-    const uint64_t k = keys[c];
-    const SphereRec sa = load_sphere(spheres, key_a(k));
-    const uint32_t cls = key_class(k);
-    uint32_t ob = 0, w = key_b(k);
-    if (cls == DEME_KEY_CLASS_SS) {
-        const SphereRec sb = load_sphere(spheres, key_b(k));
-        ob = sb.owner;
-        w = (uint32_t)sb.comp | ((uint32_t)sb.mat << 16);
-    } else if (cls == DEME_KEY_CLASS_SA) {
-        ob = p.anal[key_b(k)].owner;
-    } else {  // sphere-mesh: TriRec is 48 bytes with the owner id at byte 36 (deme_mesh.h)
-        ob = reinterpret_cast<const uint32_t*>(p.tris)[12 * (size_t)key_b(k) + 9];
-    }
-    ownerA[c] = sa.owner;
-    ownerB[c] = ob;
-    idx[c] = c;
-    info[c] = make_uint4(sa.owner | (cls << 30), ob, (uint32_t)sa.comp | ((uint32_t)sa.mat << 16), w);
-    if (smFlag)
-        smFlag[c] = (cls == DEME_KEY_CLASS_SM) ? 1 : 0;
 }
 
 // Persistent-contact qualification of every contact of the current list (DEM/APIPrivate.cpp:33-117, done there in a host

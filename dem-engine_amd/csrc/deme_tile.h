@@ -68,6 +68,7 @@ struct TileArgs {
     const int64_t* org;
     const uint32_t* tileMode;  // halo overlap: bit p = the tile is evaluated in pass p (1: reads no ghost owner, 2: does); null: no split
     const uint16_t* lOff;      // per tile NB + 1 entries: where each owner's list of contacts that hold it as B with A in the same tile begins
+    const uint32_t* lCount;    // per tile: entries of all its lists together
     const uint16_t* lPos;      // those contacts as positions in their tile's range of the list, ascending per owner; a tile's lists start
                                // at the index of the tile's first contact (there are never more of them than the tile has contacts)
     float* wc;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const uint32_t nH = a.hCount[t];
     const uint32_t c0 = a.aStart[o0], c1 = a.aStart[o0 + nLoc];
     const uint16_t* const lOffT = a.lOff + (size_t)t * (DEME_TILE_NB + 1);
-    const uint32_t nL = lOffT[nLoc];
+    const uint32_t nL = a.lCount[t];  // (a 32-bit word: a scalar load -- a 16-bit one would be a vector load, whose wait drains the loads issued before it)
     const int64_t u0x = a.org[3 * (size_t)t], u0y = a.org[3 * (size_t)t + 1], u0z = a.org[3 * (size_t)t + 2];
     const float4* wc4 = reinterpret_cast<const float4*>(a.wc);
     uint2 inf[DEME_TILE_DEPTH];
