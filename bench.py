@@ -403,7 +403,7 @@ def main():
                     help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
     ap.add_argument("--async-detection", type=int, default=0, metavar="D",
                     help="start each contact detection D steps before its list is due, on a stream of its own beside the steps "
-                         "(deme_set_async_detection; single-domain runs without a mesh).  0 = lock-step")
+                         "(deme_set_async_detection; slabs of a halo group included).  0 = lock-step")
     ap.add_argument("--adaptive", default="off", choices=["off", "bin", "freq", "both"],
                     help="let the engine tune the bin size / the update frequency on device timers during the pre-settling and "
                          "warm-up (the reference's default mode); frozen before the timed region.  Default: off (fixed K and bin size)")
@@ -574,6 +574,8 @@ def main():
             c2 = pkg.Context(local_rank)
             c2.set_params(p), c2.upload_scene(pt["scene"])
             b.compile_into(c2)
+            if args.async_detection:
+                c2.set_async_detection(args.async_detection)
             extra_ctx.append(c2)
         all_ctx = [ctx] + extra_ctx
         group = pkg.abi.HaloGroup(rank=0, world=1, device=local_rank)

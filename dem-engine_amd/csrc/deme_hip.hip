@@ -123,6 +123,7 @@ struct deme_ctx {
     // asynchronous detection (deme_set_async_detection): part 1 of a detection on its own stream, from a snapshot of the owners,
     // `asyncLead` steps before the list it builds is swapped in
     uint32_t asyncLead = 0;
+    bool snapPending = false;  // (slab group) take the owner snapshot of an asynchronous detection in this step, once the ghosts are in place
     DevBuf ownersSnap;
     hipStream_t detStream = nullptr;
     hipEvent_t evSnap = nullptr, evP1 = nullptr;
@@ -1808,14 +1809,19 @@ static bool async_detection_can_start(deme_ctx* c, uint32_t stepsLeftInCall) {
     const uint32_t K = c->hp.cdUpdateFreq, D = c->asyncLead;
     if (!D || K <= D || stepsLeftInCall < D)
         return false;
-    if (!c->haveList || c->seeded || c->listStale || c->mapFresh || c->hasGhosts || !c->hShared.empty() || c->nTri)
+    // (a mesh, ghosts and marked contacts are fine: part 1 reads the owner snapshot, static scene data and the marked set, and
+    // writes detection scratch only; whatever changes them between detections marks the list stale, and a stale list is rebuilt
+    // in lock-step.  Replicated free owners and the adaptive controllers -- which time a detection on the main stream -- stay
+    // with the lock-step detection.)
+    if (!c->haveList || c->seeded || c->listStale || c->mapFresh || !c->hShared.empty())
         return false;
-    if (c->ad.autoBinSize || c->ad.autoUpdateFreq || !c->hPersist.empty())
+    if (c->ad.autoBinSize || c->ad.autoUpdateFreq)
         return false;
     return c->stepsSinceCD == K - D;
 }
-static int async_detection_cycle(deme_ctx* c) {
-    const uint32_t K = c->hp.cdUpdateFreq, D = c->asyncLead;
+// the three phases of one asynchronous detection: the owner snapshot (on the main stream, between two integrations), part 1 beside
+// the next D steps, the swap
+static int async_snapshot(deme_ctx* c) {
     if (!c->detStream) {
         HIPCK(hipStreamCreateWithFlags(&c->detStream, hipStreamNonBlocking));
         HIPCK(hipEventCreateWithFlags(&c->evSnap, hipEventDisableTiming));
@@ -1823,27 +1829,25 @@ static int async_detection_cycle(deme_ctx* c) {
     }
     if (int rc = ensure(c, c->ownersSnap, (size_t)c->nOwners * sizeof(OwnerRec)))
         return rc;
-    // the copy is ordered on the main stream: after the step just integrated, before the next one
     HIPCK(hipMemcpyAsync(c->ownersSnap.p, c->owners.p, (size_t)c->nOwners * sizeof(OwnerRec), hipMemcpyDeviceToDevice, c->stream));
     HIPCK(hipEventRecord(c->evSnap, c->stream));
-    for (uint32_t d = 0; d < D; d++) {  // D steps with the current list (its margins were sized for them)
-        if (int rc = launch_forces(c))
-            return rc;
-        if (int rc = step_tail(c))
-            return rc;
-    }
+    c->snapPending = false;
+    return DEME_OK;
+}
+static int async_part1(deme_ctx* c, uint64_t* nC) {
+    const uint32_t K = c->hp.cdUpdateFreq, D = c->asyncLead;
     HIPCK(hipStreamWaitEvent(c->detStream, c->evSnap, 0));
-    uint64_t nC = 0;
-    {
-        ScopedTimer tm(c, "detect_async_part1", true, c->detStream);
-        HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->detStream));
-        hipLaunchKernelGGL(k_margins, dim3(grid_for(c->nOwners)), dim3(256), 0, c->detStream, c->dp, c->ownersSnap.as<OwnerRec>(),
-                           K + D, c->ctr.as<DetectCounters>());
-        c->ctrFresh = true;
-        if (int rc = detect_part1(c, c->detStream, c->ownersSnap.as<OwnerRec>(), true, &nC))
-            return rc;
-    }
+    ScopedTimer tm(c, "detect_async_part1", true, c->detStream);
+    HIPCK(hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->detStream));
+    hipLaunchKernelGGL(k_margins, dim3(grid_for(c->nOwners)), dim3(256), 0, c->detStream, c->dp, c->ownersSnap.as<OwnerRec>(),
+                       K + D, c->ctr.as<DetectCounters>());
+    c->ctrFresh = true;
+    if (int rc = detect_part1(c, c->detStream, c->ownersSnap.as<OwnerRec>(), true, nC))
+        return rc;
     HIPCK(hipEventRecord(c->evP1, c->detStream));
+    return DEME_OK;
+}
+static int async_part2(deme_ctx* c, uint64_t nC) {
     HIPCK(hipStreamWaitEvent(c->stream, c->evP1, 0));
     {
         ScopedTimer tm(c, "detect_async_part2", true);
@@ -1856,6 +1860,22 @@ static int async_detection_cycle(deme_ctx* c) {
     c->listStale = false;
     c->nAsyncDetections++;
     return DEME_OK;
+}
+static int async_detection_cycle(deme_ctx* c) {
+    const uint32_t D = c->asyncLead;
+    // the copy is ordered on the main stream: after the step just integrated, before the next one
+    if (int rc = async_snapshot(c))
+        return rc;
+    for (uint32_t d = 0; d < D; d++) {  // D steps with the current list (its margins were sized for them)
+        if (int rc = launch_forces(c))
+            return rc;
+        if (int rc = step_tail(c))
+            return rc;
+    }
+    uint64_t nC = 0;
+    if (int rc = async_part1(c, &nC))
+        return rc;
+    return async_part2(c, nC);
 }
 
 int deme_set_async_detection(deme_ctx* c, uint32_t leadSteps) {
@@ -2011,6 +2031,9 @@ static int overlap_forces(deme_ctx* c) {
     if (int rc = ensure_halo_stream(c))
         return rc;
     HIPCK(hipStreamWaitEvent(c->stream, c->evHaloDone, 0));
+    if (c->snapPending)  // an asynchronous detection starts from this moment: own clumps and ghosts both hold the state of the step just integrated
+        if (int rc = async_snapshot(c))
+            return rc;
     if (c->overlapDetect) {
         c->overlapDetect = false;
         if (detection_due(c))
@@ -2427,7 +2450,7 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
     if (!g || !g->comm)
         return DEME_ERR_INVALID;
     GHIP(hipSetDevice(g->device));
-    for (uint32_t i = 0; i < nsteps; i++) {
+    auto one_step = [&]() -> int {
         const double t0 = now_us();
         for (auto& s : g->slabs)
             if (int rc = deme_step_overlap_begin(s.ctx, nullptr))
@@ -2448,6 +2471,39 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
             return rc;
         }
         g->hostUs[3] += now_us() - t1;
+        return DEME_OK;
+    };
+    for (uint32_t i = 0; i < nsteps; i++) {
+        // asynchronous detection (deme_set_async_detection on the slabs' contexts): every slab decides for itself -- a detection
+        // is local, the exchange of a step does not depend on it.  The slabs whose lists retire D steps from now take their owner
+        // snapshot inside the next step (after its ghosts arrive), the D steps are enqueued -- exchanges included: everything is
+        // stream-ordered --, and while the GPU works through them the host drives part 1 of those slabs on their detection streams.
+        std::vector<deme_ctx*> starters;
+        uint32_t D = 0;
+        if (g->nShared == 0)
+            for (auto& s : g->slabs)
+                if (async_detection_can_start(s.ctx, nsteps - i) && (starters.empty() || s.ctx->asyncLead == D)) {
+                    D = s.ctx->asyncLead;
+                    starters.push_back(s.ctx);
+                }
+        if (!starters.empty()) {
+            for (deme_ctx* c : starters)
+                c->snapPending = true;
+            for (uint32_t d = 0; d < D; d++)
+                if (int rc = one_step())
+                    return rc;
+            std::vector<uint64_t> nC(starters.size(), 0);
+            for (size_t k = 0; k < starters.size(); k++)
+                if (int rc = async_part1(starters[k], &nC[k]))
+                    return gfail(g, rc, "asynchronous detection: %s", starters[k]->err.c_str());
+            for (size_t k = 0; k < starters.size(); k++)
+                if (int rc = async_part2(starters[k], nC[k]))
+                    return gfail(g, rc, "asynchronous detection: %s", starters[k]->err.c_str());
+            i += D - 1;
+            continue;
+        }
+        if (int rc = one_step())
+            return rc;
     }
     return DEME_OK;
 }

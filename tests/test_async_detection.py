@@ -62,3 +62,74 @@ def test_async_detection_falls_back_when_it_cannot_run(pkg):
     for _ in range(40):  # one step per call: never 3 steps left in a call
         a.step(1), c.step(1)
     assert np.array_equal(a.download_state()["locZ"], c.download_state()["locZ"])
+
+
+def test_async_detection_with_a_mesh_in_the_bed(pkg, orc):
+    """a bed falling onto a fixed, wavy mesh plate: part 1 of the asynchronous detection carries the triangle half as well
+    (triangle prep, (bin, triangle) incidences, their sort, the sphere-triangle sweep) -- same statement, same comparison"""
+    from tests.test_mesh import mesh_bed
+    K, D, settle, steps = 20, 6, 1500, 803
+    b = mesh_bed(pkg, 1500, cd_freq=K)
+    b.SetExpandSafetyAdder(1.0)
+    p, sc = b.Initialize()
+    lock, asyn = pkg.Context(0), pkg.Context(0)
+    for c in (lock, asyn):
+        c.set_arith_mode("exact")
+        c.set_params(p), c.upload_scene(sc)
+    one = orc.make_sim(pkg, p, sc)
+    lock.step(settle), asyn.step(settle)
+    asyn.set_async_detection(D)
+    asyn.set_timing(1)
+    lock.step(steps), asyn.step(steps), one.step(settle + steps)
+    assert asyn.kernel_time_ms("detect_async_part1")[1] >= steps // K - 1  # (the asynchronous path really served)
+    s_lock, s_asyn, s_one = lock.download_state(), asyn.download_state(), one.download_state()
+    for k in KEYS:
+        assert np.array_equal(s_asyn[k], s_lock[k]), k
+        assert np.array_equal(s_asyn[k], s_one[k]), k
+    ta = asyn.contacts()[2]
+    assert (ta == 2).sum() > 20, "sphere-triangle contacts in the asynchronous list"  # (DEME_SPHERE_MESH_CONTACT)
+
+
+def test_async_detection_in_a_pair_of_slabs(pkg):
+    """two x-slabs stepped through the library's halo loop (deme_halo_group_step): every slab takes its owner snapshot inside a
+    step, once that step's ghosts are in place, and runs part 1 beside the next D steps -- exchanges included.  Against the same
+    slabs with the lock-step detection: identical states and histories (exact arithmetic), while the lists differ (the
+    asynchronous ones hold more near-pairs)."""
+    from tests.test_decomp import GKEYS, build_global
+    K, D, steps = 20, 6, 407
+    b = pkg.model.packed_bed(3000, seed=6, cd_freq=K, spacing_mult=2.5, init_vz=-0.4, aspect=(2.0, 1.0, 0.5))
+    b.SetExpandSafetyAdder(1.0)
+    p, sc = b.Initialize()
+    x = np.concatenate([bb.xyz for bb in b.batches])[:, 0]
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=0.035)
+
+    def run(lead):
+        ctxs = []
+        for pt in parts:
+            c = pkg.Context(0)
+            c.set_arith_mode("exact")
+            c.set_params(p), c.upload_scene(pt["scene"])
+            c.set_timing(1)
+            if lead:
+                c.set_async_detection(lead)
+            ctxs.append(c)
+        g = pkg.abi.HaloGroup(rank=0, world=1, device=0)
+        for i, (c, pt) in enumerate(zip(ctxs, parts)):
+            g.attach(c, pt, left=ctxs[i - 1] if i > 0 else None, right=ctxs[i + 1] if i + 1 < len(ctxs) else None)
+        g.step(steps)
+        g.sync()
+        return g, ctxs
+
+    g0, lock = run(0)
+    g1, asyn = run(D)
+    for a, c in zip(lock, asyn):
+        assert c.kernel_time_ms("detect_async_part1")[1] >= steps // K - 1 and a.kernel_time_ms("detect_async_part1")[1] == 0
+        sa, sc_ = a.download_state(), c.download_state()
+        for k in GKEYS:
+            assert np.array_equal(sa[k], sc_[k]), k
+        wl = {q: w for q, w in zip(zip(*[x_.tolist() for x_ in a.contacts()[:3]]), a.wildcard(3).tolist())}
+        wa = {q: w for q, w in zip(zip(*[x_.tolist() for x_ in c.contacts()[:3]]), c.wildcard(3).tolist())}
+        common = [q for q in wl if q in wa]
+        assert len(common) > 500 and all(wl[q] == wa[q] for q in common)
+        assert all(wl[q] == 0.0 for q in wl if q not in wa) and all(wa[q] == 0.0 for q in wa if q not in wl)
+    g0.close(), g1.close()
