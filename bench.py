@@ -404,6 +404,9 @@ def main():
     ap.add_argument("--async-detection", type=int, default=0, metavar="D",
                     help="start each contact detection D steps before its list is due, on a stream of its own beside the steps "
                          "(deme_set_async_detection; slabs of a halo group included).  0 = lock-step")
+    ap.add_argument("--cross-contacts", default="both", choices=["both", "once"],
+                    help="contacts that straddle a cut: evaluated by both slabs, each with its own history (default), or by the left "
+                         "slab only, which returns the reaction every step (deme_halo_group_set_cross_contacts)")
     ap.add_argument("--adaptive", default="off", choices=["off", "bin", "freq", "both"],
                     help="let the engine tune the bin size / the update frequency on device timers during the pre-settling and "
                          "warm-up (the reference's default mode); frozen before the timed region.  Default: off (fixed K and bin size)")
@@ -555,6 +558,8 @@ def main():
                 group.attach(ctx, part, left=rank - 1 if rank > 0 else None, right=rank + 1 if rank + 1 < world else None)
                 if args.migrate_every:
                     group.set_slab(ctx, globalise_part(part, b), HALO)
+                if args.cross_contacts == "once":
+                    group.set_cross_contacts(True)
             except Exception as e:  # noqa: BLE001
                 print(f"[bench] rank {rank}: library halo loop unavailable ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
                 ok = 0
@@ -583,6 +588,8 @@ def main():
             group.attach(c_, pt, left=all_ctx[i - 1] if i else None, right=all_ctx[i + 1] if i + 1 < len(all_ctx) else None)
             if args.migrate_every:
                 group.set_slab(c_, pt, HALO)
+        if args.cross_contacts == "once":
+            group.set_cross_contacts(True)
 
     host_enqueue = {"s": 0.0, "steps": 0}
     migration = {"calls": 0, "moved": 0, "since": 0, "s": 0.0}
@@ -784,6 +791,7 @@ def main():
                    "contacts_this_rank": int(c.nContacts), "bin_sphere_touches": int(c.nBinSphereTouches),
                    "triangles": int(sc.nTri), "cd_every": args.cd_freq, "presettle_steps": args.presettle,
                    "clump_numbering": args.order, "bin_multiple": args.bin_multiple, "async_detection_lead": args.async_detection,
+                   "cross_cut_contacts": (args.cross_contacts if group is not None else None),
                    "margin_safety": {"multiplier": float(p.expSafetyMulti), "adder_m_per_s": float(p.expSafetyAdder)},
                    "force_model": ("user fragment via hipRTC: frictionless Hertz + cohesion, 1 wildcard" if args.config5
                                    else "Hertzian (history, 4 wildcards)"), "integrator": "extended Taylor", "h": p.h,

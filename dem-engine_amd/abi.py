@@ -343,6 +343,12 @@ class HaloGroup:
         self._ck(self.lib.deme_halo_group_comm_count(self.h, C.byref(n)), "deme_halo_group_comm_count")
         return int(n.value)
 
+    def set_cross_contacts(self, evaluate_once=True):
+        """one evaluation and one history per contact that straddles a cut: the left slab evaluates, the reaction on the right
+        slab's clump travels back every step (deme_halo_group_set_cross_contacts); call after every slab is attached"""
+        self.lib.deme_halo_group_set_cross_contacts.argtypes = [_P, C.c_int]
+        self._ck(self.lib.deme_halo_group_set_cross_contacts(self.h, int(bool(evaluate_once))), "deme_halo_group_set_cross_contacts")
+
     def host_time(self, reset=False):
         """host microseconds spent enqueuing: (interior passes, packs, RCCL group, unpack + boundary pass + integration)"""
         us = (C.c_double * 4)()

@@ -43,10 +43,14 @@ static_assert(sizeof(OwnerRec) == 64, "OwnerRec must be 64 bytes");
 // a free body every slab keeps a replica of (a mesh or an analytical object that moves under contact forces): each slab sums the
 // contributions of the spheres it owns, the sums are added up across slabs every step, and every replica is integrated alike
 #define OWNER_SHARED_BIT 0x200u
-#define OWNER_FLAG_BITS (OWNER_GHOST_BIT | OWNER_SHARED_BIT)
+// a ghost whose contacts with this slab's own clumps are evaluated by the rank that owns it, which sends the reaction back
+// (one evaluation and one history per cross-cut contact: deme_halo_group_set_cross_contacts)
+#define OWNER_PASSIVE_BIT 0x400u
+#define OWNER_FLAG_BITS (OWNER_GHOST_BIT | OWNER_SHARED_BIT | OWNER_PASSIVE_BIT)
 __host__ __device__ inline uint32_t fam_of(uint32_t familyWord) { return familyWord & 0xFFu; }
 __host__ __device__ inline bool ghost_of(uint32_t familyWord) { return (familyWord & OWNER_GHOST_BIT) != 0; }
 __host__ __device__ inline bool shared_of(uint32_t familyWord) { return (familyWord & OWNER_SHARED_BIT) != 0; }
+__host__ __device__ inline bool passive_of(uint32_t familyWord) { return (familyWord & OWNER_PASSIVE_BIT) != 0; }
 
 struct SphereRec {  // 8 bytes: ownerClumpBody + clumpComponentOffset + sphereMaterialOffset
     uint32_t owner;
@@ -107,7 +111,9 @@ struct DevParams {
     uint32_t nOwners, nSpheres, nAnal, nMat;
     uint32_t errOutBinSphNum;
     uint32_t familyTrivial;  // 1: all masks allow and all extra margins are 0 -> skip family logic
-    uint32_t hasGhosts;      // some owners are ghost copies: the sweep reads the family words to leave ghost-ghost pairs out
+    uint32_t hasGhosts;      // bit 0: some owners are ghost copies (the sweep reads the family words to leave ghost-ghost pairs out);
+                             // bit 1: every cross-cut contact is evaluated by ONE rank (pairs of an own clump with a passive ghost,
+                             // and a ghost sphere's contacts with walls and meshes, are the owning rank's)
     // tables
     const float4* comp;       // per component: relx, rely, relz, radius
     const float4* massProps;  // per mass property: mass, moiX, moiY, moiZ

@@ -123,6 +123,10 @@ struct deme_ctx {
     // asynchronous detection (deme_set_async_detection): part 1 of a detection on its own stream, from a snapshot of the owners,
     // `asyncLead` steps before the list it builds is swapped in
     uint32_t asyncLead = 0;
+    // (slab group) one evaluation per cross-cut contact: where an own clump finds the a / alpha the left neighbour evaluated for it
+    DevBuf revSlot;
+    const void* revAcc = nullptr;
+    bool pairsOnce = false;
     bool snapPending = false;  // (slab group) take the owner snapshot of an asynchronous detection in this step, once the ghosts are in place
     DevBuf ownersSnap;
     hipStream_t detStream = nullptr;
@@ -892,6 +896,8 @@ GatherArgs gather_args(deme_ctx* c) {
     g.conB4 = c->conB4.as<float4>(), g.conB2 = c->conB2.as<float2>();
     g.aSum = c->aSum.as<float4>();
     g.nextAcc = c->nextAccPending ? c->nextAcc.as<AccRec>() : nullptr;
+    if (c->pairsOnce && c->revAcc)
+        g.revSlot = c->revSlot.as<uint32_t>(), g.revAcc = (const float4*)c->revAcc;
     g.world = c->arith == DEME_ARITH_FAST ? 1u : 0u;
     if (c->conTile) {  // the tile kernel's sums and its records of tile-crossing contacts
         g.bStart = c->rStart.as<uint32_t>(), g.bIdx = c->rIdx.as<uint32_t>();
@@ -1197,7 +1203,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1433,7 +1439,7 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         for (size_t i = 0; i < DEME_NUM_FAMILIES && trivial; i++)
             trivial = s->familyExtraMarginSize[i] == 0.f;
     c->dp.familyTrivial = trivial ? 1u : 0u;
-    c->dp.hasGhosts = c->hasGhosts ? 1u : 0u;
+    c->dp.hasGhosts = (c->hasGhosts ? 1u : 0u) | (c->pairsOnce ? 2u : 0u);
     // detection scratch
     if (ensure(c, c->geo, std::max<size_t>(nS, 1) * sizeof(GeoRec)) || ensure(c, c->binLo, std::max<size_t>(nS, 1) * 16) ||
         ensure(c, c->binN, std::max<size_t>(nS, 1) * 8) || ensure(c, c->counts, (nS + 1) * 4) ||
@@ -2123,6 +2129,11 @@ struct HaloSide {
     deme_ctx* peerLocal = nullptr;  // the neighbour's context when this process holds it too
     void *sendIds = nullptr, *recvIds = nullptr, *sendBuf = nullptr, *recvBuf = nullptr;
     uint32_t nSend = 0, nRecv = 0;
+    // one evaluation per cross-cut contact: a / alpha of the sums this slab evaluated for its RIGHT ghosts travel to their owner
+    // (right side: nRecv x 32 bytes out), those the left neighbour evaluated for this slab's clumps come back (left side: nSend x
+    // 32 bytes in) -- the lists of the forward exchange, read the other way round
+    void* revBuf = nullptr;
+    uint32_t revCap = 0;
 };
 struct MigBuf {  // one direction of a migration exchange: clumps, their spheres, history rows (device buffers, counts on the host)
     void *clumps = nullptr, *spheres = nullptr, *rowH = nullptr, *rowW = nullptr, *counts = nullptr;
@@ -2142,6 +2153,7 @@ struct HaloSlab {
     HaloSide side[2];  // 0 left, 1 right
     hipEvent_t evPacked = nullptr;
     hipEvent_t evAcc = nullptr;  // this slab's share of the replicated owners' a / alpha is in its buffer
+    hipEvent_t evRev = nullptr;  // the sums of this slab's right ghosts are packed
 };
 }  // namespace
 
@@ -2151,6 +2163,9 @@ struct deme_halo_group {
     int rank = 0, world = 1, device = 0;
     hipStream_t xstream = nullptr;  // the exchange runs here: after every slab's pack, before every slab's unpack
     hipEvent_t evExchanged = nullptr;
+    hipEvent_t evRevDone = nullptr;
+    bool pairsOnce = false;  // deme_halo_group_set_cross_contacts: one evaluation per cross-cut contact, reactions sent back
+    uint64_t nRevExchanges = 0;
     std::vector<HaloSlab> slabs;
     uint32_t nShared = 0;            // replicated free owners (the same on every slab): a / alpha summed across slabs every step
     void* sharedSum = nullptr;       // nShared x AccRec
@@ -2237,7 +2252,14 @@ void deme_halo_group_destroy(deme_halo_group* g) {
             hipEventDestroy(s.evPacked);
         if (s.evAcc)
             hipEventDestroy(s.evAcc);
+        if (s.evRev)
+            hipEventDestroy(s.evRev);
+        for (auto& sd : s.side)
+            if (sd.revBuf)
+                hipFree(sd.revBuf);
     }
+    if (g->evRevDone)
+        hipEventDestroy(g->evRevDone);
     if (g->sharedSum)
         hipFree(g->sharedSum);
     if (g->evReduced)
@@ -2406,6 +2428,121 @@ static int halo_exchange(deme_halo_group* g) {
     return DEME_OK;
 }
 
+// ---- one evaluation per cross-cut contact ----------------------------------------------------------------------------------------
+// By default a contact between an own clump and a ghost is evaluated on both ranks (each keeps a history copy, the force on the
+// ghost is dropped).  With deme_halo_group_set_cross_contacts(g, 1) the LEFT slab of a cut evaluates it -- the right slab marks its
+// left ghosts passive (OWNER_PASSIVE_BIT) and the sweep leaves their pairs with own clumps out, along with every ghost sphere's
+// wall and mesh contacts -- and after its ghost-dependent force pass it sends a / alpha of each right ghost's contact sum to the
+// ghost's owner, which adds them to the clump's own before integrating ("reverse exchange of the ghost's force").
+static int rev_setup_slab(deme_halo_group* g, HaloSlab& s) {
+    deme_ctx* c = s.ctx;
+    c->pairsOnce = g->pairsOnce;
+    c->dp.hasGhosts = (c->hasGhosts ? 1u : 0u) | (c->pairsOnce ? 2u : 0u);
+    c->revAcc = nullptr;
+    HaloSide &l = s.side[0], &r = s.side[1];
+    if (l.peerRank >= 0 && l.nRecv)  // my left ghosts: passive or not
+        hipLaunchKernelGGL(k_owner_set_bits, dim3(grid_for(l.nRecv)), dim3(256), 0, c->stream, l.nRecv, (const uint32_t*)l.recvIds,
+                           c->owners.as<OwnerRec>(), (uint32_t)OWNER_PASSIVE_BIT, g->pairsOnce ? (uint32_t)OWNER_PASSIVE_BIT : 0u);
+    c->listStale = true;  // the rule changes what belongs on the list
+    if (!g->pairsOnce)
+        return DEME_OK;
+    if (!s.evRev)
+        GHIP(hipEventCreateWithFlags(&s.evRev, hipEventDisableTiming));
+    if (!g->evRevDone)
+        GHIP(hipEventCreateWithFlags(&g->evRevDone, hipEventDisableTiming));
+    const uint32_t want[2] = {l.peerRank >= 0 ? l.nSend : 0u, r.peerRank >= 0 ? r.nRecv : 0u};
+    for (int k = 0; k < 2; k++) {
+        HaloSide& sd = s.side[k];
+        if (want[k] > sd.revCap) {
+            if (sd.revBuf)
+                GHIP(hipFree(sd.revBuf));
+            sd.revCap = want[k] + want[k] / 4 + 64;
+            GHIP(hipMalloc(&sd.revBuf, (size_t)sd.revCap * 32));
+        }
+    }
+    if (ensure(c, c->revSlot, std::max<size_t>(c->nOwners, 1) * 4))
+        return gfail(g, c->lastStatus, "cross contacts: %s", c->err.c_str());
+    GHIP(hipMemsetAsync(c->revSlot.p, 0xFF, std::max<size_t>(c->nOwners, 1) * 4, c->stream));
+    if (want[0]) {
+        hipLaunchKernelGGL(k_rev_slots, dim3(grid_for(l.nSend)), dim3(256), 0, c->stream, l.nSend, (const uint32_t*)l.sendIds,
+                           c->revSlot.as<uint32_t>());
+        GHIP(hipMemsetAsync(l.revBuf, 0, (size_t)l.nSend * 32, c->stream));  // (nothing has been received yet)
+        c->revAcc = l.revBuf;
+    }
+    return DEME_OK;
+}
+
+int deme_halo_group_set_cross_contacts(deme_halo_group* g, int evaluateOnce) {
+    if (!g || !g->comm)
+        return DEME_ERR_INVALID;
+    GHIP(hipSetDevice(g->device));
+    if (evaluateOnce && g->nShared)
+        return gfail(g, DEME_ERR_INVALID, "cross contacts: replicated free owners are summed over both evaluations of a cross-cut contact; not combined with the single evaluation yet");
+    g->pairsOnce = evaluateOnce != 0;
+    for (auto& s : g->slabs) {
+        if (int rc = rev_setup_slab(g, s))
+            return rc;
+        GHIP(hipStreamSynchronize(s.ctx->stream));
+    }
+    return DEME_OK;
+}
+
+// after every slab's ghost-dependent force pass: pack the right ghosts' sums, one RCCL group (each cut: left slab -> right slab),
+// the integrations wait for what they receive
+static int reverse_exchange(deme_halo_group* g) {
+    auto find = [&](deme_ctx* c) -> HaloSlab* {
+        for (auto& s : g->slabs)
+            if (s.ctx == c)
+                return &s;
+        return nullptr;
+    };
+    for (auto& s : g->slabs) {
+        deme_ctx* c = s.ctx;
+        HaloSide& r = s.side[1];
+        if (r.peerRank >= 0 && r.nRecv)
+            hipLaunchKernelGGL(k_ghost_acc_pack, dim3(grid_for(r.nRecv)), dim3(256), 0, c->stream, c->dp, r.nRecv, (const uint32_t*)r.recvIds,
+                               gather_args(c), c->owners.as<OwnerRec>(), (float4*)r.revBuf);
+        GHIP(hipEventRecord(s.evRev, c->stream));
+        GHIP(hipStreamWaitEvent(g->xstream, s.evRev, 0));
+    }
+    for (auto& s : g->slabs) {  // (checks before the group opens)
+        HaloSide& r = s.side[1];
+        if (r.peerRank >= 0 && r.peerLocal && !find(r.peerLocal))
+            return gfail(g, DEME_ERR_INVALID, "a local neighbour context is not attached to the group");
+    }
+    GNCCL(g->api->GroupStart());
+#define GNCCL_IN_GROUP(call)                                                                                                     \
+    do {                                                                                                                         \
+        int _r = (call);                                                                                                         \
+        if (_r != 0) {                                                                                                           \
+            g->api->GroupEnd();                                                                                                  \
+            return gfail(g, DEME_ERR_HIP, "%s failed: %s (%s:%d)", #call, g->api->GetErrorString(_r), __FILE__, __LINE__);        \
+        }                                                                                                                        \
+    } while (0)
+    for (auto& s : g->slabs) {
+        HaloSide& r = s.side[1];
+        if (r.peerRank >= 0 && r.nRecv) {
+            if (r.peerLocal) {  // to self: the send right before the receive it feeds
+                HaloSide& l = find(r.peerLocal)->side[0];
+                GNCCL_IN_GROUP(g->api->Send(r.revBuf, (size_t)r.nRecv * 32, kNcclUint8, g->rank, g->comm, g->xstream));
+                GNCCL_IN_GROUP(g->api->Recv(l.revBuf, (size_t)l.nSend * 32, kNcclUint8, g->rank, g->comm, g->xstream));
+            } else {
+                GNCCL_IN_GROUP(g->api->Send(r.revBuf, (size_t)r.nRecv * 32, kNcclUint8, r.peerRank, g->comm, g->xstream));
+            }
+        }
+        HaloSide& l = s.side[0];
+        if (l.peerRank >= 0 && !l.peerLocal && l.nSend)
+            GNCCL_IN_GROUP(g->api->Recv(l.revBuf, (size_t)l.nSend * 32, kNcclUint8, l.peerRank, g->comm, g->xstream));
+    }
+#undef GNCCL_IN_GROUP
+    GNCCL(g->api->GroupEnd());
+    GHIP(hipEventRecord(g->evRevDone, g->xstream));
+    for (auto& s : g->slabs)
+        GHIP(hipStreamWaitEvent(s.ctx->stream, g->evRevDone, 0));
+    g->nRevExchanges++;
+    return DEME_OK;
+}
+
 // Second half of a step when the scene has replicated free owners (a mesh or an analytical body that moves under contact forces,
 // kept on every slab): every slab finishes its force passes and reduces its own spheres' contributions to those owners; the
 // per-slab sums are added up -- first across the slabs of this process, in slab order, then across the ranks with one all-reduce --
@@ -2459,7 +2596,16 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
         if (int rc = halo_exchange(g))
             return rc;
         const double t1 = now_us();
-        if (g->nShared == 0) {
+        if (g->pairsOnce) {
+            for (auto& s : g->slabs)
+                if (int rc = overlap_forces(s.ctx))
+                    return gfail(g, rc, "step (boundary forces): %s", s.ctx->err.c_str());
+            if (int rc = reverse_exchange(g))
+                return rc;
+            for (auto& s : g->slabs)
+                if (int rc = step_tail(s.ctx))
+                    return gfail(g, rc, "step (integration): %s", s.ctx->err.c_str());
+        } else if (g->nShared == 0) {
             for (auto& s : g->slabs) {
                 s.ctx->inGroupStep = true;
                 const int rc = deme_step_overlap_end(s.ctx);

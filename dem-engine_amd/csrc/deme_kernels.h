@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
     d3 pos{0, 0, 0};
     double rBin = 0;
     uint32_t fam = 0, myCount = 0;
+    bool ghostOnce = false;
     if (valid) {
         const SphereRec sr = load_sphere(spheres, s);
         const OwnerRec o = load_owner(owners, sr.owner);
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
         float rSweep = c.w;
         rSweep += o.margin;  // fp32 sum, DEMContactKernels_SphereSphere.cu:40
         fam = fam_of(o.family);
+        ghostOnce = ghost_of(o.family) && (p.hasGhosts & 2u);  // (its own rank lists a ghost sphere's wall contacts)
         GeoRec g;
         g.x = pos.x, g.y = pos.y, g.z = pos.z, g.r = rSweep, g.owner = sr.owner;
         geo[s] = g;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
             const uint32_t lane = threadIdx.x & 63u;
             for (uint32_t k = 0; k < nHere; k++) {
                 const ObjWorld w = sObj[k];
-                bool hit = valid;
+                bool hit = valid && !ghostOnce;
                 float thres = 0.f;
                 if (hit && !p.familyTrivial) {
                     if (p.familyMasks[mask_pair(fam, w.family)] != 0)
@@ -310,6 +312,8 @@ __device__ inline bool pair_test(const DevParams& p, double ax, double ay, doubl
     float am = 0.f;
     if (ghost_of(af) && ghost_of(bf))
         return false;  // both are copies of clumps other ranks own: the pair is theirs
+    if ((passive_of(af) && !ghost_of(bf)) || (passive_of(bf) && !ghost_of(af)))
+        return false;  // an own clump against a passive ghost: the ghost's rank evaluates the pair and sends the reaction
     if (!p.familyTrivial) {
         af = fam_of(af), bf = fam_of(bf);
         if (p.familyMasks[mask_pair(af, bf)] != 0)
@@ -809,6 +813,10 @@ struct GatherArgs {
     // (A and B sides); bStart / bIdx list only the contacts whose B owner lives in another tile than A's, with records in conB
     uint32_t tile;
     const float4* rec32;     // tile form: the crossing contacts' B-side records, 32 bytes each, dense; bIdx holds record numbers
+    // one evaluation per cross-cut contact (deme_halo_group_set_cross_contacts): the neighbour that evaluated an own clump's
+    // contacts with ITS clumps sends a / alpha of their sum; revSlot[o] = the clump's place in that message, 0xFFFFFFFF = none
+    const uint32_t* revSlot;
+    const float4* revAcc;    // two float4 per place
 };
 
 // one B-side record for the per-owner gather: by contact index from the two per-contact arrays, or (tile form) by record number
@@ -1288,6 +1296,14 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
 __device__ inline void integrate_owner(const DevParams& p, OwnerRec& r, float4 a, float4 al, uint32_t o, uint32_t fflags, bool fixed,
                                        const GatherArgs& g, const PrescArgs& pa) {
 
+    if (g.revSlot) {  // the share of the contacts a neighbouring rank evaluated for this clump
+        const uint32_t slot = g.revSlot[o];
+        if (slot != 0xFFFFFFFFu) {
+            const float4 ea = g.revAcc[2 * (size_t)slot], el = g.revAcc[2 * (size_t)slot + 1];
+            a.x += ea.x, a.y += ea.y, a.z += ea.z;
+            al.x += el.x, al.y += el.y, al.z += el.z;
+        }
+    }
     if (g.nextAcc) {  // DEMTracker::AddAcc / AddAngAcc: on top of the contact sums (added last: the sums keep their order)
         const float4* ep = reinterpret_cast<const float4*>(g.nextAcc + o);
         const float4 ea = ep[0], el = ep[1];
@@ -1589,6 +1605,32 @@ __global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const uint32_t* i
     g.qw = r.qw, g.qx = r.qx, g.qy = r.qy, g.qz = r.qz;
     g.vx = r.vx, g.vy = r.vy, g.vz = r.vz, g.wx = r.wx, g.wy = r.wy, g.wz = r.wz;
     buf[i] = g;
+}
+// One evaluation per cross-cut contact: the evaluating rank turns each ghost's contact sum into the a / alpha its owner rank adds
+// to the clump's own before integrating (the ghost's record carries what the conversion needs: orientation, mass properties)
+__global__ __launch_bounds__(256) void k_ghost_acc_pack(const DevParams p, uint32_t n, const uint32_t* __restrict__ ids,
+                                                        const GatherArgs g, const OwnerRec* __restrict__ owners,
+                                                        float4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t o = ids[i];
+    float4 a, al;
+    gather_owner(g, o, a, al);
+    if (g.world)
+        acc_from_world(p, load_owner(owners, o), a, al);
+    out[2 * (size_t)i] = a, out[2 * (size_t)i + 1] = al;
+}
+__global__ __launch_bounds__(256) void k_owner_set_bits(uint32_t n, const uint32_t* __restrict__ ids, OwnerRec* owners, uint32_t clear,
+                                                        uint32_t set) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        owners[ids[i]].family = (owners[ids[i]].family & ~clear) | set;
+}
+__global__ __launch_bounds__(256) void k_rev_slots(uint32_t n, const uint32_t* __restrict__ ids, uint32_t* __restrict__ slot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        slot[ids[i]] = i;
 }
 __global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n, const uint32_t* ids, OwnerRec* owners, const GhostRec* buf) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -166,6 +166,8 @@ __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t T
             const GeoRec g = geo[sp];
             bool ok = g.owner != w.owner;
             float am = 0.f;
+            if (ok && (p.hasGhosts & 2u))
+                ok = !ghost_of(owners[g.owner].family);  // (its own rank lists a ghost sphere's mesh contacts)
             if (ok && !p.familyTrivial) {
                 const uint32_t fS = fam_of(owners[g.owner].family);
                 ok = p.familyMasks[mask_pair(fS, w.family)] == 0;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_mig_pack_clumps(uint32_t nClumps, const
     const uint32_t fs = firstSph[o], ns = firstSph[o + 1] - fs;
     MigClump m;
     m.rec = owners[o];
-    m.rec.family &= ~OWNER_GHOST_BIT;
+    m.rec.family &= ~(OWNER_GHOST_BIT | OWNER_PASSIVE_BIT);
     m.gid = ownerGid[o];
     m.nsph = ns;
     outC[pos[o].c[d]] = m;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_mig_unpack(uint32_t n, const MigClump* 
     if (i >= n)
         return;
     MigClump m = inC[i];
-    m.rec.family = (m.rec.family & ~OWNER_GHOST_BIT) | ghostBit;
+    m.rec.family = (m.rec.family & ~(OWNER_GHOST_BIT | OWNER_PASSIVE_BIT)) | ghostBit;
     owners[ownerBase + i] = m.rec;
     ownerGid[ownerBase + i] = m.gid;
     const uint32_t s0 = sphOff[i];

@@ -467,6 +467,15 @@ int deme_halo_group_download_ids(deme_halo_group* g, deme_ctx* ctx, uint32_t* ow
 /* how many ranks the group's RCCL communicator spans, as RCCL itself reports it (ncclCommCount): a scaling run checks this
  * against the number of processes it believes it launched */
 int deme_halo_group_comm_count(const deme_halo_group* g, int* ranks);
+/* One evaluation -- and one contact history -- per contact that straddles a cut (the reference's rule that a pair
+ * belongs to exactly one bin, DEMContactKernels_SphereSphere.cu:212, carried over to ranks).  0 (default): both ranks evaluate a
+ * contact between an own clump and a ghost, each keeps its history copy, the force on the ghost is dropped.  1: the LEFT slab of a
+ * cut evaluates it; the right slab leaves the pair (and its ghosts' wall / mesh contacts) off its list, and after the
+ * ghost-dependent force pass of every step the left slab sends a / alpha of each right ghost's contact sum to the ghost's owner
+ * (32 bytes per ghost, ncclSend / ncclRecv in one group, the forward exchange's lists read backwards), which adds them before
+ * integrating.  Call after every slab is attached; the contact lists are rebuilt at the next step.  Not combined with replicated
+ * free owners (DemeScene.ownerGhost = 2). */
+int deme_halo_group_set_cross_contacts(deme_halo_group* g, int evaluateOnce);
 
 #ifdef __cplusplus
 }

@@ -315,6 +315,43 @@ def test_drifting_bed_with_repeated_library_migrations_against_single_domain_ora
     grp.close()
 
 
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_cross_cut_contacts_evaluated_once(pkg, mode):
+    """deme_halo_group_set_cross_contacts on three slabs of a settling bed (detection every 7 steps), against the same slabs in
+    the default mode (both sides evaluate, each with its own history): the union of the lists is the same set, but now no pair
+    is on two lists and the lists together are exactly as long as the set; the clumps land where the default mode puts them
+    within 2e-7 m / 2e-4 m/s after 120 steps (the reaction a neighbour returns is added to a clump's own sum in another order than
+    the slab's own evaluation would add it); the exchange ran every step in both directions."""
+    b, p, sc, x = build_global(pkg, n=3000, seed=6, cd_freq=7)
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=0.035)
+    nc = int(sc.nOwnerClumps)
+    res = []
+    for once in (False, True):
+        ctxs = [_make(pkg, p, pt["scene"], mode) for pt in parts]
+        g = _group(pkg, ctxs, parts)
+        if once:
+            g.set_cross_contacts(True)
+        g.step(120)
+        g.sync()
+        rows_all = np.concatenate([_global_pairs(pt, c) for pt, c in zip(parts, ctxs)])
+        X, V = gather_positions(pkg, parts, ctxs, p, nc)
+        res.append((rows_all, X, V))
+        g.close()
+        for c in ctxs:
+            c.close()
+    (r0, X0, V0), (r1, X1, V1) = res
+    u0, u1 = np.unique(r0, axis=0), np.unique(r1, axis=0)
+    assert len(r0) > len(u0) + 100, "the default mode lists every straddling pair twice"
+    assert len(r1) == len(u1), "a pair on two lists"
+    # the two runs are 120 steps apart from a common start: their lists agree up to the handful of near-pairs whose margins the
+    # trajectories' last bits decide
+    common = len(set(map(tuple, u0.tolist())) & set(map(tuple, u1.tolist())))
+    assert common >= 0.995 * max(len(u0), len(u1)), (common, len(u0), len(u1))
+    dx, dv = np.abs(X1 - X0).max(), np.abs(V1 - V0).max()
+    print(f"one evaluation per cross-cut contact, {mode}: {len(r0) - len(u0)} straddling pairs, |dx| {dx:.3e} m, |dv| {dv:.3e} m/s vs both-sides evaluation")
+    assert dx <= 2e-7 and dv <= 2e-4, (dx, dv)
+
+
 @pytest.fixture(scope="module")
 def packed_million(pkg):
     """configs[1] bed, settled on one GPU context (exact mode): params, scene, builder, state, contact list + history"""
@@ -341,8 +378,8 @@ def _global_pairs(part, ctx):
     return np.stack([lo, hi, t.astype(np.int64)], 1)
 
 
-@pytest.mark.parametrize("n_slabs,mode", [(2, "exact"), (8, "exact"), (8, "fast")])
-def test_million_clumps_in_slabs_against_single_domain_oracle(pkg, orc, packed_million, n_slabs, mode):
+@pytest.mark.parametrize("n_slabs,mode,once", [(2, "exact", False), (8, "exact", False), (8, "fast", False), (2, "exact", True), (8, "fast", True)])
+def test_million_clumps_in_slabs_against_single_domain_oracle(pkg, orc, packed_million, n_slabs, mode, once):
     """STATED TOLERANCE: contact sets identical (every pair of the single-domain oracle list is found by the slab that owns
     either clump, and nothing else is); after 100 steps (h = 5e-6 s, detection every 40 with the bench's margins) positions
     within 5e-9 m and velocities within 5e-6 m/s of the oracle's single-domain run.  The slabs number their clumps locally, so
@@ -350,7 +387,10 @@ def test_million_clumps_in_slabs_against_single_domain_oracle(pkg, orc, packed_m
     sensitivity -- not an error of the exchange (the small test above is bit-identical to the ordered exchange).
     The `fast` leg is the library's default arithmetic (what bench.py --gpus N times: owner-tile force pass, split into the
     interior / ghost-dependent passes of the halo overlap): same contact sets, the fast mode's own bounds of
-    tests/test_fast_mode.py (5e-8 m, 2e-4 m/s after 100 steps)."""
+    tests/test_fast_mode.py (5e-8 m, 2e-4 m/s after 100 steps).
+    The `once` legs: deme_halo_group_set_cross_contacts -- every contact that straddles a cut is evaluated by ONE slab (the left
+    one), which returns the reaction every step: the slabs' lists put together ARE the single-domain list, row for row, no pair
+    twice; same bounds."""
     b, p, sc, st, cnt, W = packed_million
     nc = int(sc.nOwnerClumps)
     g_arrays = dict(b.arrays)
@@ -370,6 +410,8 @@ def test_million_clumps_in_slabs_against_single_domain_oracle(pkg, orc, packed_m
     for c, sd in zip(ctxs, seeds):
         c.seed_contacts(*sd)
     grp = _group(pkg, ctxs, parts)
+    if once:
+        grp.set_cross_contacts(True)
     sim = orc.make_sim(pkg, p, sc)
     sim.upload_state({k: st[k] for k in GKEYS})
     sim.seed_contacts(cnt[0], cnt[1], cnt[2], W)
@@ -379,7 +421,10 @@ def test_million_clumps_in_slabs_against_single_domain_oracle(pkg, orc, packed_m
         grp.sync()
         ref = sim.contacts()
         ref_rows = np.stack([ref[0].astype(np.int64), ref[1].astype(np.int64), ref[2].astype(np.int64)], 1)
-        rows = np.unique(np.concatenate([_global_pairs(pt, c) for pt, c in zip(parts, ctxs)]), axis=0)
+        rows_all = np.concatenate([_global_pairs(pt, c) for pt, c in zip(parts, ctxs)])
+        rows = np.unique(rows_all, axis=0)
+        if once:  # no pair on two lists (and no ghost-wall pair on the list of a slab that does not own the clump)
+            assert len(rows_all) == len(ref_rows) == len(rows), (len(rows_all), len(ref_rows), len(rows))
         # a slab also lists ghost-wall pairs of its ghosts?  No: a ghost's sphere-analytical contacts belong to its owner rank, but
         # the slab evaluates them too (forces on ghosts are discarded) -- as a set the union is still the single-domain list
         ref_sorted = np.unique(ref_rows, axis=0)
