@@ -610,3 +610,50 @@ def test_neighbour_migration_oracle(pkg, orc):
     # the history travelled: with it the two runs agree to fp32 summation order (different local numbering); without it a
     # migrated clump's tangential springs would restart from zero (1e-6 m after 20 steps in the all-gather twin of this test)
     assert np.abs(X - X0).max() < 1e-9 and np.abs(V - V0).max() < 1e-5
+
+
+def test_migration_carries_the_current_state_of_moving_replicated_owners(pkg, orc):
+    """a bed over a plate that rises with a prescribed velocity, in two slabs: after 100 steps the slabs are re-assembled by the
+    neighbour migration and by the all-gather re-decomposition -- the plate (a replicated owner, the same on every slab) must keep
+    the pose and the velocity it HAS, not the ones of the first decomposition (it used to jump back), and the run must carry on
+    like the slabs that simply continue"""
+    b, p, sc, x = _bed_on_moving_plate(pkg, n=900)
+    halo = 0.035
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 2, halo=halo)
+    edges = parts[0]["all_edges"]
+
+    def mk(pp, s):
+        sim = orc.make_sim(pkg, pp, s)
+        _plate_prescription(sim)
+        return sim
+
+    sims = run_slabs(pkg, mk, parts, p, 100, host_exchange(pkg, parts))
+    nW = int(p.nContactWildcards)
+    states = [s.download_state() for s in sims]
+    cnts = [s.contacts() for s in sims]
+    Ws = [np.stack([s.wildcard(w) for w in range(nW)], 1) for s in sims]
+    parts2, seeds = pkg.decomp.migrate_neighbours_in_process(parts, states, cnts, Ws, edges, halo, _state_x(pkg, p))
+    plate_old = int(parts[0]["counts"]["nOwners"]) - 1   # replicated owners sit behind the clumps: the plate is the last one
+    z_now = pkg.model.decode_positions(states[0]["voxelID"], states[0]["locX"], states[0]["locY"], states[0]["locZ"], p.nvXp2, p.nvYp2,
+                                       p.voxelSize, p.l)[plate_old, 2]
+    z_start = pkg.model.decode_positions(parts[0]["arrays"]["voxelID"], parts[0]["arrays"]["locX"], parts[0]["arrays"]["locY"],
+                                         parts[0]["arrays"]["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[plate_old, 2]
+    assert z_now - z_start > 1e-4  # 100 steps at 0.3 m/s
+    for pt in parts2:
+        a = pt["arrays"]
+        plate = int(pt["counts"]["nOwners"]) - 1
+        z_new = pkg.model.decode_positions(a["voxelID"], a["locX"], a["locY"], a["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[plate, 2]
+        assert abs(z_new - z_now) < 1e-12 and a["vZ"][plate] == states[0]["vZ"][plate_old] != 0.0
+    sims2 = []
+    for pt, sd in zip(parts2, seeds):
+        s = mk(p, pt["scene"])
+        s.seed_contacts(*sd)
+        sims2.append(s)
+    ex, ex2 = host_exchange(pkg, parts), host_exchange(pkg, parts2)
+    for _ in range(20):
+        ex(sims), ex2(sims2)
+        for s in sims + sims2:
+            s.step(1)
+    X, V = gather_positions(pkg, parts2, sims2, p, sc.nOwnerClumps)
+    X0, V0 = gather_positions(pkg, parts, sims, p, sc.nOwnerClumps)
+    assert np.abs(X - X0).max() < 1e-8 and np.abs(V - V0).max() < 1e-4
