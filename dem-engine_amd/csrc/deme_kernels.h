@@ -906,7 +906,7 @@ __device__ inline void gather_owner(const GatherArgs& g, uint32_t o, float4& a, 
 // lane walks a chain of dependent global loads any more.  `want` is false for lanes that do not need a sum
 // (beyond the end, fixed, ghost, heavy); all lanes of the workgroup must call.
 #ifndef DEME_GATHER_TILE
-#define DEME_GATHER_TILE 1024
+#define DEME_GATHER_TILE 768  // 18 KB: with the 20 KB of the record transposes the integrator keeps 8 workgroups per CU (1024: 6; -4 %)
 #endif
 struct GatherLds {
     float4 c4[DEME_GATHER_TILE];
@@ -1246,8 +1246,8 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = o < p.nOwners;
     // one LDS area: the record transposes at both ends of the kernel, the gather tiles of the fused path in between
-    __shared__ uint4 smem[FUSED ? sizeof(GatherLds) / 16 : 4 * DEME_INT_STAGE];
-    static_assert(sizeof(GatherLds) / 16 >= 4 * DEME_INT_STAGE, "the gather tile area also holds the four record stages");
+    constexpr uint32_t kStage16 = DEME_INT_COOP ? 4u * DEME_INT_STAGE : 1u, kGather16 = FUSED ? (uint32_t)(sizeof(GatherLds) / 16) : 1u;
+    __shared__ uint4 smem[kStage16 > kGather16 ? kStage16 : kGather16];
 #if DEME_INT_COOP
     uint4* stage = smem + (threadIdx.x >> 6) * DEME_INT_STAGE;
     const uint32_t waveBase = o - (threadIdx.x & 63u);
