@@ -127,6 +127,10 @@ struct deme_ctx {
     DevBuf revSlot;
     const void* revAcc = nullptr;
     bool pairsOnce = false;
+    hipEvent_t evPass1 = nullptr;
+    int pass1Beside = 0;       // DEME_PASS1_BESIDE=1: the ghost-dependent force pass on the halo stream, beside the tail of the interior
+                               // pass (off: on the one-GPU harness -- two slabs competing for one GPU -- it costs 5 %; not measured with
+                               // one slab per GPU, where the interior pass leaves the GPU to a few per cent of the tiles)
     bool snapPending = false;  // (slab group) take the owner snapshot of an asynchronous detection in this step, once the ghosts are in place
     DevBuf ownersSnap;
     hipStream_t detStream = nullptr;
@@ -933,7 +937,9 @@ void launch_reduce_heavy(deme_ctx* c, bool skipFixed) {
 }
 
 // pass: -1 everything in one launch; 0 / 1 the two halves of a split step (contacts that read no ghost owner / the rest)
-int launch_forces(deme_ctx* c, int pass = -1) {
+// `fs`: the stream of a tile-form launch when it is not the context's (the ghost-dependent pass of a split step runs on the halo
+// stream, beside the tail of the interior pass)
+int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
     if (c->nContacts == 0) {
         c->conValid = true;
         c->conTile = false;
@@ -998,11 +1004,12 @@ int launch_forces(deme_ctx* c, int pass = -1) {
         ta.nComp = c->nComp, ta.nAnal = c->nAnal, ta.nMass = c->nMassProps;
         static const uint32_t ldsPad = getenv("DEME_TILE_LDS_PAD") ? (uint32_t)atoi(getenv("DEME_TILE_LDS_PAD")) : 0u;  // occupancy experiments
         const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial)) + ldsPad;
-        ScopedTimer tm(c, "calc_forces");
+        hipStream_t st = fs ? fs : c->stream;
+        ScopedTimer tm(c, "calc_forces", false, st);
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
-            hipLaunchKernelGGL((k_tile_forces<0>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, c->stream, c->dp, ta);
+            hipLaunchKernelGGL((k_tile_forces<0>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
         else
-            hipLaunchKernelGGL((k_tile_forces<1>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, c->stream, c->dp, ta);
+            hipLaunchKernelGGL((k_tile_forces<1>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
         c->conValid = true;
         c->conTile = true;
         return DEME_OK;
@@ -1164,6 +1171,8 @@ int deme_ctx_create(int device, deme_ctx** out) {
         c->xcdGroup = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("DEME_TILE"))  // 0: keep the per-contact-block force kernel (A/B measurements)
         c->tileEnable = atoi(e);
+    if (const char* e = getenv("DEME_PASS1_BESIDE"))
+        c->pass1Beside = atoi(e);
     if (const char* e = getenv("DEME_KEY_SEG_MIN"))  // tests lower it to put small scenes through the segmented arena; 0 = one segment always
         c->keySegMin = (size_t)std::max(0ll, atoll(e));
     *out = c;
@@ -1193,6 +1202,8 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
+    if (c->evPass1)
+        hipEventDestroy(c->evPass1);
     if (c->hrPinned) {
         hipHostFree(c->hrPinned);
         hipEventDestroy(c->hrEvent);
@@ -2036,6 +2047,20 @@ static int overlap_forces(deme_ctx* c) {
         return rc;
     if (int rc = ensure_halo_stream(c))
         return rc;
+    // The ghost-dependent pass of a split step touches a few per cent of the tiles: launched behind the interior pass it would run
+    // alone on a mostly empty GPU.  In the tile form it goes to the halo stream instead -- which holds the ghosts as soon as its
+    // unpack is done -- and its workgroups take the slots the interior pass frees; the integration waits for both.
+    const bool pass1Beside = !c->overlapDetect && !c->snapPending && c->tileActive && c->tileEnable && c->arith == DEME_ARITH_FAST &&
+                             !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM && c->nContacts != 0 && c->pass1Beside;
+    if (pass1Beside) {
+        if (!c->evPass1)
+            HIPCK(hipEventCreateWithFlags(&c->evPass1, hipEventDisableTiming));
+        if (int rc = launch_forces(c, 1, c->haloStream))
+            return rc;
+        HIPCK(hipEventRecord(c->evPass1, c->haloStream));
+        HIPCK(hipStreamWaitEvent(c->stream, c->evPass1, 0));
+        return DEME_OK;
+    }
     HIPCK(hipStreamWaitEvent(c->stream, c->evHaloDone, 0));
     if (c->snapPending)  // an asynchronous detection starts from this moment: own clumps and ghosts both hold the state of the step just integrated
         if (int rc = async_snapshot(c))
