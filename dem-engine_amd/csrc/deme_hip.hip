@@ -205,7 +205,9 @@ int fail(deme_ctx* c, int code, const char* fmt, ...) {
 int ensure(deme_ctx* c, DevBuf& b, size_t bytes, bool keep = false) {
     if (bytes <= b.bytes && b.p)
         return DEME_OK;
-    const size_t want = std::max<size_t>(bytes, 256);
+    size_t want = std::max<size_t>(bytes, 256);
+    if (b.p)  // a buffer that grows once usually grows again (a settling bed: every detection a few more contacts): leave room
+        want = std::max(want, b.bytes + b.bytes / 4);
     void* np = nullptr;
     HIPCK(hipMalloc(&np, want));
     if (keep && b.p && b.bytes)
@@ -2165,6 +2167,11 @@ struct MigBuf {  // one direction of a migration exchange: clumps, their spheres
     uint32_t nC = 0, nS = 0, nR = 0;
     bool borrowed = false;  // the buffers belong to a neighbour slab of this process
 };
+struct MigPool {  // the scratch of one slab's migrations: one device block, kept between calls (three dozen hipMalloc / hipFree
+                  // pairs per call cost more than the kernels of a migration)
+    void* base = nullptr;
+    size_t cap = 0, lastNeed = 0;
+};
 struct SlabGeom {  // what deme_halo_group_migrate needs to know about a slab (deme_halo_group_set_slab)
     bool set = false;
     void *ownerGid = nullptr, *sphereGid = nullptr;
@@ -2179,6 +2186,7 @@ struct HaloSlab {
     hipEvent_t evPacked = nullptr;
     hipEvent_t evAcc = nullptr;  // this slab's share of the replicated owners' a / alpha is in its buffer
     hipEvent_t evRev = nullptr;  // the sums of this slab's right ghosts are packed
+    MigPool pool;
 };
 }  // namespace
 
@@ -2279,6 +2287,8 @@ void deme_halo_group_destroy(deme_halo_group* g) {
             hipEventDestroy(s.evAcc);
         if (s.evRev)
             hipEventDestroy(s.evRev);
+        if (s.pool.base)
+            hipFree(s.pool.base);
         for (auto& sd : s.side)
             if (sd.revBuf)
                 hipFree(sd.revBuf);
