@@ -747,7 +747,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
         // per-owner gather lists for the atomics-free accumulation
         HIPCK(hipMemsetAsync(c->rangeCtr.p, 0, sizeof(RangeCounters), c->stream));
         const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM &&
-                                  c->nTri == 0 && c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535 &&
+                                  c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535 &&
                                   tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial) <= DEME_TILE_TABLE_MAX &&
                                   c->nComp + c->nMat * c->nMat * 2u + c->nAnal * 4u <= DEME_TILE_T && c->nMassProps <= DEME_TILE_T;
         const uint32_t nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
@@ -1008,10 +1008,29 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial)) + ldsPad;
         hipStream_t st = fs ? fs : c->stream;
         ScopedTimer tm(c, "calc_forces", false, st);
-        if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
-            hipLaunchKernelGGL((k_tile_forces<0>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
-        else
-            hipLaunchKernelGGL((k_tile_forces<1>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+        const bool mesh = c->nTri > 0 && c->nSM > 0;
+        if (mesh) {
+            ta.conA4 = a.conA4, ta.conA2 = a.conA2, ta.conB4 = a.conB4, ta.conB2 = a.conB2;
+            if (pass != 1) {  // sphere-triangle contacts: the mesh variant of the general kernel, before the tiles that read its records
+                              // (they read no ghost owner -- meshes are replicated, not ghosted --: all of them go with pass 0)
+                const dim3 gm(grid_for(std::max<uint32_t>(c->nSM, 1u), DEME_FORCE_BLOCK)), bm(DEME_FORCE_BLOCK);
+                if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
+                    hipLaunchKernelGGL((k_calc_forces<0, 1>), gm, bm, 0, c->stream, c->dp, a);
+                else
+                    hipLaunchKernelGGL((k_calc_forces<1, 1>), gm, bm, 0, c->stream, c->dp, a);
+            }
+        }
+        if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
+            if (mesh)
+                hipLaunchKernelGGL((k_tile_forces<0, true>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+            else
+                hipLaunchKernelGGL((k_tile_forces<0, false>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+        } else {
+            if (mesh)
+                hipLaunchKernelGGL((k_tile_forces<1, true>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+            else
+                hipLaunchKernelGGL((k_tile_forces<1, false>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+        }
         c->conValid = true;
         c->conTile = true;
         return DEME_OK;
@@ -1272,7 +1291,7 @@ int deme_force_kernel_name(const deme_ctx* c, char* name, size_t cap, uint32_t* 
     if (c->hp.forceModel == DEME_FORCE_CUSTOM)
         snprintf(name, cap, "deme_custom_forces_ss");
     else if (fastKernel && c->tileActive && c->tileEnable)
-        snprintf(name, cap, "k_tile_forces<%d>", m);
+        snprintf(name, cap, "k_tile_forces<%d, %s>", m, (c->nTri > 0 && c->nSM > 0) ? "true" : "false");
     else if (fastKernel)
         snprintf(name, cap, "k_forces_fast<%d>", m);
     else

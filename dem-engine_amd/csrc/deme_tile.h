@@ -76,6 +76,10 @@ struct TileArgs {
     float4* rec32;             // the B-side records of the contacts whose B owner lives in another tile: 32 bytes each, dense, in
                                // list order (the k-th such contact writes record k: full cache lines instead of scattered pieces)
     const uint32_t* rankC;     // per contact: the number of such contacts before it
+    // scenes with a mesh (k_tile_forces<MODEL, true>): the sphere-triangle contacts were evaluated by the mesh variant of the general
+    // kernel just before (launch_forces); the tile takes their per-contact records instead of evaluating them
+    const float4 *conA4, *conB4;
+    const float2 *conA2, *conB2;
     uint32_t nOwners, nTiles, pass, xcdGroup;
     uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
     uint32_t nComp, nAnal, nMass;  // table sizes (tile_table_bytes)
@@ -315,7 +319,7 @@ __host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap,
            tableBytes + 16u;
 }
 
-template <int MODEL>
+template <int MODEL, bool MESH>
 __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(const DevParams p, const TileArgs a) {
     extern __shared__ uint4 tileLds[];
     uint4* const sOwn = tileLds;
@@ -442,9 +446,15 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
             const TileOwner A = tile_read_owner(sOwn, slotA), B = tile_read_owner(sOwn, slotB);
             f3 force, tA, tB;
-            tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
-            if (MODEL == 0)
-                stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
+            if (MESH && ((ci.x >> 20) & 3u) == DEME_KEY_CLASS_SM) {  // (rare, and only in tiles along the mesh: the loads sit behind a branch)
+                const float4 a4 = a.conA4[c], b4 = a.conB4[c];
+                const float2 a2 = a.conA2[c], b2 = a.conB2[c];
+                force = mk3(a4.x, a4.y, a4.z), tA = mk3(a4.w, a2.x, a2.y), tB = mk3(b4.w, b2.x, b2.y);
+            } else {
+                tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
+                if (MODEL == 0)
+                    stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
+            }
             recA4[tid] = make_float4(force.x, force.y, force.z, tA.x);
             recA2[tid] = make_float2(tA.y, tA.z);
             if (slotB < DEME_TILE_NB) {

@@ -40,7 +40,7 @@ def main():
     bench = json.load(open(f"{d}/{tag}_bench.json"))
     nc = bench["config"]["contacts_this_rank"]
     out = {"contacts": nc, "source": [f"{tag}_fetch_pmc.txt", f"{tag}_write_pmc.txt"], "unit": "bytes per launch", "kernels": {}}
-    force = next(k for k in ("k_tile_forces<0>", "k_forces_fast<0>", "k_calc_forces<0, 0>") if k in fetch)
+    force = next(k for k in ("k_tile_forces<0, false>", "k_tile_forces<0>", "k_forces_fast<0>", "k_calc_forces<0, 0>") if k in fetch)
     out["force_kernel"] = force
     for k in (force, "k_integrate<true>", "k_sweep"):
         if k not in fetch or k not in write:
