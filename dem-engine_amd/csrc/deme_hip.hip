@@ -131,6 +131,8 @@ struct deme_ctx {
     int pass1Beside = 0;       // DEME_PASS1_BESIDE=1: the ghost-dependent force pass on the halo stream, beside the tail of the interior
                                // pass (off: on the one-GPU harness -- two slabs competing for one GPU -- it costs 5 %; not measured with
                                // one slab per GPU, where the interior pass leaves the GPU to a few per cent of the tiles)
+    bool listOwnersSnap = false;  // (asynchronous detection) part 2 runs beside the steps too: it reads the snapshot, writes the spare set
+    DevBuf spare[40];              // the second set of the list structures (list_set): the steps in flight read one, part 2 builds the other
     bool snapPending = false;  // (slab group) take the owner snapshot of an asynchronous detection in this step, once the ghosts are in place
     DevBuf ownersSnap;
     hipStream_t detStream = nullptr;
@@ -679,6 +681,12 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
     return fail(c, DEME_ERR_OVERFLOW, "contact arena kept overflowing");
 }
 
+// The owner records the list builders read (tile origins, ghost and family flags): the live ones -- or, while an asynchronous
+// detection builds its list beside steps that are integrating them, the snapshot part 1 was made from
+static inline const OwnerRec* list_owners(deme_ctx* c) {
+    return c->listOwnersSnap ? c->ownersSnap.as<OwnerRec>() : c->owners.as<OwnerRec>();
+}
+
 // The B-sorted contact list of the round-2 kernels (k_forces_fast / k_calc_forces + the integrator's gather): owner-B sort, run
 // starts, heavy / fixed flags, the deferral flags of the halo overlap.  Enqueued on the main stream; the caller reads rangeCtr.
 int build_legacy_lists(deme_ctx* c) {
@@ -709,7 +717,7 @@ int build_legacy_lists(deme_ctx* c) {
     // (the counters may hold the tile builders' count of the same owners)
     HIPCK(hipMemsetAsync(&c->rangeCtr.as<RangeCounters>()->nHeavy, 0, 2 * sizeof(unsigned int), c->stream));
     hipLaunchKernelGGL(k_owner_ranges, dim3(grid_for((size_t)c->nOwners + 1)), dim3(256), 0, c->stream, c->dp, (uint32_t)nC,
-                       c->ownerA.as<uint32_t>(), c->ownerB[1].as<uint32_t>(), c->owners.as<OwnerRec>(), c->aStart.as<uint32_t>(),
+                       c->ownerA.as<uint32_t>(), c->ownerB[1].as<uint32_t>(), list_owners(c), c->aStart.as<uint32_t>(),
                        c->bStart.as<uint32_t>(), c->heavy.as<uint8_t>(), c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(),
                        (uint32_t)(c->heavyList.bytes / 4), c->rangeCtr.as<RangeCounters>(), c->info.as<uint4>(),
                        c->hasGhosts ? c->cDefer.as<uint8_t>() : (uint8_t*)nullptr, c->blockMode.as<uint32_t>());
@@ -789,7 +797,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
             HIPCK(rocprim::exclusive_scan(c->scanTmp.p, need, c->tileRem.as<uint32_t>(), c->tileBase.as<uint32_t>(), 0u, (size_t)nTiles + 1,
                                           rocprim::plus<uint32_t>(), c->stream));
             hipLaunchKernelGGL(k_tile_build, dim3(nTiles), dim3(256), 0, c->stream, c->dp, c->nOwners, c->info.as<uint4>(),
-                               c->aStart.as<uint32_t>(), c->owners.as<OwnerRec>(), c->tileBase.as<uint32_t>(), c->tInfo.as<uint2>(),
+                               c->aStart.as<uint32_t>(), list_owners(c), c->tileBase.as<uint32_t>(), c->tInfo.as<uint2>(),
                                c->hList.as<uint32_t>(), c->hCount.as<uint32_t>(),
                                c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr, c->lOff.as<uint16_t>(),
                                c->lPos.as<uint16_t>(), c->lCount.as<uint32_t>(), c->rankC.as<uint32_t>(), c->remKey[0].as<uint32_t>(),
@@ -818,7 +826,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                 } else {
                     HIPCK(hipMemsetAsync(c->rStart.p, 0, ((size_t)c->nOwners + 1) * 4, c->stream));
                 }
-                hipLaunchKernelGGL(k_owner_ranges_tile, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
+                hipLaunchKernelGGL(k_owner_ranges_tile, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp, list_owners(c),
                                    c->aStart.as<uint32_t>(), c->lOff.as<uint16_t>(), c->rStart.as<uint32_t>(), c->heavy.as<uint8_t>(),
                                    c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(), (uint32_t)(c->heavyList.bytes / 4),
                                    c->rangeCtr.as<RangeCounters>());
@@ -1225,6 +1233,9 @@ void deme_ctx_destroy(deme_ctx* c) {
     }
     if (c->evPass1)
         hipEventDestroy(c->evPass1);
+    for (DevBuf& b : c->spare)
+        if (b.p)
+            hipFree(b.p);
     if (c->hrPinned) {
         hipHostFree(c->hrPinned);
         hipEventDestroy(c->hrEvent);
@@ -1885,15 +1896,47 @@ static int async_part1(deme_ctx* c, uint64_t* nC) {
     HIPCK(hipEventRecord(c->evP1, c->detStream));
     return DEME_OK;
 }
+// Everything detect_part2 / build_legacy_lists write and the stepping kernels read.  While the D steps of an asynchronous cycle are
+// in flight (they were enqueued with the current buffers' addresses) the names are swapped to a second set, which part 2 fills on
+// the detection stream; when the main stream has waited for it, the names already point at the new list.
+static std::vector<DevBuf*> list_set(deme_ctx* c) {
+    return {&c->mapping, &c->rangeCtr, &c->tileRem, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->info,
+            &c->smFlag, &c->smList, &c->aStart, &c->bStart, &c->tileBase, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->lOff,
+            &c->lPos, &c->lCount, &c->rankC, &c->remKey[0], &c->remKey[1], &c->remVal, &c->tileOrg, &c->rIdx, &c->rStart, &c->heavy,
+            &c->fixedFlag, &c->heavyList, &c->cDefer, &c->blockMode};
+}
 static int async_part2(deme_ctx* c, uint64_t nC) {
-    HIPCK(hipStreamWaitEvent(c->stream, c->evP1, 0));
+    // (every step that reads the current list has been enqueued: from here on the names belong to the list being built)
+    const std::vector<DevBuf*> set = list_set(c);
+    static_assert(sizeof(c->spare) / sizeof(c->spare[0]) >= 33, "spare set too small");
+    hipStream_t mainStream = c->stream;
+    for (size_t k = 0; k < set.size(); k++) {
+        if (c->spare[k].bytes < set[k]->bytes) {  // same sizes as the set in use (sized by the arenas / the scene)
+            if (c->spare[k].p)
+                HIPCK(hipFree(c->spare[k].p));  // (nothing in flight reads the spare set)
+            c->spare[k].p = nullptr, c->spare[k].bytes = 0;
+            HIPCK(hipMalloc(&c->spare[k].p, set[k]->bytes));
+            c->spare[k].bytes = set[k]->bytes;
+        }
+        std::swap(*set[k], c->spare[k]);
+    }
+    c->stream = c->detStream;
+    c->listOwnersSnap = true;
+    int rc = DEME_OK;
     {
         ScopedTimer tm(c, "detect_async_part2", true);
-        if (int rc = detect_part2(c, nC))
-            return rc;
-        if (int rc = do_migrate(c))
-            return rc;
+        HIPCK(hipMemsetAsync(c->heavy.p, 0, c->heavy.bytes, c->stream));
+        HIPCK(hipMemsetAsync(c->fixedFlag.p, 0, c->fixedFlag.bytes, c->stream));
+        rc = detect_part2(c, nC);
     }
+    c->listOwnersSnap = false;
+    c->stream = mainStream;
+    if (rc)
+        return rc;
+    HIPCK(hipEventRecord(c->evP1, c->detStream));
+    HIPCK(hipStreamWaitEvent(c->stream, c->evP1, 0));
+    if (int rc2 = do_migrate(c))  // the history follows its contacts into the new order: with the wildcards the last step left
+        return rc2;
     c->stepsSinceCD = 0;
     c->listStale = false;
     c->nAsyncDetections++;
