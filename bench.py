@@ -690,8 +690,11 @@ def main():
             run(1)
             if int(ctx.counts().nDetections) > d0:
                 break
-        # stepsSinceCD == 1 now; the first timed step detects when it equals K there
-        run((K - 1 - args.warmup) % K)
+        # stepsSinceCD == 1 now; the first timed step detects when it equals K there.  With --async-detection D the cycle of a
+        # detection BEGINS D steps before its list is due (owner snapshot, then part 1 and 2 beside the next D steps): that
+        # beginning is put on the first timed step instead, so that the region holds all of the detection's work
+        lead = args.async_detection if 0 < args.async_detection < K else 0
+        run((K - lead - 1 - args.warmup) % K)
     if args.drift:
         for c_ in [ctx] + extra_ctx:
             st_ = c_.download_state()

@@ -1905,21 +1905,44 @@ static std::vector<DevBuf*> list_set(deme_ctx* c) {
             &c->lPos, &c->lCount, &c->rankC, &c->remKey[0], &c->remKey[1], &c->remVal, &c->tileOrg, &c->rIdx, &c->rStart, &c->heavy,
             &c->fixedFlag, &c->heavyList, &c->cDefer, &c->blockMode};
 }
-static int async_part2(deme_ctx* c, uint64_t nC) {
-    // (every step that reads the current list has been enqueued: from here on the names belong to the list being built)
+// the second set at the sizes of the one in use (sized by the arenas / the scene); nothing in flight reads the spare set
+static int async_size_spare(deme_ctx* c) {
     const std::vector<DevBuf*> set = list_set(c);
     static_assert(sizeof(c->spare) / sizeof(c->spare[0]) >= 33, "spare set too small");
-    hipStream_t mainStream = c->stream;
-    for (size_t k = 0; k < set.size(); k++) {
-        if (c->spare[k].bytes < set[k]->bytes) {  // same sizes as the set in use (sized by the arenas / the scene)
+    for (size_t k = 0; k < set.size(); k++)
+        if (c->spare[k].bytes < set[k]->bytes) {
             if (c->spare[k].p)
-                HIPCK(hipFree(c->spare[k].p));  // (nothing in flight reads the spare set)
+                HIPCK(hipFree(c->spare[k].p));
             c->spare[k].p = nullptr, c->spare[k].bytes = 0;
             HIPCK(hipMalloc(&c->spare[k].p, set[k]->bytes));
             c->spare[k].bytes = set[k]->bytes;
         }
-        std::swap(*set[k], c->spare[k]);
+    return DEME_OK;
+}
+// streams, events and buffers of the asynchronous detection, made when it is switched on (a first cycle that allocates a
+// gigabyte of list structures inside a short timed run costs more than the detection it hides)
+static int async_prepare(deme_ctx* c) {
+    if (!c->detStream) {
+        HIPCK(hipStreamCreateWithFlags(&c->detStream, hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&c->evSnap, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&c->evP1, hipEventDisableTiming));
     }
+    if (!c->haveParams || !c->haveScene)
+        return DEME_OK;
+    if (int rc = ensure(c, c->ownersSnap, (size_t)c->nOwners * sizeof(OwnerRec)))
+        return rc;
+    if (int rc = ensure(c, c->keysMid, (size_t)c->cntCap * 8))
+        return rc;
+    return async_size_spare(c);
+}
+static int async_part2(deme_ctx* c, uint64_t nC) {
+    // (every step that reads the current list has been enqueued: from here on the names belong to the list being built)
+    const std::vector<DevBuf*> set = list_set(c);
+    hipStream_t mainStream = c->stream;
+    if (int rc = async_size_spare(c))
+        return rc;
+    for (size_t k = 0; k < set.size(); k++)
+        std::swap(*set[k], c->spare[k]);
     c->stream = c->detStream;
     c->listOwnersSnap = true;
     int rc = DEME_OK;
@@ -1963,6 +1986,10 @@ int deme_set_async_detection(deme_ctx* c, uint32_t leadSteps) {
     if (!c)
         return DEME_ERR_INVALID;
     c->asyncLead = leadSteps;
+    if (leadSteps) {
+        hipSetDevice(c->device);
+        return async_prepare(c);
+    }
     return DEME_OK;
 }
 
