@@ -713,7 +713,7 @@ def main():
             print(f"[adaptive] bin size {adaptive_state[0]:.6g} K {adaptive_state[1]} changes {adaptive_state[2:]}", file=sys.stderr)
     # every 8th launch of the force / integration kernels is bracketed with HIP events (the detection always is: its timer
     # only ticks once per K steps); timing every launch costs 4.7 % of the step in dispatch gaps
-    stride = max(1, min(8, args.steps // 10))  # short runs (--steps < 80) time more of their launches so that the mean exists
+    stride = max(1, min(8, args.steps // 5))  # short runs (--steps < 40) time more of their launches so that the mean exists (>= 5 samples)
     ctx.set_timing(0 if os.environ.get("DEME_BENCH_NO_KERNEL_TIMING") else stride)
     ctx.kernel_time_reset()
     det_before = int(ctx.counts().nDetections)

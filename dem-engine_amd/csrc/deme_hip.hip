@@ -86,6 +86,7 @@ struct deme_ctx {
     bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
     bool conTile = false;     // the contributions in memory were written by the tile kernel
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
+    uint64_t lastSegMax = 0;             // longest segment of the last detection (sizes the early launch of k_compact_keys)
     size_t keySegMin = (size_t)1 << 20;  // arenas from this many slots on are cut into DEME_KEY_SEGS segments (DEME_KEY_SEG_MIN; 0: never)
     uint32_t tileMaxHalo = 0, tileMaxList = 0;
     // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
@@ -466,6 +467,14 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
                                           (size_t)nS + 1, rocprim::plus<uint32_t>(), st));
         }
         uint32_t P = 0;
+        bool filled = false;
+        if (nS && c->incCap) {  // the incidences go out before the host knows how many there are (the kernel guards the arena's end):
+                                // the GPU works through the read-back below instead of idling; repeated if the arena has to grow
+            hipLaunchKernelGGL(k_fill_incidence, dim3(grid_for(nS)), dim3(256), 0, st, c->dp,
+                               c->binLo.as<uint4>(), c->binN.as<uint2>(), c->offsets.as<uint32_t>(),
+                               c->incKeys[0].as<uint32_t>(), c->incVals[0].as<uint32_t>(), (uint64_t)c->incCap);
+            filled = true;
+        }
         if (nS) {
             HIPCK(hipMemcpyAsync(&P, c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, st));
             HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
@@ -502,13 +511,15 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
         if (P > c->incCap) {
             if (int rc = grow_incidence_arena(c, (size_t)P + P / 4 + 1024))
                 return rc;
+            filled = false;
         }
         c->nInc = P;
         int sortedIdx = 0;
         if (P) {
-            hipLaunchKernelGGL(k_fill_incidence, dim3(grid_for(nS)), dim3(256), 0, st, c->dp,
-                               c->binLo.as<uint4>(), c->binN.as<uint2>(), c->offsets.as<uint32_t>(),
-                               c->incKeys[0].as<uint32_t>(), c->incVals[0].as<uint32_t>(), (uint64_t)c->incCap);
+            if (!filled)
+                hipLaunchKernelGGL(k_fill_incidence, dim3(grid_for(nS)), dim3(256), 0, st, c->dp,
+                                   c->binLo.as<uint4>(), c->binN.as<uint2>(), c->offsets.as<uint32_t>(),
+                                   c->incKeys[0].as<uint32_t>(), c->incVals[0].as<uint32_t>(), (uint64_t)c->incCap);
             const uint64_t nBins = (uint64_t)c->hp.nbX * c->hp.nbY * c->hp.nbZ;
             unsigned bits = 1;
             while (bits < 32 && (1ull << bits) < nBins)
@@ -581,6 +592,15 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
                                    ow, ar);
             }
         }
+        // the gaps between the arena's segments are closed while the host waits for the counts: a launch sized from the last
+        // detection's longest segment, the rest (if a segment grew past that) after the read-back
+        const int nextEarly = c->keysCur ^ 1;
+        uint32_t compactBlocks = 0;
+        if (segmented) {
+            compactBlocks = (uint32_t)std::min<uint64_t>(grid_for(std::max<uint64_t>(c->lastSegMax + c->lastSegMax / 8 + 1024, 1)), grid_for(ar.segCap));
+            hipLaunchKernelGGL(k_compact_keys, dim3(compactBlocks, DEME_KEY_SEGS), dim3(256), 0, st, c->keysRaw.as<uint64_t>(), ar.segCap,
+                               c->segCtr.as<unsigned long long>(), 0u, c->keysSorted[nextEarly].as<uint64_t>());
+        }
         HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
         unsigned long long hseg[DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE];
         if (segmented)
@@ -591,14 +611,12 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             if (int rc = status_to_error(c, hc.status & ~DEME_ST_INCIDENCE))
                 return rc;
         }
-        KeySegOffsets so{};
         unsigned long long segMax = 0;
         if (segmented) {
             hc.nContactsRaw = 0;
             for (uint32_t g = 0; g < DEME_KEY_SEGS; g++) {
-                so.count[g] = hseg[g * DEME_KEY_SEG_STRIDE], so.start[g] = hc.nContactsRaw;
-                hc.nContactsRaw += so.count[g];
-                segMax = std::max(segMax, so.count[g]);
+                hc.nContactsRaw += hseg[g * DEME_KEY_SEG_STRIDE];
+                segMax = std::max(segMax, hseg[g * DEME_KEY_SEG_STRIDE]);
             }
         }
         if (hc.nContactsRaw > c->cntCap || segMax > ar.segCap) {  // arena (or one segment of it) too small: grow and redo the emitting kernels
@@ -629,10 +647,14 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
         }
         const int next = c->keysCur ^ 1;
         uint64_t* rawKeys = c->keysRaw.as<uint64_t>();
-        if (segmented && hc.nContactsRaw) {  // close the gaps between the segments (the next list's buffer is free until the rank sort fills it)
-            hipLaunchKernelGGL(k_compact_keys, dim3((unsigned)grid_for(segMax), DEME_KEY_SEGS), dim3(256), 0, st, c->keysRaw.as<uint64_t>(),
-                               ar.segCap, so, c->keysSorted[next].as<uint64_t>());
-            rawKeys = c->keysSorted[next].as<uint64_t>();
+        if (segmented) {  // (the gaps were closed above; the next list's buffer is free until the rank sort fills it)
+            c->lastSegMax = segMax;
+            if (grid_for(segMax) > compactBlocks)
+                hipLaunchKernelGGL(k_compact_keys, dim3((unsigned)grid_for(segMax) - compactBlocks, DEME_KEY_SEGS), dim3(256), 0, st,
+                                   c->keysRaw.as<uint64_t>(), ar.segCap, c->segCtr.as<unsigned long long>(), compactBlocks,
+                                   c->keysSorted[next].as<uint64_t>());
+            if (hc.nContactsRaw)
+                rawKeys = c->keysSorted[next].as<uint64_t>();
         }
         if (nPersist)
             HIPCK(hipMemcpyAsync(rawKeys + hc.nContactsRaw, c->persistKeys.p, nPersist * 8, hipMemcpyDeviceToDevice, st));

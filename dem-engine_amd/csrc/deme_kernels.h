@@ -56,16 +56,31 @@ __device__ inline void arena_store(const KeyArena& a, uint32_t seg, unsigned lon
     if (slot < a.segCap)  // (a full segment drops the key; its counter keeps counting and the host grows the arena and repeats)
         a.keys[(uint64_t)seg * a.segCap + slot] = key;
 }
-struct KeySegOffsets {
-    unsigned long long count[DEME_KEY_SEGS], start[DEME_KEY_SEGS];
-};
-// one thread per slot of the segmented arena: the occupied slots move to their place in the contiguous list
-__global__ __launch_bounds__(256) void k_compact_keys(const uint64_t* __restrict__ in, uint64_t segCap, const KeySegOffsets so,
+// one thread per slot of the segmented arena: the occupied slots move to their place in the contiguous list.  The counts are read
+// on the device (every workgroup adds up the 64 of them for its segment's start), so the kernel can be enqueued BEFORE the host
+// reads them: the GPU works through that read-back.  xOff: first slot-block this launch covers (the host launches the rest of a
+// segment that turned out longer than its estimate).
+__global__ __launch_bounds__(256) void k_compact_keys(const uint64_t* __restrict__ in, uint64_t segCap,
+                                                      const unsigned long long* __restrict__ segCtr, uint32_t xOff,
                                                       uint64_t* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long sStart, sCount;
     const uint32_t seg = blockIdx.y;
-    if (i < so.count[seg])
-        out[so.start[seg] + i] = in[(uint64_t)seg * segCap + i];
+    if (threadIdx.x < 64) {
+        static_assert(DEME_KEY_SEGS == 64, "one lane per segment");
+        const unsigned long long cnt = min(segCtr[threadIdx.x * DEME_KEY_SEG_STRIDE], (unsigned long long)segCap);
+        unsigned long long inc = cnt;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long u = __shfl_up(inc, d);
+            if ((int)threadIdx.x >= d)
+                inc += u;
+        }
+        if (threadIdx.x == seg)
+            sStart = inc - cnt, sCount = cnt;
+    }
+    __syncthreads();
+    const uint64_t i = ((uint64_t)xOff + blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < sCount)
+        out[sStart + i] = in[(uint64_t)seg * segCap + i];
 }
 
 // ---------------------------------------------------------------------------
@@ -223,6 +238,8 @@ __global__ __launch_bounds__(256) void k_fill_incidence(const DevParams p, const
         return;
     const uint4 lo = binLo[s];
     const uint2 n = binN[s];
+    if ((uint64_t)lo.w * n.x * n.y > DEME_MAX_BINS_PER_SPHERE)
+        return;  // (counted as zero and flagged by k_sphere_prep; the host stops the detection when it reads the flag)
     uint64_t off = offsets[s];
     for (uint32_t k = lo.z; k < lo.z + n.y; k++)
         for (uint32_t j = lo.y; j < lo.y + n.x; j++)
