@@ -807,6 +807,10 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "attainable_copy_GBs": copy_gbs, "frac_of_attainable": (achieved / copy_gbs if copy_gbs else None),
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),
+                     # SURVEY 8d adds 24 B per owner for a force kernel that reduces in-kernel, as the owner-tile pass does (its
+                     # per-owner sums are its output); `achieved` / `frac` above do NOT count them (the conservative figure)
+                     "frac_counting_the_in_kernel_reduction": ((fbytes + 24 * int(sc.nOwners)) / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                               if (f_ms > 0 and fk_name.startswith("k_tile")) else None),
                      "tile": ({"owners_per_tile": 128, "largest_tile_foreign_owners": tile_halo, "largest_tile_local_list": tile_list}
                               if fk_name.startswith("k_tile") else None),
                      "launch_sampling": f"every {stride}{'th' if stride > 3 else ('st', 'nd', 'rd')[stride - 1]} launch inside the timed region is bracketed with HIP events"},
