@@ -600,8 +600,9 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         }
     }
     __syncthreads();
-    // exclusive scan of the owners' local-B counts (two wavefronts of 64)
+    // exclusive scan of the owners' local-B counts (one value per thread, wavefront scans + the wavefronts' totals)
     {
+        static_assert(DEME_TILE_NB <= 256, "the builder has one thread per owner of the tile");
         uint32_t v = (tid < DEME_TILE_NB) ? cnt[tid] : 0u, inc = v;
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t u = (uint32_t)__shfl_up((int)inc, d);
@@ -612,7 +613,9 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
             wsum[wave] = inc;
         __syncthreads();
         if (tid < DEME_TILE_NB) {
-            const uint32_t base = (wave == 1u) ? wsum[0] : 0u;
+            uint32_t base = 0;
+            for (uint32_t w = 0; w < wave; w++)
+                base += wsum[w];
             off[tid] = base + inc - v;
             if (tid == DEME_TILE_NB - 1u)
                 off[DEME_TILE_NB] = base + inc;
@@ -733,8 +736,8 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
     __syncthreads();
     for (uint32_t i = tid; i < nLoc; i += 256)
         lPos[c0 + i] = lp[i];
-    if (tid <= DEME_TILE_NB)
-        lOff[(size_t)t * (DEME_TILE_NB + 1) + tid] = (uint16_t)off[tid];
+    for (uint32_t i = tid; i <= DEME_TILE_NB; i += 256)
+        lOff[(size_t)t * (DEME_TILE_NB + 1) + i] = (uint16_t)off[i];
 }
 
 // the largest tile's foreign-owner count and local-B list length (they size the LDS of k_tile_forces): a reduction over the
