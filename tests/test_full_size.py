@@ -243,3 +243,57 @@ def test_mesh_flavour_at_scale_matches_oracle(pkg, orc):
         assert np.array_equal(a, oa) and np.array_equal(bb, ob) and np.array_equal(t, ot)
     finally:
         orc.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+@pytest.mark.gpu
+def test_mesh_flavour_at_scale_fast_mode_matches_oracle(pkg, orc):
+    """The same flavour in the library's default arithmetic, the way bench.py --mesh-triangles runs it: owner tiles with the
+    sphere-triangle contacts taken from the mesh variant of the general kernel (k_tile_forces<M, true>), detection every 40 steps with
+    the bench's margins -- 3e5 clumps settled on the 30k-triangle plate, 100 steps from a common state against the oracle.  STATED
+    BOUNDS (those of tests/test_fast_mode.py): positions within 5e-8 m, velocities within 2e-4 m/s; contact lists identical up to
+    the handful of near-pairs the last bits of a position decide."""
+    import copy
+    import os
+    import bench
+    b = bench.build_bed(pkg, 300_000, 2024, 40, order="morton")  # (bench.py's default numbering: the tiles of a row-major bed do not fit LDS)
+    lo, hi = b.user_box_min, b.user_box_max
+    v, f = pkg.model.plate_mesh(122, 122, float(hi[0] - lo[0]) * 0.98, float(hi[1] - lo[1]) * 0.98, z=0.0, wavy=0.002)
+    m = b.AddMeshObject(v, f, 0)
+    m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 0.021))
+    p, sc = b.Initialize()
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+    settle = pkg.Context(0)  # (the suite's mode: exact)
+    settle.set_params(p), settle.upload_scene(sc)
+    settle.step(12000)
+    st = settle.download_state()
+    settle.compute_margins(0), settle.detect(), settle.migrate()
+    a, bb, t, _ = settle.contacts()
+    W = np.stack([settle.wildcard(w) for w in range(4)], 1)
+    settle.close()
+    fast = pkg.Context(0)
+    fast.set_arith_mode("fast")
+    fast.set_params(p), fast.upload_scene(sc)
+    fast.upload_state({k: st[k] for k in keys})
+    fast.seed_contacts(a, bb, t, W)
+    orc.set_num_threads(min(64, os.cpu_count() or 1))
+    try:
+        sim = orc.make_sim(pkg, p, sc)
+        sim.upload_state({k: st[k] for k in keys})
+        sim.seed_contacts(a, bb, t, W)
+        fast.step(100), sim.step(100)
+        assert fast.force_kernel()[0] == "k_tile_forces<0, true>", fast.force_kernel()
+        g, o = fast.download_state(), sim.download_state()
+        X = pkg.model.decode_positions(g["voxelID"], g["locX"], g["locY"], g["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+        Y = pkg.model.decode_positions(o["voxelID"], o["locX"], o["locY"], o["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+        dx = float(np.abs(X - Y).max())
+        dv = max(float(np.abs(g[k] - o[k]).max()) for k in ("vX", "vY", "vZ"))
+        print(f"fast mode, 3e5 clumps on a 30k-triangle plate, 100 steps: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s vs the oracle")
+        assert dx <= 5e-8 and dv <= 2e-4, (dx, dv)
+        ga, gb, gt, _ = fast.contacts()
+        oa, ob, ot, _ = sim.contacts()
+        kg = (ga.astype(np.uint64) << np.uint64(34)) | (gt.astype(np.uint64) << np.uint64(31)) | gb.astype(np.uint64)
+        ko = (oa.astype(np.uint64) << np.uint64(34)) | (ot.astype(np.uint64) << np.uint64(31)) | ob.astype(np.uint64)
+        assert int((gt == 2).sum()) > 50_000 and len(np.setxor1d(kg, ko)) <= 3
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+        fast.close()
