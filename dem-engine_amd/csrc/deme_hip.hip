@@ -129,6 +129,7 @@ struct deme_ctx {
     const void* revAcc = nullptr;
     bool pairsOnce = false;
     hipEvent_t evPass1 = nullptr;
+    int spinSync = 1;          // DEME_SPIN_SYNC=0: blocking waits at the detection's read-backs
     int pass1Beside = 0;       // DEME_PASS1_BESIDE=1: the ghost-dependent force pass on the halo stream, beside the tail of the interior
                                // pass (off: on the one-GPU harness -- two slabs competing for one GPU -- it costs 5 %; not measured with
                                // one slab per GPU, where the interior pass leaves the GPU to a few per cent of the tiles)
@@ -204,6 +205,23 @@ int fail(deme_ctx* c, int code, const char* fmt, ...) {
         if (_e != hipSuccess)                                                                         \
             return fail(c, DEME_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
+
+// The sizing read-backs of a detection: the host has nothing else to do, the GPU idles until it is back with the next launches,
+// and a blocking wait wakes up tens of microseconds late -- so the host polls the stream (for at most a few milliseconds; a
+// detection beside the steps, whose wait is long by design, blocks instead of burning a core).
+static hipError_t sync_readback(deme_ctx* c, hipStream_t st) {
+    if (c->spinSync && st == c->stream) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; it++) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipErrorNotReady)
+                return q;
+            if ((it & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5))
+                break;
+        }
+    }
+    return hipStreamSynchronize(st);
+}
 
 int ensure(deme_ctx* c, DevBuf& b, size_t bytes, bool keep = false) {
     if (bytes <= b.bytes && b.p)
@@ -478,7 +496,7 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
         if (nS) {
             HIPCK(hipMemcpyAsync(&P, c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, st));
             HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
-            HIPCK(hipStreamSynchronize(st));
+            HIPCK(sync_readback(c, st));
             if (!statusSeen) {
                 statusSeen = true;
                 if (int rc = status_to_error(c, hc.status & ~DEME_ST_INCIDENCE))
@@ -605,7 +623,7 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
         unsigned long long hseg[DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE];
         if (segmented)
             HIPCK(hipMemcpyAsync(hseg, c->segCtr.p, sizeof(hseg), hipMemcpyDeviceToHost, st));
-        HIPCK(hipStreamSynchronize(st));
+        HIPCK(sync_readback(c, st));
         if (!statusSeen) {
             statusSeen = true;
             if (int rc = status_to_error(c, hc.status & ~DEME_ST_INCIDENCE))
@@ -829,7 +847,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
             uint32_t nR = 0;  // crossing contacts = records = entries of the sort below: the one size the host has to know
             HIPCK(hipMemcpyAsync(&nR, c->tileBase.as<uint32_t>() + nTiles, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
-            HIPCK(hipStreamSynchronize(c->stream));
+            HIPCK(sync_readback(c, c->stream));
             if (!hr.tileOverflow) {
                 unsigned obits = 1;
                 while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
@@ -1222,6 +1240,8 @@ int deme_ctx_create(int device, deme_ctx** out) {
         c->xcdGroup = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("DEME_TILE"))  // 0: keep the per-contact-block force kernel (A/B measurements)
         c->tileEnable = atoi(e);
+    if (const char* e = getenv("DEME_SPIN_SYNC"))
+        c->spinSync = atoi(e);
     if (const char* e = getenv("DEME_PASS1_BESIDE"))
         c->pass1Beside = atoi(e);
     if (const char* e = getenv("DEME_KEY_SEG_MIN"))  // tests lower it to put small scenes through the segmented arena; 0 = one segment always
