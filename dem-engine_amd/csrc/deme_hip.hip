@@ -129,6 +129,7 @@ struct deme_ctx {
     const void* revAcc = nullptr;
     bool pairsOnce = false;
     hipEvent_t evPass1 = nullptr;
+    char* pin = nullptr;       // 16 KB of pinned host memory: where the detection's read-backs land
     int spinSync = 1;          // DEME_SPIN_SYNC=0: blocking waits at the detection's read-backs
     int pass1Beside = 0;       // DEME_PASS1_BESIDE=1: the ghost-dependent force pass on the halo stream, beside the tail of the interior
                                // pass (off: on the one-GPU harness -- two slabs competing for one GPU -- it costs 5 %; not measured with
@@ -209,6 +210,10 @@ int fail(deme_ctx* c, int code, const char* fmt, ...) {
 // The sizing read-backs of a detection: the host has nothing else to do, the GPU idles until it is back with the next launches,
 // and a blocking wait wakes up tens of microseconds late -- so the host polls the stream (for at most a few milliseconds; a
 // detection beside the steps, whose wait is long by design, blocks instead of burning a core).
+template <typename T>
+static inline T* pin_at(deme_ctx* c, size_t off) {
+    return reinterpret_cast<T*>(c->pin + off);
+}
 static hipError_t sync_readback(deme_ctx* c, hipStream_t st) {
     if (c->spinSync && st == c->stream) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -494,9 +499,12 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             filled = true;
         }
         if (nS) {
-            HIPCK(hipMemcpyAsync(&P, c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, st));
-            HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+            // (read-backs land in pinned memory: a copy into pageable memory goes through the runtime's staging buffer and costs
+            // tens of microseconds of host time before the wait even starts)
+            HIPCK(hipMemcpyAsync(pin_at<uint32_t>(c, 0), c->offsets.as<uint32_t>() + nS, 4, hipMemcpyDeviceToHost, st));
+            HIPCK(hipMemcpyAsync(pin_at<DetectCounters>(c, 64), c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
             HIPCK(sync_readback(c, st));
+            P = *pin_at<uint32_t>(c, 0), hc = *pin_at<DetectCounters>(c, 64);
             if (!statusSeen) {
                 statusSeen = true;
                 if (int rc = status_to_error(c, hc.status & ~DEME_ST_INCIDENCE))
@@ -619,11 +627,12 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             hipLaunchKernelGGL(k_compact_keys, dim3(compactBlocks, DEME_KEY_SEGS), dim3(256), 0, st, c->keysRaw.as<uint64_t>(), ar.segCap,
                                c->segCtr.as<unsigned long long>(), 0u, c->keysSorted[nextEarly].as<uint64_t>());
         }
-        HIPCK(hipMemcpyAsync(&hc, c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
-        unsigned long long hseg[DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE];
+        HIPCK(hipMemcpyAsync(pin_at<DetectCounters>(c, 64), c->ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+        const unsigned long long* hseg = pin_at<unsigned long long>(c, 1024);
         if (segmented)
-            HIPCK(hipMemcpyAsync(hseg, c->segCtr.p, sizeof(hseg), hipMemcpyDeviceToHost, st));
+            HIPCK(hipMemcpyAsync(pin_at<unsigned long long>(c, 1024), c->segCtr.p, DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE * 8, hipMemcpyDeviceToHost, st));
         HIPCK(sync_readback(c, st));
+        hc = *pin_at<DetectCounters>(c, 64);
         if (!statusSeen) {
             statusSeen = true;
             if (int rc = status_to_error(c, hc.status & ~DEME_ST_INCIDENCE))
@@ -845,9 +854,10 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
             hipLaunchKernelGGL(k_tile_stats, dim3((nTiles + 1023u) / 1024u), dim3(256), 0, c->stream, nTiles, c->hCount.as<uint32_t>(),
                                c->lCount.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
             uint32_t nR = 0;  // crossing contacts = records = entries of the sort below: the one size the host has to know
-            HIPCK(hipMemcpyAsync(&nR, c->tileBase.as<uint32_t>() + nTiles, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCK(hipMemcpyAsync(&hr, c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipMemcpyAsync(pin_at<uint32_t>(c, 8), c->tileBase.as<uint32_t>() + nTiles, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(hipMemcpyAsync(pin_at<RangeCounters>(c, 128), c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
             HIPCK(sync_readback(c, c->stream));
+            nR = *pin_at<uint32_t>(c, 8), hr = *pin_at<RangeCounters>(c, 128);
             if (!hr.tileOverflow) {
                 unsigned obits = 1;
                 while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
@@ -1234,6 +1244,10 @@ int deme_ctx_create(int device, deme_ctx** out) {
         return DEME_ERR_HIP;
     }
     hipMemsetAsync(c->ctr.p, 0, sizeof(DetectCounters), c->stream);
+    if (hipHostMalloc((void**)&c->pin, 16384, hipHostMallocDefault) != hipSuccess) {
+        deme_ctx_destroy(c);
+        return DEME_ERR_HIP;
+    }
     if (const char* e = getenv("DEME_ARITH"))  // process-wide default of deme_set_arith_mode ("exact" / "fast")
         c->arith = (strcmp(e, "exact") == 0) ? DEME_ARITH_EXACT : DEME_ARITH_FAST;
     if (const char* e = getenv("DEME_XCD_GROUP"))  // tuning knob (profiles/): see force_block_id
@@ -1273,6 +1287,8 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evHaloDone);
         hipStreamDestroy(c->haloStream);
     }
+    if (c->pin)
+        hipHostFree(c->pin);
     if (c->evPass1)
         hipEventDestroy(c->evPass1);
     for (DevBuf& b : c->spare)
