@@ -846,7 +846,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
             HIPCK(rocprim::exclusive_scan(c->scanTmp.p, need, c->tileRem.as<uint32_t>(), c->tileBase.as<uint32_t>(), 0u, (size_t)nTiles + 1,
                                           rocprim::plus<uint32_t>(), c->stream));
             hipLaunchKernelGGL(k_tile_build, dim3(nTiles), dim3(256), 0, c->stream, c->dp, c->nOwners, c->info.as<uint4>(),
-                               c->aStart.as<uint32_t>(), list_owners(c), c->tileBase.as<uint32_t>(), c->tInfo.as<uint2>(),
+                               c->ownerB[0].as<uint32_t>(), c->aStart.as<uint32_t>(), list_owners(c), c->tileBase.as<uint32_t>(), c->tInfo.as<uint2>(),
                                c->hList.as<uint32_t>(), c->hCount.as<uint32_t>(),
                                c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr, c->lOff.as<uint16_t>(),
                                c->lPos.as<uint16_t>(), c->lCount.as<uint32_t>(), c->rankC.as<uint32_t>(), c->remKey[0].as<uint32_t>(),

@@ -557,6 +557,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
 // (3) a radix sort of those pairs by owner -- 41 % of the contacts of a packed bed; the round-2 pipeline sorted all of them -- gives
 //     the integrator its per-owner lists of records (rIdx, rStart).
 __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t nOwners, const uint4* __restrict__ info,
+                                                    const uint32_t* __restrict__ ownerBList,
                                                     const uint32_t* __restrict__ aStart, const OwnerRec* __restrict__ owners,
                                                     const uint32_t* __restrict__ tileBase, uint2* __restrict__ tInfo,
                                                     uint32_t* __restrict__ hList, uint32_t* __restrict__ hCount,
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
                                                     uint32_t* __restrict__ rankC, uint32_t* __restrict__ remKey,
                                                     uint32_t* __restrict__ remVal, int64_t* __restrict__ org, RangeCounters* rc) {
     __shared__ uint32_t table[DEME_TILE_HASH];
+    __shared__ uint16_t slotTab[DEME_TILE_HASH];
     __shared__ uint32_t list[DEME_TILE_HP2];
     __shared__ uint32_t cnt[DEME_TILE_NB], off[DEME_TILE_NB + 1], wsum[4];
     __shared__ uint16_t lp[DEME_TILE_LMAX];
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         nU = 0, nL = 0, anyGhost = 0;
     __syncthreads();
     for (uint32_t c = c0 + tid; c < c1; c += 256) {
-        const uint32_t ob = info[c].y;
+        const uint32_t ob = ownerBList[c];  // (the B owners alone: 4 bytes per contact; the 16-byte gather records are read once, below)
         if (ob >= o0 && ob < o1) {
             atomicAdd(&cnt[ob - o0], 1u);
             continue;
@@ -590,8 +592,12 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         uint32_t h = (ob * 2654435761u) >> 22;  // 10 bits
         while (*(volatile uint32_t*)&nU <= DEME_TILE_HMAX) {
             const uint32_t old = atomicCAS(&table[h], 0xFFFFFFFFu, ob);
-            if (old == 0xFFFFFFFFu) {
-                atomicAdd(&nU, 1u);
+            if (old == 0xFFFFFFFFu) {  // a new foreign owner: it takes the next staging slot.  (Which one depends on who comes first: the
+                                       // slot numbers are addresses of LDS records, not an order anything is summed in)
+                const uint32_t slot = atomicAdd(&nU, 1u);
+                slotTab[h] = (uint16_t)slot;
+                if (slot < DEME_TILE_HP2)
+                    list[slot] = ob;
                 break;
             }
             if (old == ob)
@@ -631,23 +637,6 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         }
         return;
     }
-    for (uint32_t i = tid; i < DEME_TILE_HASH; i += 256) {
-        const uint32_t v = table[i];
-        if (v != 0xFFFFFFFFu)
-            list[atomicAdd(&nL, 1u)] = v;
-    }
-    // sort by rank: the n <= DEME_TILE_HMAX entries are distinct, so an entry's place is the number of smaller ones -- every
-    // thread counts for its own entry (broadcast reads, no barrier inside; a bitonic network spent 36 barriers here)
-    __syncthreads();
-    uint32_t mine = 0xFFFFFFFFu, rank = 0;
-    if (tid < n) {
-        mine = list[tid];
-        for (uint32_t j = 0; j < n; j++)
-            rank += list[j] < mine ? 1u : 0u;
-    }
-    __syncthreads();
-    if (tid < n)
-        list[rank] = mine;
     if (tid < DEME_TILE_NB)
         cnt[tid] = 0;  // (from here on: entries already placed in an owner's list)
     __syncthreads();
@@ -685,15 +674,10 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
                 slotB = ob - o0;
                 lp[off[slotB] + atomicAdd(&cnt[slotB], 1u)] = (uint16_t)(c - c0);
             } else {
-                uint32_t lo = 0, hi = n;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (list[mid] < ob)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                slotB = DEME_TILE_NB + lo;
+                uint32_t h = (ob * 2654435761u) >> 22;
+                while (table[h] != ob)  // (inserted above: found after one or two probes)
+                    h = (h + 1u) & (DEME_TILE_HASH - 1u);
+                slotB = DEME_TILE_NB + slotTab[h];
                 remote = true;
             }
             const uint32_t matA = ci.z >> 16, compA = ci.z & 0xFFFFu;
