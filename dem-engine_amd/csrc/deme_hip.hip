@@ -2349,6 +2349,7 @@ struct deme_halo_group {
     std::vector<HaloSlab> slabs;
     uint32_t nShared = 0;            // replicated free owners (the same on every slab): a / alpha summed across slabs every step
     void* sharedSum = nullptr;       // nShared x AccRec
+    void* agreeBuf = nullptr;        // 16 bytes: the error flag the ranks add up before a collective phase (mig_agree)
     hipEvent_t evReduced = nullptr;
     std::string err;
     uint64_t nExchanges = 0, nReductions = 0, bytesPerStep = 0;
@@ -2444,6 +2445,8 @@ void deme_halo_group_destroy(deme_halo_group* g) {
         hipEventDestroy(g->evRevDone);
     if (g->sharedSum)
         hipFree(g->sharedSum);
+    if (g->agreeBuf)
+        hipFree(g->agreeBuf);
     if (g->evReduced)
         hipEventDestroy(g->evReduced);
     if (g->comm)

@@ -834,6 +834,7 @@ struct GatherArgs {
     // contacts with ITS clumps sends a / alpha of their sum; revSlot[o] = the clump's place in that message, 0xFFFFFFFF = none
     const uint32_t* revSlot;
     const float4* revAcc;    // two float4 per place
+    uint32_t revInIntegrator;  // k_reduce_heavy: 1 = launched by the stepping loop (integrate_owner adds the share afterwards)
 };
 
 // one B-side record for the per-owner gather: by contact index from the two per-contact arrays, or (tile form) by record number
@@ -975,6 +976,20 @@ __device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint3
     al = make_float4(lx, ly, lz, 0.f);
 }
 
+// (slab group, one evaluation per cross-cut contact) the a / alpha of the contacts the LEFT neighbour evaluated for this clump: added
+// by the integrator and by every stand-alone reduction alike -- downloads, trackers and family rules that read accelerations see
+// the same sums the integrator uses
+__device__ inline void add_reverse_share(const GatherArgs& g, uint32_t o, float4& a, float4& al) {
+    if (!g.revSlot)
+        return;
+    const uint32_t slot = g.revSlot[o];
+    if (slot != 0xFFFFFFFFu) {
+        const float4 ea = g.revAcc[2 * (size_t)slot], el = g.revAcc[2 * (size_t)slot + 1];
+        a.x += ea.x, a.y += ea.y, a.z += ea.z;
+        al.x += el.x, al.y += el.y, al.z += el.z;
+    }
+}
+
 // stand-alone reduction (deme_calc_forces): a/alpha of every non-heavy owner
 __global__ __launch_bounds__(256) void k_gather_acc(const DevParams p, const GatherArgs g, const OwnerRec* __restrict__ owners,
                                                     AccRec* __restrict__ acc) {
@@ -985,6 +1000,7 @@ __global__ __launch_bounds__(256) void k_gather_acc(const DevParams p, const Gat
     gather_owner(g, o, a, al);
     if (g.world)
         acc_from_world(p, load_owner(owners, o), a, al);
+    add_reverse_share(g, o, a, al);
     float4* ap = reinterpret_cast<float4*>(acc + o);
     ap[0] = a;
     ap[1] = al;
@@ -1036,6 +1052,8 @@ __global__ __launch_bounds__(256) void k_reduce_heavy(const DevParams p, const G
             float4 a = make_float4(red[0][0], red[1][0], red[2][0], 0.f), al = make_float4(red[3][0], red[4][0], red[5][0], 0.f);
             if (g.world)
                 acc_from_world(p, load_owner(owners, o), a, al);
+            if (!g.revInIntegrator)  // (the stepping loop's integrator adds the share itself: integrate_owner)
+                add_reverse_share(g, o, a, al);
             float4* ap = reinterpret_cast<float4*>(acc + o);
             ap[0] = a;
             ap[1] = al;
@@ -1313,14 +1331,7 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
 __device__ inline void integrate_owner(const DevParams& p, OwnerRec& r, float4 a, float4 al, uint32_t o, uint32_t fflags, bool fixed,
                                        const GatherArgs& g, const PrescArgs& pa) {
 
-    if (g.revSlot) {  // the share of the contacts a neighbouring rank evaluated for this clump
-        const uint32_t slot = g.revSlot[o];
-        if (slot != 0xFFFFFFFFu) {
-            const float4 ea = g.revAcc[2 * (size_t)slot], el = g.revAcc[2 * (size_t)slot + 1];
-            a.x += ea.x, a.y += ea.y, a.z += ea.z;
-            al.x += el.x, al.y += el.y, al.z += el.z;
-        }
-    }
+    add_reverse_share(g, o, a, al);  // the share of the contacts a neighbouring rank evaluated for this clump
     if (g.nextAcc) {  // DEMTracker::AddAcc / AddAngAcc: on top of the contact sums (added last: the sums keep their order)
         const float4* ep = reinterpret_cast<const float4*>(g.nextAcc + o);
         const float4 ea = ep[0], el = ep[1];

@@ -51,6 +51,17 @@ static_assert(DEME_TILE_HMAX <= DEME_TILE_HP2 && DEME_TILE_HMAX <= 256, "halo li
 
 namespace deme_dev {
 
+// Measurement builds (make variant EXTRA=-DDEME_TILE_KI=bits): "knock-in" duplicates of one section of k_tile_forces behind opaque
+// values -- the physics is untouched, the extra time of a variant is what that section costs (bit 0: the two sphere-offset
+// rotations + their fp64 conversions; 1: the pulls; 2: the staging conversion; 3: the whole per-contact evaluation) -- and
+// "knock-outs" of stores (bit 4: history; 5: crossing records; 6: tile sums: wrong results, timing only).
+#ifndef DEME_TILE_KI
+#define DEME_TILE_KI 0
+#endif
+__device__ inline void ki_opaque(float& v) { asm volatile("" : "+v"(v)); }
+__device__ inline void ki_opaque(uint32_t& v) { asm volatile("" : "+v"(v)); }
+__device__ inline void ki_sink(float v) { asm volatile("" ::"v"(v)); }
+
 // tInfo.x: slot of A (10) | slot of B (10) | class (2) | B lives in another tile: write a record (1) | 1 spare | material of A (4) |
 //          material of B (4);  tInfo.y: component of A (16) | component of B or analytical-object index (16)
 __host__ __device__ inline uint32_t tile_info_x(uint32_t slotA, uint32_t slotB, uint32_t cls, uint32_t rec, uint32_t matA, uint32_t matB) {
@@ -151,6 +162,16 @@ __device__ inline void tile_contact(const DevParams& p, const TileTables& T, con
     const RotM &RA = A.R, &RB = B.R;
     const f3 relA = rot_apply(RA, mk3(cA.x, cA.y, cA.z));
     const float rA = cA.w;
+#if DEME_TILE_KI & 1
+    {
+        float qx = cA.x, qy = cA.y;
+        ki_opaque(qx), ki_opaque(qy);
+        const f3 r2 = rot_apply(RA, mk3(qx, qy, cA.z)), r3 = rot_apply(RB, mk3(qy, qx, cA.z));
+        const double e = (((A.px - B.px) + (double)r2.x) - (double)r3.x) + (((A.py - B.py) + (double)r2.y) - (double)r3.y) +
+                         (((A.pz - B.pz) + (double)r2.z) - (double)r3.z);
+        ki_sink((float)e);
+    }
+#endif
     float extraMargin = 0.f;
     if (!p.familyTrivial) {
         const float eA = T.fam[A.family & 0xFFu], eB = T.fam[B.family & 0xFFu];
@@ -418,6 +439,18 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         const_cast<float*>(T.fam)[tid & 255u] = tabFam;
     __syncthreads();  // (the staging below reads the masses)
     {   // stage the tile's owners, its halo, the owners' run bounds and local-B lists
+#if DEME_TILE_KI & 4
+        if (tid < nLoc + nH) {
+            OwnerRec r2 = rec0;
+            ki_opaque(r2.qw), ki_opaque(r2.wx), ki_opaque(r2.family);
+            tile_stage_owner(p, T.mass, r2, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * DEME_TILE_REC);
+        }
+        if (h1 < nH) {
+            OwnerRec r2 = rec1;
+            ki_opaque(r2.qw), ki_opaque(r2.wx), ki_opaque(r2.family);
+            tile_stage_owner(p, T.mass, r2, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * DEME_TILE_REC);
+        }
+#endif
         if (tid < nLoc + nH)
             tile_stage_owner(p, T.mass, rec0, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * DEME_TILE_REC);
         if (h1 < nH)
@@ -451,9 +484,21 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 const float2 a2 = a.conA2[c], b2 = a.conB2[c];
                 force = mk3(a4.x, a4.y, a4.z), tA = mk3(a4.w, a2.x, a2.y), tB = mk3(b4.w, b2.x, b2.y);
             } else {
+#if DEME_TILE_KI & 8
+                {
+                    uint2 ci2 = ci;
+                    ki_opaque(ci2.x), ki_opaque(ci2.y);
+                    float4 h2 = h;
+                    f3 f2, u2, w2;
+                    tile_contact<MODEL>(p, T, ci2, A, B, h2, f2, u2, w2);
+                    ki_sink(f2.x + f2.y + f2.z + u2.x + u2.y + u2.z + w2.x + w2.y + w2.z + h2.x + h2.y + h2.z + h2.w);
+                }
+#endif
                 tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
+#if !(DEME_TILE_KI & 16)
                 if (MODEL == 0)
                     stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
+#endif
             }
             recA4[tid] = make_float4(force.x, force.y, force.z, tA.x);
             recA2[tid] = make_float2(tA.y, tA.z);
@@ -468,8 +513,12 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             const uint64_t m = __ballot(crossing);
             if (crossing) {
                 const uint32_t k = rbase[0] + (uint32_t)__popcll(m & ((1ull << (tid & 63u)) - 1ull));
+#if !(DEME_TILE_KI & 32)
                 stream_store(a.rec32 + 2 * (size_t)k, x4);
                 stream_store(a.rec32 + 2 * (size_t)k + 1, x2);
+#else
+                ki_sink(x4.x + x2.x + (float)k);
+#endif
             }
         }
         // rotate the stream registers and refill the last stage
@@ -488,6 +537,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         }
         __syncthreads();
         const uint32_t rhi = rlo + DEME_TILE_T;
+        auto pulls = [&]() {
         if (sideA) {  // my A run's part of this round: positions [plo, min(phi, rhi))
             const uint32_t e = min(phi, rhi);
             while (plo < e) {
@@ -530,6 +580,18 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                     break;
             }
         }
+        };
+#if DEME_TILE_KI & 2
+        {
+            const float k0 = s0, k1 = s1, k2 = s2, k3 = s3, k4 = s4, k5 = s5;
+            uint32_t kp = plo;
+            pulls();
+            ki_sink(s0 + s1 + s2 + s3 + s4 + s5);
+            ki_opaque(kp);
+            s0 = k0, s1 = k1, s2 = k2, s3 = k3, s4 = k4, s5 = k5, plo = kp;
+        }
+#endif
+        pulls();
         __syncthreads();
         c += DEME_TILE_T;
     }
@@ -542,8 +604,12 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     if (sideA && po < nLoc) {
         const float4 b4 = recA4[po];
         const float2 b2 = recA2[po];
+#if !(DEME_TILE_KI & 64)
         a.tSum[2 * (size_t)(o0 + po)] = make_float4(s0 + b4.x, s1 + b4.y, s2 + b4.z, 0.f);
         a.tSum[2 * (size_t)(o0 + po) + 1] = make_float4(s3 + b4.w, s4 + b2.x, s5 + b2.y, 0.f);
+#else
+        ki_sink(s0 + b4.x + s1 + b4.y + s2 + b4.z + s3 + b4.w + s4 + b2.x + s5 + b2.y);
+#endif
     }
 }
 

@@ -63,6 +63,7 @@ extern "C" {
 #define DEME_ERR_BIN_TOO_FULL 4 /* reference: errOutBinSphNum abort, DEMContactKernels_SphereSphere.cu:121 */
 #define DEME_ERR_VELOCITY 5     /* reference: errOutVel, kT.cpp:136-149 */
 #define DEME_ERR_COMPILE 6
+#define DEME_ERR_PEER 7 /* a collective call gave up because ANOTHER rank of the halo group reported an error (its own message says which) */
 
 /* ---- parameter block: replaces deme::DEMSimParams (DEM/Defines.h:194-265) - */
 typedef struct DemeParams {

@@ -356,7 +356,7 @@ def test_cross_cut_contacts_evaluated_once(pkg, mode):
 def packed_million(pkg):
     """configs[1] bed, settled on one GPU context (exact mode): params, scene, builder, state, contact list + history"""
     import bench
-    b = bench.build_bed(pkg, 1_000_000, 2024, 40)
+    b = bench.build_bed(pkg, 1_000_000, 2024, 40, order="morton")  # bench.py's numbering (owner tiles fit LDS)
     p, sc = b.Initialize()
     ctx = _make(pkg, p, sc)
     ctx.step(22000)
@@ -434,6 +434,9 @@ def test_million_clumps_in_slabs_against_single_domain_oracle(pkg, orc, packed_m
         N = 100
         grp.step(N - 1), sim.step(N - 1)
         grp.sync()
+        if mode == "fast":  # the kernel bench.py --gpus N times, in every slab
+            for c in ctxs:
+                assert c.force_kernel()[0] == "k_tile_forces<0, false>", c.force_kernel()
     finally:
         orc.set_num_threads(min(8, os.cpu_count() or 1))
     X, V = gather_positions(pkg, parts, ctxs, p, nc)
@@ -524,7 +527,7 @@ def test_ten_million_clumps_in_eight_slabs_properties(pkg):
     opposite signs: the mass-weighted sum over clumps and walls vanishes to rounding)."""
     import bench
     n = 10_000_000
-    b = bench.build_bed(pkg, n, 2024, 40)
+    b = bench.build_bed(pkg, n, 2024, 40, order="morton")
     p, sc = b.Initialize()
     ctx = _make(pkg, p, sc, "fast")
     ctx.step(24000)  # (the bed is 3.2 times as deep as the 1e6 one: it is still closing up, which is all the better for a list test)
@@ -543,6 +546,7 @@ def test_ten_million_clumps_in_eight_slabs_properties(pkg):
     ref = np.sort(pack(a, bb, t))
     # Newton's third law, single context
     ctx.calc_forces()
+    assert ctx.force_kernel()[0] == "k_tile_forces<0, false>", ctx.force_kernel()
     s1 = ctx.download_state()
     mass = b.arrays["MassProperties"][b.arrays["inertiaPropOffsets"]].astype(np.float64)
     acc = np.stack([s1["aX"], s1["aY"], s1["aZ"]], 1).astype(np.float64)

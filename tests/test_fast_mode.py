@@ -52,6 +52,7 @@ def test_fast_accelerations_match_oracle(pkg, orc, model):
     sim.upload_state(st)
     for s in (ctx, sim):
         s.compute_margins(0), s.detect(), s.migrate(), s.calc_forces()
+    assert ctx.force_kernel()[0] == ("k_tile_forces<0, false>" if model == "hertz" else "k_tile_forces<1, false>"), ctx.force_kernel()
     ga, oa = ctx.contacts(), sim.contacts()
     assert len(ga[0]) > 1500 and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))  # decisions: bit-exact
     g, o = ctx.download_state(), sim.download_state()
@@ -86,6 +87,7 @@ def test_fast_trajectory_within_stated_tolerance(pkg, orc, cd_freq):
     sim.upload_state(st)
     N = 100
     ctx.step(N), sim.step(N)
+    assert ctx.force_kernel()[0] == "k_tile_forces<0, false>", ctx.force_kernel()
     ga, oa = ctx.contacts(), sim.contacts()
     assert len(ga[0]) == len(oa[0]) and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
     g, o = ctx.download_state(), sim.download_state()

@@ -10,7 +10,7 @@ N = 1_000_000
 @pytest.fixture(scope="module")
 def big(pkg):
     import bench
-    b = bench.build_bed(pkg, N, 2024, 0)
+    b = bench.build_bed(pkg, N, 2024, 0, order="morton")  # bench.py's numbering: the bed the headline number is measured on
     p, sc = b.Initialize()
     ctx = pkg.Context(0)
     ctx.set_params(p), ctx.upload_scene(sc)
@@ -152,7 +152,8 @@ def test_full_size_update_frequency_and_margins(pkg, big):
 
 @pytest.mark.gpu
 def test_full_size_fast_mode_matches_oracle(pkg, orc, big):
-    """The mode and the policy bench.py times -- the library's default FAST arithmetic (owner-tile force pass), detection every
+    """The mode and the policy bench.py times -- the library's default FAST arithmetic, evaluated by the owner-tile force pass
+    k_tile_forces<0, false> (asserted below: the bed is numbered along the Z-order curve like bench.py's), detection every
     K = 40 steps with the bench's margins (1.2 x own speed + 0.02 m/s) -- at the headline size against the oracle: 1e6 clumps from
     a packed, still moving state with its contact history, N = 100 steps (three detections).  STATED BOUNDS, the ones of
     tests/test_fast_mode.py at 3e3 clumps: positions within 5e-8 m, velocities within 2e-4 m/s, contact lists identical (a pair
@@ -179,6 +180,7 @@ def test_full_size_fast_mode_matches_oracle(pkg, orc, big):
         sim.upload_state({k: st[k] for k in keys})
         sim.seed_contacts(a, bb, t, W)
         fast.step(100), sim.step(100)
+        assert fast.force_kernel()[0] == "k_tile_forces<0, false>", fast.force_kernel()  # the kernel bench.py's roofline names
         assert int(fast.counts().nDetections) == int(sim.counts().nDetections) == 3
         g, o = fast.download_state(), sim.download_state()
         X = pkg.model.decode_positions(g["voxelID"], g["locX"], g["locY"], g["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
@@ -193,6 +195,51 @@ def test_full_size_fast_mode_matches_oracle(pkg, orc, big):
         ko = (oa.astype(np.uint64) << np.uint64(34)) | (ot.astype(np.uint64) << np.uint64(31)) | ob.astype(np.uint64)
         diff = np.setxor1d(kg, ko)
         assert len(ga) > 3_000_000 and len(diff) <= 3, f"{len(diff)} pairs are in one list only"
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+        fast.close()
+
+
+@pytest.mark.gpu
+def test_full_size_tile_pass_one_launch_matches_oracle(pkg, orc, big):
+    """ONE launch of k_tile_forces<0, false> on the headline bed against the oracle: the same state and the same contact history
+    (a packed 1e6-clump bed, > 3e6 contacts) -> detection -> force evaluation.  Lists bit-identical; the owners' a / alpha within
+    2e-4 of the largest acceleration per component and the updated history within 1e-5 of the largest entry (the bounds of
+    tests/test_fast_mode.py::test_fast_accelerations_match_oracle, there on 3e3 clumps)."""
+    import os
+    b, p, sc, ctx = big
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+    st = ctx.download_state()
+    ctx.compute_margins(0), ctx.detect(), ctx.migrate()
+    a, bb, t, _ = ctx.contacts()
+    W = np.stack([ctx.wildcard(w) for w in range(4)], 1)
+    fast = pkg.Context(0)
+    fast.set_arith_mode("fast")
+    fast.set_params(p), fast.upload_scene(sc)
+    fast.upload_state({k: st[k] for k in keys})
+    fast.seed_contacts(a, bb, t, W)
+    orc.set_num_threads(min(64, os.cpu_count() or 1))
+    try:
+        sim = orc.make_sim(pkg, p, sc)
+        sim.upload_state({k: st[k] for k in keys})
+        sim.seed_contacts(a, bb, t, W)
+        for s in (fast, sim):
+            s.compute_margins(0), s.detect(), s.migrate(), s.calc_forces()
+        assert fast.force_kernel()[0] == "k_tile_forces<0, false>", fast.force_kernel()
+        ga, oa = fast.contacts(), sim.contacts()
+        assert len(ga[0]) > 3_000_000 and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+        g, o = fast.download_state(), sim.download_state()
+        n = int(sc.nOwnerClumps)
+        for ks in (("aX", "aY", "aZ"), ("alphaX", "alphaY", "alphaZ")):
+            G = np.stack([g[k][:n] for k in ks], 1).astype(np.float64)
+            O = np.stack([o[k][:n] for k in ks], 1).astype(np.float64)
+            scale = np.abs(O).max()
+            err = np.abs(G - O).max()
+            print(f"1e6 clumps, one tile-pass launch, {ks[0][:-1]}: max |fast - oracle| / max |oracle| = {err / scale:.3e}")
+            assert scale > 0 and err <= 2e-4 * scale, (ks, err / scale)
+        for w in range(4):
+            gw, ow = fast.wildcard(w), sim.wildcard(w)
+            assert np.abs(gw - ow).max() <= 1e-5 * max(np.abs(ow).max(), 1e-12) + 1e-12, w
     finally:
         orc.set_num_threads(min(8, os.cpu_count() or 1))
         fast.close()
