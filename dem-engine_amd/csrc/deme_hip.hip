@@ -128,6 +128,7 @@ struct deme_ctx {
     DevBuf revSlot;
     const void* revAcc = nullptr;
     bool pairsOnce = false;
+    bool crossStale = false;  // a scene was uploaded while the group evaluates cross-cut contacts once: rev_setup_slab runs again first
     hipEvent_t evPass1 = nullptr;
     char* pin = nullptr;       // 16 KB of pinned host memory: where the detection's read-backs land
     int spinSync = 1;          // DEME_SPIN_SYNC=0: blocking waits at the detection's read-backs
@@ -976,8 +977,11 @@ void resolve_heavy_counts(deme_ctx* c) {
     if (!c->hrPending)
         return;
     c->hrPending = false;
-    if (hipEventSynchronize(c->hrEvent) != hipSuccess)
+    if (const hipError_t e = hipEventSynchronize(c->hrEvent); e != hipSuccess) {
+        fail(c, DEME_ERR_HIP, "waiting for the heavy-owner counts: %s", hipGetErrorString(e));
+        c->heavyOverflow = true;  // (the stepping loop returns the error: launch_integrate)
         return;
+    }
     const size_t cap = c->heavyList.bytes / 4;
     c->nHeavy = c->hrPinned->nHeavy, c->nHeavyFree = c->hrPinned->nHeavyFree;
     if (c->nHeavy > cap) {
@@ -1304,7 +1308,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1540,6 +1544,12 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         for (size_t i = 0; i < DEME_NUM_FAMILIES && trivial; i++)
             trivial = s->familyExtraMarginSize[i] == 0.f;
     c->dp.familyTrivial = trivial ? 1u : 0u;
+    if (c->pairsOnce) {  // the fresh owners carry no passive marks and the reaction slots were sized for the old scene: the group
+                         // sets the mode up again before its next step (rev_setup_slab), until then this context evaluates both ways
+        c->pairsOnce = false;
+        c->revAcc = nullptr;
+        c->crossStale = true;
+    }
     c->dp.hasGhosts = (c->hasGhosts ? 1u : 0u) | (c->pairsOnce ? 2u : 0u);
     // detection scratch
     if (ensure(c, c->geo, std::max<size_t>(nS, 1) * sizeof(GeoRec)) || ensure(c, c->binLo, std::max<size_t>(nS, 1) * 16) ||
@@ -2006,14 +2016,20 @@ static int async_part2(deme_ctx* c, uint64_t nC) {
     int rc = DEME_OK;
     {
         ScopedTimer tm(c, "detect_async_part2", true);
-        HIPCK(hipMemsetAsync(c->heavy.p, 0, c->heavy.bytes, c->stream));
-        HIPCK(hipMemsetAsync(c->fixedFlag.p, 0, c->fixedFlag.bytes, c->stream));
-        rc = detect_part2(c, nC);
+        // (no early return between the swap above and the restore below: a failed call must not leave the context launching on
+        // the detection stream)
+        hipError_t e = hipMemsetAsync(c->heavy.p, 0, c->heavy.bytes, c->stream);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(c->fixedFlag.p, 0, c->fixedFlag.bytes, c->stream);
+        rc = e == hipSuccess ? detect_part2(c, nC) : fail(c, DEME_ERR_HIP, "asynchronous detection, part 2: %s", hipGetErrorString(e));
     }
     c->listOwnersSnap = false;
     c->stream = mainStream;
-    if (rc)
+    if (rc) {  // the half-built set goes back to the spare slots: the names keep the list the steps are using
+        for (size_t k = 0; k < set.size(); k++)
+            std::swap(*set[k], c->spare[k]);
         return rc;
+    }
     HIPCK(hipEventRecord(c->evP1, c->detStream));
     HIPCK(hipStreamWaitEvent(c->stream, c->evP1, 0));
     if (int rc2 = do_migrate(c))  // the history follows its contacts into the new order: with the wildcards the last step left
@@ -2333,6 +2349,7 @@ struct HaloSlab {
     hipEvent_t evPacked = nullptr;
     hipEvent_t evAcc = nullptr;  // this slab's share of the replicated owners' a / alpha is in its buffer
     hipEvent_t evRev = nullptr;  // the sums of this slab's right ghosts are packed
+    uint32_t nOwnersAtAttach = 0;
     MigPool pool;
 };
 }  // namespace
@@ -2515,6 +2532,7 @@ int deme_halo_group_attach(deme_halo_group* g, deme_ctx* c, int leftRank, deme_c
             GHIP(hipMemcpy(sd.recvIds, rIds[k], (size_t)nR[k] * 4, hipMemcpyHostToDevice));
         g->bytesPerStep += (uint64_t)nS[k] * sizeof(GhostRec);
     }
+    s.nOwnersAtAttach = c->nOwners;
     g->slabs.push_back(s);
     return DEME_OK;
 }
@@ -2621,6 +2639,10 @@ static int halo_exchange(deme_halo_group* g) {
 // ghost's owner, which adds them to the clump's own before integrating ("reverse exchange of the ghost's force").
 static int rev_setup_slab(deme_halo_group* g, HaloSlab& s) {
     deme_ctx* c = s.ctx;
+    c->crossStale = false;
+    if (c->nOwners != s.nOwnersAtAttach)
+        return gfail(g, DEME_ERR_INVALID, "cross contacts: the slab's scene changed size since it was attached (%u -> %u owners): its exchange "
+                                          "lists are stale, attach it to a new group", s.nOwnersAtAttach, c->nOwners);
     c->pairsOnce = g->pairsOnce;
     c->dp.hasGhosts = (c->hasGhosts ? 1u : 0u) | (c->pairsOnce ? 2u : 0u);
     c->revAcc = nullptr;
@@ -2804,6 +2826,14 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
         g->hostUs[3] += now_us() - t1;
         return DEME_OK;
     };
+    for (auto& s : g->slabs)  // a scene re-uploaded under the single-evaluation rule: passive marks and reaction slots again
+        if (s.ctx->crossStale && g->pairsOnce)
+            if (int rc = rev_setup_slab(g, s))
+                return rc;
+    auto clear_snap = [&]() {  // a failed step must not leave a snapshot request behind for the next call
+        for (auto& s : g->slabs)
+            s.ctx->snapPending = false;
+    };
     for (uint32_t i = 0; i < nsteps; i++) {
         // asynchronous detection (deme_set_async_detection on the slabs' contexts): every slab decides for itself -- a detection
         // is local, the exchange of a step does not depend on it.  The slabs whose lists retire D steps from now take their owner
@@ -2821,8 +2851,10 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
             for (deme_ctx* c : starters)
                 c->snapPending = true;
             for (uint32_t d = 0; d < D; d++)
-                if (int rc = one_step())
+                if (int rc = one_step()) {
+                    clear_snap();
                     return rc;
+                }
             std::vector<uint64_t> nC(starters.size(), 0);
             for (size_t k = 0; k < starters.size(); k++)
                 if (int rc = async_part1(starters[k], &nC[k]))

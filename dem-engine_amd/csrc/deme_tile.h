@@ -58,6 +58,7 @@ namespace deme_dev {
 #ifndef DEME_TILE_KI
 #define DEME_TILE_KI 0
 #endif
+typedef float v2f __attribute__((ext_vector_type(2)));  // a register pair: += compiles to v_pk_add_f32
 __device__ inline void ki_opaque(float& v) { asm volatile("" : "+v"(v)); }
 __device__ inline void ki_opaque(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ inline void ki_sink(float v) { asm volatile("" ::"v"(v)); }
@@ -318,25 +319,33 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
 #ifndef DEME_TILE_OCC
 #define DEME_TILE_OCC 1
 #endif
+#ifndef DEME_TILE_UNROLL
+#define DEME_TILE_UNROLL 0  // 1: the rounds unrolled DEME_TILE_DEPTH at a time, no rotation of the stream registers (measured: no gain, 3x the code)
+#endif
+#ifndef DEME_TILE_PKPULL
+#define DEME_TILE_PKPULL 1  // the pulls add register pairs (v_pk_add_f32); a missing entry reads the zero slot
+#endif
 #ifndef DEME_TILE_DEPTH
 #define DEME_TILE_DEPTH 3  // rounds whose streams are in flight (tInfo + history: 24 bytes per thread and round)
 #endif
 // LDS of one tile, laid out at launch from the list's own extremes (TileArgs::hCap, lCap): occupancy is bound by LDS here, and
 // the compile-time capacities (DEME_TILE_HMAX foreign owners, DEME_TILE_LMAX list entries) are twice what a packed bed needs
 //   own   [(NB + hCap) x 96 B]   staged owners
-//   recA4 [T x 16 B]  recT [T x 16 B]  recA2 [T x 8 B]   a round's contributions: (F.x F.y F.z tA.x) (tB.x tB.y tB.z -) (tA.y tA.z);
-//                                                        B's side is -F and tB
+//   recA4 [(T + 2) x 16 B]  recT [(T + 2) x 16 B]  recA2 [(T + 2) x 8 B]   a round's contributions: (F.x F.y F.z tA.x) (tB.y tB.z tB.x -)
+//                                                        (tA.y tA.z); B's side is -F and tB; slot T of each array stays zero
 //   aLo, lLo [(NB + 1) x 4 B each]   owner o's A run = positions [aLo[o], aLo[o + 1]) of the tile's range, its local-B list =
 //                                    lPos[lLo[o] .. lLo[o + 1])
 //   lPos  [lCap x 2 B]
 //   tables: components [nComp x 16 B], material pairs [nMat^2 x 32 B], analytical objects [nAnal x 64 B], masses [nMass x 4 B],
 //           family margins [256 x 4 B, only when a family has one]
+#define DEME_TILE_RSLOTS (DEME_TILE_T + 2)  // a round's contribution slots + the ZERO slot (index DEME_TILE_T) the pulls read for "no entry"
+                                            // (+ 1: the arrays behind stay 16-byte aligned)
 #define DEME_TILE_TABLE_MAX 4096u  // bytes of tables a scene may have and still take the tile path
 __host__ __device__ inline uint32_t tile_table_bytes(uint32_t nComp, uint32_t nMat, uint32_t nAnal, uint32_t nMass, uint32_t famTrivial) {
     return nComp * 16u + nMat * nMat * 32u + nAnal * 64u + ((nMass * 4u + 15u) & ~15u) + (famTrivial ? 0u : 1024u);
 }
 __host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap, uint32_t tableBytes) {
-    return (DEME_TILE_NB + hCap) * DEME_TILE_REC * 16u + DEME_TILE_T * 40u + 2u * (DEME_TILE_NB + 1u) * 4u + 8u + ((lCap * 2u + 15u) & ~15u) +
+    return (DEME_TILE_NB + hCap) * DEME_TILE_REC * 16u + DEME_TILE_RSLOTS * 40u + 2u * (DEME_TILE_NB + 1u) * 4u + 8u + ((lCap * 2u + 15u) & ~15u) +
            tableBytes + 16u;
 }
 
@@ -345,9 +354,9 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     extern __shared__ uint4 tileLds[];
     uint4* const sOwn = tileLds;
     float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * DEME_TILE_REC);
-    float4* const recT = recA4 + DEME_TILE_T;
-    float2* const recA2 = reinterpret_cast<float2*>(recT + DEME_TILE_T);
-    uint32_t* const sALo = reinterpret_cast<uint32_t*>(recA2 + DEME_TILE_T);
+    float4* const recT = recA4 + DEME_TILE_RSLOTS;
+    float2* const recA2 = reinterpret_cast<float2*>(recT + DEME_TILE_RSLOTS);
+    uint32_t* const sALo = reinterpret_cast<uint32_t*>(recA2 + DEME_TILE_RSLOTS);
     uint32_t* const sLLo = sALo + (DEME_TILE_NB + 1);
     uint16_t* const sLPos = reinterpret_cast<uint16_t*>(sLLo + (DEME_TILE_NB + 1) + 2);  // (16-byte aligned: 2 x 129 + 2 words)
     const uint32_t t = tile_block_id(a.xcdGroup);
@@ -457,6 +466,8 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             tile_stage_owner(p, T.mass, rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * DEME_TILE_REC);
         if (tid <= DEME_TILE_NB)
             sALo[tid] = bA - c0, sLLo[tid] = bL;
+        if (tid == DEME_TILE_T - 1u)  // the zero slot of the contribution arrays
+            recA4[DEME_TILE_T] = make_float4(0, 0, 0, 0), recT[DEME_TILE_T] = make_float4(0, 0, 0, 0), recA2[DEME_TILE_T] = make_float2(0, 0);
 #pragma unroll
         for (int k = 0; k < DEME_TILE_LREG; k++)
             if (tid + k * DEME_TILE_T < nL)
@@ -468,147 +479,202 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const bool sideA = tid < DEME_TILE_NB, sideB = !sideA && tid < 2 * DEME_TILE_NB;
     uint32_t plo = sideB ? sLLo[po] : sALo[po];
     const uint32_t phi = (sideA || sideB) ? (sideB ? sLLo[po + 1] : sALo[po + 1]) : plo;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
-    uint32_t c = c0 + tid;
-    for (uint32_t rlo = 0; rlo < c1 - c0; rlo += DEME_TILE_T) {
-        bool crossing = false;
-        float4 x4 = make_float4(0, 0, 0, 0), x2 = x4;
-        if (c < c1) {
-            const uint2 ci = inf[0];
-            float4 h = hist[0];
-            const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
-            const TileOwner A = tile_read_owner(sOwn, slotA), B = tile_read_owner(sOwn, slotB);
-            f3 force, tA, tB;
-            if (MESH && ((ci.x >> 20) & 3u) == DEME_KEY_CLASS_SM) {  // (rare, and only in tiles along the mesh: the loads sit behind a branch)
-                const float4 a4 = a.conA4[c], b4 = a.conB4[c];
-                const float2 a2 = a.conA2[c], b2 = a.conB2[c];
-                force = mk3(a4.x, a4.y, a4.z), tA = mk3(a4.w, a2.x, a2.y), tB = mk3(b4.w, b2.x, b2.y);
-            } else {
+    // the six sums of this thread's owner and side as three register pairs (the pulls add with v_pk_add_f32):
+    //   A side: (F.x F.y) (F.z tA.x) (tA.y tA.z);  B side: (-F.x -F.y) (-F.z tB.x) (tB.y tB.z)
+    v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, s45 = {0.f, 0.f};
+    const uint32_t nCt = c1 - c0;
+    auto refill = [&](const int d, const uint32_t c) __attribute__((always_inline)) {  // stage d takes the round DEME_TILE_DEPTH rounds ahead of contact c
+        const uint32_t cd = c + DEME_TILE_DEPTH * DEME_TILE_T;
+        inf[d] = make_uint2(0, 0), hist[d] = make_float4(0, 0, 0, 0), rbase[d] = 0u;
+        if (cd < c1) {
+            inf[d] = stream_load(a.tInfo + cd);
+            if (MODEL == 0)
+                hist[d] = stream_load(wc4 + cd);
+            rbase[d] = a.rankC[cd - (tid & 63u)];
+        }
+    };
+    auto round = [&](const int d, const uint32_t rlo) __attribute__((always_inline)) {
+            const uint32_t c = c0 + rlo + tid;
+            bool crossing = false;
+            float4 x4 = make_float4(0, 0, 0, 0), x2 = x4;
+            if (c < c1) {
+                const uint2 ci = inf[d];
+                float4 h = hist[d];
+                const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
+                const TileOwner A = tile_read_owner(sOwn, slotA), B = tile_read_owner(sOwn, slotB);
+                f3 force, tA, tB;
+                if (MESH && ((ci.x >> 20) & 3u) == DEME_KEY_CLASS_SM) {  // (rare, and only in tiles along the mesh: the loads sit behind a branch)
+                    const float4 a4 = a.conA4[c], b4 = a.conB4[c];
+                    const float2 a2 = a.conA2[c], b2 = a.conB2[c];
+                    force = mk3(a4.x, a4.y, a4.z), tA = mk3(a4.w, a2.x, a2.y), tB = mk3(b4.w, b2.x, b2.y);
+                } else {
 #if DEME_TILE_KI & 8
-                {
-                    uint2 ci2 = ci;
-                    ki_opaque(ci2.x), ki_opaque(ci2.y);
-                    float4 h2 = h;
-                    f3 f2, u2, w2;
-                    tile_contact<MODEL>(p, T, ci2, A, B, h2, f2, u2, w2);
-                    ki_sink(f2.x + f2.y + f2.z + u2.x + u2.y + u2.z + w2.x + w2.y + w2.z + h2.x + h2.y + h2.z + h2.w);
-                }
-#endif
-                tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
-#if !(DEME_TILE_KI & 16)
-                if (MODEL == 0)
-                    stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
-#endif
-            }
-            recA4[tid] = make_float4(force.x, force.y, force.z, tA.x);
-            recA2[tid] = make_float2(tA.y, tA.z);
-            if (slotB < DEME_TILE_NB) {
-                recT[tid] = make_float4(tB.x, tB.y, tB.z, 0.f);
-            } else if (ci.x & (1u << 22)) {
-                crossing = true;
-                x4 = make_float4(-force.x, -force.y, -force.z, tB.x), x2 = make_float4(tB.y, tB.z, 0.f, 0.f);
-            }
-        }
-        {   // the wavefront's crossing contacts write consecutive records
-            const uint64_t m = __ballot(crossing);
-            if (crossing) {
-                const uint32_t k = rbase[0] + (uint32_t)__popcll(m & ((1ull << (tid & 63u)) - 1ull));
-#if !(DEME_TILE_KI & 32)
-                stream_store(a.rec32 + 2 * (size_t)k, x4);
-                stream_store(a.rec32 + 2 * (size_t)k + 1, x2);
-#else
-                ki_sink(x4.x + x2.x + (float)k);
-#endif
-            }
-        }
-        // rotate the stream registers and refill the last stage
-#pragma unroll
-        for (int d = 0; d + 1 < DEME_TILE_DEPTH; d++)
-            inf[d] = inf[d + 1], hist[d] = hist[d + 1], rbase[d] = rbase[d + 1];
-        {
-            const uint32_t cd = c + DEME_TILE_DEPTH * DEME_TILE_T;
-            inf[DEME_TILE_DEPTH - 1] = make_uint2(0, 0), hist[DEME_TILE_DEPTH - 1] = make_float4(0, 0, 0, 0), rbase[DEME_TILE_DEPTH - 1] = 0u;
-            if (cd < c1) {
-                inf[DEME_TILE_DEPTH - 1] = stream_load(a.tInfo + cd);
-                if (MODEL == 0)
-                    hist[DEME_TILE_DEPTH - 1] = stream_load(wc4 + cd);
-                rbase[DEME_TILE_DEPTH - 1] = a.rankC[cd - (tid & 63u)];
-            }
-        }
-        __syncthreads();
-        const uint32_t rhi = rlo + DEME_TILE_T;
-        auto pulls = [&]() {
-        if (sideA) {  // my A run's part of this round: positions [plo, min(phi, rhi))
-            const uint32_t e = min(phi, rhi);
-            while (plo < e) {
-                float4 v4[4];
-                float2 v2[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = min(plo + k, e - 1u) - rlo;
-                    v4[k] = recA4[i], v2[k] = recA2[i];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (plo + k < e)
-                        s0 += v4[k].x, s1 += v4[k].y, s2 += v4[k].z, s3 += v4[k].w, s4 += v2[k].x, s5 += v2[k].y;
-                plo = min(plo + 4u, e);
-            }
-        } else if (sideB) {  // my local-B list's entries that fall into this round: -F and tB of those contacts
-            while (plo < phi) {
-                uint32_t pos[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    pos[k] = (plo + k < phi) ? (uint32_t)sLPos[plo + k] : 0xFFFFFFFFu;
-                if (pos[0] >= rhi)
-                    break;
-                float4 v4[4], vt[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = (pos[k] < rhi ? pos[k] : pos[0]) - rlo;
-                    v4[k] = recA4[i], vt[k] = recT[i];
-                }
-                uint32_t used = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (pos[k] < rhi) {
-                        s0 -= v4[k].x, s1 -= v4[k].y, s2 -= v4[k].z, s3 += vt[k].x, s4 += vt[k].y, s5 += vt[k].z;
-                        used++;
+                    {
+                        uint2 ci2 = ci;
+                        ki_opaque(ci2.x), ki_opaque(ci2.y);
+                        float4 h2 = h;
+                        f3 f2, u2, w2;
+                        tile_contact<MODEL>(p, T, ci2, A, B, h2, f2, u2, w2);
+                        ki_sink(f2.x + f2.y + f2.z + u2.x + u2.y + u2.z + w2.x + w2.y + w2.z + h2.x + h2.y + h2.z + h2.w);
                     }
-                plo += used;
-                if (used < 4u)
-                    break;
-            }
-        }
-        };
-#if DEME_TILE_KI & 2
-        {
-            const float k0 = s0, k1 = s1, k2 = s2, k3 = s3, k4 = s4, k5 = s5;
-            uint32_t kp = plo;
-            pulls();
-            ki_sink(s0 + s1 + s2 + s3 + s4 + s5);
-            ki_opaque(kp);
-            s0 = k0, s1 = k1, s2 = k2, s3 = k3, s4 = k4, s5 = k5, plo = kp;
-        }
 #endif
-        pulls();
-        __syncthreads();
-        c += DEME_TILE_T;
+                    tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
+#if !(DEME_TILE_KI & 16)
+                    if (MODEL == 0)
+                        stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
+#endif
+                }
+                recA4[tid] = make_float4(force.x, force.y, force.z, tA.x);
+                recA2[tid] = make_float2(tA.y, tA.z);
+                if (slotB < DEME_TILE_NB) {
+                    recT[tid] = make_float4(tB.y, tB.z, tB.x, 0.f);
+                } else if (ci.x & (1u << 22)) {
+                    crossing = true;
+                    x4 = make_float4(-force.x, -force.y, -force.z, tB.x), x2 = make_float4(tB.y, tB.z, 0.f, 0.f);
+                }
+            }
+            {   // the wavefront's crossing contacts write consecutive records
+                const uint64_t m = __ballot(crossing);
+                if (crossing) {
+                    const uint32_t k = rbase[d] + (uint32_t)__popcll(m & ((1ull << (tid & 63u)) - 1ull));
+#if !(DEME_TILE_KI & 32)
+                    stream_store(a.rec32 + 2 * (size_t)k, x4);
+                    stream_store(a.rec32 + 2 * (size_t)k + 1, x2);
+#else
+                    ki_sink(x4.x + x2.x + (float)k);
+#endif
+                }
+            }
+            
+#if DEME_TILE_UNROLL
+            refill(d, c);
+#else
+#pragma unroll
+            for (int q = 0; q + 1 < DEME_TILE_DEPTH; q++)
+                inf[q] = inf[q + 1], hist[q] = hist[q + 1], rbase[q] = rbase[q + 1];
+            refill(DEME_TILE_DEPTH - 1, c);
+#endif
+
+            __syncthreads();
+            const uint32_t rhi = rlo + DEME_TILE_T;
+            auto pulls = [&]() {
+                if (sideA) {  // my A run's part of this round: positions [plo, min(phi, rhi)); a missing entry reads the zero slot
+                    const uint32_t e = min(phi, rhi);
+                    while (plo < e) {
+                        float4 v4[4];
+                        float2 v2[4];
+#if DEME_TILE_PKPULL
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t i = (plo + k < e) ? plo + k - rlo : (uint32_t)DEME_TILE_T;
+                            v4[k] = recA4[i], v2[k] = recA2[i];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            s01 += v2f{v4[k].x, v4[k].y};
+                            s23 += v2f{v4[k].z, v4[k].w};
+                            s45 += v2f{v2[k].x, v2[k].y};
+                        }
+#else
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t i = min(plo + k, e - 1u) - rlo;
+                            v4[k] = recA4[i], v2[k] = recA2[i];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (plo + k < e)
+                                s01.x += v4[k].x, s01.y += v4[k].y, s23.x += v4[k].z, s23.y += v4[k].w, s45.x += v2[k].x, s45.y += v2[k].y;
+#endif
+                        plo = min(plo + 4u, e);
+                    }
+                } else if (sideB) {  // my local-B list's entries that fall into this round: -F and tB of those contacts
+                    while (plo < phi) {
+                        uint32_t pos[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            pos[k] = (plo + k < phi) ? (uint32_t)sLPos[plo + k] : 0xFFFFFFFFu;
+                        if (pos[0] >= rhi)
+                            break;
+                        float4 v4[4], vt[4];
+                        uint32_t used = 0;
+#if DEME_TILE_PKPULL
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const bool in = pos[k] < rhi;  // (ascending: the entries of this round come first)
+                            const uint32_t i = in ? pos[k] - rlo : (uint32_t)DEME_TILE_T;
+                            v4[k] = recA4[i], vt[k] = recT[i];
+                            used += in ? 1u : 0u;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            s01 -= v2f{v4[k].x, v4[k].y};
+                            s23.x -= v4[k].z;
+                            s23.y += vt[k].z;
+                            s45 += v2f{vt[k].x, vt[k].y};
+                        }
+#else
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t i = (pos[k] < rhi ? pos[k] : pos[0]) - rlo;
+                            v4[k] = recA4[i], vt[k] = recT[i];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (pos[k] < rhi) {
+                                s01.x -= v4[k].x, s01.y -= v4[k].y, s23.x -= v4[k].z, s23.y += vt[k].z, s45.x += vt[k].x, s45.y += vt[k].y;
+                                used++;
+                            }
+#endif
+                        plo += used;
+                        if (used < 4u)
+                            break;
+                    }
+                }
+            };
+#if DEME_TILE_KI & 2
+            {
+                const v2f k01 = s01, k23 = s23, k45 = s45;
+                uint32_t kp = plo;
+                pulls();
+                ki_sink(s01.x + s01.y + s23.x + s23.y + s45.x + s45.y);
+                ki_opaque(kp);
+                s01 = k01, s23 = k23, s45 = k45, plo = kp;
+            }
+#endif
+            pulls();
+            __syncthreads();
+    };
+#if DEME_TILE_UNROLL
+    // The rounds, DEME_TILE_DEPTH at a time with the stage of the stream registers a round uses fixed at compile time: nothing is
+    // rotated between rounds
+    for (uint32_t rb = 0; rb < nCt; rb += DEME_TILE_DEPTH * DEME_TILE_T) {
+#pragma unroll
+        for (int d = 0; d < DEME_TILE_DEPTH; d++) {
+            const uint32_t rlo = rb + d * DEME_TILE_T;
+            if (rlo >= nCt)  // (uniform over the workgroup)
+                break;
+            round(d, rlo);
+        }
     }
+#else
+    for (uint32_t rlo = 0; rlo < nCt; rlo += DEME_TILE_T)  // stage 0 is the current round; the stages are rotated after it
+        round(0, rlo);
+#endif
     // A-side sum + B-side sum, through LDS (the contribution arrays are free now)
     if (sideB) {
-        recA4[po] = make_float4(s0, s1, s2, s3);
-        recA2[po] = make_float2(s4, s5);
+        recA4[po] = make_float4(s01.x, s01.y, s23.x, s23.y);
+        recA2[po] = make_float2(s45.x, s45.y);
     }
     __syncthreads();
     if (sideA && po < nLoc) {
         const float4 b4 = recA4[po];
         const float2 b2 = recA2[po];
 #if !(DEME_TILE_KI & 64)
-        a.tSum[2 * (size_t)(o0 + po)] = make_float4(s0 + b4.x, s1 + b4.y, s2 + b4.z, 0.f);
-        a.tSum[2 * (size_t)(o0 + po) + 1] = make_float4(s3 + b4.w, s4 + b2.x, s5 + b2.y, 0.f);
+        a.tSum[2 * (size_t)(o0 + po)] = make_float4(s01.x + b4.x, s01.y + b4.y, s23.x + b4.z, 0.f);
+        a.tSum[2 * (size_t)(o0 + po) + 1] = make_float4(s23.y + b4.w, s45.x + b2.x, s45.y + b2.y, 0.f);
 #else
-        ki_sink(s0 + b4.x + s1 + b4.y + s2 + b4.z + s3 + b4.w + s4 + b2.x + s5 + b2.y);
+        ki_sink(s01.x + b4.x + s01.y + b4.y + s23.x + b4.z + s23.y + b4.w + s45.x + b2.x + s45.y + b2.y);
 #endif
     }
 }
