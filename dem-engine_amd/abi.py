@@ -457,6 +457,17 @@ class Context:
         self._ck(self.lib.deme_force_kernel_name(self.h, buf, 64, C.byref(h), C.byref(l)), "deme_force_kernel_name")
         return buf.value.decode(), int(h.value), int(l.value)
 
+    def engine_order(self):
+        """(reordered, spread in the caller's order, spread along the curve): deme_get_order"""
+        r, sp = C.c_int(0), (C.c_double * 2)()
+        self.lib.deme_get_order.argtypes = [_P, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        self._ck(self.lib.deme_get_order(self.h, C.byref(r), sp), "deme_get_order")
+        return bool(r.value), float(sp[0]), float(sp[1])
+
+    def set_reorder(self, enable):
+        self.lib.deme_set_reorder.argtypes = [_P, C.c_int]
+        self._ck(self.lib.deme_set_reorder(self.h, int(bool(enable))), "deme_set_reorder")
+
     def download_state(self):
         st, out = make_state_struct(self.n_owners)
         self._ck(self.lib.deme_download_owner_state(self.h, C.byref(st)), "deme_download_owner_state")

@@ -129,6 +129,10 @@ struct DevParams {
     const uint8_t* familyFlags;
     const void* tris;  // TriRec[nTri] (deme_mesh.h)
     uint32_t nTri;
+    // engine-side spatial order (deme_order.inc): the caller's id of every sphere / owner when the engine numbers them along a
+    // Z-order curve of its own; null = the caller's order is the engine's
+    const uint32_t* s2e;
+    const uint32_t* o2e;
 };
 
 // n / d for a run-time divisor without the ~35-instruction integer division: m = floor(2^32 / d) (0xFFFFFFFF for d = 1) gives

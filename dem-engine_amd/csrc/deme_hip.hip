@@ -181,6 +181,15 @@ struct deme_ctx {
     // arithmetic mode (deme_set_arith_mode): DEME_ARITH_FAST (default) or DEME_ARITH_EXACT
     int arith = DEME_ARITH_FAST;
     uint32_t xcdGroup = 0;  // XCD-aware block order of the force kernel (ForceArgs::xcdGroup)
+    // engine-side spatial order (deme_order.inc): slot -> caller id and back, for owners and spheres (empty: the caller's order)
+    bool permuted = false;
+    int reorderEnable = 1;
+    std::vector<uint32_t> hO2E, hE2O, hS2E, hE2S;
+    DevBuf dO2E, dS2E;
+    double orderSpread[2] = {0, 0};  // cells per tile bounding box: in the caller's order, along the curve
+    uint64_t listSerial = 0, viewSerial = ~0ull;  // the caller's view of the current list (ids and order), cached per list
+    std::vector<uint64_t> viewKeys;
+    std::vector<uint32_t> viewPerm;
     int timing = 0;  // 0 off; n > 0: every n-th launch of each timed kernel is bracketed with HIP events
     std::map<std::string, TimerSlot> timers;
     std::vector<hipEvent_t> eventPool;
@@ -342,6 +351,8 @@ void refresh_dev_params(deme_ctx* c) {
     d.familyFlags = c->famFlags.as<uint8_t>();
     d.tris = c->tris.p;
     d.nTri = c->nTri;
+    d.s2e = c->permuted ? c->dS2E.as<uint32_t>() : nullptr;
+    d.o2e = c->permuted ? c->dO2E.as<uint32_t>() : nullptr;
 }
 
 int check_ready(deme_ctx* c) {
@@ -912,6 +923,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
         c->nPrev = c->haveList ? c->nContacts : 0;
         c->nContacts = nC;
         c->keysCur = next;
+        c->listSerial++;
         c->haveList = true;
         c->seeded = false;
         c->mapFresh = true;
@@ -1223,6 +1235,8 @@ void launch_full_reduction(deme_ctx* c) {
 
 }  // namespace
 
+#include "deme_order.inc"
+
 // ================================================================================================
 extern "C" {
 
@@ -1308,7 +1322,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1376,6 +1390,32 @@ int deme_force_kernel_name(const deme_ctx* c, char* name, size_t cap, uint32_t* 
     return DEME_OK;
 }
 
+int deme_get_order(const deme_ctx* c, int* reordered, double spread[2]) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    if (reordered)
+        *reordered = c->permuted ? 1 : 0;
+    if (spread)
+        spread[0] = c->orderSpread[0], spread[1] = c->orderSpread[1];
+    return DEME_OK;
+}
+int deme_order_probe(const DemeParams* p, size_t nClumps, const uint64_t* voxelID, const uint16_t* locX, const uint16_t* locY,
+                     const uint16_t* locZ, uint32_t* order, double spread[2]) {
+    if (!p || !voxelID || !locX || !locY || !locZ || !spread || !(p->binSize > 0) || !(p->l > 0))
+        return DEME_ERR_INVALID;
+    std::vector<uint32_t> ord;
+    order_compute(*p, nClumps, voxelID, locX, locY, locZ, ord, spread);
+    if (order)
+        memcpy(order, ord.data(), nClumps * 4);
+    return DEME_OK;
+}
+int deme_set_reorder(deme_ctx* c, int enable) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    c->reorderEnable = enable ? 1 : 0;
+    return DEME_OK;
+}
+
 int deme_sync(deme_ctx* c) {
     if (!c)
         return DEME_ERR_INVALID;
@@ -1416,10 +1456,18 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     c->hNextAcc.clear();
     c->nMat = s->nMat, c->nComp = s->nComp, c->nMassProps = s->nMassProps;
     const size_t nO = s->nOwners, nS = s->nSpheres;
+    // (persistent marks are kept in the engine's ids: they cross a re-upload in the caller's)
+    for (auto& k : c->hPersist)
+        k = order_key_out(c, k);
+    // the engine's own order of clumps and spheres (deme_order.inc): slot k holds the caller's owner o2e(k)
+    c->permuted = order_decide(c, s);
+    c->viewSerial = ~0ull;
+    auto o2e = [&](size_t k) { return c->permuted ? (size_t)c->hO2E[k] : k; };
     // owners
     std::vector<OwnerRec> ho(nO);
-    for (size_t i = 0; i < nO; i++) {
-        OwnerRec& r = ho[i];
+    for (size_t k = 0; k < nO; k++) {
+        const size_t i = o2e(k);
+        OwnerRec& r = ho[k];
         r.voxelID = s->voxelID[i];
         r.locX = s->locX[i], r.locY = s->locY[i], r.locZ = s->locZ[i];
         r.inertiaOff = s->inertiaPropOffsets ? s->inertiaPropOffsets[i] : 0;
@@ -1458,10 +1506,11 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     c->conValid = false;
     // spheres
     std::vector<SphereRec> hs(nS);
-    for (size_t i = 0; i < nS; i++) {
-        hs[i].owner = s->ownerClumpBody[i];
-        hs[i].comp = s->clumpComponentOffset[i];
-        hs[i].mat = s->sphereMaterialOffset ? s->sphereMaterialOffset[i] : 0;
+    for (size_t k = 0; k < nS; k++) {
+        const size_t i = c->permuted ? (size_t)c->hS2E[k] : k;
+        hs[k].owner = order_owner_in(c, s->ownerClumpBody[i]);
+        hs[k].comp = s->clumpComponentOffset[i];
+        hs[k].mat = s->sphereMaterialOffset ? s->sphereMaterialOffset[i] : 0;
     }
     if (int rc = upload(c, c->spheres, hs.data(), nS))
         return rc;
@@ -1599,7 +1648,6 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         HIPCK(hipStreamSynchronize(c->stream));
     }
     if (!c->hPersist.empty()) {  // persistent marks survive a re-upload (UpdateClumps appends) as long as their ids still exist
-        const size_t before = c->hPersist.size();
         c->hPersist.erase(std::remove_if(c->hPersist.begin(), c->hPersist.end(),
                                          [&](uint64_t k) {
                                              const uint32_t cls = key_class(k);
@@ -1607,13 +1655,22 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
                                              return key_a(k) >= s->nSpheres || key_b(k) >= nB;
                                          }),
                           c->hPersist.end());
-        if (c->hPersist.size() != before && !c->hPersist.empty())
+        for (auto& k : c->hPersist)
+            k = order_key_in(c, k);
+        std::sort(c->hPersist.begin(), c->hPersist.end());
+        if (!c->hPersist.empty()) {
+            if (int rc = ensure(c, c->persistKeys, c->hPersist.size() * 8))
+                return rc;
             HIPCK(hipMemcpyAsync(c->persistKeys.p, c->hPersist.data(), c->hPersist.size() * 8, hipMemcpyHostToDevice, c->stream));
+        }
     }
+    if (int rc = order_upload_maps(c))
+        return rc;
     c->haveScene = true;
     c->haveList = false;
     c->mapFresh = false;
     c->nContacts = c->nPrev = c->nWcStored = 0;
+    c->listSerial++;
     c->stepsSinceCD = 0;
     refresh_dev_params(c);
     HIPCK(hipStreamSynchronize(c->stream));  // host staging vectors die here
@@ -1667,7 +1724,7 @@ static int owner_state_io(deme_ctx* c, const DemeOwnerState* st, int dir) {
     AccRec* accView = c->acc.as<AccRec>();
     if (n)
         hipLaunchKernelGGL(k_pack_owners, dim3(grid_for(n)), dim3(256), 0, c->stream, (uint32_t)n,
-                           c->owners.as<OwnerRec>(), accView, soa, dir);
+                           c->owners.as<OwnerRec>(), accView, soa, dir, c->dp.o2e);
     if (dir == 1) {
         off = 0;
         for (auto& cl : cols) {
@@ -1725,7 +1782,7 @@ int deme_set_margins(deme_ctx* c, const float* m) {
         return rc;
     HIPCK(hipMemcpyAsync(c->stage.p, m, (size_t)c->nOwners * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_set_margins, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->nOwners,
-                       c->owners.as<OwnerRec>(), c->stage.as<float>());
+                       c->owners.as<OwnerRec>(), c->stage.as<float>(), c->dp.o2e);
     HIPCK(hipStreamSynchronize(c->stream));
     return DEME_OK;
 }
@@ -2526,10 +2583,20 @@ int deme_halo_group_attach(deme_halo_group* g, deme_ctx* c, int leftRank, deme_c
         GHIP(hipMalloc(&sd.recvIds, std::max<size_t>(nR[k], 1) * 4));
         GHIP(hipMalloc(&sd.sendBuf, std::max<size_t>(nS[k], 1) * sizeof(GhostRec)));
         GHIP(hipMalloc(&sd.recvBuf, std::max<size_t>(nR[k], 1) * sizeof(GhostRec)));
+        std::vector<uint32_t> ts, tr;
+        const uint32_t *ps = sIds[k], *pr = rIds[k];
+        if (c->permuted) {  // (a context with its own order holds no ghosts, so these lists are empty in practice)
+            ts.assign(ps, ps + nS[k]), tr.assign(pr, pr + nR[k]);
+            for (auto& v : ts)
+                v = c->hE2O[v];
+            for (auto& v : tr)
+                v = c->hE2O[v];
+            ps = ts.data(), pr = tr.data();
+        }
         if (nS[k])
-            GHIP(hipMemcpy(sd.sendIds, sIds[k], (size_t)nS[k] * 4, hipMemcpyHostToDevice));
+            GHIP(hipMemcpy(sd.sendIds, ps, (size_t)nS[k] * 4, hipMemcpyHostToDevice));
         if (nR[k])
-            GHIP(hipMemcpy(sd.recvIds, rIds[k], (size_t)nR[k] * 4, hipMemcpyHostToDevice));
+            GHIP(hipMemcpy(sd.recvIds, pr, (size_t)nR[k] * 4, hipMemcpyHostToDevice));
         g->bytesPerStep += (uint64_t)nS[k] * sizeof(GhostRec);
     }
     s.nOwnersAtAttach = c->nOwners;
@@ -2947,13 +3014,30 @@ int deme_download_bin_incidence(deme_ctx* c, uint32_t* bins, uint32_t* sph, size
         return rc;
     if (cap < c->nInc)
         return fail(c, DEME_ERR_INVALID, "buffer too small: need %llu", (unsigned long long)c->nInc);
+    std::vector<uint32_t> hb;
+    uint32_t* binsHost = bins;
+    if (c->permuted && sph && !bins) {  // (the bins are needed to put each bin's spheres in the caller's order)
+        hb.resize(c->nInc);
+        binsHost = hb.data();
+    }
     if (c->nInc) {
-        if (bins)
-            HIPCK(hipMemcpyAsync(bins, c->incKeys[1].p, c->nInc * 4, hipMemcpyDeviceToHost, c->stream));
+        if (binsHost)
+            HIPCK(hipMemcpyAsync(binsHost, c->incKeys[1].p, c->nInc * 4, hipMemcpyDeviceToHost, c->stream));
         if (sph)
             HIPCK(hipMemcpyAsync(sph, c->incVals[1].p, c->nInc * 4, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCK(hipStreamSynchronize(c->stream));
+    if (c->permuted && sph) {  // caller's sphere ids, ascending within every bin
+        for (size_t i = 0; i < c->nInc; i++)
+            sph[i] = c->hS2E[sph[i]];
+        for (size_t b = 0; b < c->nInc;) {
+            size_t e = b + 1;
+            while (e < c->nInc && binsHost[e] == binsHost[b])
+                e++;
+            std::sort(sph + b, sph + e);
+            b = e;
+        }
+    }
     return DEME_OK;
 }
 
@@ -2963,13 +3047,30 @@ int deme_download_contacts(deme_ctx* c, uint32_t* idA, uint32_t* idB, uint8_t* t
     const size_t n = c->nContacts;
     if (cap < n)
         return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
-    std::vector<uint64_t> k(n);
-    if (n) {
-        HIPCK(hipMemcpyAsync(k.data(), c->keysSorted[c->keysCur].p, n * 8, hipMemcpyDeviceToHost, c->stream));
-        if (mapping)
-            HIPCK(hipMemcpyAsync(mapping, c->mapping.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    // the list in the caller's ids and canonical order (the engine's own when it keeps the caller's numbering)
+    if (int rc = order_current_view(c))
+        return rc;
+    const std::vector<uint64_t>& k = c->viewKeys;
+    if (mapping && n) {
+        std::vector<uint32_t> m(n);
+        HIPCK(hipMemcpyAsync(m.data(), c->mapping.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        if (!c->permuted) {
+            memcpy(mapping, m.data(), n * 4);
+        } else {  // row i of the caller's view came from which row of the caller's view of the PREVIOUS list
+            std::vector<uint64_t> pk;
+            std::vector<uint32_t> pperm;
+            if (int rc = order_view_of(c, c->keysSorted[c->keysCur ^ 1].as<uint64_t>(), c->nPrev, pk, pperm))
+                return rc;
+            std::vector<uint32_t> pinv(c->nPrev);
+            for (size_t i = 0; i < c->nPrev; i++)
+                pinv[pperm[i]] = (uint32_t)i;
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t from = m[c->viewPerm[i]];
+                mapping[i] = from < c->nPrev ? pinv[from] : from;
+            }
+        }
     }
-    HIPCK(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < n; i++) {
         const uint32_t cls = key_class(k[i]);
         if (idA)
@@ -3005,6 +3106,13 @@ int deme_download_contact_wildcard(deme_ctx* c, uint32_t w, float* out, size_t c
     if (n)
         HIPCK(hipMemcpyAsync(h.data(), c->wc[c->wcCur].p, n * nW * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
+    if (c->permuted) {  // rows in the caller's list order
+        if (int rc = order_current_view(c))
+            return rc;
+        for (size_t i = 0; i < n; i++)
+            out[i] = h[(size_t)c->viewPerm[i] * nW + w];
+        return DEME_OK;
+    }
     for (size_t i = 0; i < n; i++)
         out[i] = h[i * nW + w];
     return DEME_OK;
@@ -3024,8 +3132,11 @@ int deme_upload_contact_wildcard(deme_ctx* c, uint32_t w, const float* in, size_
     if (n)
         HIPCK(hipMemcpyAsync(h.data(), c->wc[c->wcCur].p, n * nW * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
+    if (c->permuted)
+        if (int rc = order_current_view(c))
+            return rc;
     for (size_t i = 0; i < n; i++)
-        h[i * nW + w] = in[i];
+        h[(c->permuted ? (size_t)c->viewPerm[i] : i) * nW + w] = in[i];
     if (n)
         HIPCK(hipMemcpyAsync(c->wc[c->wcCur].p, h.data(), n * nW * 4, hipMemcpyHostToDevice, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -3061,7 +3172,7 @@ int deme_seed_contacts(deme_ctx* c, const uint32_t* idA, const uint32_t* idB, co
                 flip[i] = 1;
             }
         }
-        keys[i] = make_key(cls, a, b);
+        keys[i] = order_key_in(c, make_key(cls, a, b));  // (roles by the caller's ids; the engine's slots name the spheres)
     }
     std::vector<uint32_t> perm(n);
     for (size_t i = 0; i < n; i++)
@@ -3089,6 +3200,7 @@ int deme_seed_contacts(deme_ctx* c, const uint32_t* idA, const uint32_t* idB, co
     }
     HIPCK(hipStreamSynchronize(c->stream));
     c->nContacts = n;
+    c->listSerial++;
     c->nPrev = 0;
     c->nWcStored = n;
     c->haveList = true;
@@ -3118,6 +3230,19 @@ int deme_download_contact_records(deme_ctx* c, float* force, float* torqueOnly, 
     if (cap < n)
         return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
     float* dst[4] = {force, torqueOnly, cpA, cpB};
+    if (c->permuted) {
+        if (int rc = order_current_view(c))
+            return rc;
+        std::vector<float> h(n * 3);
+        for (int k = 0; k < 4; k++)
+            if (dst[k] && n) {
+                HIPCK(hipMemcpyAsync(h.data(), c->rec[k].p, n * 12, hipMemcpyDeviceToHost, c->stream));
+                HIPCK(hipStreamSynchronize(c->stream));
+                for (size_t i = 0; i < n; i++)
+                    memcpy(dst[k] + 3 * i, h.data() + 3 * (size_t)c->viewPerm[i], 12);
+            }
+        return DEME_OK;
+    }
     for (int k = 0; k < 4; k++)
         if (dst[k] && n)
             HIPCK(hipMemcpyAsync(dst[k], c->rec[k].p, n * 12, hipMemcpyDeviceToHost, c->stream));
@@ -3135,11 +3260,12 @@ int deme_download_sphere_geometry(deme_ctx* c, double* X, double* Y, double* Z, 
     if (n)
         HIPCK(hipMemcpyAsync(h.data(), c->geo.p, n * sizeof(GeoRec), hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < n; i++) {
-        if (X) X[i] = h[i].x;
-        if (Y) Y[i] = h[i].y;
-        if (Z) Z[i] = h[i].z;
-        if (R) R[i] = h[i].r;
+    for (size_t k = 0; k < n; k++) {
+        const size_t i = order_sphere_out(c, (uint32_t)k);
+        if (X) X[i] = h[k].x;
+        if (Y) Y[i] = h[k].y;
+        if (Z) Z[i] = h[k].z;
+        if (R) R[i] = h[k].r;
     }
     return DEME_OK;
 }
@@ -3217,6 +3343,14 @@ int deme_upload_wildcard_array(deme_ctx* c, uint32_t kind, uint32_t index, const
         return fail(c, DEME_ERR_INVALID, "wildcard array of kind %u holds %zu values, %zu given", kind, wc_array_len(c, kind), n);
     if (int rc = ensure(c, c->userWc[kind][index], std::max<size_t>(n, 1) * 4))
         return rc;
+    std::vector<float> tmp;
+    if (c->permuted && kind <= 1 && n) {  // per owner / per sphere: into the engine's slots
+        const std::vector<uint32_t>& m = kind == 0 ? c->hO2E : c->hS2E;
+        tmp.resize(n);
+        for (size_t k = 0; k < n; k++)
+            tmp[k] = in[m[k]];
+        in = tmp.data();
+    }
     if (n)
         HIPCK(hipMemcpyAsync(c->userWc[kind][index].p, in, n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -3234,6 +3368,12 @@ int deme_download_wildcard_array(deme_ctx* c, uint32_t kind, uint32_t index, flo
     if (n)
         HIPCK(hipMemcpyAsync(out, c->userWc[kind][index].p, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
+    if (c->permuted && kind <= 1 && n) {
+        const std::vector<uint32_t>& m = kind == 0 ? c->hO2E : c->hS2E;
+        std::vector<float> tmp(out, out + n);
+        for (size_t k = 0; k < n; k++)
+            out[m[k]] = tmp[k];
+    }
     return DEME_OK;
 }
 
@@ -3319,13 +3459,16 @@ int deme_add_owner_acc(deme_ctx* c, uint32_t owner, uint32_t n, const float* acc
         HIPCK(hipMemsetAsync(c->nextAcc.p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
     }
     for (uint32_t k = 0; k < n; k++) {
-        AccRec& r = c->hNextAcc[owner + k];
+        const uint32_t slot = order_owner_in(c, owner + k);
+        AccRec& r = c->hNextAcc[slot];
         if (acc)
             r.ax = acc[3 * k], r.ay = acc[3 * k + 1], r.az = acc[3 * k + 2];
         if (angAcc)
             r.lx = angAcc[3 * k], r.ly = angAcc[3 * k + 1], r.lz = angAcc[3 * k + 2];
+        if (c->permuted)  // (the caller's range is not a range of slots)
+            HIPCK(hipMemcpyAsync(c->nextAcc.as<AccRec>() + slot, &r, sizeof(AccRec), hipMemcpyHostToDevice, c->stream));
     }
-    if (n)
+    if (n && !c->permuted)
         HIPCK(hipMemcpyAsync(c->nextAcc.as<AccRec>() + owner, c->hNextAcc.data() + owner, (size_t)n * sizeof(AccRec),
                              hipMemcpyHostToDevice, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -3379,8 +3522,14 @@ int deme_download_persistent_contacts(deme_ctx* c, uint32_t* idA, uint32_t* idB,
     const size_t n = c->hPersist.size();
     if (cap < n)
         return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    std::vector<uint64_t> keys(c->hPersist);
+    if (c->permuted) {
+        for (auto& k : keys)
+            k = order_key_out(c, k);
+        std::sort(keys.begin(), keys.end());
+    }
     for (size_t i = 0; i < n; i++) {
-        const uint64_t k = c->hPersist[i];
+        const uint64_t k = keys[i];
         const uint32_t cls = key_class(k);
         if (idA)
             idA[i] = key_a(k);
@@ -3408,7 +3557,7 @@ int deme_upload_persistent_contacts(deme_ctx* c, const uint32_t* idA, const uint
         if (idA[i] >= c->dp.nSpheres || idB[i] >= nB)
             return fail(c, DEME_ERR_INVALID, "deme_upload_persistent_contacts: pair %zu (%u, %u, type %u) is out of range", i, idA[i],
                         idB[i], (unsigned)type[i]);
-        keys[i] = make_key(cls, idA[i], idB[i]);
+        keys[i] = order_key_in(c, make_key(cls, idA[i], idB[i]));
     }
     std::sort(keys.begin(), keys.end());
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
@@ -3660,6 +3809,12 @@ int deme_inspect_values(deme_ctx* c, uint32_t q, float* out, size_t cap) {
     if (n)
         HIPCK(hipMemcpyAsync(out, c->stage.p, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
+    if (c->permuted && n) {  // per sphere or per owner: back into the caller's numbering
+        const std::vector<uint32_t>& m = n == c->nSpheres && n != c->nOwners ? c->hS2E : (q <= DEME_INSPECT_CLUMP_MAX_ABSV ? c->hS2E : c->hO2E);
+        std::vector<float> tmp(out, out + n);
+        for (size_t k = 0; k < n; k++)
+            out[m[k]] = tmp[k];
+    }
     return DEME_OK;
 }
 

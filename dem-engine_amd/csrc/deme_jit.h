@@ -258,8 +258,9 @@ extern "C" __global__ __launch_bounds__(256) void deme_prescribe(const deme_dev:
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    const uint32_t ownerID = list[i];
-    OwnerRec r = load_owner(owners, ownerID);
+    const uint32_t slot = list[i];
+    OwnerRec r = load_owner(owners, slot);
+    const uint32_t ownerID = p.o2e ? p.o2e[slot] : slot;  // what user code sees is the caller's number of the owner
     const deme::family_t family = (deme::family_t)r.family;
     d3 P = decode_pos(r.voxelID, r.locX, r.locY, r.locZ, p);
     double X = P.x + (double)p.LBFX, Y = P.y + (double)p.LBFY, Z = P.z + (double)p.LBFZ;

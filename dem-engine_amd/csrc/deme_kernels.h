@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256) void k_margins(const DevParams p, OwnerRec* ow
     r->margin = (float)((double)(absv * p.expSafetyMulti + p.expSafetyAdder) * (double)p.h * (double)drift + (double)extra);
 }
 
-__global__ __launch_bounds__(256) void k_set_margins(uint32_t n, OwnerRec* owners, const float* m) {
+__global__ __launch_bounds__(256) void k_set_margins(uint32_t n, OwnerRec* owners, const float* m, const uint32_t* __restrict__ o2e) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o < n)
-        owners[o].margin = m[o];
+        owners[o].margin = m[o2e ? o2e[o] : o];
 }
 
 // ---------------------------------------------------------------------------
@@ -366,8 +366,12 @@ __device__ inline void sweep_emit(SweepLDS& L, bool hit, uint64_t key, uint32_t 
     }
 }
 
-__device__ inline uint64_t ss_key(uint32_t a, uint32_t b) {
-    return (a < b) ? make_key(DEME_KEY_CLASS_SS, a, b) : make_key(DEME_KEY_CLASS_SS, b, a);
+// Which sphere of a pair is A: the one with the smaller id IN THE CALLER'S NUMBERING (the reference's i < j loop runs over its
+// own numbering, and the choice matters: the contact point is computed from B's side).  When the engine keeps the spheres in a
+// spatial order of its own (DevParams::s2e, deme_order.inc) the roles follow the caller's ids, so that lists, contact points
+// and histories are those of the caller's numbering whatever the internal one is.
+__device__ inline bool a_before_b(const DevParams& p, uint32_t a, uint32_t b) {
+    return p.s2e ? p.s2e[a] < p.s2e[b] : a < b;
 }
 
 // all lanes of one wavefront: exact test of the first `cnt` queued pairs (entry i | entry q << 16) and emission of the hits
@@ -385,11 +389,15 @@ __device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const GeoR
         // rounding of a bin face must fall on the same side in every bin that tests the pair -- the cyclic pairing meets
         // the two entries in either order, which (measured: once per ~1e9 pair evaluations) dropped or doubled a contact.
         const uint32_t e0 = e & 0xFFFFu, e1 = e >> 16;
-        const uint32_t i = min(e0, e1), q = max(e0, e1);
+        uint32_t i = min(e0, e1), q = max(e0, e1);
+        if (p.s2e && p.s2e[L.sph[i]] > p.s2e[L.sph[q]]) {  // (entries of one bin are in ascending engine order; the roles follow the caller's ids)
+            const uint32_t t = i;
+            i = q, q = t;
+        }
         const GeoRec ga = geo[L.sph[i]], gb = geo[L.sph[q]];  // the fp64 records: only the ~3 % that pass the pre-filter need them
         hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], gb.x, gb.y, gb.z, gb.r, L.owner[q], L.fam[q], L.bin[q]);
         if (hit)
-            key = ss_key(L.sph[i], L.sph[q]);
+            key = make_key(DEME_KEY_CLASS_SS, L.sph[i], L.sph[q]);
     }
     sweep_emit(L, hit, key, lane, ar);
 }
@@ -635,9 +643,15 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                         uint64_t key = 0;
                         if (act) {
                             const GeoRec ga = geo[L.sph[i]];  // same address for every lane
-                            hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf, gbin);
-                            if (hit)
-                                key = ss_key(L.sph[i], ms);
+                            if (a_before_b(p, L.sph[i], ms)) {
+                                hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf, gbin);
+                                if (hit)
+                                    key = make_key(DEME_KEY_CLASS_SS, L.sph[i], ms);
+                            } else {  // (only with an engine-side order: the lane's sphere has the smaller caller id)
+                                hit = pair_test(p, mx, my, mz, mr, mo, mf, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], gbin);
+                                if (hit)
+                                    key = make_key(DEME_KEY_CLASS_SS, ms, L.sph[i]);
+                            }
                         }
                         sweep_emit(L, hit, key, lane, ar);
                     }
@@ -1454,59 +1468,60 @@ struct OwnerSoA {
 };
 
 // dir 0: SoA -> records (null members keep the record's value); dir 1: records -> SoA
-__global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owners, AccRec* acc, OwnerSoA s, int dir) {
+__global__ __launch_bounds__(256) void k_pack_owners(uint32_t n, OwnerRec* owners, AccRec* acc, OwnerSoA s, int dir, const uint32_t* __restrict__ o2e) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n)
         return;
     OwnerRec r = owners[o];
     AccRec a = acc[o];
+    const uint32_t e = o2e ? o2e[o] : o;  // the caller's number of this owner (engine-side spatial order, deme_order.inc)
     if (dir == 0) {
-        if (s.voxelID) r.voxelID = s.voxelID[o];
-        if (s.locX) r.locX = s.locX[o];
-        if (s.locY) r.locY = s.locY[o];
-        if (s.locZ) r.locZ = s.locZ[o];
-        if (s.oriQw) r.qw = s.oriQw[o];
-        if (s.oriQx) r.qx = s.oriQx[o];
-        if (s.oriQy) r.qy = s.oriQy[o];
-        if (s.oriQz) r.qz = s.oriQz[o];
-        if (s.vX) r.vx = s.vX[o];
-        if (s.vY) r.vy = s.vY[o];
-        if (s.vZ) r.vz = s.vZ[o];
-        if (s.omgBarX) r.wx = s.omgBarX[o];
-        if (s.omgBarY) r.wy = s.omgBarY[o];
-        if (s.omgBarZ) r.wz = s.omgBarZ[o];
-        if (s.familyID) r.family = (r.family & OWNER_FLAG_BITS) | s.familyID[o];
-        if (s.inertiaPropOffsets) r.inertiaOff = s.inertiaPropOffsets[o];
-        if (s.aX) a.ax = s.aX[o];
-        if (s.aY) a.ay = s.aY[o];
-        if (s.aZ) a.az = s.aZ[o];
-        if (s.alphaX) a.lx = s.alphaX[o];
-        if (s.alphaY) a.ly = s.alphaY[o];
-        if (s.alphaZ) a.lz = s.alphaZ[o];
+        if (s.voxelID) r.voxelID = s.voxelID[e];
+        if (s.locX) r.locX = s.locX[e];
+        if (s.locY) r.locY = s.locY[e];
+        if (s.locZ) r.locZ = s.locZ[e];
+        if (s.oriQw) r.qw = s.oriQw[e];
+        if (s.oriQx) r.qx = s.oriQx[e];
+        if (s.oriQy) r.qy = s.oriQy[e];
+        if (s.oriQz) r.qz = s.oriQz[e];
+        if (s.vX) r.vx = s.vX[e];
+        if (s.vY) r.vy = s.vY[e];
+        if (s.vZ) r.vz = s.vZ[e];
+        if (s.omgBarX) r.wx = s.omgBarX[e];
+        if (s.omgBarY) r.wy = s.omgBarY[e];
+        if (s.omgBarZ) r.wz = s.omgBarZ[e];
+        if (s.familyID) r.family = (r.family & OWNER_FLAG_BITS) | s.familyID[e];
+        if (s.inertiaPropOffsets) r.inertiaOff = s.inertiaPropOffsets[e];
+        if (s.aX) a.ax = s.aX[e];
+        if (s.aY) a.ay = s.aY[e];
+        if (s.aZ) a.az = s.aZ[e];
+        if (s.alphaX) a.lx = s.alphaX[e];
+        if (s.alphaY) a.ly = s.alphaY[e];
+        if (s.alphaZ) a.lz = s.alphaZ[e];
         owners[o] = r;
         acc[o] = a;
     } else {
-        if (s.voxelID) s.voxelID[o] = r.voxelID;
-        if (s.locX) s.locX[o] = r.locX;
-        if (s.locY) s.locY[o] = r.locY;
-        if (s.locZ) s.locZ[o] = r.locZ;
-        if (s.oriQw) s.oriQw[o] = r.qw;
-        if (s.oriQx) s.oriQx[o] = r.qx;
-        if (s.oriQy) s.oriQy[o] = r.qy;
-        if (s.oriQz) s.oriQz[o] = r.qz;
-        if (s.vX) s.vX[o] = r.vx;
-        if (s.vY) s.vY[o] = r.vy;
-        if (s.vZ) s.vZ[o] = r.vz;
-        if (s.omgBarX) s.omgBarX[o] = r.wx;
-        if (s.omgBarY) s.omgBarY[o] = r.wy;
-        if (s.omgBarZ) s.omgBarZ[o] = r.wz;
-        if (s.familyID) s.familyID[o] = (uint8_t)r.family;
-        if (s.aX) s.aX[o] = a.ax;
-        if (s.aY) s.aY[o] = a.ay;
-        if (s.aZ) s.aZ[o] = a.az;
-        if (s.alphaX) s.alphaX[o] = a.lx;
-        if (s.alphaY) s.alphaY[o] = a.ly;
-        if (s.alphaZ) s.alphaZ[o] = a.lz;
+        if (s.voxelID) s.voxelID[e] = r.voxelID;
+        if (s.locX) s.locX[e] = r.locX;
+        if (s.locY) s.locY[e] = r.locY;
+        if (s.locZ) s.locZ[e] = r.locZ;
+        if (s.oriQw) s.oriQw[e] = r.qw;
+        if (s.oriQx) s.oriQx[e] = r.qx;
+        if (s.oriQy) s.oriQy[e] = r.qy;
+        if (s.oriQz) s.oriQz[e] = r.qz;
+        if (s.vX) s.vX[e] = r.vx;
+        if (s.vY) s.vY[e] = r.vy;
+        if (s.vZ) s.vZ[e] = r.vz;
+        if (s.omgBarX) s.omgBarX[e] = r.wx;
+        if (s.omgBarY) s.omgBarY[e] = r.wy;
+        if (s.omgBarZ) s.omgBarZ[e] = r.wz;
+        if (s.familyID) s.familyID[e] = (uint8_t)r.family;
+        if (s.aX) s.aX[e] = a.ax;
+        if (s.aY) s.aY[e] = a.ay;
+        if (s.aZ) s.aZ[e] = a.az;
+        if (s.alphaX) s.alphaX[e] = a.lx;
+        if (s.alphaY) s.alphaY[e] = a.ly;
+        if (s.alphaZ) s.alphaZ[e] = a.lz;
     }
 }
 

@@ -196,6 +196,19 @@ int deme_get_arith_mode(const deme_ctx* ctx);
  * with history, 1 frictionless.  Also the largest tile's foreign-owner count and local list length of the current list. */
 int deme_force_kernel_name(const deme_ctx* ctx, char* name, size_t cap, uint32_t* tileMaxHalo, uint32_t* tileMaxList);
 
+/* The engine's own numbering (csrc/deme_order.inc).  Owner and sphere ids at this boundary are ALWAYS the caller's -- load order,
+ * as in the reference (DEM/dT.cpp:700-800).  Inside, a scene uploaded in the fast arithmetic mode (no ghosts, built-in force
+ * model) whose clumps are not already numbered compactly is kept in box-shaped tiles of 128 clumps (recursive bisection), so that
+ * the owner tiles of the force pass are clusters of the bed; every entry point translates.  *reordered = 1 if the current scene is
+ * kept that way; spread[0] / [1]: mean surface of the bounding box of 128 consecutive clumps (in squares of one bin edge), in the
+ * caller's order / in the engine's (0 when the question was not asked).  deme_set_reorder(ctx, 0) before deme_upload_scene keeps the caller's order (env DEME_REORDER=0
+ * does it for the process). */
+int deme_get_order(const deme_ctx* ctx, int* reordered, double spread[2]);
+int deme_set_reorder(deme_ctx* ctx, int enable);
+/* The order itself, without a context or a GPU (host code; tests): order[k] = the caller's clump kept in slot k. */
+int deme_order_probe(const DemeParams* p, size_t nClumps, const uint64_t* voxelID, const uint16_t* locX, const uint16_t* locY,
+                     const uint16_t* locZ, uint32_t* order, double spread[2]);
+
 /* setSimParams / UpdateSimParams (APIPrivate.cpp:1121, dT.cpp:2463-2466) */
 int deme_set_params(deme_ctx* ctx, const DemeParams* p);
 /* allocateGPUArrays + initGPUArrays + packDataPointers (APIPrivate.cpp:1169-1290) */

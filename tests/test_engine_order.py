@@ -1,0 +1,193 @@
+"""The engine's own numbering (csrc/deme_order.inc): a scene handed over in an order that is not spatial -- the reference's ids are
+load order, DEM/dT.cpp:700-800 -- is kept along a Z-order curve inside, and every id at the C-ABI stays the caller's.
+
+What must hold, against the oracle (which works in the caller's numbering throughout):
+  * the owner-tile force pass evaluates the list (that is what the order is for);
+  * contact lists, bin incidences and history maps BIT-IDENTICAL in the caller's ids and canonical order (which sphere of a pair
+    is A follows the caller's ids inside as well, so even the contact-point-in-bin decisions are the oracle's);
+  * per-contact history, owner accelerations, trajectories within the fast mode's stated bounds (tests/test_fast_mode.py);
+  * every per-owner / per-sphere / per-contact array crossing the boundary lands on the caller's index: state round trips,
+    margins, wildcards, seeds, persistent marks, sphere geometry, added accelerations, inspection values.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+
+
+def _positions(pkg, p, st):
+    return pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+
+
+def _bed(pkg, n=6000, order="random", **kw):
+    return pkg.model.packed_bed(n, seed=5, cd_freq=0, spacing_mult=3.0, init_vz=-1.0, aspect=(1.0, 1.0, 0.25), order=order, **kw)
+
+
+def _settled(pkg, b, steps=9000):
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("exact")  # the caller's order is kept: this context is the plain reference for the state
+    ctx.set_params(p), ctx.upload_scene(sc)
+    assert not ctx.engine_order()[0]
+    ctx.step(steps)
+    st = ctx.download_state()
+    ctx.close()
+    return p, sc, {k: st[k] for k in KEYS}
+
+
+def test_random_order_scene_is_tiled_and_matches_the_oracle(pkg, orc):
+    b = _bed(pkg)
+    p, sc, st = _settled(pkg, b)
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
+    reordered, given, best = ctx.engine_order()
+    assert reordered and given > 3 * best, (reordered, given, best)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st)
+    # a state round trip lands on the caller's indices
+    back = ctx.download_state()
+    assert all(np.array_equal(back[k], st[k]) for k in KEYS)
+    for s in (ctx, sim):
+        s.compute_margins(0), s.detect(), s.migrate(), s.calc_forces()
+    assert ctx.force_kernel()[0] == "k_tile_forces<0, false>", ctx.force_kernel()
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert len(ga[0]) > 4000 and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    gi, oi = ctx.bin_incidence(), sim.bin_incidence()
+    assert np.array_equal(gi[0], oi[0]) and np.array_equal(gi[1], oi[1])
+    gx, ox = ctx.sphere_geometry(), sim.sphere_geometry()
+    assert all(np.array_equal(x, y) for x, y in zip(gx, ox))
+    g, o = ctx.download_state(), sim.download_state()
+    n = int(sc.nOwnerClumps)
+    for keys in (("aX", "aY", "aZ"), ("alphaX", "alphaY", "alphaZ")):
+        G = np.stack([g[k][:n] for k in keys], 1).astype(np.float64)
+        O = np.stack([o[k][:n] for k in keys], 1).astype(np.float64)
+        assert np.abs(G - O).max() <= 2e-4 * np.abs(O).max(), keys
+    for w in range(4):
+        gw, ow = ctx.wildcard(w), sim.wildcard(w)
+        assert np.abs(gw - ow).max() <= 1e-5 * max(np.abs(ow).max(), 1e-12) + 1e-12, w
+    # 100 further steps (detection at every step: the history map is exercised with the engine's list order every time)
+    ctx.step(100), sim.step(100)
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    g, o = ctx.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g) - _positions(pkg, p, o)).max()
+    dv = max(np.abs(g[k] - o[k]).max() for k in ("vX", "vY", "vZ"))
+    print(f"random-order bed kept along the curve, 100 steps vs the oracle: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
+    assert dx <= 5e-8 and dv <= 2e-4
+    # the map of an idempotent detection is the identity in the caller's order too
+    ctx.detect()
+    a2 = ctx.contacts()
+    ctx.migrate()
+    ctx.detect()
+    a3 = ctx.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(a2[:3], a3[:3]))
+    assert np.array_equal(a3[3], np.arange(len(a3[0]), dtype=np.uint32))
+    ctx.close()
+
+
+def test_boundary_arrays_keep_the_callers_indices(pkg, orc):
+    b = _bed(pkg, n=4000)
+    p, sc, st = _settled(pkg, b, steps=7000)
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
+    assert ctx.engine_order()[0]
+    twin = pkg.Context(0)  # the same scene kept in the caller's order (deme_set_reorder(0)): the reference for what an index means
+    twin.set_arith_mode("fast")
+    twin.set_reorder(False)
+    twin.set_params(p), twin.upload_scene(sc), twin.upload_state(st)
+    assert not twin.engine_order()[0]
+    nO, nS = int(sc.nOwners), int(sc.nSpheres)
+    rng = np.random.default_rng(3)
+    # margins: per owner
+    m = rng.uniform(1e-5, 3e-5, nO).astype(np.float32)
+    for c in (ctx, twin):
+        c.set_margins(m), c.detect(), c.migrate()
+    ga, ta = ctx.contacts(), twin.contacts()
+    assert len(ga[0]) > 1500 and all(np.array_equal(x, y) for x, y in zip(ga[:3], ta[:3]))
+    # contact wildcards: written by list row, read back, and seeded lists
+    W = rng.normal(size=(len(ga[0]), 4)).astype(np.float32) * 1e-7
+    for w in range(4):
+        ctx.set_wildcard(w, W[:, w])
+    assert all(np.array_equal(ctx.wildcard(w), W[:, w]) for w in range(4))
+    sel = rng.permutation(len(ga[0]))[: len(ga[0]) // 2]  # a seed need not be sorted
+    ctx.seed_contacts(ga[0][sel], ga[1][sel], ga[2][sel], W[sel])
+    sa = ctx.contacts()
+    order = np.sort(sel)
+    assert all(np.array_equal(x, y[order]) for x, y in zip(sa[:3], ga[:3]))
+    assert all(np.array_equal(ctx.wildcard(w), W[order, w]) for w in range(4))
+    # the seeded history is found again by the next detection, row for row
+    ctx.detect(), ctx.migrate()
+    full = ctx.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(full[:3], ga[:3]))
+    got = np.stack([ctx.wildcard(w) for w in range(4)], 1)
+    expect = np.zeros_like(W)
+    expect[order] = W[order]
+    assert np.array_equal(got, expect)
+    # persistent marks travel in the caller's ids
+    ctx.mark_persistent_contacts(0)
+    pa = ctx.persistent_contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(pa, ga[:3]))
+    ctx.mark_persistent_contacts(0, mark=False)
+    # added accelerations reach the owner the caller named (the twin gets the same history first: same forces up to rounding)
+    for w in range(4):
+        twin.set_wildcard(w, expect[:, w])
+    for c in (ctx, twin):
+        c.calc_forces()
+    s0 = ctx.download_state()
+    pick = np.array([7, 1234, 3999])
+    for o in pick:
+        ctx.add_owner_acc(int(o), acc=np.array([[3.0, -2.0, 1.0]], np.float32))
+    ctx.integrate()
+    s1 = ctx.download_state()
+    twin.integrate()
+    t1 = twin.download_state()
+    dv = np.stack([s1[k] - t1[k] for k in ("vX", "vY", "vZ")], 1)[: int(sc.nOwnerClumps)]
+    hit = np.abs(dv).max(1) > 1e-6
+    assert np.array_equal(np.nonzero(hit)[0], pick), np.nonzero(hit)[0]
+    assert np.allclose(dv[pick], np.array([3.0, -2.0, 1.0]) * p.h, rtol=1e-3, atol=3e-7)
+    # per-owner inspection values
+    iv, tv = ctx.inspect_values("absv", nO), twin.inspect_values("absv", nO)
+    assert np.allclose(iv[np.setdiff1d(np.arange(int(sc.nOwnerClumps)), pick)], tv[np.setdiff1d(np.arange(int(sc.nOwnerClumps)), pick)], rtol=1e-5, atol=1e-7)
+    ctx.close(), twin.close()
+
+
+def _probe(pkg, p, arrays, n):
+    """deme_order_probe: the engine's order of n clumps and the two tile-surface figures (host code, no context)"""
+    import ctypes as C
+    lib = C.CDLL(pkg.library_path())
+    vox = np.ascontiguousarray(arrays["voxelID"][:n], np.uint64)
+    lx, ly, lz = (np.ascontiguousarray(arrays[k][:n], np.uint16) for k in ("locX", "locY", "locZ"))
+    order, sp = np.zeros(n, np.uint32), (C.c_double * 2)()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.deme_order_probe(C.byref(p), C.c_size_t(n), vp(vox), vp(lx), vp(ly), vp(lz), vp(order), sp) == 0
+    return order, float(sp[0]), float(sp[1])
+
+
+def test_compact_order_is_left_alone_and_the_switch_works(pkg):
+    b = _bed(pkg, n=4000, order="random")
+    p, sc = b.Initialize()
+    n = int(sc.nOwnerClumps)
+    order, given, best = _probe(pkg, p, b.arrays, n)
+    assert np.array_equal(np.sort(order), np.arange(n)) and given > 3 * best
+    # the same bed loaded in the engine's order: nothing to improve, no translation at the boundary
+    (bt,) = b.batches
+    bt.xyz, bt.vel, bt.angvel, bt.oriq, bt.family = bt.xyz[order], bt.vel[order], bt.angvel[order], bt.oriq[order], bt.family[order]
+    bt.templates = [bt.templates[i] for i in order]
+    p2, sc2 = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p2), ctx.upload_scene(sc2)
+    reordered, given2, best2 = ctx.engine_order()
+    assert not reordered and given2 <= 1.15 * best2 and abs(best2 - best) < 1e-6 * best, (reordered, given2, best2, best)
+    ctx.close()
+    b = _bed(pkg, n=4000, order="random")
+    p, sc = b.Initialize()
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("exact")  # bit-identity with the oracle is the exact mode's contract: the caller's order stays
+    ctx.set_params(p), ctx.upload_scene(sc)
+    assert not ctx.engine_order()[0]
+    ctx.close()
