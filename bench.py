@@ -399,6 +399,12 @@ def main():
                          "DEMdemo_FlexibleMesh.cpp:203-255); every update makes the next step start with a contact detection")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE configs[4] flavour: polydisperse spheres + a user cohesion model compiled at run time")
+    ap.add_argument("--custom-model", action="store_true",
+                    help="the headline bed of three-sphere clumps with the --config5 fragment as its force model (run-time compiled, "
+                         "one contact wildcard): the tile pass of a user model at the headline's contact density")
+    ap.add_argument("--tile-policy", type=int, default=-1, metavar="N",
+                    help="deme_set_tile_policy: a run-time compiled model takes the tile pass when a tile holds >= N contacts on average "
+                         "(default: the library's 320; 0 = always)")
     ap.add_argument("--bin-multiple", type=float, default=5.0,
                     help="bin edge as a multiple of the smallest sphere radius (SetInitBinSizeAsMultipleOfSmallestSphere)")
     ap.add_argument("--async-detection", type=int, default=0, metavar="D",
@@ -497,6 +503,11 @@ def main():
         # N > 1: every rank builds its own slab of the N-times-longer bed (its clumps and their ghosts), not the whole bed
         b = build_bed(pkg, args.clumps, args.seed, args.cd_freq, x_mult=world, order=args.order, bin_multiple=args.bin_multiple,
                       slab=(rank, world, HALO) if (world > 1 and not args.mesh_triangles) else None)
+    if args.custom_model and not args.config5:
+        b.materials[0]["Cohesion"] = 0.002
+        b.SetMustPairwiseMatProp(["Cohesion"])
+        b.DefineContactForceModel(COHESIVE_FRAGMENT)
+        b.SetPerContactWildcards(["contact_age"])
     mesh_obj = None
     if args.mesh_triangles:
         lo, hi = b.user_box_min, b.user_box_max
@@ -534,6 +545,8 @@ def main():
     ctx.set_params(p)
     ctx.upload_scene(sc)
     b.compile_into(ctx)  # user force model / prescriptions, if the scene has any
+    if args.tile_policy >= 0:
+        ctx.set_tile_policy(args.tile_policy)
     if args.async_detection:
         ctx.set_async_detection(args.async_detection)
     if args.adaptive != "off":
@@ -785,6 +798,7 @@ def main():
         "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "arith_mode": ctx.arith_mode(), "data": "synthetic",
         "config": {"workload": ("BASELINE configs[4] flavour: polydisperse spheres (8 templates, r..3r) with a run-time compiled "
                                 "cohesion model" if args.config5 else
+                                f"BASELINE configs[1]'s bed ({args.clumps} three-sphere clumps) with the run-time compiled cohesion model of configs[4]" if args.custom_model else
                                 f"BASELINE configs[{2 if args.clumps_total else 1}]: {args.clumps} three-sphere clumps (3_clump.csv x0.005) per GPU in a box, gravity settling"
                                 + (f"; one bed {world} times as long cut into {world} x-slabs (configs[2] flavour)" if world > 1 else ""))
                                + (f" + {int(sc.nTri)}-triangle plate (configs[3] flavour)" if int(sc.nTri) else "")
@@ -796,14 +810,14 @@ def main():
                    "clump_numbering": args.order, "bin_multiple": args.bin_multiple, "async_detection_lead": args.async_detection,
                    "cross_cut_contacts": (args.cross_contacts if group is not None else None),
                    "margin_safety": {"multiplier": float(p.expSafetyMulti), "adder_m_per_s": float(p.expSafetyAdder)},
-                   "force_model": ("user fragment via hipRTC: frictionless Hertz + cohesion, 1 wildcard" if args.config5
+                   "force_model": ("user fragment via hipRTC: frictionless Hertz + cohesion, 1 wildcard" if (args.config5 or args.custom_model)
                                    else "Hertzian (history, 4 wildcards)"), "integrator": "extended Taylor", "h": p.h,
                    "parallelism": par,
                    "adaptive": (None if adaptive_state is None else
                                 {"mode": args.adaptive, "bin_size": adaptive_state[0], "cd_every": adaptive_state[1],
                                  "bin_size_changes": adaptive_state[2], "update_freq_changes": adaptive_state[3]}),
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
-        "roofline": {"kernel": fk_name + (" (hipRTC)" if args.config5 else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": fk_name + (" (hipRTC)" if (args.config5 or args.custom_model) else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "attainable_copy_GBs": copy_gbs, "frac_of_attainable": (achieved / copy_gbs if copy_gbs else None),
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),

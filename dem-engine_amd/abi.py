@@ -457,6 +457,17 @@ class Context:
         self._ck(self.lib.deme_force_kernel_name(self.h, buf, 64, C.byref(h), C.byref(l)), "deme_force_kernel_name")
         return buf.value.decode(), int(h.value), int(l.value)
 
+    def tile_stats(self):
+        """(tiles, tiles evaluated by the per-tile fallback kernel, largest halo, largest local list) of the current list"""
+        out = (C.c_uint32 * 4)()
+        self.lib.deme_tile_stats.argtypes = [_P, C.POINTER(C.c_uint32)]
+        self._ck(self.lib.deme_tile_stats(self.h, out), "deme_tile_stats")
+        return tuple(int(v) for v in out)
+
+    def set_tile_policy(self, min_contacts_per_tile_custom):
+        self.lib.deme_set_tile_policy.argtypes = [_P, C.c_uint32]
+        self._ck(self.lib.deme_set_tile_policy(self.h, int(min_contacts_per_tile_custom)), "deme_set_tile_policy")
+
     def engine_order(self):
         """(reordered, spread in the caller's order, spread along the curve): deme_get_order"""
         r, sp = C.c_int(0), (C.c_double * 2)()

@@ -422,10 +422,13 @@ __device__ inline void calc_forces_body(const DevParams& p, const ForceArgs& a, 
             io.ARotVel = make_float3(in.ARotVel.x, in.ARotVel.y, in.ARotVel.z);
             io.BRotVel = make_float3(in.BRotVel.x, in.BRotVel.y, in.BRotVel.z);
             io.AOwnerMOI = make_float3(mpA.y, mpA.z, mpA.w), io.BOwnerMOI = make_float3(mpB.y, mpB.z, mpB.w);
-            io.AOwner = AOwner, io.BOwner = BOwner, io.myContactID = myContactID;
+            // ids in the user vocabulary are the CALLER's (the engine may keep owners and spheres in an order of its own:
+            // deme_order.inc); the user's owner / sphere wildcard arrays are indexed by them and stay in the caller's order
+            io.AOwner = p.o2e ? p.o2e[AOwner] : AOwner, io.BOwner = p.o2e ? p.o2e[BOwner] : BOwner, io.myContactID = myContactID;
             {
                 const uint64_t key = a.keys[myContactID];
-                io.AGeo = key_a(key), io.BGeo = key_b(key);
+                const uint32_t ga = key_a(key), gb = key_b(key);
+                io.AGeo = p.s2e ? p.s2e[ga] : ga, io.BGeo = (p.s2e && cls == DEME_KEY_CLASS_SS) ? p.s2e[gb] : gb;
             }
             io.wc = a.wc + (size_t)myContactID * p.nW;
             io.ownerWc = a.ownerWc;

@@ -66,11 +66,14 @@ typedef unsigned int nt_u2 __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ inline T stream_load(const T* p) {
 #if DEME_FAST_NT
-    static_assert(sizeof(T) == 16 || sizeof(T) == 8, "16- or 8-byte records");
+    static_assert(sizeof(T) == 16 || sizeof(T) == 8 || sizeof(T) == 4, "16-, 8- or 4-byte records");
     T out;
     if constexpr (sizeof(T) == 16) {
         const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p));
         __builtin_memcpy(&out, &v, 16);
+    } else if constexpr (sizeof(T) == 4) {
+        const unsigned int v = __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(p));
+        __builtin_memcpy(&out, &v, 4);
     } else {
         const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p));
         __builtin_memcpy(&out, &v, 8);
@@ -87,6 +90,10 @@ __device__ inline void stream_store(T* p, T v) {
         nt_u4 w;
         __builtin_memcpy(&w, &v, 16);
         __builtin_nontemporal_store(w, reinterpret_cast<nt_u4*>(p));
+    } else if constexpr (sizeof(T) == 4) {
+        unsigned int w;
+        __builtin_memcpy(&w, &v, 4);
+        __builtin_nontemporal_store(w, reinterpret_cast<unsigned int*>(p));
     } else {
         nt_u2 w;
         __builtin_memcpy(&w, &v, 8);
@@ -207,8 +214,11 @@ __device__ inline void forces_fast_body(const DevParams& p, const ForceArgs& a, 
         const double dy = (dOy + (double)relA.y) - (double)relB.y;
         const double dz = (dOz + (double)relA.z) - (double)relB.z;
         const double d2 = dx * dx + dy * dy + dz * dz;
-        const float sumR = rA + rB;
-        const double num = (double)sumR * (double)sumR - d2;  // > 0 iff the spheres overlap; no cancellation left after this
+        // (the sum of the radii in fp64: rounded to fp32 it is off by up to 3e-8 of itself -- nothing for equal radii, whose sum is
+        // exact, but 5e-10 m between unequal ones, 1e-5 of a typical overlap: found on the polydisperse bed of configs[4])
+        const double sumRd = (double)rA + (double)rB;
+        const float sumR = (float)sumRd;
+        const double num = sumRd * sumRd - d2;  // > 0 iff the spheres overlap; no cancellation left after this
         const float d2f = (float)d2;
         const float inv = frsq(d2f);
         const float dist = d2f * inv;

@@ -73,7 +73,7 @@ struct deme_ctx {
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
     // owner-tile form of the force pass (deme_tile.h), rebuilt per detection
-    DevBuf tInfo, hList, hCount, tileMode, tileOrg, rIdx, rStart, remKey[2], remVal, lPos, lOff, lCount, tileRem, tileBase, rankC, rec32;
+    DevBuf tileBig, bigList, tInfo, hList, hCount, tileMode, tileOrg, rIdx, rStart, remKey[2], remVal, lPos, lOff, lCount, tileRem, tileBase, rankC, rec32;
     // the heavy-owner counts of a tiled list are fetched without stopping the stream: the copy lands in pinned memory, the first
     // reader (launch_reduce_heavy, one force launch later) waits for its event
     RangeCounters* hrPinned = nullptr;
@@ -86,9 +86,13 @@ struct deme_ctx {
     bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
     bool conTile = false;     // the contributions in memory were written by the tile kernel
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
+    // A run-time compiled model takes the tile pass only when a tile holds enough contacts to pay for its staging (measured on
+    // configs[4], 1e6 single spheres with 1.6 contacts each = 200 per tile: tile pass 0.058 ms against 0.044 ms for the general
+    // kernel; at the 555 per tile of three-sphere clumps the tile pass wins as it does for the built-in models).
+    uint32_t tileMinContactsCustom = 320;
     uint64_t lastSegMax = 0;             // longest segment of the last detection (sizes the early launch of k_compact_keys)
     size_t keySegMin = (size_t)1 << 20;  // arenas from this many slots on are cut into DEME_KEY_SEGS segments (DEME_KEY_SEG_MIN; 0: never)
-    uint32_t tileMaxHalo = 0, tileMaxList = 0;
+    uint32_t tileMaxHalo = 0, tileMaxList = 0, nBigTiles = 0;
     // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
     DevBuf persistKeys, binStat;
     // acceleration the script adds for the next step only (deme_add_owner_acc): device records + host mirror
@@ -105,6 +109,7 @@ struct deme_ctx {
     deme_jit::MaterialTables mt;
     hipModule_t customMod = nullptr;
     hipFunction_t customFn[3] = {nullptr, nullptr, nullptr};
+    hipFunction_t customTileFn[4] = {nullptr, nullptr, nullptr, nullptr};  // the tile pass with the user's model (deme_jit::kTileEntry)
     std::map<size_t, std::vector<char>> jitCache;
     bool conValid = false;
     int keysCur = 0, wcCur = 0;
@@ -815,7 +820,9 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
         }
         // per-owner gather lists for the atomics-free accumulation
         HIPCK(hipMemsetAsync(c->rangeCtr.p, 0, sizeof(RangeCounters), c->stream));
-        const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM &&
+        const bool tileEligible = c->tileEnable && nC && c->arith == DEME_ARITH_FAST &&
+                                  (c->hp.forceModel != DEME_FORCE_CUSTOM ||
+                                   (c->customTileFn[0] && nC >= (uint64_t)c->tileMinContactsCustom * ((c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB))) &&
                                   c->hShared.empty() && c->nMat <= 16 && c->nAnal <= 65535 && c->nComp <= 65535 &&
                                   tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial) <= DEME_TILE_TABLE_MAX &&
                                   c->nComp + c->nMat * c->nMat * 2u + c->nAnal * 4u <= DEME_TILE_T && c->nMassProps <= DEME_TILE_T;
@@ -862,7 +869,8 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                                c->hList.as<uint32_t>(), c->hCount.as<uint32_t>(),
                                c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr, c->lOff.as<uint16_t>(),
                                c->lPos.as<uint16_t>(), c->lCount.as<uint32_t>(), c->rankC.as<uint32_t>(), c->remKey[0].as<uint32_t>(),
-                               c->remVal.as<uint32_t>(), c->tileOrg.as<int64_t>(), c->rangeCtr.as<RangeCounters>());
+                               c->remVal.as<uint32_t>(), c->tileOrg.as<int64_t>(), c->rangeCtr.as<RangeCounters>(), nTiles,
+                               c->tileBig.as<uint32_t>(), c->bigList.as<uint32_t>());
             hipLaunchKernelGGL(k_tile_stats, dim3((nTiles + 1023u) / 1024u), dim3(256), 0, c->stream, nTiles, c->hCount.as<uint32_t>(),
                                c->lCount.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
             uint32_t nR = 0;  // crossing contacts = records = entries of the sort below: the one size the host has to know
@@ -870,7 +878,9 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
             HIPCK(hipMemcpyAsync(pin_at<RangeCounters>(c, 128), c->rangeCtr.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
             HIPCK(sync_readback(c, c->stream));
             nR = *pin_at<uint32_t>(c, 8), hr = *pin_at<RangeCounters>(c, 128);
-            if (!hr.tileOverflow) {
+            nR += hr.nExtra;  // the records of the tiles that do not fit (k_tile_forces_big): every contact of such a tile has one
+            c->nBigTiles = hr.nBig;
+            {
                 unsigned obits = 1;
                 while (obits < 32 && (1ull << obits) < (uint64_t)c->nOwners)
                     obits++;
@@ -1054,7 +1064,8 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
     // the fast kernel covers the built-in models' hot classes; contact recording (body-frame contact points) and user
     // fragments (the reference's body-frame vocabulary) run the general kernel, with world-frame contributions in fast mode
     const bool fastKernel = fastMode && !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM;
-    if (fastKernel && c->tileActive && c->tileEnable) {  // owner tiles: deme_tile.h
+    const bool customTile = fastMode && !c->record && c->hp.forceModel == DEME_FORCE_CUSTOM && c->customTileFn[0];
+    if ((fastKernel || customTile) && c->tileActive && c->tileEnable) {  // owner tiles: deme_tile.h
         TileArgs ta{};
         ta.owners = a.owners;
         ta.tInfo = c->tInfo.as<uint2>();
@@ -1067,6 +1078,10 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         ta.nOwners = c->nOwners;
         ta.nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
         ta.xcdGroup = c->xcdGroup;
+        ta.tileBig = c->tileBig.as<uint32_t>(), ta.bigList = c->bigList.as<uint32_t>(), ta.info = a.info;
+        ta.keys = a.keys, ta.timeElapsed = a.timeElapsed;
+        for (int k = 0; k < 8; k++)
+            ta.ownerWc[k] = a.ownerWc[k], ta.geoWcSph[k] = a.geoWcSph[k], ta.geoWcAnal[k] = a.geoWcAnal[k];
         if (pass >= 0 && c->hasGhosts) {
             ta.tileMode = c->tileMode.as<uint32_t>();
             ta.pass = (uint32_t)pass;
@@ -1079,7 +1094,8 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         ta.lCap = std::min<uint32_t>(DEME_TILE_LMAX, (c->tileMaxList + 63u) & ~63u);
         ta.nComp = c->nComp, ta.nAnal = c->nAnal, ta.nMass = c->nMassProps;
         static const uint32_t ldsPad = getenv("DEME_TILE_LDS_PAD") ? (uint32_t)atoi(getenv("DEME_TILE_LDS_PAD")) : 0u;  // occupancy experiments
-        const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial)) + ldsPad;
+        const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial),
+                                                 tile_rec16(customTile ? 2 : 0)) + ldsPad;
         hipStream_t st = fs ? fs : c->stream;
         ScopedTimer tm(c, "calc_forces", false, st);
         const bool mesh = c->nTri > 0 && c->nSM > 0;
@@ -1088,22 +1104,41 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
             if (pass != 1) {  // sphere-triangle contacts: the mesh variant of the general kernel, before the tiles that read its records
                               // (they read no ghost owner -- meshes are replicated, not ghosted --: all of them go with pass 0)
                 const dim3 gm(grid_for(std::max<uint32_t>(c->nSM, 1u), DEME_FORCE_BLOCK)), bm(DEME_FORCE_BLOCK);
-                if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
+                if (customTile) {
+                    void* args0[] = {&c->dp, &a};
+                    HIPCK(hipModuleLaunchKernel(c->customFn[1], gm.x, 1, 1, DEME_FORCE_BLOCK, 1, 1, 0, c->stream, args0, nullptr));
+                } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
                     hipLaunchKernelGGL((k_calc_forces<0, 1>), gm, bm, 0, c->stream, c->dp, a);
                 else
                     hipLaunchKernelGGL((k_calc_forces<1, 1>), gm, bm, 0, c->stream, c->dp, a);
             }
         }
-        if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
-            if (mesh)
+        const unsigned nBig = c->nBigTiles;  // tiles that do not fit LDS: one workgroup each, the same outputs (deme_tile.h)
+        if (customTile) {  // the same kernels compiled at run time around the user's statements (deme_jit.h)
+            void* argsT[] = {&c->dp, &ta};
+            HIPCK(hipModuleLaunchKernel(c->customTileFn[mesh ? 1 : 0], nBlk, 1, 1, DEME_TILE_T, 1, 1, ldsBytes, st, argsT, nullptr));
+            if (nBig && c->customTileFn[mesh ? 3 : 2])
+                HIPCK(hipModuleLaunchKernel(c->customTileFn[mesh ? 3 : 2], nBig, 1, 1, DEME_TILE_T, 1, 1, 0, st, argsT, nullptr));
+        } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
+            if (mesh) {
                 hipLaunchKernelGGL((k_tile_forces<0, true>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
-            else
+                if (nBig)
+                    hipLaunchKernelGGL((k_tile_forces_big<0, true>), dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
+            } else {
                 hipLaunchKernelGGL((k_tile_forces<0, false>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+                if (nBig)
+                    hipLaunchKernelGGL((k_tile_forces_big<0, false>), dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
+            }
         } else {
-            if (mesh)
+            if (mesh) {
                 hipLaunchKernelGGL((k_tile_forces<1, true>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
-            else
+                if (nBig)
+                    hipLaunchKernelGGL((k_tile_forces_big<1, true>), dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
+            } else {
                 hipLaunchKernelGGL((k_tile_forces<1, false>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+                if (nBig)
+                    hipLaunchKernelGGL((k_tile_forces_big<1, false>), dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
+            }
         }
         c->conValid = true;
         c->conTile = true;
@@ -1322,7 +1357,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->tileBig, &c->bigList, &c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1375,7 +1410,9 @@ int deme_force_kernel_name(const deme_ctx* c, char* name, size_t cap, uint32_t* 
         return DEME_ERR_INVALID;
     const int m = c->hp.forceModel == DEME_FORCE_HERTZIAN ? 0 : 1;
     const bool fastKernel = c->arith == DEME_ARITH_FAST && !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM;
-    if (c->hp.forceModel == DEME_FORCE_CUSTOM)
+    if (c->hp.forceModel == DEME_FORCE_CUSTOM && c->arith == DEME_ARITH_FAST && !c->record && c->customTileFn[0] && c->tileActive && c->tileEnable)
+        snprintf(name, cap, "deme_custom_tile<%s>", (c->nTri > 0 && c->nSM > 0) ? "true" : "false");
+    else if (c->hp.forceModel == DEME_FORCE_CUSTOM)
         snprintf(name, cap, "deme_custom_forces_ss");
     else if (fastKernel && c->tileActive && c->tileEnable)
         snprintf(name, cap, "k_tile_forces<%d, %s>", m, (c->nTri > 0 && c->nSM > 0) ? "true" : "false");
@@ -1390,6 +1427,21 @@ int deme_force_kernel_name(const deme_ctx* c, char* name, size_t cap, uint32_t* 
     return DEME_OK;
 }
 
+int deme_tile_stats(const deme_ctx* c, uint32_t out[4]) {
+    if (!c || !out)
+        return DEME_ERR_INVALID;
+    out[0] = c->tileActive ? (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB : 0u;
+    out[1] = c->tileActive ? c->nBigTiles : 0u;
+    out[2] = c->tileMaxHalo, out[3] = c->tileMaxList;
+    return DEME_OK;
+}
+int deme_set_tile_policy(deme_ctx* c, uint32_t minContactsPerTileCustom) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    c->tileMinContactsCustom = minContactsPerTileCustom;
+    c->listStale = true;
+    return DEME_OK;
+}
 int deme_get_order(const deme_ctx* c, int* reordered, double spread[2]) {
     if (!c)
         return DEME_ERR_INVALID;
@@ -1491,7 +1543,8 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         const size_t nTiles = (nO + DEME_TILE_NB - 1) / DEME_TILE_NB + 1;
         if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) || ensure(c, c->tileOrg, nTiles * 24) ||
             ensure(c, c->rStart, (nO + 1) * 4) || ensure(c, c->lOff, nTiles * (DEME_TILE_NB + 1) * 2) || ensure(c, c->lCount, nTiles * 4) ||
-            ensure(c, c->tileRem, (nTiles + 1) * 4) || ensure(c, c->tileBase, (nTiles + 1) * 4))
+            ensure(c, c->tileRem, (nTiles + 1) * 4) || ensure(c, c->tileBase, (nTiles + 1) * 4) || ensure(c, c->tileBig, nTiles * 4) ||
+            ensure(c, c->bigList, nTiles * 4))
             return c->lastStatus;
         HIPCK(hipMemsetAsync(c->hCount.p, 0, c->hCount.bytes, c->stream));
         c->tileActive = c->conTile = false;
@@ -2028,7 +2081,7 @@ static std::vector<DevBuf*> list_set(deme_ctx* c) {
     return {&c->mapping, &c->rangeCtr, &c->tileRem, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->info,
             &c->smFlag, &c->smList, &c->aStart, &c->bStart, &c->tileBase, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->lOff,
             &c->lPos, &c->lCount, &c->rankC, &c->remKey[0], &c->remKey[1], &c->remVal, &c->tileOrg, &c->rIdx, &c->rStart, &c->heavy,
-            &c->fixedFlag, &c->heavyList, &c->cDefer, &c->blockMode};
+            &c->fixedFlag, &c->heavyList, &c->cDefer, &c->blockMode, &c->tileBig, &c->bigList};
 }
 // the second set at the sizes of the one in use (sized by the arenas / the scene); nothing in flight reads the spare set
 static int async_size_spare(deme_ctx* c) {
@@ -3322,10 +3375,15 @@ int deme_compile_force_model_ex(deme_ctx* c, const char* src, size_t len, const 
         (void)hipModuleUnload(c->customMod);
         c->customMod = nullptr;
         c->customFn[0] = c->customFn[1] = c->customFn[2] = nullptr;
+        c->customTileFn[0] = c->customTileFn[1] = c->customTileFn[2] = c->customTileFn[3] = nullptr;
     }
     HIPCK(hipModuleLoadData(&c->customMod, it->second.data()));
     HIPCK(hipModuleGetFunction(&c->customFn[0], c->customMod, "deme_custom_forces_ss"));
     HIPCK(hipModuleGetFunction(&c->customFn[1], c->customMod, "deme_custom_forces_sm"));
+    for (int k = 0; k < 4; k++)
+        if (hipModuleGetFunction(&c->customTileFn[k], c->customMod, deme_jit::kTileEntry[k]) != hipSuccess)
+            c->customTileFn[k] = nullptr;  // (lists of this model are evaluated by the general kernel then)
+    c->listStale = true;  // the list structures depend on which kernel evaluates the list
     return DEME_OK;
 }
 
@@ -3343,14 +3401,8 @@ int deme_upload_wildcard_array(deme_ctx* c, uint32_t kind, uint32_t index, const
         return fail(c, DEME_ERR_INVALID, "wildcard array of kind %u holds %zu values, %zu given", kind, wc_array_len(c, kind), n);
     if (int rc = ensure(c, c->userWc[kind][index], std::max<size_t>(n, 1) * 4))
         return rc;
-    std::vector<float> tmp;
-    if (c->permuted && kind <= 1 && n) {  // per owner / per sphere: into the engine's slots
-        const std::vector<uint32_t>& m = kind == 0 ? c->hO2E : c->hS2E;
-        tmp.resize(n);
-        for (size_t k = 0; k < n; k++)
-            tmp[k] = in[m[k]];
-        in = tmp.data();
-    }
+    // (owner and sphere wildcard arrays are indexed by the ids user code sees -- the caller's -- and stay in the caller's order
+    // whatever order the engine keeps the owners in: deme_order.inc)
     if (n)
         HIPCK(hipMemcpyAsync(c->userWc[kind][index].p, in, n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -3368,12 +3420,6 @@ int deme_download_wildcard_array(deme_ctx* c, uint32_t kind, uint32_t index, flo
     if (n)
         HIPCK(hipMemcpyAsync(out, c->userWc[kind][index].p, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
-    if (c->permuted && kind <= 1 && n) {
-        const std::vector<uint32_t>& m = kind == 0 ? c->hO2E : c->hS2E;
-        std::vector<float> tmp(out, out + n);
-        for (size_t k = 0; k < n; k++)
-            out[m[k]] = tmp[k];
-    }
     return DEME_OK;
 }
 

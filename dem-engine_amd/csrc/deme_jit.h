@@ -160,7 +160,10 @@ inline int generate_source(const std::string& user, const std::vector<std::strin
             }
     }
     std::ostringstream o;
-    o << "#define DEME_JIT 1\n#include \"deme_force.h\"\n" << kVocabulary << "\n";
+    // the owner-tile form of the force pass (deme_tile.h) is compiled with the user's model too: DEME_JIT_NW wildcards ride in the
+    // kernel's history stream
+    o << "#define DEME_JIT 1\n#define DEME_TILE_OCC 4\n#define DEME_JIT_NW " << std::max<size_t>(wildcards.size(), 1) << "\n#define DEME_JIT_HAS_WC " << (wildcards.empty() ? 0 : 1)
+      << "\n#include \"deme_tile.h\"\n" << kVocabulary << "\n";
     emit_array(o, "E", mt.E, mt.nMat, false);
     emit_array(o, "nu", mt.nu, mt.nMat, false);
     emit_array(o, "CoR", mt.CoR, mt.nMat, true);
@@ -204,6 +207,13 @@ inline int generate_source(const std::string& user, const std::vector<std::strin
         o << "extern \"C\" __global__ __launch_bounds__(256) void deme_custom_forces_" << ent[cls]
           << "(const deme_dev::DevParams p, const deme_dev::ForceArgs a) {\n    deme_dev::calc_forces_block<2, " << cls
           << ">(p, a);\n}\n";
+    // the tile pass with the user's model where the Hertzian block is: the instances of the kernel templates of deme_tile.h are
+    // named through function pointers (hipModuleGetFunction takes the mangled names, listed by deme_tile_entry_names below)
+    o << "namespace deme_dev {\n"
+         "template __global__ void k_tile_forces<2, false>(const DevParams, const TileArgs);\n"
+         "template __global__ void k_tile_forces<2, true>(const DevParams, const TileArgs);\n"
+         "template __global__ void k_tile_forces_big<2, false>(const DevParams, const TileArgs);\n"
+         "template __global__ void k_tile_forces_big<2, true>(const DevParams, const TileArgs);\n}\n";
     out = o.str();
     return 0;
 }
@@ -377,18 +387,24 @@ extern "C" __global__ __launch_bounds__(256) void deme_region_filter(const deme_
     out = o.str();
 }
 
+// mangled names of the four tile-pass instances of a compiled model (plain / with mesh records, fitting tiles / the others)
+static const char* const kTileEntry[4] = {"_ZN8deme_dev13k_tile_forcesILi2ELb0EEEvNS_9DevParamsENS_8TileArgsE",
+                                          "_ZN8deme_dev13k_tile_forcesILi2ELb1EEEvNS_9DevParamsENS_8TileArgsE",
+                                          "_ZN8deme_dev17k_tile_forces_bigILi2ELb0EEEvNS_9DevParamsENS_8TileArgsE",
+                                          "_ZN8deme_dev17k_tile_forces_bigILi2ELb1EEEvNS_9DevParamsENS_8TileArgsE"};
+
 // hipRTC: source -> gfx950 code object.  Needs no GPU (used by the CPU test through deme_jit_probe).
 inline int compile(const std::string& src, std::vector<char>& code, std::string& log) {
     hiprtcProgram prog;
-    const char* hdrs[] = {kSrcDeviceH, kSrcMeshH, kSrcForceH};
-    const char* names[] = {"deme_device.h", "deme_mesh.h", "deme_force.h"};
-    if (hiprtcCreateProgram(&prog, src.c_str(), "deme_custom_force_model.hip", 3, hdrs, names) != HIPRTC_SUCCESS) {
+    const char* hdrs[] = {kSrcDeviceH, kSrcMeshH, kSrcForceH, kSrcForceFastH, kSrcTileH};
+    const char* names[] = {"deme_device.h", "deme_mesh.h", "deme_force.h", "deme_force_fast.h", "deme_tile.h"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "deme_custom_force_model.hip", 5, hdrs, names) != HIPRTC_SUCCESS) {
         log = "hiprtcCreateProgram failed";
         return 1;
     }
     // user kernel includes (DEMSolver::AddKernelInclude, DEM/API.h:1362-1367) resolve against the ROCm installation and against the
     // directories of DEME_KERNEL_INCLUDE_PATH (':'-separated), like the reference's jitify include path
-    std::vector<std::string> optStr = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I/opt/rocm/include"};
+    std::vector<std::string> optStr = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-I/opt/rocm/include"};
     if (const char* e = getenv("DEME_KERNEL_INCLUDE_PATH")) {
         std::string all = e;
         size_t pos = 0;
@@ -423,6 +439,12 @@ inline int compile(const std::string& src, std::vector<char>& code, std::string&
     code.resize(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    if (const char* dump = getenv("DEME_JIT_DUMP")) {  // (debugging: the code object, e.g. for llvm-readelf / tools/co_info.py)
+        if (FILE* f = fopen(dump, "wb")) {
+            fwrite(code.data(), 1, code.size(), f);
+            fclose(f);
+        }
+    }
     return 0;
 }
 

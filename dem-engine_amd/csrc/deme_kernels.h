@@ -1168,9 +1168,11 @@ struct RangeCounters {
     unsigned int nHeavy;
     unsigned int nHeavyFree;  // heavy owners that are not fixed (they must be reduced every step)
     unsigned int nSA, nSM;    // sphere-analytical / sphere-mesh contacts in the list
-    unsigned int tileOverflow;  // a tile's halo did not fit (deme_tile.h): the list is evaluated without tiles
+    unsigned int tileOverflow;  // (unused since the per-tile fallback: an overflowing tile is evaluated by k_tile_forces_big)
     unsigned int tileMaxHalo, tileMaxList;  // the largest tile's foreign owners / local-B list entries: they size the kernel's LDS
-    unsigned int pad[9];
+    unsigned int nBig;    // tiles whose halo, contact range or local lists do not fit the LDS area of k_tile_forces (deme_tile.h)
+    unsigned int nExtra;  // records of those tiles' contacts that hold a B owner of the same tile (every contact of such a tile writes a record)
+    unsigned int pad[7];
 };
 
 // start[o] = first index i with owner[i] >= o, for o = 0 .. nOwners (owner[] ascending): every element fills the owners that

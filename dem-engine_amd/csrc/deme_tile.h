@@ -21,8 +21,8 @@
 //     24-byte record, which the integrator gathers through the per-owner list of such contacts (deme_kernels.h:
 //     k_integrate<true> with GatherArgs::tile).
 // What the per-detection builder below leaves behind: tInfo (8 B per contact), the halo list of every tile, the per-owner lists
-// of tile-crossing contacts.  A tile whose halo does not fit the LDS area switches the whole context back to k_forces_fast for
-// that list (RangeCounters::tileOverflow).
+// of tile-crossing contacts.  A tile whose halo, contact range or local lists do not fit the LDS area is evaluated by
+// k_tile_forces_big (below: one workgroup, nothing staged, every contact writes a record); the rest of the list stays tiled.
 #pragma once
 #include "deme_force_fast.h"
 
@@ -42,7 +42,18 @@ static_assert(DEME_TILE_T >= 2 * DEME_TILE_NB, "one pulling thread per owner and
 static_assert(DEME_TILE_NB + DEME_TILE_HMAX <= 2 * DEME_TILE_T, "a thread stages at most two owner records");
 static_assert(DEME_TILE_LMAX == DEME_TILE_LREG * DEME_TILE_T, "list entries per thread");
 #define DEME_TILE_HASH 1024u
-#define DEME_TILE_REC 6    // uint4 per staged owner (96 bytes)
+#define DEME_TILE_REC 6    // uint4 per staged owner (96 bytes) for the built-in models
+// A run-time compiled model (MODEL 2, deme_jit.h) is written against the reference's body-frame vocabulary (AOriQ, ARotVel, locCPA):
+// its staged record carries the quaternion and the body-frame angular velocity instead of the nine rotation coefficients and the
+// world-frame one -- 80 bytes; the coefficients are formed per contact.
+#define DEME_TILE_REC_USER 5
+#ifndef DEME_JIT_NW
+#define DEME_JIT_NW 1  // contact wildcards of the run-time compiled model (the generated source defines it; at least 1)
+#endif
+#ifndef DEME_JIT_HAS_WC
+#define DEME_JIT_HAS_WC 1  // 0: the model declares no contact wildcards (nothing is streamed)
+#endif
+__host__ __device__ constexpr uint32_t tile_rec16(int model) { return model == 2 ? DEME_TILE_REC_USER : DEME_TILE_REC; }
 #define DEME_TILE_CMAX 8192   // contacts of one tile (their tile-local positions are 16-bit)
 static_assert(DEME_TILE_NB + DEME_TILE_HMAX <= 1024, "slot numbers are 10 bits");
 static_assert(DEME_TILE_HMAX <= DEME_TILE_HP2 && DEME_TILE_HMAX <= 256, "halo list: one entry per builder thread");
@@ -92,6 +103,15 @@ struct TileArgs {
     // kernel just before (launch_forces); the tile takes their per-contact records instead of evaluating them
     const float4 *conA4, *conB4;
     const float2 *conA2, *conB2;
+    const uint32_t* tileBig;   // per tile: 1 = its halo / contact range / local lists do not fit: k_tile_forces leaves it to k_tile_forces_big
+    const uint32_t* bigList;   // those tiles (k_tile_forces_big takes one per workgroup)
+    const uint4* info;         // their contacts are evaluated from the 16-byte gather records (owner ids instead of staging slots)
+    // a run-time compiled model (MODEL 2): sphere ids of the pairs, the user's owner / geometry wildcard arrays, the time
+    const uint64_t* keys;
+    float* ownerWc[8];
+    float* geoWcSph[8];
+    float* geoWcAnal[8];
+    float timeElapsed;
     uint32_t nOwners, nTiles, pass, xcdGroup;
     uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
     uint32_t nComp, nAnal, nMass;  // table sizes (tile_table_bytes)
@@ -104,17 +124,17 @@ struct TileOwner {
     uint32_t family;
     RotM R;            // rotation coefficients of the orientation (reference rounding: rot_coeffs of deme_device.h)
     float vx, vy, vz;
-    float wx, wy, wz;  // angular velocity in the WORLD frame
+    float wx, wy, wz;  // angular velocity in the WORLD frame (MODEL 2: in the body frame, as the user vocabulary wants it)
+    float qw, qx, qy, qz;  // MODEL 2 only
 };
 
-__device__ inline void tile_stage_owner(const DevParams& p, const float* massTable, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z,
-                                        uint4* dst) {
+__device__ inline void tile_stage_owner_m(const DevParams& p, const float mass, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z,
+                                          uint4* dst) {
     int64_t ux, uy, uz;
     pos_units(r, p, ux, uy, uz);
     const double px = (double)(ux - u0x) * p.l, py = (double)(uy - u0y) * p.l, pz = (double)(uz - u0z) * p.l;
     const RotM R = rot_coeffs(r.qw, r.qx, r.qy, r.qz);
     const f3 w = frot_apply(R, mk3(r.wx, r.wy, r.wz));
-    const float mass = massTable[r.inertiaOff];
     uint2 bx, by, bz;
     __builtin_memcpy(&bx, &px, 8), __builtin_memcpy(&by, &py, 8), __builtin_memcpy(&bz, &pz, 8);
     dst[0] = make_uint4(bx.x, bx.y, by.x, by.y);
@@ -124,6 +144,48 @@ __device__ inline void tile_stage_owner(const DevParams& p, const float* massTab
     dst[4] = make_uint4(__float_as_uint(R.zz), __float_as_uint(r.vx), __float_as_uint(r.vy), __float_as_uint(r.vz));
     dst[5] = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), 0u);
 }
+__device__ inline void tile_stage_owner(const DevParams& p, const float* massTable, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z,
+                                        uint4* dst) {
+    tile_stage_owner_m(p, massTable[r.inertiaOff], r, u0x, u0y, u0z, dst);
+}
+// MODEL 2: position, mass, family | inertia offset << 16, quaternion, velocity, body-frame angular velocity
+__device__ inline void tile_stage_owner_user(const DevParams& p, const float mass, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z,
+                                             uint4* dst) {
+    int64_t ux, uy, uz;
+    pos_units(r, p, ux, uy, uz);
+    const double px = (double)(ux - u0x) * p.l, py = (double)(uy - u0y) * p.l, pz = (double)(uz - u0z) * p.l;
+    uint2 bx, by, bz;
+    __builtin_memcpy(&bx, &px, 8), __builtin_memcpy(&by, &py, 8), __builtin_memcpy(&bz, &pz, 8);
+    dst[0] = make_uint4(bx.x, bx.y, by.x, by.y);
+    dst[1] = make_uint4(bz.x, bz.y, __float_as_uint(mass), (r.family & 0xFFFFu) | ((uint32_t)r.inertiaOff << 16));
+    dst[2] = make_uint4(__float_as_uint(r.qw), __float_as_uint(r.qx), __float_as_uint(r.qy), __float_as_uint(r.qz));
+    dst[3] = make_uint4(__float_as_uint(r.vx), __float_as_uint(r.vy), __float_as_uint(r.vz), __float_as_uint(r.wx));
+    dst[4] = make_uint4(__float_as_uint(r.wy), __float_as_uint(r.wz), 0u, 0u);
+}
+__device__ inline TileOwner tile_read_owner_user(const uint4* sOwn, uint32_t slot) {
+    const uint4* q = sOwn + slot * DEME_TILE_REC_USER;
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    TileOwner o;
+    uint2 t;
+    t = make_uint2(a.x, a.y), __builtin_memcpy(&o.px, &t, 8);
+    t = make_uint2(a.z, a.w), __builtin_memcpy(&o.py, &t, 8);
+    t = make_uint2(b.x, b.y), __builtin_memcpy(&o.pz, &t, 8);
+    o.mass = __uint_as_float(b.z), o.family = b.w;
+    o.qw = __uint_as_float(c.x), o.qx = __uint_as_float(c.y), o.qy = __uint_as_float(c.z), o.qz = __uint_as_float(c.w);
+    o.R = rot_coeffs(o.qw, o.qx, o.qy, o.qz);
+    o.vx = __uint_as_float(d.x), o.vy = __uint_as_float(d.y), o.vz = __uint_as_float(d.z);
+    o.wx = __uint_as_float(d.w), o.wy = __uint_as_float(e.x), o.wz = __uint_as_float(e.y);
+    return o;
+}
+template <int MODEL>
+__device__ inline void tile_stage(const DevParams& p, const float mass, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z, uint4* dst) {
+    if (MODEL == 2)
+        tile_stage_owner_user(p, mass, r, u0x, u0y, u0z, dst);
+    else
+        tile_stage_owner_m(p, mass, r, u0x, u0y, u0z, dst);
+}
+template <int MODEL>
+__device__ inline TileOwner tile_read(const uint4* sOwn, uint32_t slot);
 __device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t slot) {
     const uint4* q = sOwn + slot * DEME_TILE_REC;
     const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
@@ -139,6 +201,25 @@ __device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t slot) {
     o.wx = __uint_as_float(f.x), o.wy = __uint_as_float(f.y), o.wz = __uint_as_float(f.z);
     return o;
 }
+template <>
+__device__ inline TileOwner tile_read<0>(const uint4* sOwn, uint32_t slot) { return tile_read_owner(sOwn, slot); }
+template <>
+__device__ inline TileOwner tile_read<1>(const uint4* sOwn, uint32_t slot) { return tile_read_owner(sOwn, slot); }
+template <>
+__device__ inline TileOwner tile_read<2>(const uint4* sOwn, uint32_t slot) { return tile_read_owner_user(sOwn, slot); }
+
+// what only a run-time compiled model needs beside the staged records (MODEL 2; everything here that the user's statements do
+// not name is dead code after inlining)
+struct TileUser {
+    double ox, oy, oz;        // the tile's origin in world coordinates: the vocabulary's positions are world positions
+    uint32_t ownerA, ownerB;  // engine slots of the two owners
+    uint32_t c;               // the contact's index in the list
+    const uint64_t* keys;     // (AGeo, BGeo)
+    float* const* ownerWc;
+    float* const* geoWcSph;
+    float* const* geoWcAnal;
+    float time;
+};
 
 // One contact of the hot classes between two staged owners.  Arithmetic: forces_fast_body (deme_force_fast.h), with the
 // owner-level quantities taken from the staged records.  Returns the world-frame force on A, the torques about A's and B's
@@ -155,7 +236,7 @@ struct TileTables {
 };
 template <int MODEL>
 __device__ inline void tile_contact(const DevParams& p, const TileTables& T, const uint2 inf, const TileOwner& A, const TileOwner& B,
-                                    float4& hist, f3& force, f3& tA, f3& tB) {
+                                    float4& hist, f3& force, f3& tA, f3& tB, float* uw = nullptr, const TileUser* U = nullptr) {
     const uint32_t cls = (inf.x >> 20) & 3u;
     const float4 cA = T.comp[inf.y & 0xFFFFu];
     const uint32_t matA = (inf.x >> 24) & 15u;
@@ -181,6 +262,8 @@ __device__ inline void tile_contact(const DevParams& p, const TileTables& T, con
     const double dOx = A.px - B.px, dOy = A.py - B.py, dOz = A.pz - B.pz;
     const f3 dO = mk3((float)dOx, (float)dOy, (float)dOz);
     f3 n, rAv, rBv;
+    f3 relBw = mk3(0, 0, 0);      // B's geometry relative to its owner, world frame (a run-time compiled model's bodyBPos)
+    uint32_t userType = 1u;       // ... and its ContactType
     float depth, rB, massB;
     uint32_t matB;
     bool touching;
@@ -190,12 +273,16 @@ __device__ inline void tile_contact(const DevParams& p, const TileTables& T, con
         rB = cB.w;
         massB = B.mass;
         const f3 relB = rot_apply(RB, mk3(cB.x, cB.y, cB.z));
+        relBw = relB;
         const double dx = (dOx + (double)relA.x) - (double)relB.x;
         const double dy = (dOy + (double)relA.y) - (double)relB.y;
         const double dz = (dOz + (double)relA.z) - (double)relB.z;
         const double d2 = dx * dx + dy * dy + dz * dz;
-        const float sumR = rA + rB;
-        const double num = (double)sumR * (double)sumR - d2;
+        // (the sum of the radii in fp64: rounded to fp32 it is off by up to 3e-8 of itself -- nothing for equal radii, whose sum is
+        // exact, but 5e-10 m between unequal ones, 1e-5 of a typical overlap: found on the polydisperse bed of configs[4])
+        const double sumRd = (double)rA + (double)rB;
+        const float sumR = (float)sumRd;
+        const double num = sumRd * sumRd - d2;
         const float d2f = (float)d2;
         const float inv = frsq(d2f);
         const float dist = d2f * inv;
@@ -212,6 +299,8 @@ __device__ inline void tile_contact(const DevParams& p, const TileTables& T, con
         massB = ob.mass;
         const f3 relB = rot_apply(RB, mk3(ob.relx, ob.rely, ob.relz));
         const f3 dir = rot_apply(RB, mk3(ob.rotx, ob.roty, ob.rotz));
+        relBw = relB;
+        userType = ob.type == 0u ? 11u : 13u;
         if (ob.type == 0u) {  // a plane -- the walls of every box -- in a few lines (checkSphereEntityOverlap's plane branch,
             // DEMHelperKernels.cuh:459-478): half of a packed bed's tiles touch the floor, and the general branch below is 150
             // instructions that every wavefront with one wall contact among its 64 would execute
@@ -240,6 +329,56 @@ __device__ inline void tile_contact(const DevParams& p, const TileTables& T, con
     }
     force = mk3(0, 0, 0);
     f3 torque_only = mk3(0, 0, 0);
+#ifdef DEME_JIT
+    if (MODEL == 2) {  // the user's statements, written against the reference's vocabulary (DEMCalcForceKernels.cu:233-251, Models.h:219-378)
+        if (touching) {
+            UserModelIO io;
+            io.overlapDepth = (double)depth;
+            io.B2A = make_float3(n.x, n.y, n.z);
+            io.AOwnerPos = make_double3(U->ox + A.px, U->oy + A.py, U->oz + A.pz);
+            io.BOwnerPos = make_double3(U->ox + B.px, U->oy + B.py, U->oz + B.pz);
+            io.contactPnt = make_double3(io.AOwnerPos.x + (double)rAv.x, io.AOwnerPos.y + (double)rAv.y, io.AOwnerPos.z + (double)rAv.z);
+            io.bodyAPos = make_double3(io.AOwnerPos.x + (double)relA.x, io.AOwnerPos.y + (double)relA.y, io.AOwnerPos.z + (double)relA.z);
+            io.bodyBPos = make_double3(io.BOwnerPos.x + (double)relBw.x, io.BOwnerPos.y + (double)relBw.y, io.BOwnerPos.z + (double)relBw.z);
+            io.AOwnerMass = A.mass, io.BOwnerMass = massB, io.ARadius = rA, io.BRadius = rB;
+            io.AOriQ = make_float4(A.qx, A.qy, A.qz, A.qw), io.BOriQ = make_float4(B.qx, B.qy, B.qz, B.qw);  // float4 is (x, y, z, w)
+            io.bodyAMatType = (uint16_t)matA, io.bodyBMatType = (uint16_t)matB;
+            io.ContactType = (uint8_t)userType, io.AOwnerFamily = (uint8_t)(A.family & 0xFFu), io.BOwnerFamily = (uint8_t)(B.family & 0xFFu);
+            const f3 lA = rot_apply(rot_transpose(RA), rAv), lB = rot_apply(rot_transpose(RB), rBv);
+            io.locCPA = make_float3(lA.x, lA.y, lA.z), io.locCPB = make_float3(lB.x, lB.y, lB.z);
+            io.force = make_float3(0, 0, 0), io.torque_only_force = make_float3(0, 0, 0);
+            io.ts = p.h, io.time = U->time;
+            io.ALinVel = make_float3(A.vx, A.vy, A.vz), io.BLinVel = make_float3(B.vx, B.vy, B.vz);
+            io.ARotVel = make_float3(A.wx, A.wy, A.wz), io.BRotVel = make_float3(B.wx, B.wy, B.wz);
+            {
+                const float4 mA = p.massProps[A.family >> 16], mB = p.massProps[B.family >> 16];
+                io.AOwnerMOI = make_float3(mA.y, mA.z, mA.w), io.BOwnerMOI = make_float3(mB.y, mB.z, mB.w);
+            }
+            io.AOwner = p.o2e ? p.o2e[U->ownerA] : U->ownerA, io.BOwner = p.o2e ? p.o2e[U->ownerB] : U->ownerB;
+            io.myContactID = U->c;
+            {
+                const uint64_t key = U->keys[U->c];
+                const uint32_t ga = key_a(key), gb = key_b(key);
+                io.AGeo = p.s2e ? p.s2e[ga] : ga, io.BGeo = (p.s2e && cls == DEME_KEY_CLASS_SS) ? p.s2e[gb] : gb;
+            }
+            io.wc = uw;
+            io.ownerWc = U->ownerWc;
+            io.geoWcA = U->geoWcSph;
+            io.geoWcB = (cls == DEME_KEY_CLASS_SS) ? U->geoWcSph : U->geoWcAnal;
+            deme_user_model(io);
+            force = mk3(io.force.x, io.force.y, io.force.z);
+            const f3 tot = fadd(force, mk3(io.torque_only_force.x, io.torque_only_force.y, io.torque_only_force.z));
+            tA = fcross(rAv, tot);
+            tB = fcross(tot, rBv);
+        } else {
+            tA = mk3(0, 0, 0), tB = mk3(0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < DEME_JIT_NW; k++)
+                uw[k] = 0.f;  // _forceModelContactWildcardDestroy_
+        }
+        return;
+    }
+#endif
     if (touching) {
         if (depth > 0.f) {
             const float massA = A.mass;
@@ -344,8 +483,8 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
 __host__ __device__ inline uint32_t tile_table_bytes(uint32_t nComp, uint32_t nMat, uint32_t nAnal, uint32_t nMass, uint32_t famTrivial) {
     return nComp * 16u + nMat * nMat * 32u + nAnal * 64u + ((nMass * 4u + 15u) & ~15u) + (famTrivial ? 0u : 1024u);
 }
-__host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap, uint32_t tableBytes) {
-    return (DEME_TILE_NB + hCap) * DEME_TILE_REC * 16u + DEME_TILE_RSLOTS * 40u + 2u * (DEME_TILE_NB + 1u) * 4u + 8u + ((lCap * 2u + 15u) & ~15u) +
+__host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap, uint32_t tableBytes, uint32_t rec16 = DEME_TILE_REC) {
+    return (DEME_TILE_NB + hCap) * rec16 * 16u + DEME_TILE_RSLOTS * 40u + 2u * (DEME_TILE_NB + 1u) * 4u + 8u + ((lCap * 2u + 15u) & ~15u) +
            tableBytes + 16u;
 }
 
@@ -353,7 +492,8 @@ template <int MODEL, bool MESH>
 __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(const DevParams p, const TileArgs a) {
     extern __shared__ uint4 tileLds[];
     uint4* const sOwn = tileLds;
-    float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * DEME_TILE_REC);
+    constexpr uint32_t REC = tile_rec16(MODEL);
+    float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * REC);
     float4* const recT = recA4 + DEME_TILE_RSLOTS;
     float2* const recA2 = reinterpret_cast<float2*>(recT + DEME_TILE_RSLOTS);
     uint32_t* const sALo = reinterpret_cast<uint32_t*>(recA2 + DEME_TILE_RSLOTS);
@@ -363,6 +503,8 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     if (t >= a.nTiles)
         return;
     if (a.tileMode && !(a.tileMode[t] & (1u << a.pass)))
+        return;
+    if (a.tileBig[t])
         return;
     const uint32_t tid = threadIdx.x;
     const uint32_t o0 = t * DEME_TILE_NB;
@@ -411,15 +553,25 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const float4* wc4 = reinterpret_cast<const float4*>(a.wc);
     uint2 inf[DEME_TILE_DEPTH];
     float4 hist[DEME_TILE_DEPTH];
+    constexpr int NWU = MODEL == 2 ? DEME_JIT_NW : 1;
+    float uwv[DEME_TILE_DEPTH][NWU];  // MODEL 2: the contact wildcards of the user's model ride where the history does
     uint32_t rbase[DEME_TILE_DEPTH];  // record number of the first crossing contact of this wavefront's 64 contacts
 #pragma unroll
     for (int d = 0; d < DEME_TILE_DEPTH; d++) {
         const uint32_t cd = c0 + tid + d * DEME_TILE_T;
         inf[d] = make_uint2(0, 0), hist[d] = make_float4(0, 0, 0, 0), rbase[d] = 0u;
+#pragma unroll
+        for (int k = 0; k < NWU; k++)
+            uwv[d][k] = 0.f;
         if (cd < c1) {
             inf[d] = stream_load(a.tInfo + cd);
             if (MODEL == 0)
                 hist[d] = stream_load(wc4 + cd);
+            if (MODEL == 2 && DEME_JIT_HAS_WC) {
+#pragma unroll
+                for (int k = 0; k < NWU; k++)
+                    uwv[d][k] = stream_load(a.wc + (size_t)cd * NWU + k);
+            }
             rbase[d] = a.rankC[cd - (tid & 63u)];
         }
     }
@@ -452,18 +604,18 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         if (tid < nLoc + nH) {
             OwnerRec r2 = rec0;
             ki_opaque(r2.qw), ki_opaque(r2.wx), ki_opaque(r2.family);
-            tile_stage_owner(p, T.mass, r2, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * DEME_TILE_REC);
+            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * REC);
         }
         if (h1 < nH) {
             OwnerRec r2 = rec1;
             ki_opaque(r2.qw), ki_opaque(r2.wx), ki_opaque(r2.family);
-            tile_stage_owner(p, T.mass, r2, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * DEME_TILE_REC);
+            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * REC);
         }
 #endif
         if (tid < nLoc + nH)
-            tile_stage_owner(p, T.mass, rec0, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * DEME_TILE_REC);
+            tile_stage<MODEL>(p, T.mass[rec0.inertiaOff], rec0, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * REC);
         if (h1 < nH)
-            tile_stage_owner(p, T.mass, rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * DEME_TILE_REC);
+            tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * REC);
         if (tid <= DEME_TILE_NB)
             sALo[tid] = bA - c0, sLLo[tid] = bL;
         if (tid == DEME_TILE_T - 1u)  // the zero slot of the contribution arrays
@@ -486,10 +638,18 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     auto refill = [&](const int d, const uint32_t c) __attribute__((always_inline)) {  // stage d takes the round DEME_TILE_DEPTH rounds ahead of contact c
         const uint32_t cd = c + DEME_TILE_DEPTH * DEME_TILE_T;
         inf[d] = make_uint2(0, 0), hist[d] = make_float4(0, 0, 0, 0), rbase[d] = 0u;
+#pragma unroll
+        for (int k = 0; k < NWU; k++)
+            uwv[d][k] = 0.f;
         if (cd < c1) {
             inf[d] = stream_load(a.tInfo + cd);
             if (MODEL == 0)
                 hist[d] = stream_load(wc4 + cd);
+            if (MODEL == 2 && DEME_JIT_HAS_WC) {
+#pragma unroll
+                for (int k = 0; k < NWU; k++)
+                    uwv[d][k] = stream_load(a.wc + (size_t)cd * NWU + k);
+            }
             rbase[d] = a.rankC[cd - (tid & 63u)];
         }
     };
@@ -501,7 +661,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 const uint2 ci = inf[d];
                 float4 h = hist[d];
                 const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
-                const TileOwner A = tile_read_owner(sOwn, slotA), B = tile_read_owner(sOwn, slotB);
+                const TileOwner A = tile_read<MODEL>(sOwn, slotA), B = tile_read<MODEL>(sOwn, slotB);
                 f3 force, tA, tB;
                 if (MESH && ((ci.x >> 20) & 3u) == DEME_KEY_CLASS_SM) {  // (rare, and only in tiles along the mesh: the loads sit behind a branch)
                     const float4 a4 = a.conA4[c], b4 = a.conB4[c];
@@ -518,7 +678,25 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                         ki_sink(f2.x + f2.y + f2.z + u2.x + u2.y + u2.z + w2.x + w2.y + w2.z + h2.x + h2.y + h2.z + h2.w);
                     }
 #endif
-                    tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
+                    if (MODEL == 2) {
+                        float uw[NWU];
+#pragma unroll
+                        for (int k = 0; k < NWU; k++)
+                            uw[k] = uwv[d][k];
+                        TileUser U;
+                        U.ox = (double)u0x * p.l + (double)p.LBFX, U.oy = (double)u0y * p.l + (double)p.LBFY, U.oz = (double)u0z * p.l + (double)p.LBFZ;
+                        U.ownerA = o0 + slotA;
+                        U.ownerB = slotB < DEME_TILE_NB ? o0 + slotB : hl[slotB - DEME_TILE_NB];
+                        U.c = c, U.keys = a.keys, U.ownerWc = a.ownerWc, U.geoWcSph = a.geoWcSph, U.geoWcAnal = a.geoWcAnal, U.time = a.timeElapsed;
+                        tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB, uw, &U);
+                        if (DEME_JIT_HAS_WC) {
+#pragma unroll
+                            for (int k = 0; k < NWU; k++)
+                                stream_store(a.wc + (size_t)c * NWU + k, uw[k]);
+                        }
+                    } else {
+                        tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
+                    }
 #if !(DEME_TILE_KI & 16)
                     if (MODEL == 0)
                         stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
@@ -550,8 +728,12 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             refill(d, c);
 #else
 #pragma unroll
-            for (int q = 0; q + 1 < DEME_TILE_DEPTH; q++)
+            for (int q = 0; q + 1 < DEME_TILE_DEPTH; q++) {
                 inf[q] = inf[q + 1], hist[q] = hist[q + 1], rbase[q] = rbase[q + 1];
+#pragma unroll
+                for (int k = 0; k < NWU; k++)
+                    uwv[q][k] = uwv[q + 1][k];
+            }
             refill(DEME_TILE_DEPTH - 1, c);
 #endif
 
@@ -679,6 +861,117 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     }
 }
 
+// ---- the tiles that do not fit ---------------------------------------------------------------------------------------------------
+// A tile whose foreign owners exceed DEME_TILE_HMAX (a big sphere with hundreds of neighbours, a polydisperse pocket, a numbering
+// that is not spatial), whose contact range exceeds DEME_TILE_CMAX or whose local-B lists exceed DEME_TILE_LMAX is evaluated by this
+// kernel instead -- one workgroup per such tile, the rest of the list stays with k_tile_forces.  Same arithmetic (tile_contact), same
+// outputs (the per-owner sums of the A runs in tSum, 32-byte records for the integrator's gather), but nothing is staged: a contact
+// loads its two owner records from memory and converts them itself, the small tables are read where they lie, and EVERY contact
+// writes a B-side record (the builder numbered them: rankC holds a contact's own record number here), also those whose B owner
+// belongs to the tile.  Slower per contact -- it is the exception path -- and exact about the order of the sums like the tile pass.
+template <int MODEL, bool MESH>
+__global__ __launch_bounds__(DEME_TILE_T) void k_tile_forces_big(const DevParams p, const TileArgs a) {
+    __shared__ float4 recA4[DEME_TILE_RSLOTS];
+    __shared__ float2 recA2[DEME_TILE_RSLOTS];
+    const uint32_t t = a.bigList[blockIdx.x];
+    if (a.tileMode && !(a.tileMode[t] & (1u << a.pass)))
+        return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t o0 = t * DEME_TILE_NB;
+    const uint32_t nLoc = min((uint32_t)DEME_TILE_NB, a.nOwners - o0);
+    const uint32_t c0 = a.aStart[o0], c1 = a.aStart[o0 + nLoc];
+    const int64_t u0x = a.org[3 * (size_t)t], u0y = a.org[3 * (size_t)t + 1], u0z = a.org[3 * (size_t)t + 2];
+    TileTables T;
+    T.comp = p.comp, T.mat = p.matPair, T.anal = p.anal, T.fam = p.familyExtra, T.mass = nullptr;
+    if (tid == DEME_TILE_T - 1u)
+        recA4[DEME_TILE_T] = make_float4(0, 0, 0, 0), recA2[DEME_TILE_T] = make_float2(0, 0);
+    const bool sideA = tid < nLoc;
+    uint32_t plo = 0, phi = 0;
+    if (sideA)
+        plo = a.aStart[o0 + tid] - c0, phi = a.aStart[o0 + tid + 1] - c0;
+    v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, s45 = {0.f, 0.f};
+    float4* const wc4 = reinterpret_cast<float4*>(a.wc);
+    __syncthreads();
+    const uint32_t nCt = c1 - c0;
+    for (uint32_t rlo = 0; rlo < nCt; rlo += DEME_TILE_T) {
+        const uint32_t c = c0 + rlo + tid;
+        if (c < c1) {
+            const uint4 gi = a.info[c];
+            const uint32_t oa = gi.x & 0x3FFFFFFFu, cls = gi.x >> 30, ob = gi.y;
+            const uint32_t matA = gi.z >> 16, compA = gi.z & 0xFFFFu;
+            const uint32_t matB = (cls == DEME_KEY_CLASS_SS) ? (gi.w >> 16) : 0u, wB = (cls == DEME_KEY_CLASS_SS) ? (gi.w & 0xFFFFu) : gi.w;
+            const uint2 ci = make_uint2(tile_info_x(0u, 0u, cls, 1u, matA, matB), compA | (wB << 16));
+            float4 h = make_float4(0, 0, 0, 0);
+            if (MODEL == 0)
+                h = stream_load(wc4 + c);
+            f3 force, tA, tB;
+            if (MESH && cls == DEME_KEY_CLASS_SM) {
+                const float4 a4 = a.conA4[c], b4 = a.conB4[c];
+                const float2 a2 = a.conA2[c], b2 = a.conB2[c];
+                force = mk3(a4.x, a4.y, a4.z), tA = mk3(a4.w, a2.x, a2.y), tB = mk3(b4.w, b2.x, b2.y);
+            } else {
+                __attribute__((aligned(16))) uint4 sa[DEME_TILE_REC], sb[DEME_TILE_REC];
+                const OwnerRec ra = load_owner(a.owners, oa), rb = load_owner(a.owners, ob);
+                tile_stage<MODEL>(p, p.massProps[ra.inertiaOff].x, ra, u0x, u0y, u0z, sa);
+                tile_stage<MODEL>(p, p.massProps[rb.inertiaOff].x, rb, u0x, u0y, u0z, sb);
+                const TileOwner A = tile_read<MODEL>(sa, 0u), B = tile_read<MODEL>(sb, 0u);
+                if (MODEL == 2) {
+                    constexpr int NWU = DEME_JIT_NW;
+                    float uw[NWU];
+#pragma unroll
+                    for (int k = 0; k < NWU; k++)
+                        uw[k] = DEME_JIT_HAS_WC ? a.wc[(size_t)c * NWU + k] : 0.f;
+                    TileUser U;
+                    U.ox = (double)u0x * p.l + (double)p.LBFX, U.oy = (double)u0y * p.l + (double)p.LBFY, U.oz = (double)u0z * p.l + (double)p.LBFZ;
+                    U.ownerA = oa, U.ownerB = ob;
+                    U.c = c, U.keys = a.keys, U.ownerWc = a.ownerWc, U.geoWcSph = a.geoWcSph, U.geoWcAnal = a.geoWcAnal, U.time = a.timeElapsed;
+                    tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB, uw, &U);
+                    if (DEME_JIT_HAS_WC) {
+#pragma unroll
+                        for (int k = 0; k < NWU; k++)
+                            a.wc[(size_t)c * NWU + k] = uw[k];
+                    }
+                } else {
+                    tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
+                }
+                if (MODEL == 0)
+                    stream_store(wc4 + c, h);
+            }
+            recA4[tid] = make_float4(force.x, force.y, force.z, tA.x);
+            recA2[tid] = make_float2(tA.y, tA.z);
+            const uint32_t k = a.rankC[c];  // (this contact's own record)
+            stream_store(a.rec32 + 2 * (size_t)k, make_float4(-force.x, -force.y, -force.z, tB.x));
+            stream_store(a.rec32 + 2 * (size_t)k + 1, make_float4(tB.y, tB.z, 0.f, 0.f));
+        }
+        __syncthreads();
+        if (sideA) {
+            const uint32_t e = min(phi, rlo + DEME_TILE_T);
+            while (plo < e) {
+                float4 v4[4];
+                float2 v2[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = (plo + k < e) ? plo + k - rlo : (uint32_t)DEME_TILE_T;
+                    v4[k] = recA4[i], v2[k] = recA2[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    s01 += v2f{v4[k].x, v4[k].y};
+                    s23 += v2f{v4[k].z, v4[k].w};
+                    s45 += v2f{v2[k].x, v2[k].y};
+                }
+                plo = min(plo + 4u, e);
+            }
+        }
+        __syncthreads();
+    }
+    if (sideA) {
+        a.tSum[2 * (size_t)(o0 + tid)] = make_float4(s01.x, s01.y, s23.x, 0.f);
+        a.tSum[2 * (size_t)(o0 + tid) + 1] = make_float4(s23.y, s45.x, s45.y, 0.f);
+    }
+}
+
+#ifndef DEME_JIT  // (the run-time compiled copy of this header holds the force pass only)
 // ---- per-detection builders ----------------------------------------------------------------------------------------------------
 // (1) k_contact_owners counts, per tile, the contacts whose B owner lives in another tile (tileRem; deme_kernels.h); an exclusive
 //     scan gives every tile the number of its first record (tileBase).
@@ -696,7 +989,8 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
                                                     uint32_t* __restrict__ tileMode, uint16_t* __restrict__ lOff,
                                                     uint16_t* __restrict__ lPos, uint32_t* __restrict__ lCount,
                                                     uint32_t* __restrict__ rankC, uint32_t* __restrict__ remKey,
-                                                    uint32_t* __restrict__ remVal, int64_t* __restrict__ org, RangeCounters* rc) {
+                                                    uint32_t* __restrict__ remVal, int64_t* __restrict__ org, RangeCounters* rc,
+                                                    uint32_t nTiles, uint32_t* __restrict__ tileBig, uint32_t* __restrict__ bigList) {
     __shared__ uint32_t table[DEME_TILE_HASH];
     __shared__ uint16_t slotTab[DEME_TILE_HASH];
     __shared__ uint32_t list[DEME_TILE_HP2];
@@ -761,14 +1055,69 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         __syncthreads();
     }
     const uint32_t n = nU, nLoc = off[DEME_TILE_NB];
-    if (n > DEME_TILE_HMAX || c1 - c0 > DEME_TILE_CMAX || nLoc > DEME_TILE_LMAX) {  // the tile does not fit the LDS area of k_tile_forces: this list is evaluated by k_forces_fast
+    if (n > DEME_TILE_HMAX || c1 - c0 > DEME_TILE_CMAX || nLoc > DEME_TILE_LMAX) {
+        // The tile does not fit the LDS area of k_tile_forces: k_tile_forces_big evaluates it (nothing staged, EVERY contact writes a
+        // record).  Its crossing contacts take the record numbers the scan reserved for them; the contacts that hold an owner of the
+        // tile as B get numbers behind all of those -- one reservation per such tile -- and join the pairs the integrator's per-owner
+        // record lists are sorted from.
+        __shared__ uint32_t extraBase, bigGhost;
         if (tid == 0) {
-            atomicOr(&rc->tileOverflow, 1u);
+            tileBig[t] = 1u;
+            bigList[atomicAdd(&rc->nBig, 1u)] = t;
+            extraBase = tileBase[nTiles] + atomicAdd(&rc->nExtra, nLoc);
+            bigGhost = 0;
             hCount[t] = 0;
             lCount[t] = 0;
+            int64_t ux, uy, uz;
+            pos_units(load_owner(owners, o0), p, ux, uy, uz);
+            org[3 * (size_t)t] = ux, org[3 * (size_t)t + 1] = uy, org[3 * (size_t)t + 2] = uz;
+        }
+        for (uint32_t i = tid; i <= DEME_TILE_NB; i += 256)
+            lOff[(size_t)t * (DEME_TILE_NB + 1) + i] = 0;
+        __syncthreads();
+        uint32_t runR = tileBase[t], runL = extraBase;
+        bool g = false;
+        for (uint32_t cb = c0; cb < c1; cb += 256) {
+            const uint32_t c = cb + tid;
+            bool remote = false, local = false;
+            uint32_t ob = 0;
+            if (c < c1) {
+                ob = ownerBList[c];
+                local = ob >= o0 && ob < o1;
+                remote = !local;
+                if (tileMode)
+                    g = g || ghost_of(owners[ob].family) || ghost_of(owners[info[c].x & 0x3FFFFFFFu].family);
+            }
+            const unsigned long long mr = __ballot(remote), ml = __ballot(local);
+            if (lane == 0)
+                wsum[wave] = (uint32_t)__popcll(mr) | ((uint32_t)__popcll(ml) << 16);
+            __syncthreads();
+            uint32_t beforeR = 0, beforeL = 0, totR = 0, totL = 0;
+            for (uint32_t w = 0; w < 4; w++) {
+                const uint32_t v = wsum[w];
+                beforeR += (w < wave) ? (v & 0xFFFFu) : 0u, beforeL += (w < wave) ? (v >> 16) : 0u;
+                totR += v & 0xFFFFu, totL += v >> 16;
+            }
+            if (c < c1) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t r = remote ? runR + beforeR + (uint32_t)__popcll(mr & below) : runL + beforeL + (uint32_t)__popcll(ml & below);
+                rankC[c] = r;  // (the contact's OWN record, whichever kind it is)
+                remKey[r] = ob, remVal[r] = r;
+            }
+            runR += totR, runL += totL;
+            __syncthreads();
+        }
+        if (tileMode) {
+            if (g)
+                bigGhost = 1;
+            __syncthreads();
+            if (tid == 0)
+                tileMode[t] = bigGhost ? 2u : 1u;
         }
         return;
     }
+    if (tid == 0)
+        tileBig[t] = 0u;
     if (tid < DEME_TILE_NB)
         cnt[tid] = 0;  // (from here on: entries already placed in an owner's list)
     __syncthreads();
@@ -907,6 +1256,8 @@ __global__ __launch_bounds__(256) void k_owner_ranges_tile(const DevParams p, co
             atomicAdd(&rc->nHeavyFree, 1u);
     }
 }
+
+#endif  // DEME_JIT
 
 }  // namespace deme_dev
 

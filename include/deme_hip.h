@@ -190,10 +190,20 @@ int deme_sync(deme_ctx* ctx);
 int deme_set_arith_mode(deme_ctx* ctx, int mode);
 int deme_get_arith_mode(const deme_ctx* ctx);
 /* Which kernel evaluates the contact forces of the current list (what a profile of the stepping loop shows as its dominant
- * kernel): "k_tile_forces<M>" -- the owner-tile pass of the fast mode, csrc/deme_tile.h -- , "k_forces_fast<M>" (fast mode, a
- * list or scene the tile pass does not take: a mesh, replicated free owners, a tile whose foreign owners do not fit LDS),
- * "k_calc_forces<M, 0>" (exact mode, contact recording) or "deme_custom_forces_ss" (a run-time compiled model); M = 0 Hertzian
- * with history, 1 frictionless.  Also the largest tile's foreign-owner count and local list length of the current list. */
+ * kernel): "k_tile_forces<M, MESH>" -- the owner-tile pass of the fast mode, csrc/deme_tile.h; MESH = true when the list holds
+ * sphere-triangle contacts, which the mesh variant of the general kernel evaluates first -- , "k_forces_fast<M>" (fast mode, a
+ * scene the tile pass does not take: replicated free owners, more than 16 materials, tables beyond 4 KB), "k_calc_forces<M, 0>"
+ * (exact mode, contact recording) or "deme_custom_forces_ss" (a run-time compiled model); M = 0 Hertzian with history, 1
+ * frictionless.  Also the largest tile's foreign-owner count and local list length of the current list.
+ * deme_tile_stats: {tiles, tiles that do not fit the LDS area and are evaluated by k_tile_forces_big -- one workgroup each, the
+ * rest of the list stays tiled --, largest halo, largest local list} of the current list (zeros when it is not tiled). */
+int deme_tile_stats(const deme_ctx* ctx, uint32_t out[4]);
+/* A run-time compiled force model is compiled into the tile pass as well ("deme_custom_tile<MESH>": csrc/deme_jit.h splices the
+ * user's statements where the Hertzian block of k_tile_forces is, the reference's vocabulary filled from the staged records,
+ * DEMCalcForceKernels.cu:233-251).  A list takes it when its tiles hold at least minContactsPerTile contacts on average (default
+ * 320: below that -- single spheres with one or two contacts each -- the general kernel is faster, measured on configs[4]);
+ * 0 = always. */
+int deme_set_tile_policy(deme_ctx* ctx, uint32_t minContactsPerTileCustom);
 int deme_force_kernel_name(const deme_ctx* ctx, char* name, size_t cap, uint32_t* tileMaxHalo, uint32_t* tileMaxList);
 
 /* The engine's own numbering (csrc/deme_order.inc).  Owner and sphere ids at this boundary are ALWAYS the caller's -- load order,

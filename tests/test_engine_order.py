@@ -191,3 +191,107 @@ def test_compact_order_is_left_alone_and_the_switch_works(pkg):
     ctx.set_params(p), ctx.upload_scene(sc)
     assert not ctx.engine_order()[0]
     ctx.close()
+
+
+# ---- tiles that do not fit LDS: the per-tile fallback (k_tile_forces_big) ------------------------------------------------------------
+def _fast_vs_oracle(pkg, orc, p, sc, st, steps, ctx):
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st)
+    for s in (ctx, sim):
+        s.compute_margins(0), s.detect(), s.migrate(), s.calc_forces()
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    g, o = ctx.download_state(), sim.download_state()
+    n = int(sc.nOwnerClumps)
+    for keys in (("aX", "aY", "aZ"), ("alphaX", "alphaY", "alphaZ")):
+        G = np.stack([g[k][:n] for k in keys], 1).astype(np.float64)
+        O = np.stack([o[k][:n] for k in keys], 1).astype(np.float64)
+        assert np.abs(G - O).max() <= 2e-4 * np.abs(O).max(), (keys, np.abs(G - O).max() / np.abs(O).max())
+    for w in range(4):
+        gw, ow = ctx.wildcard(w), sim.wildcard(w)
+        assert np.abs(gw - ow).max() <= 1e-5 * max(np.abs(ow).max(), 1e-12) + 1e-12, w
+    ctx.step(steps), sim.step(steps)
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    g, o = ctx.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g) - _positions(pkg, p, o)).max()
+    dv = max(np.abs(g[k] - o[k]).max() for k in ("vX", "vY", "vZ"))
+    return dx, dv
+
+
+def test_tiles_that_do_not_fit_are_evaluated_one_by_one(pkg, orc):
+    """A random numbering kept as it is (deme_set_reorder(0)): the 128 owners of a tile are scattered over the bed, every tile
+    touches hundreds of foreign owners and none fits the LDS area.  The list stays with the tile structures -- tSum, records,
+    the integrator's gather -- and k_tile_forces_big evaluates every tile; against the oracle with the fast mode's bounds."""
+    b = _bed(pkg)
+    b.SetFamilyExtraMargin(0, 0.004)  # (lists every clump's whole neighbourhood: a dozen partners per clump, all over the bed)
+    p, sc, st = _settled(pkg, b)
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_reorder(False)
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
+    assert not ctx.engine_order()[0]
+    dx, dv = _fast_vs_oracle(pkg, orc, p, sc, st, 100, ctx)
+    tiles, big, halo, _ = ctx.tile_stats()
+    assert ctx.force_kernel()[0] == "k_tile_forces<0, false>" and tiles > 40 and big > 0.5 * tiles, (ctx.force_kernel(), tiles, big)
+    print(f"{big} of {tiles} tiles through the per-tile fallback, 100 steps vs the oracle: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
+    assert dx <= 5e-8 and dv <= 2e-4
+    ctx.close()
+
+
+def test_one_tile_with_a_big_sphere_does_not_fit_the_rest_stays_tiled(pkg, orc):
+    """A 12 mm sphere, loaded FIRST (the smallest id of all: it is sphere A of every pair it is in), among 1 mm spheres, with a
+    margin that lists its whole first shell: its tile has to stage ~300 foreign owners, more than the LDS area takes (192).
+    That ONE tile goes through k_tile_forces_big, the others through k_tile_forces; lists and physics against the oracle."""
+    import math
+    r, R = 0.001, 0.012
+    b = pkg.model.packed_bed(20000, seed=31, cd_freq=0, scale=r, spacing_mult=2.02, jitter=0.01, three_sphere=False,
+                             aspect=(1.0, 1.0, 1.0), init_vz=0.0)
+    batch = b.batches[0]
+    c = (batch.xyz.min(0) + batch.xyz.max(0)) / 2
+    keep = np.linalg.norm(batch.xyz - c, axis=1) > (R + 0.9 * r)
+    for name in ("xyz", "vel", "angvel", "oriq", "family"):
+        setattr(batch, name, getattr(batch, name)[keep])
+    if isinstance(batch.templates, list):
+        batch.templates = [t for t, k in zip(batch.templates, keep) if k]
+    t = b.LoadSphereType(2.6e3 * 4 / 3 * math.pi * R ** 3, R, 0)
+    big = b.AddClumps(t, [c.tolist()])
+    big.SetVel(np.array([[0.05, 0.02, -0.08]], np.float32))
+    b.batches = [b.batches[-1]] + b.batches[:-1]  # the big sphere is owner 0 / sphere 0
+    b.SetExpandSafetyAdder(0.0)
+    p, sc = b.Initialize()
+    assert abs(float(b.arrays["Radii"][b.arrays["clumpComponentOffset"][0]]) - R) < 1e-9
+    st0 = pkg.Context(0)
+    st0.set_arith_mode("exact")
+    st0.set_params(p), st0.upload_scene(sc)
+    st = {k: v for k, v in st0.download_state().items() if k in KEYS}
+    st0.close()
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc)
+    sim = orc.make_sim(pkg, p, sc)
+    m = np.full(int(sc.nOwners), 0.6 * r, np.float32)  # (every pair within 1.2 r of touching is listed: the big sphere's first shell)
+    for s in (ctx, sim):
+        s.set_margins(m), s.detect(), s.migrate(), s.calc_forces()
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    assert int(((ga[0] == 0) & (ga[2] == 1)).sum()) > 200, int((ga[0] == 0).sum())  # the shell around the big sphere
+    tiles, nbig, halo, _ = ctx.tile_stats()
+    assert ctx.force_kernel()[0] == "k_tile_forces<1, false>" or ctx.force_kernel()[0] == "k_tile_forces<0, false>"
+    assert 1 <= nbig <= 20 and tiles > 100, (tiles, nbig, halo)
+    g, o = ctx.download_state(), sim.download_state()
+    n = int(sc.nOwnerClumps)
+    for keys in (("aX", "aY", "aZ"), ("alphaX", "alphaY", "alphaZ")):
+        G = np.stack([g[k][:n] for k in keys], 1).astype(np.float64)
+        O = np.stack([o[k][:n] for k in keys], 1).astype(np.float64)
+        scale = max(np.abs(O).max(), 1e-30)
+        assert np.abs(G - O).max() <= 2e-4 * scale, keys
+    for s in (ctx, sim):
+        for _ in range(30):  # the K-step policy by hand: the same margins, a detection every step
+            s.set_margins(m), s.detect(), s.migrate(), s.calc_forces(), s.integrate()
+    g, o = ctx.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g) - _positions(pkg, p, o)).max()
+    dv = max(np.abs(g[k] - o[k]).max() for k in ("vX", "vY", "vZ"))
+    print(f"a big sphere's tile through the per-tile fallback ({nbig} of {tiles} tiles), 30 steps vs the oracle: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
+    assert dx <= 5e-8 and dv <= 2e-4
+    ctx.close()

@@ -159,6 +159,7 @@ def test_config5_polydisperse_cohesive_bed_against_the_oracle(pkg, orc, mode):
     ctx.set_arith_mode(mode)
     ctx.set_params(p), ctx.upload_scene(sc)
     b.compile_into(ctx)
+    ctx.set_tile_policy(0)  # the tile pass whatever the density (by default this bed -- 200 contacts per tile -- keeps the general kernel)
     for _ in range(20):  # settle: the lattice is dropped at 1 m/s
         ctx.step(3000)
         if int(ctx.counts().nContacts) > 1.5 * n:
@@ -177,6 +178,10 @@ def test_config5_polydisperse_cohesive_bed_against_the_oracle(pkg, orc, mode):
     N = 60
     ctx.step(N), sim.step(N)
     orc.set_num_threads(min(8, os.cpu_count() or 1))
+    if mode == "fast":  # the user's statements compiled into the owner-tile pass (deme_jit.h + deme_tile.h MODEL 2)
+        assert ctx.force_kernel()[0] == "deme_custom_tile<false>", ctx.force_kernel()
+    else:
+        assert ctx.force_kernel()[0] == "deme_custom_forces_ss", ctx.force_kernel()
     ga, oa = ctx.contacts(), sim.contacts()
     assert len(ga[0]) == len(oa[0]) and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
     g, o = ctx.download_state(), sim.download_state()

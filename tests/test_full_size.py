@@ -246,6 +246,56 @@ def test_full_size_tile_pass_one_launch_matches_oracle(pkg, orc, big):
 
 
 @pytest.mark.gpu
+def test_full_size_row_major_bed_is_tiled_either_way(pkg):
+    """The headline bed handed over ROW-MAJOR (the sampler's order, what a reference script does: DEMdemo_Mixer.cpp:77-82), 1e6
+    clumps.  By default the engine keeps it in its own order (csrc/deme_order.inc) and every tile fits: k_tile_forces, no tile
+    through the fallback.  With the engine-side order switched off (deme_set_reorder(0)) the 128 consecutive owners of a tile are
+    a row of the lattice, most tiles overflow the LDS area and go through k_tile_forces_big one by one -- the switch is per tile
+    and it is a tested behaviour: both contexts list the same pairs after 120 steps (three detections) and their clumps agree
+    within the fast mode's bounds (the two sum an owner's contributions in different orders)."""
+    import bench
+    b = bench.build_bed(pkg, N, 2024, 40, order="lattice")
+    p, sc = b.Initialize()
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+    a = pkg.Context(0)
+    a.set_arith_mode("fast")
+    a.set_params(p), a.upload_scene(sc)
+    reordered, given, best = a.engine_order()
+    assert reordered and given > 1.5 * best, (reordered, given, best)
+    a.step(22000)  # settle (tiled all the way)
+    tiles, nbig, halo, _ = a.tile_stats()
+    assert a.force_kernel()[0] == "k_tile_forces<0, false>" and nbig == 0 and halo <= 160, (a.force_kernel(), tiles, nbig, halo)
+    st = a.download_state()
+    a.compute_margins(40), a.detect(), a.migrate()
+    la, lb, lt, _ = a.contacts()
+    W = np.stack([a.wildcard(w) for w in range(4)], 1)
+    assert len(la) > 3_000_000
+    t = pkg.Context(0)
+    t.set_arith_mode("fast")
+    t.set_reorder(False)
+    t.set_params(p), t.upload_scene(sc)
+    assert not t.engine_order()[0]
+    t.upload_state({k: st[k] for k in keys})
+    t.seed_contacts(la, lb, lt, W)
+    a.upload_state({k: st[k] for k in keys})  # (both start with a detection on the same state and history)
+    a.step(120), t.step(120)
+    tiles_t, nbig_t, _, _ = t.tile_stats()
+    assert t.force_kernel()[0] == "k_tile_forces<0, false>" and nbig_t > 0.5 * tiles_t, (t.force_kernel(), tiles_t, nbig_t)
+    ga, gt = a.contacts(), t.contacts()
+    ka = (ga[0].astype(np.uint64) << np.uint64(34)) | (ga[2].astype(np.uint64) << np.uint64(31)) | ga[1].astype(np.uint64)
+    kt = (gt[0].astype(np.uint64) << np.uint64(34)) | (gt[2].astype(np.uint64) << np.uint64(31)) | gt[1].astype(np.uint64)
+    assert len(np.setxor1d(ka, kt)) <= 3
+    sa, s2 = a.download_state(), t.download_state()
+    X = pkg.model.decode_positions(sa["voxelID"], sa["locX"], sa["locY"], sa["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    Y = pkg.model.decode_positions(s2["voxelID"], s2["locX"], s2["locY"], s2["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    dx = float(np.abs(X - Y).max())
+    dv = max(float(np.abs(sa[k] - s2[k]).max()) for k in ("vX", "vY", "vZ"))
+    print(f"row-major 1e6 bed: engine order ({tiles} tiles, none through the fallback) vs caller's order ({nbig_t} of {tiles_t} through it): |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
+    assert dx <= 5e-8 and dv <= 2e-4
+    a.close(), t.close()
+
+
+@pytest.mark.gpu
 def test_mesh_flavour_at_scale_matches_oracle(pkg, orc):
     """BASELINE configs[3] flavour at scale: 3e5 clumps settled on a wavy 30k-triangle plate (1e5 sphere-triangle contacts among
     8e5): contact list and 15 further steps bit-identical to the oracle.  (A one-off run of the same check at 1e6 clumps + 50k
