@@ -579,6 +579,10 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if not int(flag.item()):
+            if os.environ.get("DEME_BENCH_STRICT", "0") not in ("", "0"):
+                # a scaling measurement is a measurement of the LIBRARY loop: no silent change of what is being timed
+                raise SystemExit(f"[bench] rank {rank}: the library's halo loop could not be set up on every rank and DEME_BENCH_STRICT is set "
+                                 f"(the Python loop over torch.distributed is not what --gpus {world} is meant to measure)")
             if group is not None:
                 group.close()
             group = None
@@ -652,11 +656,14 @@ def main():
             for _ in range(n):
                 halo.step()
 
-    def barrier():
+    def local_sync():
         if group is not None:
             group.sync()
         ctx.sync()
         torch.cuda.synchronize()
+
+    def barrier():
+        local_sync()
         if world > 1:
             dist.barrier()
 
@@ -736,6 +743,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
+    local_sync()
+    dt_local = time.perf_counter() - t0  # this rank's own clock, before it waits for the others (reported per rank; not the metric)
     barrier()
     dt = time.perf_counter() - t0
     total_clumps = n_own
@@ -745,6 +754,15 @@ def main():
         tot = torch.tensor([float(n_own)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt, total_clumps = float(tmax.item()), int(tot.item())
+    # per rank: what it holds and how long ITS timed region took -- the first real multi-GPU run shows imbalance at a glance
+    per_rank = None
+    if world > 1:
+        n_ghost = int(sc.nOwnerClumps) - int(n_own)
+        mine = torch.tensor([float(n_own), float(n_ghost), float(ctx.counts().nContacts), 1e3 * dt_local / args.steps], dtype=torch.float64, device=red_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"owners": [int(v[0].item()) for v in allr], "ghosts": [int(v[1].item()) for v in allr],
+                    "contacts": [int(v[2].item()) for v in allr], "ms_per_step": [round(float(v[3].item()), 5) for v in allr]}
     n_det = int(ctx.counts().nDetections) - det_before
     f_ms, f_n = ctx.kernel_time_ms("calc_forces")
     i_ms, _ = ctx.kernel_time_ms("integrate")
@@ -792,7 +810,7 @@ def main():
         "scaling": "strong" if args.clumps_total else "weak",
         # who moved the ghosts, and how many ranks the communicator that moved them spans (ncclCommCount of the library's own
         # communicator; the world size of torch's for the Python loop): a run whose count differs from --gpus exits non-zero
-        "halo_loop": halo_loop, "rccl_ranks": rccl_ranks,
+        "halo_loop": halo_loop, "rccl_ranks": rccl_ranks, "per_rank": per_rank,
         "migration": ({"every_steps": args.migrate_every, "calls_in_timed_region": migration["calls"], "clumps_moved": migration["moved"],
                        "host_seconds": migration["s"], "drift_m_per_s": args.drift} if args.migrate_every else None),
         "vs_baseline": value / README_CLUMP_STEPS_PER_S, "dtype": "f32 physics / f64 geometry", "arith_mode": ctx.arith_mode(), "data": "synthetic",

@@ -370,8 +370,10 @@ __device__ inline void sweep_emit(SweepLDS& L, bool hit, uint64_t key, uint32_t 
 // own numbering, and the choice matters: the contact point is computed from B's side).  When the engine keeps the spheres in a
 // spatial order of its own (DevParams::s2e, deme_order.inc) the roles follow the caller's ids, so that lists, contact points
 // and histories are those of the caller's numbering whatever the internal one is.
-__device__ inline bool a_before_b(const DevParams& p, uint32_t a, uint32_t b) {
-    return p.s2e ? p.s2e[a] < p.s2e[b] : a < b;
+__device__ inline bool a_before_b(const DevParams& p, uint32_t a, uint32_t b, uint32_t ownerA, uint32_t ownerB) {
+    // (spheres are clump-major in the caller's numbering too, and a pair of one owner is no pair: the owners' ids decide -- a
+    // third of the spheres' table to gather from)
+    return p.o2e ? p.o2e[ownerA] < p.o2e[ownerB] : a < b;
 }
 
 // all lanes of one wavefront: exact test of the first `cnt` queued pairs (entry i | entry q << 16) and emission of the hits
@@ -390,11 +392,19 @@ __device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const GeoR
         // the two entries in either order, which (measured: once per ~1e9 pair evaluations) dropped or doubled a contact.
         const uint32_t e0 = e & 0xFFFFu, e1 = e >> 16;
         uint32_t i = min(e0, e1), q = max(e0, e1);
-        if (p.s2e && p.s2e[L.sph[i]] > p.s2e[L.sph[q]]) {  // (entries of one bin are in ascending engine order; the roles follow the caller's ids)
-            const uint32_t t = i;
-            i = q, q = t;
+        // the fp64 records: only the ~3 % that pass the pre-filter need them.  (With an engine-side order the caller's ids of the two
+        // spheres are fetched beside them -- four independent loads, not a look-up in front of the records -- and decide the roles:
+        // entries of one bin are in ascending engine order.)
+        GeoRec ga = geo[L.sph[i]], gb = geo[L.sph[q]];
+        if (p.o2e) {  // (spheres are clump-major in the caller's numbering too: the owners' ids decide -- a pair of one owner is no pair)
+            const uint32_t ea = p.o2e[L.owner[i]], eb = p.o2e[L.owner[q]];
+            if (ea > eb) {
+                const uint32_t t = i;
+                i = q, q = t;
+                const GeoRec g = ga;
+                ga = gb, gb = g;
+            }
         }
-        const GeoRec ga = geo[L.sph[i]], gb = geo[L.sph[q]];  // the fp64 records: only the ~3 % that pass the pre-filter need them
         hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], gb.x, gb.y, gb.z, gb.r, L.owner[q], L.fam[q], L.bin[q]);
         if (hit)
             key = make_key(DEME_KEY_CLASS_SS, L.sph[i], L.sph[q]);
@@ -643,7 +653,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                         uint64_t key = 0;
                         if (act) {
                             const GeoRec ga = geo[L.sph[i]];  // same address for every lane
-                            if (a_before_b(p, L.sph[i], ms)) {
+                            if (a_before_b(p, L.sph[i], ms, L.owner[i], mo)) {
                                 hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf, gbin);
                                 if (hit)
                                     key = make_key(DEME_KEY_CLASS_SS, L.sph[i], ms);
