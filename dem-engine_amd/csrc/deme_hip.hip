@@ -66,6 +66,7 @@ struct deme_ctx {
     DevBuf owners, spheres, acc, comp, massProps, anal, matPair, E, nu, CoR, mu, Crr, famMasks, famExtra, famFlags;
     std::vector<uint8_t> hObjType;  // host copy for contact-type decoding on download
     // detection scratch
+    DevBuf sphFam;  // per sphere: its owner's family word, for the sweeps (written by k_sphere_prep when masks, margins or ghosts are in play)
     DevBuf geo, binLo, binN, counts, offsets, incKeys[2], incVals[2], keysRaw, keysMid, keysSorted[2], mapping, wc[2], ctr, segCtr,
         scanTmp, sortTmp, rec[4], stage;
     // per-contact contributions and the per-owner gather lists (built once per detection)
@@ -501,7 +502,7 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             hipLaunchKernelGGL(k_sphere_prep, dim3(grid_for(nS)), dim3(256), 0, st, c->dp,
                                ow, c->spheres.as<SphereRec>(), c->geo.as<GeoRec>(),
                                c->binLo.as<uint4>(), c->binN.as<uint2>(), c->counts.as<uint32_t>(),
-                               ar, c->ctr.as<DetectCounters>());
+                               ar, c->ctr.as<DetectCounters>(), c->sphFam.as<uint16_t>());
             size_t tmp = c->scanTmp.bytes;
             HIPCK(rocprim::exclusive_scan(c->scanTmp.p, tmp, c->counts.as<uint32_t>(), c->offsets.as<uint32_t>(), 0u,
                                           (size_t)nS + 1, rocprim::plus<uint32_t>(), st));
@@ -584,7 +585,7 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             static_assert(SW_WPB == 1, "k_sweep writes one statistics record per window");
             hipLaunchKernelGGL(k_sweep, dim3(nWin), dim3(SW_T), 0, st, c->dp,
                                c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), P, c->geo.as<GeoRec>(),
-                               ow, ar, c->binStat.as<uint2>());
+                               c->sphFam.as<uint16_t>(), ar, c->binStat.as<uint2>());
             hipLaunchKernelGGL(k_bin_stats_final, dim3((nWin + 2047u) / 2048u), dim3(256), 0, st, c->binStat.as<uint2>(), nWin,
                                c->ctr.as<DetectCounters>());
         }
@@ -632,7 +633,7 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
                 hipLaunchKernelGGL(k_tri_sweep, dim3(grid_for(TP)), dim3(256), 0, st, c->dp, TP,
                                    c->triKeys[1].as<uint32_t>(), c->triVals[1].as<uint32_t>(), c->triWorld.as<TriWorld>(), P,
                                    c->incKeys[1].as<uint32_t>(), c->incVals[1].as<uint32_t>(), c->geo.as<GeoRec>(),
-                                   ow, ar);
+                                   c->sphFam.as<uint16_t>(), ar);
             }
         }
         // the gaps between the arena's segments are closed while the host waits for the counts: a launch sized from the last
@@ -1357,7 +1358,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->tileBig, &c->bigList, &c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->sphFam, &c->tileBig, &c->bigList, &c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1654,7 +1655,7 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     }
     c->dp.hasGhosts = (c->hasGhosts ? 1u : 0u) | (c->pairsOnce ? 2u : 0u);
     // detection scratch
-    if (ensure(c, c->geo, std::max<size_t>(nS, 1) * sizeof(GeoRec)) || ensure(c, c->binLo, std::max<size_t>(nS, 1) * 16) ||
+    if (ensure(c, c->sphFam, std::max<size_t>(nS, 1) * 2) || ensure(c, c->geo, std::max<size_t>(nS, 1) * sizeof(GeoRec)) || ensure(c, c->binLo, std::max<size_t>(nS, 1) * 16) ||
         ensure(c, c->binN, std::max<size_t>(nS, 1) * 8) || ensure(c, c->counts, (nS + 1) * 4) ||
         ensure(c, c->offsets, (nS + 1) * 4))
         return c->lastStatus;

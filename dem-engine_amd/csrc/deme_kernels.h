@@ -126,7 +126,8 @@ struct ObjWorld {
 __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const OwnerRec* __restrict__ owners,
                                                      const SphereRec* __restrict__ spheres, GeoRec* __restrict__ geo,
                                                      uint4* __restrict__ binLo, uint2* __restrict__ binN,
-                                                     uint32_t* __restrict__ counts, const KeyArena ar, DetectCounters* ctr) {
+                                                     uint32_t* __restrict__ counts, const KeyArena ar, DetectCounters* ctr,
+                                                     uint16_t* __restrict__ sphFam) {
     __shared__ ObjWorld sObj[64];
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = s < p.nSpheres;
@@ -148,8 +149,13 @@ __global__ __launch_bounds__(256) void k_sphere_prep(const DevParams p, const Ow
         fam = fam_of(o.family);
         ghostOnce = ghost_of(o.family) && (p.hasGhosts & 2u);  // (its own rank lists a ghost sphere's wall contacts)
         GeoRec g;
-        g.x = pos.x, g.y = pos.y, g.z = pos.z, g.r = rSweep, g.owner = sr.owner;
+        // The owner number the sweeps see is the CALLER's (engine-side order, deme_order.inc): it serves their same-owner test and
+        // decides which sphere of a pair is A -- spheres are clump-major in the caller's numbering too.  The family word they need
+        // when masks, margins or ghosts are in play travels per sphere (the sweeps have no use for the engine's owner slot then).
+        g.x = pos.x, g.y = pos.y, g.z = pos.z, g.r = rSweep, g.owner = p.o2e ? p.o2e[sr.owner] : sr.owner;
         geo[s] = g;
+        if (!(p.familyTrivial && !p.hasGhosts))
+            sphFam[s] = (uint16_t)o.family;
         uint32_t lx, hx, ly, hy, lz, hz;
         bin_range(pos.x, rBin, p.binSize, p.nbX, lx, hx);
         bin_range(pos.y, rBin, p.binSize, p.nbY, ly, hy);
@@ -368,13 +374,9 @@ __device__ inline void sweep_emit(SweepLDS& L, bool hit, uint64_t key, uint32_t 
 
 // Which sphere of a pair is A: the one with the smaller id IN THE CALLER'S NUMBERING (the reference's i < j loop runs over its
 // own numbering, and the choice matters: the contact point is computed from B's side).  When the engine keeps the spheres in a
-// spatial order of its own (DevParams::s2e, deme_order.inc) the roles follow the caller's ids, so that lists, contact points
-// and histories are those of the caller's numbering whatever the internal one is.
-__device__ inline bool a_before_b(const DevParams& p, uint32_t a, uint32_t b, uint32_t ownerA, uint32_t ownerB) {
-    // (spheres are clump-major in the caller's numbering too, and a pair of one owner is no pair: the owners' ids decide -- a
-    // third of the spheres' table to gather from)
-    return p.o2e ? p.o2e[ownerA] < p.o2e[ownerB] : a < b;
-}
+// spatial order of its own (DevParams::o2e, deme_order.inc) the sweep stages the CALLER's owner numbers in LDS and takes the roles
+// from them (spheres are clump-major in the caller's numbering too, and a pair of one owner is no pair), so that lists, contact
+// points and histories are those of the caller's numbering whatever the internal one is.
 
 // all lanes of one wavefront: exact test of the first `cnt` queued pairs (entry i | entry q << 16) and emission of the hits
 __device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const GeoRec* __restrict__ geo, const uint32_t* wq, uint32_t cnt,
@@ -392,19 +394,12 @@ __device__ inline void sweep_confirm(const DevParams& p, SweepLDS& L, const GeoR
         // the two entries in either order, which (measured: once per ~1e9 pair evaluations) dropped or doubled a contact.
         const uint32_t e0 = e & 0xFFFFu, e1 = e >> 16;
         uint32_t i = min(e0, e1), q = max(e0, e1);
-        // the fp64 records: only the ~3 % that pass the pre-filter need them.  (With an engine-side order the caller's ids of the two
-        // spheres are fetched beside them -- four independent loads, not a look-up in front of the records -- and decide the roles:
-        // entries of one bin are in ascending engine order.)
-        GeoRec ga = geo[L.sph[i]], gb = geo[L.sph[q]];
-        if (p.o2e) {  // (spheres are clump-major in the caller's numbering too: the owners' ids decide -- a pair of one owner is no pair)
-            const uint32_t ea = p.o2e[L.owner[i]], eb = p.o2e[L.owner[q]];
-            if (ea > eb) {
-                const uint32_t t = i;
-                i = q, q = t;
-                const GeoRec g = ga;
-                ga = gb, gb = g;
-            }
+        // the fp64 records: only the ~3 % that pass the pre-filter need them
+        if (L.owner[i] > L.owner[q]) {  // the staged owner numbers are the caller's: the smaller one's sphere is A (in the caller's own
+            const uint32_t t = i;       // order entries i < q never swap: spheres are clump-major)
+            i = q, q = t;
         }
+        const GeoRec ga = geo[L.sph[i]], gb = geo[L.sph[q]];
         hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], gb.x, gb.y, gb.z, gb.r, L.owner[q], L.fam[q], L.bin[q]);
         if (hit)
             key = make_key(DEME_KEY_CLASS_SS, L.sph[i], L.sph[q]);
@@ -429,7 +424,7 @@ __device__ inline void sweep_flush(SweepLDS& L, uint32_t t, const KeyArena& ar) 
 
 __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_t* __restrict__ keys,
                                                 const uint32_t* __restrict__ sphIds, uint32_t P,
-                                                const GeoRec* __restrict__ geo, const OwnerRec* __restrict__ owners,
+                                                const GeoRec* __restrict__ geo, const uint16_t* __restrict__ sphFam,
                                                 const KeyArena ar, uint2* __restrict__ winStats) {
     __shared__ SweepLDS L;
     const uint32_t t = threadIdx.x;
@@ -498,8 +493,10 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
             const float fx = (float)(g.x - (double)ix * p.binSize), fy = (float)(g.y - (double)iy * p.binSize),
                         fz = (float)(g.z - (double)iz * p.binSize);
             L.f[q] = make_float4(fx, fy, fz, sweep_radius(fx, fy, fz, g.r));
+            // (the owner number of the geometry record is the caller's: k_sphere_prep.  Looking it up here -- in this loop or in a
+            // pass of its own -- cost 45 us of the kernel's 340 even with no order to translate: measured, profiles/r04)
             L.owner[q] = g.owner, L.sph[q] = sph;
-            L.fam[q] = (uint16_t)((p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family);
+            L.fam[q] = (uint16_t)((p.familyTrivial && !p.hasGhosts) ? 0u : sphFam[sph]);
         }
         // keys were loaded at offset `start`: shift so that L.bin[q] matches entry q of the range
         uint32_t b0 = DEME_NULL_BINID_DEV, b1 = DEME_NULL_BINID_DEV;
@@ -632,7 +629,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                     const uint32_t sph = sphIds[ta + t];
                     const GeoRec g = geo[sph];
                     L.owner[t] = g.owner, L.sph[t] = sph;
-                    L.fam[t] = (uint16_t)((p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family);
+                    L.fam[t] = (uint16_t)((p.familyTrivial && !p.hasGhosts) ? 0u : sphFam[sph]);
                 }
                 __syncthreads();
                 for (uint32_t tb = ta; tb < ge; tb += SW_T) {
@@ -645,7 +642,7 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                         ms = sphIds[jb];
                         const GeoRec g = geo[ms];
                         mx = g.x, my = g.y, mz = g.z, mr = g.r, mo = g.owner;
-                        mf = (p.familyTrivial && !p.hasGhosts) ? 0u : owners[g.owner].family;
+                        mf = (p.familyTrivial && !p.hasGhosts) ? 0u : sphFam[ms];
                     }
                     for (uint32_t i = 0; i < na; i++) {  // uniform trip count
                         const bool act = valid && (ta + i < jb);  // each unordered pair once
@@ -653,15 +650,18 @@ __global__ __launch_bounds__(SW_T) void k_sweep(const DevParams p, const uint32_
                         uint64_t key = 0;
                         if (act) {
                             const GeoRec ga = geo[L.sph[i]];  // same address for every lane
-                            if (a_before_b(p, L.sph[i], ms, L.owner[i], mo)) {
-                                hit = pair_test(p, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], mx, my, mz, mr, mo, mf, gbin);
-                                if (hit)
-                                    key = make_key(DEME_KEY_CLASS_SS, L.sph[i], ms);
-                            } else {  // (only with an engine-side order: the lane's sphere has the smaller caller id)
-                                hit = pair_test(p, mx, my, mz, mr, mo, mf, ga.x, ga.y, ga.z, ga.r, L.owner[i], L.fam[i], gbin);
-                                if (hit)
-                                    key = make_key(DEME_KEY_CLASS_SS, ms, L.sph[i]);
-                            }
+                            // A is the sphere of the owner with the smaller number in the caller's numbering (the staged numbers): the
+                            // entry, unless an engine-side order put the lane's sphere first -- ONE test with the arguments in place
+                            // (two calls cost the whole kernel registers: its hot loop spilled)
+                            const bool entryFirst = L.owner[i] <= mo;
+                            const double ax = entryFirst ? ga.x : mx, ay = entryFirst ? ga.y : my, az = entryFirst ? ga.z : mz;
+                            const double bx = entryFirst ? mx : ga.x, by = entryFirst ? my : ga.y, bz = entryFirst ? mz : ga.z;
+                            const float ar_ = entryFirst ? ga.r : mr, br_ = entryFirst ? mr : ga.r;
+                            const uint32_t ao = entryFirst ? L.owner[i] : mo, bo = entryFirst ? mo : L.owner[i];
+                            const uint32_t af = entryFirst ? (uint32_t)L.fam[i] : mf, bf = entryFirst ? mf : (uint32_t)L.fam[i];
+                            hit = pair_test(p, ax, ay, az, ar_, ao, af, bx, by, bz, br_, bo, bf, gbin);
+                            if (hit)
+                                key = entryFirst ? make_key(DEME_KEY_CLASS_SS, L.sph[i], ms) : make_key(DEME_KEY_CLASS_SS, ms, L.sph[i]);
                         }
                         sweep_emit(L, hit, key, lane, ar);
                     }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t T
                                                    const uint32_t* __restrict__ triIds, const TriWorld* __restrict__ tw,
                                                    uint32_t P, const uint32_t* __restrict__ sphKeys,
                                                    const uint32_t* __restrict__ sphIds, const GeoRec* __restrict__ geo,
-                                                   const OwnerRec* __restrict__ owners, const KeyArena ar) {
+                                                   const uint16_t* __restrict__ sphFam, const KeyArena ar) {
     __shared__ uint64_t wbufAll[4][TRI_WBUF];
     uint64_t* wbuf = wbufAll[threadIdx.x >> 6];
     uint32_t nBuf = 0;
@@ -164,12 +164,12 @@ __global__ __launch_bounds__(256) void k_tri_sweep(const DevParams p, uint32_t T
         if (act) {
             const uint32_t sp = sphIds[x];
             const GeoRec g = geo[sp];
-            bool ok = g.owner != w.owner;
+            bool ok = g.owner != w.owner;  // (the caller's owner number of the sphere; a mesh owner has the same number inside and out)
             float am = 0.f;
             if (ok && (p.hasGhosts & 2u))
-                ok = !ghost_of(owners[g.owner].family);  // (its own rank lists a ghost sphere's mesh contacts)
+                ok = !ghost_of(sphFam[sp]);  // (its own rank lists a ghost sphere's mesh contacts)
             if (ok && !p.familyTrivial) {
-                const uint32_t fS = fam_of(owners[g.owner].family);
+                const uint32_t fS = fam_of(sphFam[sp]);
                 ok = p.familyMasks[mask_pair(fS, w.family)] == 0;
                 const float ea = p.familyExtra[fS], eb = p.familyExtra[w.family];
                 am = (ea < eb) ? ea : eb;
