@@ -202,7 +202,7 @@ def test_reference_demo_scripts_compile_and_link_unchanged_against_the_shell(tmp
 
 
 def _collide_scene(pkg):
-    """the scene of host/demo_collide.cpp through the Python set-up path (model.py), for the oracle"""
+    """the scene of tests/clients/demo_collide.cpp through the Python set-up path (model.py), for the oracle"""
     b = pkg.model.SceneBuilder()
     m1 = b.LoadMaterial({"E": 1e9, "nu": 0.3, "CoR": 0.8, "mu": 0.3, "Crr": 0.01})
     m2 = b.LoadMaterial({"E": 2e9, "nu": 0.4, "CoR": 0.6, "mu": 0.3, "Crr": 0.01})
@@ -236,7 +236,7 @@ def test_collide_demo_matches_the_oracle(pkg, orc):
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     frames = 30
     env = dict(os.environ, DEME_ARITH="exact")
-    out = subprocess.run([os.path.join(HOST, "demo_collide"), str(frames)], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([os.path.join(ROOT, "tests", "clients", "demo_collide"), str(frames)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     state = np.array([[float(x) for x in ln.split()[2:8]] for ln in out.stdout.splitlines() if ln.startswith("STATE")])
     fams = [int(ln.split()[8]) for ln in out.stdout.splitlines() if ln.startswith("STATE")]
