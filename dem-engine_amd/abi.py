@@ -475,6 +475,15 @@ class Context:
         self._ck(self.lib.deme_get_order(self.h, C.byref(r), sp), "deme_get_order")
         return bool(r.value), float(sp[0]), float(sp[1])
 
+    def order_renewals(self):
+        n = C.c_uint64(0)
+        self.lib.deme_order_renewals.argtypes = [_P, C.POINTER(C.c_uint64)]
+        self._ck(self.lib.deme_order_renewals(self.h, C.byref(n)), "deme_order_renewals")
+        return int(n.value)
+
+    def renew_order(self):
+        self._ck(self.lib.deme_renew_order(self.h), "deme_renew_order")
+
     def set_reorder(self, enable):
         self.lib.deme_set_reorder.argtypes = [_P, C.c_int]
         self._ck(self.lib.deme_set_reorder(self.h, int(bool(enable))), "deme_set_reorder")

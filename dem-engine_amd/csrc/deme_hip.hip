@@ -193,6 +193,12 @@ struct deme_ctx {
     std::vector<uint32_t> hO2E, hE2O, hS2E, hE2S;
     DevBuf dO2E, dS2E;
     double orderSpread[2] = {0, 0};  // cells per tile bounding box: in the caller's order, along the curve
+    // renewing the order at run time (order_renew): the engine watches the tiles of every detection -- mean foreign owners per
+    // tile, tiles that no longer fit -- against what they were right after the last (re)ordering
+    bool orderEligible = false;     // the scene may be reordered (fast mode, no ghosts: what order_decide checks)
+    bool orderRenewDue = false;
+    uint32_t orderBaseHalo = 0;     // mean halo (x 16) at the first detection after the last ordering; 0 = not taken yet
+    uint64_t orderDetAt = 0, nOrderRenewals = 0;
     uint64_t listSerial = 0, viewSerial = ~0ull;  // the caller's view of the current list (ids and order), cached per list
     std::vector<uint64_t> viewKeys;
     std::vector<uint32_t> viewPerm;
@@ -928,6 +934,17 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
         }
         c->tileActive = tiled;
         c->tileMaxHalo = hr.tileMaxHalo, c->tileMaxList = hr.tileMaxList;
+        if (tiled && c->orderEligible) {  // has the bed drifted away from the order it was given?  (order_renew at the next detection)
+            const uint32_t fit = std::max(1u, nTiles - std::min(nTiles, hr.nBig));
+            const uint32_t mean16 = (uint32_t)(16ull * hr.tileHaloSum / fit);
+            if (!c->orderBaseHalo) {
+                c->orderBaseHalo = std::max(mean16, 16u);
+                c->orderDetAt = c->nDetections;
+            } else if (c->nDetections - c->orderDetAt >= 20 && nTiles > 4 &&
+                       (hr.nBig > std::max(4u, nTiles / 64u) || mean16 > c->orderBaseHalo + c->orderBaseHalo / 2)) {
+                c->orderRenewDue = true;
+            }
+        }
         c->nSA = hr.nSA;
         c->nSM = hr.nSM;
         c->conValid = false;
@@ -1452,6 +1469,19 @@ int deme_get_order(const deme_ctx* c, int* reordered, double spread[2]) {
         spread[0] = c->orderSpread[0], spread[1] = c->orderSpread[1];
     return DEME_OK;
 }
+int deme_order_renewals(const deme_ctx* c, uint64_t* n) {
+    if (!c || !n)
+        return DEME_ERR_INVALID;
+    *n = c->nOrderRenewals;
+    return DEME_OK;
+}
+int deme_renew_order(deme_ctx* c) {
+    if (int rc = check_ready(c))
+        return rc;
+    if (!c->orderEligible)
+        return fail(c, DEME_ERR_INVALID, "this scene keeps the caller's order (exact arithmetic mode, ghosts, or reordering switched off)");
+    return order_renew(c);
+}
 int deme_order_probe(const DemeParams* p, size_t nClumps, const uint64_t* voxelID, const uint16_t* locX, const uint16_t* locY,
                      const uint16_t* locZ, uint32_t* order, double spread[2]) {
     if (!p || !voxelID || !locX || !locY || !locZ || !spread || !(p->binSize > 0) || !(p->l > 0))
@@ -1515,6 +1545,7 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     // the engine's own order of clumps and spheres (deme_order.inc): slot k holds the caller's owner o2e(k)
     c->permuted = order_decide(c, s);
     c->viewSerial = ~0ull;
+    c->orderRenewDue = false, c->orderBaseHalo = 0;
     auto o2e = [&](size_t k) { return c->permuted ? (size_t)c->hO2E[k] : k; };
     // owners
     std::vector<OwnerRec> ho(nO);
@@ -1959,7 +1990,11 @@ static int ensure_adaptive_events(deme_ctx* c) {
 }
 
 // margins + detection + history migration of a step whose list is due, with the controllers' timing around it
+static int order_renew(deme_ctx* c);
 static int detection_phase(deme_ctx* c) {
+    if (c->orderRenewDue && c->asyncLead == 0 && !c->inGroupStep)
+        if (int rc = order_renew(c))
+            return rc;
     const bool adaptive = c->ad.autoBinSize || c->ad.autoUpdateFreq;
     if (adaptive) {
         if (int rc = ensure_adaptive_events(c))

@@ -1182,7 +1182,8 @@ struct RangeCounters {
     unsigned int tileMaxHalo, tileMaxList;  // the largest tile's foreign owners / local-B list entries: they size the kernel's LDS
     unsigned int nBig;    // tiles whose halo, contact range or local lists do not fit the LDS area of k_tile_forces (deme_tile.h)
     unsigned int nExtra;  // records of those tiles' contacts that hold a B owner of the same tile (every contact of such a tile writes a record)
-    unsigned int pad[7];
+    unsigned int tileHaloSum;  // foreign owners staged by all fitting tiles together (the engine watches its mean: deme_order.inc)
+    unsigned int pad[6];
 };
 
 // start[o] = first index i with owner[i] >= o, for o = 0 .. nOwners (owner[] ascending): every element fills the owners that

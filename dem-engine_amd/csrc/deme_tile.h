@@ -1210,21 +1210,23 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
 // (same-address atomics serialise at ~12 ns)
 __global__ __launch_bounds__(256) void k_tile_stats(uint32_t nTiles, const uint32_t* __restrict__ hCount,
                                                     const uint32_t* __restrict__ lCount, RangeCounters* rc) {
-    __shared__ uint32_t mh[4], ml[4];
-    uint32_t a = 0, b = 0;
+    __shared__ uint32_t mh[4], ml[4], sh[4];
+    uint32_t a = 0, b = 0, sum = 0;
     for (uint32_t k = 0; k < 4; k++) {
         const uint32_t t = (blockIdx.x * 4u + k) * 256u + threadIdx.x;
         if (t < nTiles)
-            a = max(a, hCount[t]), b = max(b, lCount[t]);
+            a = max(a, hCount[t]), b = max(b, lCount[t]), sum += hCount[t];
     }
     for (int o = 32; o > 0; o >>= 1) {
         a = max(a, (uint32_t)__shfl_xor((int)a, o));
         b = max(b, (uint32_t)__shfl_xor((int)b, o));
+        sum += (uint32_t)__shfl_xor((int)sum, o);
     }
     if ((threadIdx.x & 63u) == 0)
-        mh[threadIdx.x >> 6] = a, ml[threadIdx.x >> 6] = b;
+        mh[threadIdx.x >> 6] = a, ml[threadIdx.x >> 6] = b, sh[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
+        atomicAdd(&rc->tileHaloSum, sh[0] + sh[1] + sh[2] + sh[3]);
         atomicMax(&rc->tileMaxHalo, max(max(mh[0], mh[1]), max(mh[2], mh[3])));
         atomicMax(&rc->tileMaxList, max(max(ml[0], ml[1]), max(ml[2], ml[3])));
     }

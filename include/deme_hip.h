@@ -215,6 +215,13 @@ int deme_force_kernel_name(const deme_ctx* ctx, char* name, size_t cap, uint32_t
  * does it for the process). */
 int deme_get_order(const deme_ctx* ctx, int* reordered, double spread[2]);
 int deme_set_reorder(deme_ctx* ctx, int enable);
+/* A running simulation drifts away from the order it was given (a mixer, a flow).  The engine watches the tiles of every detection
+ * (mean foreign owners per tile, tiles that no longer fit) and renews its order at the start of a detection when they have
+ * degraded by half since the last ordering, at most every 20 detections; deme_renew_order does it now.  The caller's ids never
+ * change.  Host-driven (positions to the host, the order as at upload, records, the current contact list and its history
+ * re-keyed): about a second at 1e6 clumps. */
+int deme_renew_order(deme_ctx* ctx);
+int deme_order_renewals(const deme_ctx* ctx, uint64_t* n); /* how many times the order was renewed (by the engine or by the call above) */
 /* The order itself, without a context or a GPU (host code; tests): order[k] = the caller's clump kept in slot k. */
 int deme_order_probe(const DemeParams* p, size_t nClumps, const uint64_t* voxelID, const uint16_t* locX, const uint16_t* locY,
                      const uint16_t* locZ, uint32_t* order, double spread[2]);

@@ -295,3 +295,90 @@ def test_one_tile_with_a_big_sphere_does_not_fit_the_rest_stays_tiled(pkg, orc):
     print(f"a big sphere's tile through the per-tile fallback ({nbig} of {tiles} tiles), 30 steps vs the oracle: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
     assert dx <= 5e-8 and dv <= 2e-4
     ctx.close()
+
+
+def test_order_is_renewed_in_a_running_simulation(pkg, orc):
+    """The clumps of a settled bed swap places (their states are permuted among the caller's ids: the same bed, but no id is where
+    the engine's tiles expect it -- what a mixer does to a numbering over time).  The tiles of the old order stage owners from all
+    over the bed and most stop fitting; deme_renew_order recomputes the order from the current positions and carries everything
+    kept in engine slots across -- records, the contact list with its history, re-keyed and re-sorted -- while the caller's ids
+    stay what they were.  Against the oracle before and after: lists bit-identical, history and states within the fast mode's
+    bounds, and the tiles fit again."""
+    b = _bed(pkg)
+    p, sc, st = _settled(pkg, b)
+    n = int(sc.nOwnerClumps)
+    rng = np.random.default_rng(17)
+    perm = rng.permutation(n)
+    st2 = {k: v.copy() for k, v in st.items()}
+    for k in KEYS:
+        st2[k][:n] = st[k][:n][perm]
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st2)
+    assert ctx.engine_order()[0]
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st2)
+    ctx.step(5), sim.step(5)
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert len(ga[0]) > 4000 and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    tiles, big0, halo0, _ = ctx.tile_stats()
+    spread_before = ctx.engine_order()[1]
+    ctx.renew_order()
+    reordered, given, best = ctx.engine_order()
+    assert reordered and given > 3 * best  # (what the renewal found: the slots it inherited were far from compact)
+    # the list survives the renewal in the caller's ids and order, with its history
+    gb = ctx.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(gb[:3], ga[:3]))
+    for w in range(4):
+        gw, ow = ctx.wildcard(w), sim.wildcard(w)
+        assert np.abs(gw - ow).max() <= 1e-5 * max(np.abs(ow).max(), 1e-12) + 1e-12, w
+    back = ctx.download_state()
+    osb = sim.download_state()
+    assert np.abs(_positions(pkg, p, back) - _positions(pkg, p, osb)).max() <= 5e-8
+    ctx.step(60), sim.step(60)
+    g2, o2 = ctx.contacts(), sim.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(g2[:3], o2[:3]))
+    g, o = ctx.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g) - _positions(pkg, p, o)).max()
+    dv = max(np.abs(g[k] - o[k]).max() for k in ("vX", "vY", "vZ"))
+    tiles, big1, halo1, _ = ctx.tile_stats()
+    print(f"order renewed in a running bed: tiles through the fallback {big0} -> {big1} of {tiles}, largest halo {halo0} -> {halo1}; "
+          f"65 steps vs the oracle: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
+    assert dx <= 5e-8 and dv <= 2e-4
+    assert big1 == 0 and halo1 < halo0
+    ctx.close()
+
+
+def test_the_engine_renews_a_degraded_order_by_itself(pkg, orc):
+    """The same swapped bed, left alone: the first detection after the upload takes the tiles' mean halo as the baseline -- that IS
+    the degraded state here, so the bed is swapped AFTER a first detection in good order -- and once twenty detections have passed
+    with the mean halo half as large again, the next detection starts with a renewal.  Results against the oracle throughout."""
+    b = _bed(pkg)
+    p, sc, st = _settled(pkg, b)
+    n = int(sc.nOwnerClumps)
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st)
+    ctx.step(2), sim.step(2)  # detections in the order of the upload: the baseline
+    halo_good = ctx.tile_stats()[2]
+    g = ctx.download_state()
+    perm = np.random.default_rng(23).permutation(n)
+    st2 = {k: g[k].copy() for k in KEYS}
+    for k in KEYS:
+        st2[k][:n] = g[k][:n][perm]
+    ctx.upload_state(st2), sim.upload_state(st2)
+    ctx.step(3), sim.step(3)
+    assert ctx.order_renewals() == 0 and ctx.tile_stats()[2] > 2 * halo_good
+    ctx.step(40), sim.step(40)  # > 20 detections (one per step) later
+    assert ctx.order_renewals() == 1, ctx.order_renewals()
+    assert ctx.tile_stats()[2] < 1.5 * halo_good and ctx.tile_stats()[1] == 0
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    g, o = ctx.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g) - _positions(pkg, p, o)).max()
+    dv = max(np.abs(g[k] - o[k]).max() for k in ("vX", "vY", "vZ"))
+    print(f"order renewed by the engine after the bed was swapped: largest halo back to {ctx.tile_stats()[2]} (was {halo_good}); |dx| {dx:.3e} m, |dv| {dv:.3e} m/s vs the oracle")
+    assert dx <= 5e-8 and dv <= 2e-4
+    ctx.close()
