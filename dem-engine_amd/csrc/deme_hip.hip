@@ -2513,6 +2513,7 @@ struct deme_halo_group {
     uint32_t nShared = 0;            // replicated free owners (the same on every slab): a / alpha summed across slabs every step
     void* sharedSum = nullptr;       // nShared x AccRec
     void* agreeBuf = nullptr;        // 16 bytes: the error flag the ranks add up before a collective phase (mig_agree)
+    bool anyPersist = false;         // (during a migration) some slab of some rank holds persistent marks: the rows carry them
     hipEvent_t evReduced = nullptr;
     std::string err;
     uint64_t nExchanges = 0, nReductions = 0, bytesPerStep = 0;

@@ -27,8 +27,9 @@ struct MigSphere {  // its spheres follow in a second stream, clump-major
 };
 #define DEME_MIG_MAXW 8u
 struct MigRowHead {  // a history row: header + nW floats
-    uint32_t gA, gB, cls;
+    uint32_t gA, gB, cls;  // cls: contact class (2 bits) | DEME_MIG_PERSIST_BIT
 };
+#define DEME_MIG_PERSIST_BIT 0x100u
 
 struct MigCount {  // per class (0 stay, 1 to the left, 2 to the right): clumps and spheres; a scan element
     uint32_t c[3], s[3];
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256) void k_mig_rows(uint32_t nC, uint32_t nW, uint
                                                   const float* __restrict__ wc, const SphereRec* __restrict__ spheres,
                                                   const uint32_t* __restrict__ sphereGid, const uint8_t* __restrict__ dest,
                                                   uint32_t nClumps, MigRowHead* __restrict__ head, float* __restrict__ rw,
-                                                  uint32_t* __restrict__ toL, uint32_t* __restrict__ toR) {
+                                                  uint32_t* __restrict__ toL, uint32_t* __restrict__ toR,
+                                                  const uint64_t* __restrict__ persist, uint32_t nPersist) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > nC)
         return;
@@ -166,7 +168,19 @@ __global__ __launch_bounds__(256) void k_mig_rows(uint32_t nC, uint32_t nW, uint
             flip = true;
         }
     }
-    head[c] = MigRowHead{gA, gB, cls};
+    uint32_t mark = 0;  // a persistent contact (deme_mark_persistent_contacts) keeps its mark wherever its clumps go: bit 8 of the class word
+    if (nPersist) {
+        uint32_t lo = 0, hi = nPersist;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (persist[mid] < k)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        mark = (lo < nPersist && persist[lo] == k) ? DEME_MIG_PERSIST_BIT : 0u;
+    }
+    head[c] = MigRowHead{gA, gB, cls | mark};
     for (uint32_t w = 0; w < nW; w++) {
         const float v = wc[(size_t)c * nW + w];
         rw[(size_t)c * nW + w] = (flip && ((flipMask >> w) & 1u)) ? -v : v;
@@ -284,7 +298,8 @@ __global__ __launch_bounds__(256) void k_mig_localise(uint32_t nRows, uint32_t n
     if (i >= nRows)
         return;
     rowIdx[i] = i;
-    const MigRowHead h = head[i];
+    MigRowHead h = head[i];
+    h.cls &= 3u;  // (bit 8 is the persistent mark: k_mig_seed reads it from the row)
     uint32_t la = mig_lookup(sortedGid, sortedIdx, nS, h.gA), lb = h.gB;
     bool ok = la != 0xFFFFFFFFu;
     bool own = ok && spheres[la].owner < nOwn;
@@ -315,12 +330,15 @@ __global__ __launch_bounds__(256) void k_mig_keep_flags(uint32_t n, const uint64
 }
 __global__ __launch_bounds__(256) void k_mig_seed(uint32_t n, uint32_t nW, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ rowIdx,
                                                   const uint32_t* __restrict__ keep, const uint32_t* __restrict__ pos,
-                                                  const float* __restrict__ rw, uint64_t* __restrict__ outKeys, float* __restrict__ outWc) {
+                                                  const float* __restrict__ rw, uint64_t* __restrict__ outKeys, float* __restrict__ outWc,
+                                                  const MigRowHead* __restrict__ head, uint8_t* __restrict__ outMark) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !keep[i])
         return;
     const uint32_t j = pos[i], r = rowIdx[i];
     outKeys[j] = keys[i];
+    if (outMark)
+        outMark[j] = (head[r].cls & DEME_MIG_PERSIST_BIT) ? 1 : 0;
     for (uint32_t w = 0; w < nW; w++)
         outWc[(size_t)j * nW + w] = rw[(size_t)r * nW + w];
 }

@@ -105,8 +105,8 @@ def test_family_masks_and_margins_hold_across_cuts_on_the_gpu(pkg, orc, mode):
     g.close()
 
 
-@pytest.mark.parametrize("mode,n_slabs", [("exact", 2), ("fast", 3)])
-def test_free_mesh_body_across_slabs(pkg, orc, mode, n_slabs):
+@pytest.mark.parametrize("mode,n_slabs,migrate", [("exact", 2, False), ("fast", 3, False), ("fast", 3, True)])
+def test_free_mesh_body_across_slabs(pkg, orc, mode, n_slabs, migrate):
     """A mesh body that moves under contact forces (a plate lying on the bed, wider than any slab) is kept on every slab
     (DemeScene.ownerGhost = 2): each slab sums the forces of its own spheres on it, deme_halo_group_step all-reduces the sums, and
     every replica takes the same step.  Against the single-domain oracle: same contact list, plate and clumps within the stated
@@ -126,8 +126,24 @@ def test_free_mesh_body_across_slabs(pkg, orc, mode, n_slabs):
     g = _group(pkg, ctxs, parts)
     one = orc.make_sim(pkg, p, sc)
     steps = 121  # detections at steps 0, 5, ..., 120
-    g.step(steps), one.step(steps)
-    g.sync()
+    if migrate:  # the `migrate` leg: the slabs are re-assembled inside the library half way (deme_halo_group_migrate with a
+                 # replicated free body: its owner number moves with the slab's clump count, the all-reduce list follows)
+        for c, pt in zip(ctxs, parts):
+            g.set_slab(c, pt, 0.035)
+        g.step(60)
+        g.migrate()
+        g.step(steps - 60)
+        one.step(steps)
+        g.sync()
+        ids = [g.slab_ids(c) for c in ctxs]
+        cnts = [g.slab_counts(c) for c in ctxs]
+        parts = [dict(pt, sphere_global=np.asarray(i[1], np.int64), owner_global=np.asarray(i[0], np.int64), n_own=k[0],
+                      global_ids=np.asarray(i[0], np.int64)[:k[0]],
+                      arrays=dict(pt["arrays"], ownerClumpBody=np.asarray(i[2], np.int64))) for pt, i, k in zip(parts, ids, cnts)]
+        mesh_local = [int(k[3]) - 1 for k in cnts]  # the plate is the last owner of every re-assembled slab
+    else:
+        g.step(steps), one.step(steps)
+        g.sync()
     rows = np.unique(np.concatenate([_global_rows(pt, c) for pt, c in zip(parts, ctxs)]), axis=0)
     a, bb, t, _ = one.contacts()
     ref = np.unique(np.stack([a.astype(np.int64), bb.astype(np.int64), t.astype(np.int64)], 1), axis=0)
@@ -236,6 +252,58 @@ def test_library_migration_equals_the_numpy_statement(pkg):
     assert np.abs(X - X0).max() < 1e-9 and np.abs(V - V0).max() < 1e-5, (np.abs(X - X0).max(), np.abs(V - V0).max())
     for g in (g0, g1, gP, g2):
         g.close()
+
+
+def test_library_migration_carries_persistent_marks(pkg):
+    """Marked (persistent) contacts across a migration inside the library: the marks ride in the history rows (a bit of the row
+    header), so a pair stays marked wherever its clumps go.  A sheared bed in three slabs, every contact of every slab marked after
+    150 steps, then deme_halo_group_migrate: the union of the slabs' marked sets, in GLOBAL sphere ids, is what it was (a pair is
+    kept by every slab that owns one of its clumps), every slab's marks are pairs of its own re-assembled list, and the slabs step
+    on (a detection with the marks appended)."""
+    b, p, sc, x = _sheared_bed(pkg, 3000, 6)
+    halo = 0.035
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=halo)
+    ctxs = [_make(pkg, p, pt["scene"]) for pt in parts]
+    g = _group(pkg, ctxs, parts)
+    g.step(150)
+    g.sync()
+
+    def marked_global(c, sphere_global, n_own, owner_of):
+        a, bb, t = c.persistent_contacts()
+        sg = np.asarray(sphere_global, np.int64)
+        ss = t == 1
+        gA = sg[a]
+        gB = np.where(ss, sg[np.where(ss, bb, 0)], bb.astype(np.int64))
+        lo, hi = np.where(ss & (gA > gB), gB, gA), np.where(ss & (gA > gB), gA, gB)
+        own = (owner_of[a] < n_own) | (ss & (owner_of[np.where(ss, bb, 0)] < n_own))
+        return {(int(l), int(h), int(k)) for l, h, k, o in zip(lo, hi, t, own) if o}
+
+    before = set()
+    for c, pt in zip(ctxs, parts):
+        c.mark_persistent_contacts(0)
+        assert c.num_persistent_contacts() == int(c.counts().nContacts) > 100
+        before |= marked_global(c, pt["sphere_global"], pt["n_own"], np.asarray(pt["arrays"]["ownerClumpBody"]))
+    for c, pt in zip(ctxs, parts):
+        g.set_slab(c, pt, halo)
+    moved = g.migrate()
+    assert moved >= 3
+    after = set()
+    for c in ctxs:
+        n_own, n_gl, n_gr, n_o, n_s, n_seed = g.slab_counts(c)
+        og, sg, so, scmp = g.slab_ids(c)
+        after |= marked_global(c, sg, n_own, so)
+        a, bb, t = c.persistent_contacts()
+        la, lb, lt, _ = c.contacts()
+        have = set(zip(la.tolist(), lb.tolist(), lt.tolist()))
+        assert all((int(x), int(y), int(z)) in have for x, y, z in zip(a, bb, t))
+    assert after == before and len(before) > 1000, (len(before), len(after), len(before ^ after))
+    g.step(20)
+    g.sync()
+    for c in ctxs:
+        st = c.download_state()
+        assert np.isfinite(st["vX"]).all()
+        assert int(c.counts().nContacts) >= c.num_persistent_contacts() > 100
+    g.close()
 
 
 def test_drifting_bed_with_repeated_library_migrations_against_single_domain_oracle(pkg, orc):
