@@ -1081,7 +1081,9 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
     a.world = fastMode ? 1u : 0u;
     // the fast kernel covers the built-in models' hot classes; contact recording (body-frame contact points) and user
     // fragments (the reference's body-frame vocabulary) run the general kernel, with world-frame contributions in fast mode
-    const bool fastKernel = fastMode && !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM;
+    // contact recording: the tile pass writes the records itself (REC instances) for the built-in models; user models record
+    // through the general kernel
+    const bool fastKernel = fastMode && c->hp.forceModel != DEME_FORCE_CUSTOM;
     const bool customTile = fastMode && !c->record && c->hp.forceModel == DEME_FORCE_CUSTOM && c->customTileFn[0];
     if ((fastKernel || customTile) && c->tileActive && c->tileEnable) {  // owner tiles: deme_tile.h
         TileArgs ta{};
@@ -1098,6 +1100,12 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         ta.xcdGroup = c->xcdGroup;
         ta.tileBig = c->tileBig.as<uint32_t>(), ta.bigList = c->bigList.as<uint32_t>(), ta.info = a.info;
         ta.keys = a.keys, ta.timeElapsed = a.timeElapsed;
+        if (c->record) {
+            for (int k = 0; k < 4; k++)
+                ta.rec[k] = c->rec[k].as<float>();
+            a.recForce = c->rec[0].as<float>(), a.recTorque = c->rec[1].as<float>(), a.recCPA = c->rec[2].as<float>(),
+            a.recCPB = c->rec[3].as<float>();  // (the mesh variant of the general kernel records its own contacts)
+        }
         for (int k = 0; k < 8; k++)
             ta.ownerWc[k] = a.ownerWc[k], ta.geoWcSph[k] = a.geoWcSph[k], ta.geoWcAnal[k] = a.geoWcAnal[k];
         if (pass >= 0 && c->hasGhosts) {
@@ -1137,25 +1145,24 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
             HIPCK(hipModuleLaunchKernel(c->customTileFn[mesh ? 1 : 0], nBlk, 1, 1, DEME_TILE_T, 1, 1, ldsBytes, st, argsT, nullptr));
             if (nBig && c->customTileFn[mesh ? 3 : 2])
                 HIPCK(hipModuleLaunchKernel(c->customTileFn[mesh ? 3 : 2], nBig, 1, 1, DEME_TILE_T, 1, 1, 0, st, argsT, nullptr));
-        } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
-            if (mesh) {
-                hipLaunchKernelGGL((k_tile_forces<0, true>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
-                if (nBig)
-                    hipLaunchKernelGGL((k_tile_forces_big<0, true>), dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
-            } else {
-                hipLaunchKernelGGL((k_tile_forces<0, false>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
-                if (nBig)
-                    hipLaunchKernelGGL((k_tile_forces_big<0, false>), dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
-            }
         } else {
-            if (mesh) {
-                hipLaunchKernelGGL((k_tile_forces<1, true>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+            // (model, mesh records, recording) -> the instance of the two kernels
+            const int model = c->hp.forceModel == DEME_FORCE_HERTZIAN ? 0 : 1;
+            auto go = [&](auto tileK, auto bigK) {
+                hipLaunchKernelGGL(tileK, dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
                 if (nBig)
-                    hipLaunchKernelGGL((k_tile_forces_big<1, true>), dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
-            } else {
-                hipLaunchKernelGGL((k_tile_forces<1, false>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
-                if (nBig)
-                    hipLaunchKernelGGL((k_tile_forces_big<1, false>), dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
+                    hipLaunchKernelGGL(bigK, dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
+            };
+            const int which = model * 4 + (mesh ? 2 : 0) + (c->record ? 1 : 0);
+            switch (which) {
+                case 0: go(k_tile_forces<0, false, false>, k_tile_forces_big<0, false, false>); break;
+                case 1: go(k_tile_forces<0, false, true>, k_tile_forces_big<0, false, true>); break;
+                case 2: go(k_tile_forces<0, true, false>, k_tile_forces_big<0, true, false>); break;
+                case 3: go(k_tile_forces<0, true, true>, k_tile_forces_big<0, true, true>); break;
+                case 4: go(k_tile_forces<1, false, false>, k_tile_forces_big<1, false, false>); break;
+                case 5: go(k_tile_forces<1, false, true>, k_tile_forces_big<1, false, true>); break;
+                case 6: go(k_tile_forces<1, true, false>, k_tile_forces_big<1, true, false>); break;
+                default: go(k_tile_forces<1, true, true>, k_tile_forces_big<1, true, true>); break;
             }
         }
         c->conValid = true;
@@ -1182,14 +1189,14 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN) {
             if (hasSM)  // mesh variant first: the hot variant folds its A-side records into the in-block sums
                 hipLaunchKernelGGL((k_calc_forces<0, 1>), gm, b, 0, c->stream, c->dp, a);
-            if (fastKernel)
+            if (fastKernel && !c->record)
                 hipLaunchKernelGGL((k_forces_fast<0>), g, b, 0, c->stream, c->dp, a);
             else
                 hipLaunchKernelGGL((k_calc_forces<0, 0>), g, b, 0, c->stream, c->dp, a);
         } else if (c->hp.forceModel == DEME_FORCE_HERTZIAN_FRICTIONLESS) {
             if (hasSM)
                 hipLaunchKernelGGL((k_calc_forces<1, 1>), gm, b, 0, c->stream, c->dp, a);
-            if (fastKernel)
+            if (fastKernel && !c->record)
                 hipLaunchKernelGGL((k_forces_fast<1>), g, b, 0, c->stream, c->dp, a);
             else
                 hipLaunchKernelGGL((k_calc_forces<1, 0>), g, b, 0, c->stream, c->dp, a);
@@ -1427,14 +1434,14 @@ int deme_force_kernel_name(const deme_ctx* c, char* name, size_t cap, uint32_t* 
     if (!c || !name || !cap)
         return DEME_ERR_INVALID;
     const int m = c->hp.forceModel == DEME_FORCE_HERTZIAN ? 0 : 1;
-    const bool fastKernel = c->arith == DEME_ARITH_FAST && !c->record && c->hp.forceModel != DEME_FORCE_CUSTOM;
+    const bool fastKernel = c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM;
     if (c->hp.forceModel == DEME_FORCE_CUSTOM && c->arith == DEME_ARITH_FAST && !c->record && c->customTileFn[0] && c->tileActive && c->tileEnable)
         snprintf(name, cap, "deme_custom_tile<%s>", (c->nTri > 0 && c->nSM > 0) ? "true" : "false");
     else if (c->hp.forceModel == DEME_FORCE_CUSTOM)
         snprintf(name, cap, "deme_custom_forces_ss");
     else if (fastKernel && c->tileActive && c->tileEnable)
         snprintf(name, cap, "k_tile_forces<%d, %s>", m, (c->nTri > 0 && c->nSM > 0) ? "true" : "false");
-    else if (fastKernel)
+    else if (fastKernel && !c->record)
         snprintf(name, cap, "k_forces_fast<%d>", m);
     else
         snprintf(name, cap, "k_calc_forces<%d, 0>", m);

@@ -210,10 +210,10 @@ inline int generate_source(const std::string& user, const std::vector<std::strin
     // the tile pass with the user's model where the Hertzian block is: the instances of the kernel templates of deme_tile.h are
     // named through function pointers (hipModuleGetFunction takes the mangled names, listed by deme_tile_entry_names below)
     o << "namespace deme_dev {\n"
-         "template __global__ void k_tile_forces<2, false>(const DevParams, const TileArgs);\n"
-         "template __global__ void k_tile_forces<2, true>(const DevParams, const TileArgs);\n"
-         "template __global__ void k_tile_forces_big<2, false>(const DevParams, const TileArgs);\n"
-         "template __global__ void k_tile_forces_big<2, true>(const DevParams, const TileArgs);\n}\n";
+         "template __global__ void k_tile_forces<2, false, false>(const DevParams, const TileArgs);\n"
+         "template __global__ void k_tile_forces<2, true, false>(const DevParams, const TileArgs);\n"
+         "template __global__ void k_tile_forces_big<2, false, false>(const DevParams, const TileArgs);\n"
+         "template __global__ void k_tile_forces_big<2, true, false>(const DevParams, const TileArgs);\n}\n";
     out = o.str();
     return 0;
 }
@@ -388,10 +388,10 @@ extern "C" __global__ __launch_bounds__(256) void deme_region_filter(const deme_
 }
 
 // mangled names of the four tile-pass instances of a compiled model (plain / with mesh records, fitting tiles / the others)
-static const char* const kTileEntry[4] = {"_ZN8deme_dev13k_tile_forcesILi2ELb0EEEvNS_9DevParamsENS_8TileArgsE",
-                                          "_ZN8deme_dev13k_tile_forcesILi2ELb1EEEvNS_9DevParamsENS_8TileArgsE",
-                                          "_ZN8deme_dev17k_tile_forces_bigILi2ELb0EEEvNS_9DevParamsENS_8TileArgsE",
-                                          "_ZN8deme_dev17k_tile_forces_bigILi2ELb1EEEvNS_9DevParamsENS_8TileArgsE"};
+static const char* const kTileEntry[4] = {"_ZN8deme_dev13k_tile_forcesILi2ELb0ELb0EEEvNS_9DevParamsENS_8TileArgsE",
+                                          "_ZN8deme_dev13k_tile_forcesILi2ELb1ELb0EEEvNS_9DevParamsENS_8TileArgsE",
+                                          "_ZN8deme_dev17k_tile_forces_bigILi2ELb0ELb0EEEvNS_9DevParamsENS_8TileArgsE",
+                                          "_ZN8deme_dev17k_tile_forces_bigILi2ELb1ELb0EEEvNS_9DevParamsENS_8TileArgsE"};
 
 // hipRTC: source -> gfx950 code object.  Needs no GPU (used by the CPU test through deme_jit_probe).
 inline int compile(const std::string& src, std::vector<char>& code, std::string& log) {

@@ -112,6 +112,7 @@ struct TileArgs {
     float* geoWcSph[8];
     float* geoWcAnal[8];
     float timeElapsed;
+    float* rec[4];             // contact recording (REC variants): force, torque-only force, contact point in A's / B's body frame
     uint32_t nOwners, nTiles, pass, xcdGroup;
     uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
     uint32_t nComp, nAnal, nMass;  // table sizes (tile_table_bytes)
@@ -221,6 +222,12 @@ struct TileUser {
     float time;
 };
 
+// what contact recording keeps per contact beside the force (deme_set_record_contacts; ContactInfoWriteBack.cu): the torque-only
+// force and the contact point in the two owners' body frames
+struct TileRecOut {
+    f3 torqueOnly, locA, locB;
+};
+
 // One contact of the hot classes between two staged owners.  Arithmetic: forces_fast_body (deme_force_fast.h), with the
 // owner-level quantities taken from the staged records.  Returns the world-frame force on A, the torques about A's and B's
 // centres, and the updated history.
@@ -236,7 +243,8 @@ struct TileTables {
 };
 template <int MODEL>
 __device__ inline void tile_contact(const DevParams& p, const TileTables& T, const uint2 inf, const TileOwner& A, const TileOwner& B,
-                                    float4& hist, f3& force, f3& tA, f3& tB, float* uw = nullptr, const TileUser* U = nullptr) {
+                                    float4& hist, f3& force, f3& tA, f3& tB, float* uw = nullptr, const TileUser* U = nullptr,
+                                    TileRecOut* ro = nullptr) {
     const uint32_t cls = (inf.x >> 20) & 3u;
     const float4 cA = T.comp[inf.y & 0xFFFFu];
     const uint32_t matA = (inf.x >> 24) & 15u;
@@ -440,9 +448,15 @@ __device__ inline void tile_contact(const DevParams& p, const TileTables& T, con
         const f3 tot = fadd(force, torque_only);
         tA = fcross(rAv, tot);
         tB = fcross(tot, rBv);  // = r_B x (-F)
+        if (ro) {
+            ro->torqueOnly = torque_only;
+            ro->locA = rot_apply(rot_transpose(RA), rAv), ro->locB = rot_apply(rot_transpose(RB), rBv);
+        }
     } else {
         tA = mk3(0, 0, 0), tB = mk3(0, 0, 0);
         hist = make_float4(0, 0, 0, 0);  // _forceModelContactWildcardDestroy_
+        if (ro)
+            ro->torqueOnly = mk3(0, 0, 0), ro->locA = mk3(0, 0, 0), ro->locB = mk3(0, 0, 0);
     }
 }
 
@@ -488,12 +502,12 @@ __host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap,
            tableBytes + 16u;
 }
 
-template <int MODEL, bool MESH>
+template <int MODEL, bool MESH, bool REC = false>
 __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(const DevParams p, const TileArgs a) {
     extern __shared__ uint4 tileLds[];
     uint4* const sOwn = tileLds;
-    constexpr uint32_t REC = tile_rec16(MODEL);
-    float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * REC);
+    constexpr uint32_t RSZ = tile_rec16(MODEL);
+    float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * RSZ);
     float4* const recT = recA4 + DEME_TILE_RSLOTS;
     float2* const recA2 = reinterpret_cast<float2*>(recT + DEME_TILE_RSLOTS);
     uint32_t* const sALo = reinterpret_cast<uint32_t*>(recA2 + DEME_TILE_RSLOTS);
@@ -604,18 +618,18 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         if (tid < nLoc + nH) {
             OwnerRec r2 = rec0;
             ki_opaque(r2.qw), ki_opaque(r2.wx), ki_opaque(r2.family);
-            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * REC);
+            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * RSZ);
         }
         if (h1 < nH) {
             OwnerRec r2 = rec1;
             ki_opaque(r2.qw), ki_opaque(r2.wx), ki_opaque(r2.family);
-            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * REC);
+            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * RSZ);
         }
 #endif
         if (tid < nLoc + nH)
-            tile_stage<MODEL>(p, T.mass[rec0.inertiaOff], rec0, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * REC);
+            tile_stage<MODEL>(p, T.mass[rec0.inertiaOff], rec0, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * RSZ);
         if (h1 < nH)
-            tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * REC);
+            tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * RSZ);
         if (tid <= DEME_TILE_NB)
             sALo[tid] = bA - c0, sLLo[tid] = bL;
         if (tid == DEME_TILE_T - 1u)  // the zero slot of the contribution arrays
@@ -694,6 +708,17 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                             for (int k = 0; k < NWU; k++)
                                 stream_store(a.wc + (size_t)c * NWU + k, uw[k]);
                         }
+                    } else if (REC) {  // the script wants per-contact forces and contact points (the reference's default contact output)
+                        TileRecOut ro;
+                        tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB, nullptr, nullptr, &ro);
+                        float* r = a.rec[0] + 3ull * c;
+                        r[0] = force.x, r[1] = force.y, r[2] = force.z;
+                        r = a.rec[1] + 3ull * c;
+                        r[0] = ro.torqueOnly.x, r[1] = ro.torqueOnly.y, r[2] = ro.torqueOnly.z;
+                        r = a.rec[2] + 3ull * c;
+                        r[0] = ro.locA.x, r[1] = ro.locA.y, r[2] = ro.locA.z;
+                        r = a.rec[3] + 3ull * c;
+                        r[0] = ro.locB.x, r[1] = ro.locB.y, r[2] = ro.locB.z;
                     } else {
                         tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
                     }
@@ -869,7 +894,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
 // loads its two owner records from memory and converts them itself, the small tables are read where they lie, and EVERY contact
 // writes a B-side record (the builder numbered them: rankC holds a contact's own record number here), also those whose B owner
 // belongs to the tile.  Slower per contact -- it is the exception path -- and exact about the order of the sums like the tile pass.
-template <int MODEL, bool MESH>
+template <int MODEL, bool MESH, bool REC = false>
 __global__ __launch_bounds__(DEME_TILE_T) void k_tile_forces_big(const DevParams p, const TileArgs a) {
     __shared__ float4 recA4[DEME_TILE_RSLOTS];
     __shared__ float2 recA2[DEME_TILE_RSLOTS];
@@ -931,6 +956,17 @@ __global__ __launch_bounds__(DEME_TILE_T) void k_tile_forces_big(const DevParams
                         for (int k = 0; k < NWU; k++)
                             a.wc[(size_t)c * NWU + k] = uw[k];
                     }
+                } else if (REC) {
+                    TileRecOut ro;
+                    tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB, nullptr, nullptr, &ro);
+                    float* r = a.rec[0] + 3ull * c;
+                    r[0] = force.x, r[1] = force.y, r[2] = force.z;
+                    r = a.rec[1] + 3ull * c;
+                    r[0] = ro.torqueOnly.x, r[1] = ro.torqueOnly.y, r[2] = ro.torqueOnly.z;
+                    r = a.rec[2] + 3ull * c;
+                    r[0] = ro.locA.x, r[1] = ro.locA.y, r[2] = ro.locA.z;
+                    r = a.rec[3] + 3ull * c;
+                    r[0] = ro.locB.x, r[1] = ro.locB.y, r[2] = ro.locB.z;
                 } else {
                     tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
                 }

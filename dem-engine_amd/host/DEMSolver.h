@@ -1340,6 +1340,23 @@ class DEMSolver {
     void EnableContactWildcardOutput(bool enable = true) {
         m_cnt_out_content = enable ? (m_cnt_out_content | CNT_WILDCARD) : (m_cnt_out_content & ~CNT_WILDCARD);
     }
+    /// (no reference equivalent) which kernel evaluates the current contact list, whether the engine keeps the clumps in an order of
+    /// its own (ids seen here are always load order), and how many owner tiles go through the per-tile fallback
+    std::string GetForceKernelName() const {
+        char name[64] = {0};
+        deme_force_kernel_name(m_ctx, name, sizeof(name), nullptr, nullptr);
+        return name;
+    }
+    bool IsEngineReordered() const {
+        int r = 0;
+        deme_get_order(m_ctx, &r, nullptr);
+        return r != 0;
+    }
+    unsigned GetNumFallbackTiles() const {
+        uint32_t t[4] = {0, 0, 0, 0};
+        deme_tile_stats(m_ctx, t);
+        return t[1];
+    }
     /// ShowMemStats (API.h:584): device memory in use by this process, as the HIP runtime reports it through the library
     void ShowMemStats() const {
         size_t used = 0, total = 0;

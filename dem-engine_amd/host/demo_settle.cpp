@@ -75,6 +75,8 @@ int main(int argc, char** argv) {
         std::printf("t=%.5f contacts=%zu vmax=%.4f zmean=%.5f\n", DEMSim.GetSimTime(), DEMSim.GetNumContacts(),
                     DEMSim.GetMaxOwnerSpeed(), zsum / (double)DEMSim.GetNumClumps());
     }
+    std::printf("KERNEL %s reordered=%d fallback_tiles=%u\n", DEMSim.GetForceKernelName().c_str(), DEMSim.IsEngineReordered() ? 1 : 0,
+                DEMSim.GetNumFallbackTiles());
     std::printf("LID z=%.6f vz=%.6f\n", lid_tracker->Pos().z, lid_tracker->Vel().z);
     {   // AddAcc: 1000 m/s^2 upwards on the lid for one step = +5e-3 m/s on top of... nothing: the lid's velocity is dictated
         // by its prescription, so use a clump instead -- clump 11 gains a*h in x over what its twin step would have given

@@ -40,14 +40,18 @@ def main():
     bench = json.load(open(f"{d}/{tag}_bench.json"))
     nc = bench["config"]["contacts_this_rank"]
     out = {"contacts": nc, "source": [f"{tag}_fetch_pmc.txt", f"{tag}_write_pmc.txt"], "unit": "bytes per launch", "kernels": {}}
-    force = next(k for k in ("k_tile_forces<0, false>", "k_tile_forces<0>", "k_forces_fast<0>", "k_calc_forces<0, 0>") if k in fetch)
-    out["force_kernel"] = force
+    # (the profiler prints all template arguments -- <MODEL, MESH, REC> since round 4 --, the library's deme_force_kernel_name the first two)
+    force = next(k for k in ("k_tile_forces<0, false, false>", "k_tile_forces<0, false>", "k_tile_forces<0>", "k_forces_fast<0>", "k_calc_forces<0, 0>") if k in fetch)
+    out["force_kernel"] = "k_tile_forces<0, false>" if force.startswith("k_tile_forces<0, false") else force
     for k in (force, "k_integrate<true>", "k_sweep"):
         if k not in fetch or k not in write:
             continue
         f_kib, w_kib = fetch[k][1], write[k][1]
         out["kernels"][k] = {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "traffic_prescribed": int((2 * f_kib + w_kib) * 1024)}
     # force kernel: coalesced streams read per contact = gather record (16; 8 in the tile pass) + wildcards (16)
+    if force != out["force_kernel"]:
+        out["kernels"][out["force_kernel"]] = out["kernels"].pop(force)
+        force = out["force_kernel"]
     fk = out["kernels"][force]
     stream_read = nc * (24 if force.startswith("k_tile") else 32)
     raw = fk["FETCH_SIZE_KiB"] * 1024

@@ -74,6 +74,39 @@ def test_fast_accelerations_match_oracle(pkg, orc, model):
     ctx.close()
 
 
+@pytest.mark.parametrize("model", ["hertz", "frictionless"])
+def test_contact_records_of_the_tile_pass_match_oracle(pkg, orc, model):
+    """Contact recording (the reference's default contact output: force and contact points per pair) is written by the tile pass
+    itself (k_tile_forces<M, MESH, REC = true>): a script that leaves the default output content on keeps the fast kernel.
+    Per-contact force, torque-only force and the contact point in both owners' body frames against the oracle's records:
+    forces within 1e-5 of the largest, points within 2e-8 m."""
+    b = _bed(pkg, Crr=0.05)  # (rolling resistance on: the torque-only force is not identically zero)
+    if model == "frictionless":
+        b.UseFrictionlessHertzianModel()
+    p, sc, st = _settled(pkg, b)
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
+    ctx.set_record_contacts(True)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st)
+    for s in (ctx, sim):
+        s.compute_margins(0), s.detect(), s.migrate()
+    ctx.calc_forces(), sim.calc_forces(record=True)
+    assert ctx.force_kernel()[0] == ("k_tile_forces<0, false>" if model == "hertz" else "k_tile_forces<1, false>"), ctx.force_kernel()
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert len(ga[0]) > 1500 and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    F, T, PA, PB = ctx.contact_records()
+    oF, oT, oPA, oPB = sim.contact_records()
+    scale = np.abs(oF).max()
+    assert scale > 0 and np.abs(F - oF).max() <= 1e-5 * scale, np.abs(F - oF).max() / scale
+    assert np.abs(T - oT).max() <= 1e-5 * scale + 1e-12
+    ss = ga[2] == 1  # (a wall's body frame is the world frame shifted by metres: its contact point is compared relatively)
+    assert np.abs(PA - oPA).max() <= 2e-8 and np.abs(PB - oPB)[ss].max() <= 2e-8
+    assert np.abs(PB - oPB)[~ss].max() <= 1e-6 * max(np.abs(oPB)[~ss].max(), 1.0) if (~ss).any() else True
+    ctx.close()
+
+
 @pytest.mark.parametrize("cd_freq", [0, 10])
 def test_fast_trajectory_within_stated_tolerance(pkg, orc, cd_freq):
     b = _bed(pkg, cd_freq=cd_freq)
@@ -173,7 +206,7 @@ def test_a_tiled_list_serves_the_other_kernels_on_demand(pkg):
     assert a.force_kernel()[0].startswith("k_tile_forces") and int(a.counts().nContacts) > 2000
     sa, st = a.download_state(), t.download_state()
     assert all(np.array_equal(sa[k], st[k]) for k in keys)
-    a.set_record_contacts(True)  # the tiled list is now evaluated by the general kernel: its B-sorted form is built on demand
+    a.set_record_contacts(True)  # (since round 4 the tile pass records itself: the list keeps its kernel; case (b) is the on-demand one)
     a.step(5)
     # the twin: the same state and history, re-detected with recording on from the start of its list (no tiles at all)
     t.set_record_contacts(True)

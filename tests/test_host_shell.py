@@ -22,12 +22,22 @@ def test_demo_builds_and_fails_loudly_without_a_gpu():
 
 
 @pytest.mark.gpu
-def test_demo_runs_and_settles(tmp_path):
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_demo_runs_and_settles(tmp_path, arith):
+    """demo_settle.cpp through the C++ shell: sampler-order clumps, trackers, inspectors, writers, restart.  In the library's default
+    (fast) arithmetic the scene is one the engine reorders -- a reference script loads clumps in sampler order -- and the owner-tile
+    pass evaluates it: every id the script uses (tracked owners, AddAcc, per-contact forces, output files) is load order all the
+    same, so the checks below are the same in both modes."""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(HOST, "demo_settle"), "10", "3000", str(tmp_path)], capture_output=True, text=True,
-                         timeout=600)
+                         timeout=600, env=dict(os.environ, DEME_ARITH=arith))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DEMO_OK clumps=1000" in out.stdout
+    kern = [l for l in out.stdout.splitlines() if l.startswith("KERNEL")][0]
+    if arith == "fast":
+        assert "k_tile_forces<0, false>" in kern and "reordered=1" in kern, kern
+    else:
+        assert "k_calc_forces<0, 0>" in kern and "reordered=0" in kern, kern
     rows = [l for l in out.stdout.splitlines() if l.startswith("t=")]
     z = [float(l.split("zmean=")[1]) for l in rows]
     c = [int(l.split("contacts=")[1].split()[0]) for l in rows]
