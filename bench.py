@@ -811,6 +811,13 @@ def main():
     value = total_clumps * args.steps / dt
     fbytes = force_kernel_bytes(int(sc.nOwners), int(sc.nSpheres), int(c.nContacts), int(p.nContactWildcards))
     fk_name, tile_halo, tile_list = ctx.force_kernel()
+    fused = fk_name.startswith("k_tile_step")
+    # the one-kernel step (deme_tile_step.h) integrates too: its algorithmic bytes are the force pass's (owner state is read ONCE) plus
+    # the integrator's write-back, 54 B per owner; what the kernel pays for closing its tiles -- the contacts that
+    # straddle two tiles are evaluated by both -- is NOT counted
+    force_only_bytes = fbytes
+    if fused:
+        fbytes += 54 * int(sc.nOwners)
     achieved = fbytes / (f_ms * 1e-3) / 1e9 if f_ms > 0 else 0.0
     par = f"{world} x-slab(s)"
     if group is not None:
@@ -872,6 +879,10 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "attainable_copy_GBs": copy_gbs, "frac_of_attainable": (achieved / copy_gbs if copy_gbs else None),
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),
+                     "fused_step": ({"what": "contact forces + accumulation + integration in one kernel (closed owner tiles)",
+                                     "force_pass_bytes": force_only_bytes, "integration_write_back_bytes": 54 * int(sc.nOwners),
+                                     "frac_on_the_force_pass_bytes_alone": force_only_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if f_ms > 0 else None}
+                                    if fused else None),
                      # SURVEY 8d adds 24 B per owner for a force kernel that reduces in-kernel, as the owner-tile pass does (its
                      # per-owner sums are its output); `achieved` / `frac` above do NOT count them (the conservative figure)
                      "frac_counting_the_in_kernel_reduction": ((fbytes + 24 * int(sc.nOwners)) / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

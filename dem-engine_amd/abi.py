@@ -468,6 +468,11 @@ class Context:
         self.lib.deme_set_tile_policy.argtypes = [_P, C.c_uint32]
         self._ck(self.lib.deme_set_tile_policy(self.h, int(min_contacts_per_tile_custom)), "deme_set_tile_policy")
 
+    def set_fused_step(self, on):
+        """the one-kernel step (k_tile_step<M>, deme_tile_step.h); off by default: deme_set_fused_step"""
+        self.lib.deme_set_fused_step.argtypes = [_P, C.c_int]
+        self._ck(self.lib.deme_set_fused_step(self.h, 1 if on else 0), "deme_set_fused_step")
+
     def engine_order(self):
         """(reordered, spread in the caller's order, spread along the curve): deme_get_order"""
         r, sp = C.c_int(0), (C.c_double * 2)()

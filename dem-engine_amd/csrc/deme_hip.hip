@@ -28,6 +28,7 @@
 #include "deme_jit.h"
 #include "deme_kernels.h"
 #include "deme_tile.h"
+#include "deme_tile_step.h"
 #include "deme_migrate.h"
 #include "deme_mesh_kernels.h"
 
@@ -87,13 +88,21 @@ struct deme_ctx {
     bool tileActive = false;  // the current list has tile structures (built-in model, fast mode, every halo fits)
     bool conTile = false;     // the contributions in memory were written by the tile kernel
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
+    // the whole step in one kernel (deme_tile_step.h): closed tiles -- a contact that straddles two tiles is evaluated by both --
+    // integrate their own owners; owners and history are double-buffered
+    int fusedEnable = 0;          // deme_set_fused_step / DEME_FUSED=1: the one-kernel step (measured slower on the packed bed: DESIGN 3.7)
+    bool fusedList = false;       // the current list has the incoming structures (decided per detection)
+    bool fusedChecked = false;    // ... and the device has been asked whether every closed tile fits
+    bool fusedPrevValid = false;  // the last step was a fused one: the buffers of its start are intact (a / alpha can be replayed from them)
+    uint64_t nFusedSteps = 0;
+    DevBuf ownersNext, recContact, inCnt, inStart, tInfoIn, inContact, hCountIn;
     // A run-time compiled model takes the tile pass only when a tile holds enough contacts to pay for its staging (measured on
     // configs[4], 1e6 single spheres with 1.6 contacts each = 200 per tile: tile pass 0.058 ms against 0.044 ms for the general
     // kernel; at the 555 per tile of three-sphere clumps the tile pass wins as it does for the built-in models).
     uint32_t tileMinContactsCustom = 320;
     uint64_t lastSegMax = 0;             // longest segment of the last detection (sizes the early launch of k_compact_keys)
     size_t keySegMin = (size_t)1 << 20;  // arenas from this many slots on are cut into DEME_KEY_SEGS segments (DEME_KEY_SEG_MIN; 0: never)
-    uint32_t tileMaxHalo = 0, tileMaxList = 0, nBigTiles = 0;
+    uint32_t tileMaxHalo = 0, tileMaxList = 0, nBigTiles = 0, tileMaxHaloIn = 0;
     // persistent contacts: the sorted set of marked keys (host copy + device copy appended to every detection's raw keys)
     DevBuf persistKeys, binStat;
     // acceleration the script adds for the next step only (deme_add_owner_acc): device records + host mirror
@@ -427,6 +436,9 @@ int grow_contact_arena(deme_ctx* c, size_t cap) {
     rc |= ensure(c, c->lPos, cap * 2);
     rc |= ensure(c, c->remVal, (cap + 1) * 4);
     rc |= ensure(c, c->rankC, (cap + 1) * 4);
+    rc |= ensure(c, c->recContact, (cap + 1) * 4);
+    rc |= ensure(c, c->tInfoIn, cap * 8);
+    rc |= ensure(c, c->inContact, cap * 4);
     rc |= ensure(c, c->rec32, cap * 32);
     rc |= ensure(c, c->remKey[0], (cap + 1) * 4);
     rc |= ensure(c, c->remKey[1], (cap + 1) * 4);
@@ -877,7 +889,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                                c->hasGhosts ? c->tileMode.as<uint32_t>() : (uint32_t*)nullptr, c->lOff.as<uint16_t>(),
                                c->lPos.as<uint16_t>(), c->lCount.as<uint32_t>(), c->rankC.as<uint32_t>(), c->remKey[0].as<uint32_t>(),
                                c->remVal.as<uint32_t>(), c->tileOrg.as<int64_t>(), c->rangeCtr.as<RangeCounters>(), nTiles,
-                               c->tileBig.as<uint32_t>(), c->bigList.as<uint32_t>());
+                               c->tileBig.as<uint32_t>(), c->bigList.as<uint32_t>(), c->recContact.as<uint32_t>());
             hipLaunchKernelGGL(k_tile_stats, dim3((nTiles + 1023u) / 1024u), dim3(256), 0, c->stream, nTiles, c->hCount.as<uint32_t>(),
                                c->lCount.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
             uint32_t nR = 0;  // crossing contacts = records = entries of the sort below: the one size the host has to know
@@ -910,6 +922,29 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                                    c->fixedFlag.as<uint8_t>(), c->heavyList.as<uint32_t>(), (uint32_t)(c->heavyList.bytes / 4),
                                    c->rangeCtr.as<RangeCounters>());
                 tiled = true;
+                // closed tiles (deme_tile_step.h): the contacts that hold a tile's owners as B from other tiles, in the tile's frame
+                static const int fusedEnv = getenv("DEME_FUSED") ? atoi(getenv("DEME_FUSED")) : -1;  // (1 / 0 override the context's switch)
+                c->fusedList = false;
+                if ((fusedEnv < 0 ? c->fusedEnable : fusedEnv) && hr.nBig == 0 && c->hp.forceModel != DEME_FORCE_CUSTOM && !c->record && c->nTri == 0 &&
+                    !c->hasGhosts && !c->prescFn && !c->rulesFn && c->hShared.empty() && c->asyncLead == 0 && !c->listOwnersSnap &&
+                    !c->ad.autoBinSize && !c->ad.autoUpdateFreq) {
+                    hipLaunchKernelGGL(k_in_count, dim3(grid_for((size_t)c->nOwners + 1)), dim3(256), 0, c->stream, c->dp, list_owners(c),
+                                       c->rStart.as<uint32_t>(), c->inCnt.as<uint32_t>());
+                    size_t needI = 0;
+                    HIPCK(rocprim::exclusive_scan(nullptr, needI, c->inCnt.as<uint32_t>(), c->inStart.as<uint32_t>(), 0u, (size_t)c->nOwners + 1,
+                                                  rocprim::plus<uint32_t>(), c->stream));
+                    if (int rc = ensure(c, c->scanTmp, needI))
+                        return rc;
+                    needI = c->scanTmp.bytes;
+                    HIPCK(rocprim::exclusive_scan(c->scanTmp.p, needI, c->inCnt.as<uint32_t>(), c->inStart.as<uint32_t>(), 0u, (size_t)c->nOwners + 1,
+                                                  rocprim::plus<uint32_t>(), c->stream));
+                    hipLaunchKernelGGL(k_tile_incoming, dim3(nTiles), dim3(256), 0, c->stream, c->dp, c->nOwners, c->info.as<uint4>(),
+                                       c->rStart.as<uint32_t>(), c->rIdx.as<uint32_t>(), c->recContact.as<uint32_t>(), c->inStart.as<uint32_t>(),
+                                       c->hList.as<uint32_t>(), c->hCount.as<uint32_t>(), c->hCountIn.as<uint32_t>(), c->tInfoIn.as<uint2>(),
+                                       c->inContact.as<uint32_t>(), c->rangeCtr.as<RangeCounters>());
+                    c->fusedList = true;  // (whether every closed tile fits comes back with the counters below: fused_ready)
+                }
+                c->fusedChecked = false;
             }
         }
         c->hrPending = c->heavyOverflow = false;
@@ -933,6 +968,7 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
             c->nHeavyFree = hr.nHeavyFree;
         }
         c->tileActive = tiled;
+        c->fusedPrevValid = false;  // (a replay of the last fused step would read the list it was taken with)
         c->tileMaxHalo = hr.tileMaxHalo, c->tileMaxList = hr.tileMaxList;
         if (tiled && c->orderEligible) {  // has the bed drifted away from the order it was given?  (order_renew at the next detection)
             const uint32_t fit = std::max(1u, nTiles - std::min(nTiles, hr.nBig));
@@ -1024,6 +1060,12 @@ void resolve_heavy_counts(deme_ctx* c) {
     }
     const size_t cap = c->heavyList.bytes / 4;
     c->nHeavy = c->hrPinned->nHeavy, c->nHeavyFree = c->hrPinned->nHeavyFree;
+    if (c->fusedList) {  // the halos were extended by the incoming contacts' owners (k_tile_incoming): the kernels' LDS follows
+        c->tileMaxHaloIn = c->hrPinned->tileMaxHaloIn;
+        if (c->hrPinned->nBigIn)  // a closed tile does not fit: this list keeps force pass + integrator
+            c->fusedList = false;
+        c->fusedChecked = true;
+    }
     if (c->nHeavy > cap) {
         fail(c, DEME_ERR_OVERFLOW, "%u owners exceed the heavy-owner list", c->nHeavy);
         c->nHeavy = (uint32_t)cap;
@@ -1044,6 +1086,7 @@ void launch_reduce_heavy(deme_ctx* c, bool skipFixed) {
 // `fs`: the stream of a tile-form launch when it is not the context's (the ghost-dependent pass of a split step runs on the halo
 // stream, beside the tail of the interior pass)
 int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
+    c->fusedPrevValid = false;
     if (c->nContacts == 0) {
         c->conValid = true;
         c->conTile = false;
@@ -1086,6 +1129,8 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
     const bool fastKernel = fastMode && c->hp.forceModel != DEME_FORCE_CUSTOM;
     const bool customTile = fastMode && !c->record && c->hp.forceModel == DEME_FORCE_CUSTOM && c->customTileFn[0];
     if ((fastKernel || customTile) && c->tileActive && c->tileEnable) {  // owner tiles: deme_tile.h
+        if (c->fusedList && !c->fusedChecked)
+            resolve_heavy_counts(c);
         TileArgs ta{};
         ta.owners = a.owners;
         ta.tInfo = c->tInfo.as<uint2>();
@@ -1210,6 +1255,70 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         }
     }
     c->conValid = true;
+    return DEME_OK;
+}
+
+// The whole step in one launch (deme_tile_step.h).  dry: replay the force evaluation of the step just taken on the buffers of its
+// start and leave a / alpha (state downloads).
+bool fused_ready(deme_ctx* c) {
+    if (!c->fusedList || !c->tileActive || !c->tileEnable || c->arith != DEME_ARITH_FAST || c->record || c->hp.forceModel == DEME_FORCE_CUSTOM ||
+        c->prescFn || c->rulesFn || c->nContacts == 0)
+        return false;
+    if (!c->fusedChecked)
+        resolve_heavy_counts(c);
+    return c->fusedList && c->nHeavyFree == 0;
+}
+int launch_fused_step(deme_ctx* c, bool dry) {
+    StepArgs sa{};
+    TileArgs& ta = sa.t;
+    const int cur = dry ? (c->wcCur ^ 1) : c->wcCur;  // (dry: the step is over, the names are swapped already)
+    ta.owners = dry ? c->ownersNext.as<OwnerRec>() : c->owners.as<OwnerRec>();
+    ta.tInfo = c->tInfo.as<uint2>();
+    ta.aStart = c->aStart.as<uint32_t>();
+    ta.hList = c->hList.as<uint32_t>(), ta.hCount = c->hCountIn.as<uint32_t>(), ta.org = c->tileOrg.as<int64_t>();
+    ta.lOff = c->lOff.as<uint16_t>(), ta.lPos = c->lPos.as<uint16_t>(), ta.lCount = c->lCount.as<uint32_t>();
+    ta.wc = c->wc[cur].as<float>();
+    ta.nOwners = c->nOwners;
+    ta.nTiles = (c->nOwners + DEME_TILE_NB - 1) / DEME_TILE_NB;
+    ta.xcdGroup = c->xcdGroup;
+    ta.tileBig = c->tileBig.as<uint32_t>(), ta.bigList = c->bigList.as<uint32_t>(), ta.info = c->info.as<uint4>();
+    ta.hCap = std::min<uint32_t>(DEME_TILE_HMAX, (c->tileMaxHaloIn + 15u) & ~15u);
+    ta.lCap = std::min<uint32_t>(DEME_TILE_LMAX, (c->tileMaxList + 63u) & ~63u);
+    ta.nComp = c->nComp, ta.nAnal = c->nAnal, ta.nMass = c->nMassProps;
+    sa.ownersNext = dry ? c->owners.as<OwnerRec>() : c->ownersNext.as<OwnerRec>();
+    sa.wcNext = c->wc[cur ^ 1].as<float>();
+    sa.tInfoIn = c->tInfoIn.as<uint2>(), sa.inContact = c->inContact.as<uint32_t>(), sa.inStart = c->inStart.as<uint32_t>();
+    sa.acc = c->acc.as<AccRec>();
+    sa.nextAcc = (!dry && c->nextAccPending) ? c->nextAcc.as<AccRec>() : nullptr;
+    sa.dry = dry ? 1u : 0u;
+    unsigned nBlk = ta.nTiles;
+    if (ta.xcdGroup)
+        nBlk = (nBlk + 8u * ta.xcdGroup - 1u) / (8u * ta.xcdGroup) * (8u * ta.xcdGroup);
+    const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial));
+    {
+        ScopedTimer tm(c, dry ? "fused_replay" : "calc_forces");
+        if (c->hp.forceModel == DEME_FORCE_HERTZIAN)
+            hipLaunchKernelGGL((k_tile_step<0>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, c->stream, c->dp, sa);
+        else
+            hipLaunchKernelGGL((k_tile_step<1>), dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, c->stream, c->dp, sa);
+    }
+    if (dry)
+        return DEME_OK;
+    std::swap(c->owners, c->ownersNext);
+    c->wcCur ^= 1;
+    if (c->nextAccPending) {
+        c->nextAccPending = false;
+        std::fill(c->hNextAcc.begin(), c->hNextAcc.end(), AccRec{});
+        HIPCK(hipMemsetAsync(c->nextAcc.p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
+    }
+    c->conValid = false, c->conTile = false;
+    c->fusedPrevValid = true;
+    c->nFusedSteps++;
+    c->stepsSinceCD++;
+    c->nSteps++;
+    c->timeElapsed += (double)c->hp.h;
+    if (c->evStepDone)
+        HIPCK(hipEventRecord(c->evStepDone, c->stream));
     return DEME_OK;
 }
 
@@ -1382,7 +1491,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->sphFam, &c->tileBig, &c->bigList, &c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->hCountIn, &c->ownersNext, &c->recContact, &c->inCnt, &c->inStart, &c->tInfoIn, &c->inContact, &c->sphFam, &c->tileBig, &c->bigList, &c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],
@@ -1435,7 +1544,9 @@ int deme_force_kernel_name(const deme_ctx* c, char* name, size_t cap, uint32_t* 
         return DEME_ERR_INVALID;
     const int m = c->hp.forceModel == DEME_FORCE_HERTZIAN ? 0 : 1;
     const bool fastKernel = c->arith == DEME_ARITH_FAST && c->hp.forceModel != DEME_FORCE_CUSTOM;
-    if (c->hp.forceModel == DEME_FORCE_CUSTOM && c->arith == DEME_ARITH_FAST && !c->record && c->customTileFn[0] && c->tileActive && c->tileEnable)
+    if (c->fusedPrevValid && c->fusedList && c->tileActive)  // the last step went through the one-kernel step (deme_tile_step.h)
+        snprintf(name, cap, "k_tile_step<%d>", m);
+    else if (c->hp.forceModel == DEME_FORCE_CUSTOM && c->arith == DEME_ARITH_FAST && !c->record && c->customTileFn[0] && c->tileActive && c->tileEnable)
         snprintf(name, cap, "deme_custom_tile<%s>", (c->nTri > 0 && c->nSM > 0) ? "true" : "false");
     else if (c->hp.forceModel == DEME_FORCE_CUSTOM)
         snprintf(name, cap, "deme_custom_forces_ss");
@@ -1464,6 +1575,13 @@ int deme_set_tile_policy(deme_ctx* c, uint32_t minContactsPerTileCustom) {
     if (!c)
         return DEME_ERR_INVALID;
     c->tileMinContactsCustom = minContactsPerTileCustom;
+    c->listStale = true;
+    return DEME_OK;
+}
+int deme_set_fused_step(deme_ctx* c, int on) {
+    if (!c)
+        return DEME_ERR_INVALID;
+    c->fusedEnable = on ? 1 : 0;
     c->listStale = true;
     return DEME_OK;
 }
@@ -1574,13 +1692,16 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         return rc;
     if (int rc = ensure(c, c->acc, std::max<size_t>(nO, 1) * sizeof(AccRec)))
         return rc;
+    if (ensure(c, c->ownersNext, std::max<size_t>(nO, 1) * sizeof(OwnerRec)) || ensure(c, c->inCnt, (nO + 2) * 4) || ensure(c, c->inStart, (nO + 2) * 4))
+        return c->lastStatus;
+    c->fusedList = c->fusedPrevValid = false;
     HIPCK(hipMemsetAsync(c->acc.p, 0, c->acc.bytes, c->stream));
     if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->aSum, (nO + 1) * 32) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
         ensure(c, c->fixedFlag, nO + 1) || ensure(c, c->heavyList, 4096 * 4) || ensure(c, c->rangeCtr, sizeof(RangeCounters)))
         return c->lastStatus;
     {
         const size_t nTiles = (nO + DEME_TILE_NB - 1) / DEME_TILE_NB + 1;
-        if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) || ensure(c, c->tileOrg, nTiles * 24) ||
+        if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->hCountIn, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) || ensure(c, c->tileOrg, nTiles * 24) ||
             ensure(c, c->rStart, (nO + 1) * 4) || ensure(c, c->lOff, nTiles * (DEME_TILE_NB + 1) * 2) || ensure(c, c->lCount, nTiles * 4) ||
             ensure(c, c->tileRem, (nTiles + 1) * 4) || ensure(c, c->tileBase, (nTiles + 1) * 4) || ensure(c, c->tileBig, nTiles * 4) ||
             ensure(c, c->bigList, nTiles * 4))
@@ -1811,6 +1932,9 @@ static int owner_state_io(deme_ctx* c, const DemeOwnerState* st, int dir) {
     // downloads see a/alpha of EVERY owner (fixed and heavy ones are only reduced on demand)
     if (dir == 1 && c->conValid && c->haveList)
         launch_full_reduction(c);
+    else if (dir == 1 && c->fusedPrevValid && c->haveList && (st->aX || st->aY || st->aZ || st->alphaX || st->alphaY || st->alphaZ))
+        if (int rc = launch_fused_step(c, true))  // the last step was a fused one: replay its force evaluation on the buffers of its start
+            return rc;
     if (dir == 0 && (st->aX || st->aY || st->aZ || st->alphaX || st->alphaY || st->alphaZ))
         c->conValid = false;  // the caller now owns a/alpha
     AccRec* accView = c->acc.as<AccRec>();
@@ -1833,6 +1957,8 @@ static int owner_state_io(deme_ctx* c, const DemeOwnerState* st, int dir) {
 int deme_upload_owner_state(deme_ctx* c, const DemeOwnerState* st) {
     if (c && st && st->familyID)
         c->prescDirty = true;  // owners may have changed family
+    if (c)
+        c->fusedPrevValid = false;
     if (c && st && (st->voxelID || st->locX || st->locY || st->locZ || st->oriQw || st->oriQx || st->oriQy || st->oriQz || st->vX ||
                     st->vY || st->vZ || st->omgBarX || st->omgBarY || st->omgBarZ || st->familyID))
         c->listStale = true;  // pose, velocity (it sizes the margins) or family (masks) changed under the K-step list
@@ -2235,6 +2361,12 @@ int deme_step(deme_ctx* c, uint32_t nsteps) {
         if (detection_due(c))
             if (int rc = detection_phase(c))
                 return rc;
+        if (fused_ready(c)) {  // the whole step in one launch: closed tiles integrate their own owners (deme_tile_step.h)
+            if (int rc = launch_fused_step(c, false))
+                return rc;
+            continue;
+        }
+        c->fusedPrevValid = false;
         if (int rc = launch_forces(c))
             return rc;
         if (int rc = step_tail(c))

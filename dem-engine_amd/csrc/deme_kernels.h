@@ -1183,7 +1183,9 @@ struct RangeCounters {
     unsigned int nBig;    // tiles whose halo, contact range or local lists do not fit the LDS area of k_tile_forces (deme_tile.h)
     unsigned int nExtra;  // records of those tiles' contacts that hold a B owner of the same tile (every contact of such a tile writes a record)
     unsigned int tileHaloSum;  // foreign owners staged by all fitting tiles together (the engine watches its mean: deme_order.inc)
-    unsigned int pad[6];
+    unsigned int nBigIn;         // closed tiles (deme_tile_step.h) whose halo, extended by their incoming contacts' owners, does not fit
+    unsigned int tileMaxHaloIn;  // the largest closed tile's foreign owners
+    unsigned int pad[4];
 };
 
 // start[o] = first index i with owner[i] >= o, for o = 0 .. nOwners (owner[] ascending): every element fills the owners that

@@ -1026,7 +1026,8 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
                                                     uint16_t* __restrict__ lPos, uint32_t* __restrict__ lCount,
                                                     uint32_t* __restrict__ rankC, uint32_t* __restrict__ remKey,
                                                     uint32_t* __restrict__ remVal, int64_t* __restrict__ org, RangeCounters* rc,
-                                                    uint32_t nTiles, uint32_t* __restrict__ tileBig, uint32_t* __restrict__ bigList) {
+                                                    uint32_t nTiles, uint32_t* __restrict__ tileBig, uint32_t* __restrict__ bigList,
+                                                    uint32_t* __restrict__ recContact) {
     __shared__ uint32_t table[DEME_TILE_HASH];
     __shared__ uint16_t slotTab[DEME_TILE_HASH];
     __shared__ uint32_t list[DEME_TILE_HP2];
@@ -1138,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
                 const unsigned long long below = (1ull << lane) - 1ull;
                 const uint32_t r = remote ? runR + beforeR + (uint32_t)__popcll(mr & below) : runL + beforeL + (uint32_t)__popcll(ml & below);
                 rankC[c] = r;  // (the contact's OWN record, whichever kind it is)
-                remKey[r] = ob, remVal[r] = r;
+                remKey[r] = ob, remVal[r] = r, recContact[r] = c;
             }
             runR += totR, runL += totL;
             __syncthreads();
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const DevParams p, uint32_t 
         if (c < c1) {
             rankC[c] = r;
             if (remote)
-                remKey[r] = ob, remVal[r] = r;
+                remKey[r] = ob, remVal[r] = r, recContact[r] = c;  // (recContact: which contact a record belongs to -- deme_tile_step.h)
         }
         run += total;
         __syncthreads();

@@ -205,6 +205,15 @@ int deme_tile_stats(const deme_ctx* ctx, uint32_t out[4]);
  * 0 = always. */
 int deme_set_tile_policy(deme_ctx* ctx, uint32_t minContactsPerTileCustom);
 int deme_force_kernel_name(const deme_ctx* ctx, char* name, size_t cap, uint32_t* tileMaxHalo, uint32_t* tileMaxList);
+/* The one-kernel time step (csrc/deme_tile_step.h, "k_tile_step<M>"): every tile is CLOSED -- it also evaluates the contacts that
+ * hold its owners as B from other tiles (a contact that straddles two tiles is evaluated by both, bit-identically) -- so that the
+ * tile owns the complete sums of its owners and integrates them in the same launch (calculateForces + integrateOwners of
+ * dT.cpp:2424-2447 in one kernel; owners and contact history are double-buffered).  OFF by default: on the packed bed of BASELINE
+ * configs[1] the closed tiles stage ~220 foreign owners instead of ~95 and evaluate 1.2x the contacts, and the one launch
+ * (143 us) is slower than force pass + integrator (92 + 43 us) -- DESIGN.md 3.7.  Built-in models, FAST arithmetic, no mesh,
+ * no ghosts, no prescription / family-rule kernels, no recording; anything else keeps the two-kernel form silently.
+ * Environment DEME_FUSED=1 / 0 overrides the switch for every context of the process. */
+int deme_set_fused_step(deme_ctx* ctx, int on);
 
 /* The engine's own numbering (csrc/deme_order.inc).  Owner and sphere ids at this boundary are ALWAYS the caller's -- load order,
  * as in the reference (DEM/dT.cpp:700-800).  Inside, a scene uploaded in the fast arithmetic mode (no ghosts, built-in force

@@ -107,20 +107,22 @@ def test_contact_records_of_the_tile_pass_match_oracle(pkg, orc, model):
     ctx.close()
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["two_kernels", "one_kernel_step"])
 @pytest.mark.parametrize("cd_freq", [0, 10])
-def test_fast_trajectory_within_stated_tolerance(pkg, orc, cd_freq):
+def test_fast_trajectory_within_stated_tolerance(pkg, orc, cd_freq, fused):
     b = _bed(pkg, cd_freq=cd_freq)
     if cd_freq:
         b.SetExpandSafetyAdder(0.5)
     p, sc, st = _settled(pkg, b)
     ctx = pkg.Context(0)
     ctx.set_arith_mode("fast")
+    ctx.set_fused_step(fused)  # (deme_tile_step.h: closed tiles that integrate their own owners -- an option, off by default)
     ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
     sim = orc.make_sim(pkg, p, sc)
     sim.upload_state(st)
     N = 100
     ctx.step(N), sim.step(N)
-    assert ctx.force_kernel()[0] == "k_tile_forces<0, false>", ctx.force_kernel()
+    assert ctx.force_kernel()[0] == ("k_tile_step<0>" if fused else "k_tile_forces<0, false>"), ctx.force_kernel()
     ga, oa = ctx.contacts(), sim.contacts()
     assert len(ga[0]) == len(oa[0]) and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
     g, o = ctx.download_state(), sim.download_state()
@@ -130,6 +132,16 @@ def test_fast_trajectory_within_stated_tolerance(pkg, orc, cd_freq):
     dq = max(np.abs(g[k] - o[k]).max() for k in ("oriQw", "oriQx", "oriQy", "oriQz"))
     print(f"fast vs oracle after {N} steps (K={cd_freq}): |dx| {dx:.3e} m, |dv| {dv:.3e} m/s, |dw| {dw:.3e} rad/s, |dq| {dq:.3e}")
     assert dx <= 5e-8 and dv <= 2e-4 and dw <= 5e-2 and dq <= 2e-5
+    # a / alpha of the LAST step (the one-kernel step keeps none: the download replays its force evaluation on the buffers of its start)
+    n = int(sc.nOwnerClumps)
+    for keys in (("aX", "aY", "aZ"), ("alphaX", "alphaY", "alphaZ")):
+        G = np.stack([g[k][:n] for k in keys], 1).astype(np.float64)
+        O = np.stack([o[k][:n] for k in keys], 1).astype(np.float64)
+        assert np.abs(G - O).max() <= 5e-3 * np.abs(O).max(), (keys, np.abs(G - O).max() / np.abs(O).max())
+    for w in range(4):  # ... and the contact history it carries in its second buffer
+        gw, ow = ctx.wildcard(w), sim.wildcard(w)
+        print(f"wildcard {w} after {N} steps: max diff {np.abs(gw - ow).max():.3e} of {np.abs(ow).max():.3e}")
+        assert np.abs(gw - ow).max() <= 2e-3 * max(np.abs(ow).max(), 1e-12) + 1e-9, (w, np.abs(gw - ow).max(), np.abs(ow).max())
     ctx.close()
 
 
@@ -203,7 +215,7 @@ def test_a_tiled_list_serves_the_other_kernels_on_demand(pkg):
     keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
     # (a) recording
     a, t = fresh(), fresh()
-    assert a.force_kernel()[0].startswith("k_tile_forces") and int(a.counts().nContacts) > 2000
+    assert a.force_kernel()[0].startswith("k_tile_") and int(a.counts().nContacts) > 2000
     sa, st = a.download_state(), t.download_state()
     assert all(np.array_equal(sa[k], st[k]) for k in keys)
     a.set_record_contacts(True)  # (since round 4 the tile pass records itself: the list keeps its kernel; case (b) is the on-demand one)
