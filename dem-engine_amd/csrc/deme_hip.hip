@@ -18,6 +18,15 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
+// Radix-sort configurations measured on MI355X for the detection's list sizes (a few million entries: the library's defaults are
+// tuned for lists that fill the chip many times over; at these sizes workgroups of 1024 with 8 keys each shorten the chained
+// look-back of every pass).  tools/rsbench.hip, profiles/r04/r04j_radix_configs.txt: incidences (4.4e6 pairs, 21 bits) 192 -> 149 us,
+// crossing records by B owner (1.4e6 pairs, 20 bits, two 10-bit passes) 108 -> 68 us, contact keys (4.3e6 u64, 24 bits) 150 -> 141 us.
+template <unsigned RB>
+using DemeRadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, RB,
+                                                                                    rocprim::block_radix_rank_algorithm::match>,
+                                                1024 * 1024>;
 #include <iterator>
 #include <limits>
 
@@ -587,13 +596,13 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             while (bits < 32 && (1ull << bits) < nBins)
                 bits++;
             size_t need = 0;
-            HIPCK(rocprim::radix_sort_pairs(nullptr, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
+            HIPCK(rocprim::radix_sort_pairs<DemeRadixCfg<8>>(nullptr, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
                                             c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
                                             st));
             if (int rc = ensure(c, c->sortTmp, need))
                 return rc;
             need = c->sortTmp.bytes;
-            HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
+            HIPCK(rocprim::radix_sort_pairs<DemeRadixCfg<8>>(c->sortTmp.p, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
                                             c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
                                             st));
             sortedIdx = 1;
@@ -736,11 +745,11 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
                 return rc;
             uint64_t* mid = c->keysMid.as<uint64_t>();
             size_t needHi = 0;
-            HIPCK(rocprim::radix_sort_keys(nullptr, needHi, rawKeys, mid, (size_t)nC, 31, 33 + bitsA, st));
+            HIPCK(rocprim::radix_sort_keys<DemeRadixCfg<8>>(nullptr, needHi, rawKeys, mid, (size_t)nC, 31, 33 + bitsA, st));
             if (int rc = ensure(c, c->sortTmp, needHi))
                 return rc;
             needHi = c->sortTmp.bytes;
-            HIPCK(rocprim::radix_sort_keys(c->sortTmp.p, needHi, rawKeys, mid, (size_t)nC, 31, 33 + bitsA, st));
+            HIPCK(rocprim::radix_sort_keys<DemeRadixCfg<8>>(c->sortTmp.p, needHi, rawKeys, mid, (size_t)nC, 31, 33 + bitsA, st));
             hipLaunchKernelGGL(k_segment_rank_sort, dim3(grid_for(nC)), dim3(256), 0, st, (uint32_t)nC, mid,
                                c->keysSorted[next].as<uint64_t>());
             if (nPersist) {  // a marked contact the sweep found as well appears once (markDuplicateContacts)
@@ -905,12 +914,12 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                     obits++;
                 if (nR) {
                     size_t needS = 0;
-                    HIPCK(rocprim::radix_sort_pairs(nullptr, needS, c->remKey[0].as<uint32_t>(), c->remKey[1].as<uint32_t>(),
+                    HIPCK(rocprim::radix_sort_pairs<DemeRadixCfg<10>>(nullptr, needS, c->remKey[0].as<uint32_t>(), c->remKey[1].as<uint32_t>(),
                                                     c->remVal.as<uint32_t>(), c->rIdx.as<uint32_t>(), (size_t)nR, 0, obits, c->stream));
                     if (int rc = ensure(c, c->sortTmp, needS))
                         return rc;
                     needS = c->sortTmp.bytes;
-                    HIPCK(rocprim::radix_sort_pairs(c->sortTmp.p, needS, c->remKey[0].as<uint32_t>(), c->remKey[1].as<uint32_t>(),
+                    HIPCK(rocprim::radix_sort_pairs<DemeRadixCfg<10>>(c->sortTmp.p, needS, c->remKey[0].as<uint32_t>(), c->remKey[1].as<uint32_t>(),
                                                     c->remVal.as<uint32_t>(), c->rIdx.as<uint32_t>(), (size_t)nR, 0, obits, c->stream));
                     hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nR)), dim3(256), 0, c->stream, nR, c->remKey[1].as<uint32_t>(),
                                        c->nOwners, c->rStart.as<uint32_t>());
