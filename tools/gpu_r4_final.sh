@@ -27,6 +27,10 @@ python bench.py --no-cpu-baseline --clumps 10000000 --presettle 24000 > $out/${T
 python bench.py --no-cpu-baseline --async-detection 20 > $out/${TAG}_fl_async20.json 2>/dev/null
 DEME_ARITH=exact python bench.py --no-cpu-baseline > $out/${TAG}_fl_exact.json 2>/dev/null
 line $out/${TAG}_fl_*.json > $out/flavours.txt; cat $out/flavours.txt
+# kernel traces of the flavours the review asked to keep: configs[3] (mesh variant of the tile pass) and configs[4] (run-time compiled model)
+BENCH_ARGS="--steps 80 --warmup 10 --no-cpu-baseline --clumps 2000000 --mesh-triangles 50000 --state-cache /tmp/deme_bed_mesh.npz" bash tools/prof.sh ${TAG}_mesh r04 trace > $out/${TAG}_mesh_log.txt 2>&1
+BENCH_ARGS="--steps 80 --warmup 10 --no-cpu-baseline --config5" bash tools/prof.sh ${TAG}_config5 r04 trace > $out/${TAG}_config5_log.txt 2>&1
+BENCH_ARGS="--steps 80 --warmup 10 --no-cpu-baseline --config5 --tile-policy 0" bash tools/prof.sh ${TAG}_config5_tilepass r04 trace > $out/${TAG}_config5_tilepass_log.txt 2>&1
 python bench.py --steps 20 --warmup 5 > $out/final_bench_driver_shape.json 2>/dev/null
 python bench.py > $out/final_bench_default.json 2>/dev/null
 line $out/final_bench_*.json
