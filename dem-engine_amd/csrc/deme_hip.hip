@@ -152,6 +152,7 @@ struct deme_ctx {
     DevBuf revSlot;
     const void* revAcc = nullptr;
     bool pairsOnce = false;
+    PrescArgs laterPa{nullptr, nullptr};  // the prescription records of the step whose integration is split (launch_integrate_later)
     bool crossStale = false;  // a scene was uploaded while the group evaluates cross-cut contacts once: rev_setup_slab runs again first
     hipEvent_t evPass1 = nullptr;
     char* pin = nullptr;       // 16 KB of pinned host memory: where the detection's read-backs land
@@ -1366,7 +1367,9 @@ int rebuild_presc_list(deme_ctx* c) {
     return DEME_OK;
 }
 
-int launch_integrate(deme_ctx* c, bool fused, bool heavyDone = false) {
+// `laterIds` (slab group, one evaluation per cross-cut contact): the owners that wait for a reverse share are left out of this launch
+// (GatherArgs::revPhase) and integrated by launch_integrate_later once the share has arrived
+int launch_integrate(deme_ctx* c, bool fused, bool heavyDone = false, bool splitLater = false) {
     ScopedTimer tm(c, "integrate");
     PrescArgs pa{nullptr, nullptr};
     if (c->prescFn) {
@@ -1390,13 +1393,31 @@ int launch_integrate(deme_ctx* c, bool fused, bool heavyDone = false) {
             launch_reduce_heavy(c, true);
         if (c->heavyOverflow)
             return c->lastStatus;
+        GatherArgs ga = gather_args(c);
+        ga.revPhase = splitLater ? 1u : 0u;
         hipLaunchKernelGGL(k_integrate<true>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
-                           c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c), pa);
+                           c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), ga, pa);
     } else {
         hipLaunchKernelGGL(k_integrate<false>, dim3(grid_for(c->nOwners)), dim3(256), 0, c->stream, c->dp,
                            c->owners.as<OwnerRec>(), c->acc.as<AccRec>(), gather_args(c), pa);
     }
+    c->laterPa = pa;
+    if (splitLater)
+        return DEME_OK;  // (launch_integrate_later finishes the step)
     if (c->nextAccPending) {  // one step only (cleanUpAcc clears the flag when it honours it, DEMPrepForceKernels.cu:14-31)
+        c->nextAccPending = false;
+        std::fill(c->hNextAcc.begin(), c->hNextAcc.end(), AccRec{});
+        HIPCK(hipMemsetAsync(c->nextAcc.p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
+    }
+    return DEME_OK;
+}
+int launch_integrate_later(deme_ctx* c, const uint32_t* ids, uint32_t n) {
+    if (n) {
+        ScopedTimer tm(c, "integrate_later");
+        hipLaunchKernelGGL(k_integrate_list, dim3(grid_for(n)), dim3(256), 0, c->stream, c->dp, c->owners.as<OwnerRec>(),
+                           c->acc.as<AccRec>(), gather_args(c), c->laterPa, ids, n);
+    }
+    if (c->nextAccPending) {
         c->nextAccPending = false;
         std::fill(c->hNextAcc.begin(), c->hNextAcc.end(), AccRec{});
         HIPCK(hipMemsetAsync(c->nextAcc.p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
@@ -2415,9 +2436,13 @@ static int step_tail_pre(deme_ctx* c) {
         return c->lastStatus;
     return DEME_OK;
 }
-static int step_tail_post(deme_ctx* c) {
-    if (int rc = launch_integrate(c, c->tailFused, true))
+// `later` / `nLater` (slab group, one evaluation per cross-cut contact): the owners that wait for a reverse share; this half of the
+// step leaves them out and returns before the step's bookkeeping -- step_tail_later finishes it when the share has arrived
+static int step_tail_post(deme_ctx* c, bool splitLater = false) {
+    if (int rc = launch_integrate(c, c->tailFused, true, splitLater))
         return rc;
+    if (splitLater)
+        return DEME_OK;
     c->stepsSinceCD++;
     c->nSteps++;
     c->timeElapsed += (double)c->hp.h;
@@ -2429,6 +2454,16 @@ static int step_tail(deme_ctx* c) {
     if (int rc = step_tail_pre(c))
         return rc;
     return step_tail_post(c);
+}
+static int step_tail_later(deme_ctx* c, const uint32_t* ids, uint32_t n) {
+    if (int rc = launch_integrate_later(c, ids, n))
+        return rc;
+    c->stepsSinceCD++;
+    c->nSteps++;
+    c->timeElapsed += (double)c->hp.h;
+    if (c->evStepDone)
+        HIPCK(hipEventRecord(c->evStepDone, c->stream));
+    return DEME_OK;
 }
 
 static bool detection_due(deme_ctx* c) {
@@ -3001,7 +3036,9 @@ int deme_halo_group_set_cross_contacts(deme_halo_group* g, int evaluateOnce) {
 
 // after every slab's ghost-dependent force pass: pack the right ghosts' sums, one RCCL group (each cut: left slab -> right slab),
 // the integrations wait for what they receive
-static int reverse_exchange(deme_halo_group* g) {
+// `waitNow` false: the compute streams are NOT made to wait here -- the caller integrates the owners that expect no share beside the
+// exchange and waits on evRevDone before the ones that do (one_step)
+static int reverse_exchange(deme_halo_group* g, bool waitNow = true) {
     auto find = [&](deme_ctx* c) -> HaloSlab* {
         for (auto& s : g->slabs)
             if (s.ctx == c)
@@ -3049,8 +3086,9 @@ static int reverse_exchange(deme_halo_group* g) {
 #undef GNCCL_IN_GROUP
     GNCCL(g->api->GroupEnd());
     GHIP(hipEventRecord(g->evRevDone, g->xstream));
-    for (auto& s : g->slabs)
-        GHIP(hipStreamWaitEvent(s.ctx->stream, g->evRevDone, 0));
+    if (waitNow)
+        for (auto& s : g->slabs)
+            GHIP(hipStreamWaitEvent(s.ctx->stream, g->evRevDone, 0));
     g->nRevExchanges++;
     return DEME_OK;
 }
@@ -3112,11 +3150,35 @@ int deme_halo_group_step(deme_halo_group* g, uint32_t nsteps) {
             for (auto& s : g->slabs)
                 if (int rc = overlap_forces(s.ctx))
                     return gfail(g, rc, "step (boundary forces): %s", s.ctx->err.c_str());
-            if (int rc = reverse_exchange(g))
-                return rc;
+            // The reactions travel while every slab integrates the owners that expect none (all but the clumps on its send-left
+            // list); those are integrated when the share has arrived.  (Family rules that read accelerations see the complete sums
+            // of every owner before anything is integrated: the unsplit order serves then.)
+            static const int splitEnv = getenv("DEME_REV_SPLIT") ? atoi(getenv("DEME_REV_SPLIT")) : 1;
+            bool split = splitEnv != 0;
             for (auto& s : g->slabs)
-                if (int rc = step_tail(s.ctx))
-                    return gfail(g, rc, "step (integration): %s", s.ctx->err.c_str());
+                if (s.ctx->rulesFn)
+                    split = false;
+            if (int rc = reverse_exchange(g, !split))
+                return rc;
+            if (!split) {
+                for (auto& s : g->slabs)
+                    if (int rc = step_tail(s.ctx))
+                        return gfail(g, rc, "step (integration): %s", s.ctx->err.c_str());
+            } else {
+                for (auto& s : g->slabs) {
+                    if (int rc = step_tail_pre(s.ctx))
+                        return gfail(g, rc, "step (reductions): %s", s.ctx->err.c_str());
+                    if (int rc = step_tail_post(s.ctx, true))
+                        return gfail(g, rc, "step (integration beside the reverse exchange): %s", s.ctx->err.c_str());
+                }
+                for (auto& s : g->slabs) {
+                    const HaloSide& l = s.side[0];
+                    GHIP(hipStreamWaitEvent(s.ctx->stream, g->evRevDone, 0));
+                    const bool waits = l.peerRank >= 0 && l.nSend && s.ctx->revAcc;
+                    if (int rc = step_tail_later(s.ctx, waits ? (const uint32_t*)l.sendIds : nullptr, waits ? l.nSend : 0u))
+                        return gfail(g, rc, "step (integration of the clumps that waited for their share): %s", s.ctx->err.c_str());
+                }
+            }
         } else if (g->nShared == 0) {
             for (auto& s : g->slabs) {
                 s.ctx->inGroupStep = true;

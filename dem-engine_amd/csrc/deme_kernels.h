@@ -858,6 +858,7 @@ struct GatherArgs {
     // contacts with ITS clumps sends a / alpha of their sum; revSlot[o] = the clump's place in that message, 0xFFFFFFFF = none
     const uint32_t* revSlot;
     const float4* revAcc;    // two float4 per place
+    uint32_t revPhase;  // k_integrate: 1 = leave the owners that wait for a reverse share (revSlot set) to k_integrate_list
     uint32_t revInIntegrator;  // k_reduce_heavy: 1 = launched by the stepping loop (integrate_owner adds the share afterwards)
 };
 
@@ -1324,6 +1325,9 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
     const uint32_t fflags = p.familyFlags[fam_of(r.family)];
     const bool ghost = ghost_of(r.family);  // its owner rank integrates it; refreshed by deme_halo_unpack
     const bool fixed = (fflags & 1u) != 0;
+    // (slab group, one evaluation per cross-cut contact) an owner whose share of the left neighbour's contacts is still on its way is
+    // left as it is: k_integrate_list takes it when the share has arrived, the rest of the slab integrates beside the exchange
+    const bool later = g.revPhase == 1u && g.revSlot && valid && g.revSlot[o] != 0xFFFFFFFFu;
     float4 a = make_float4(0, 0, 0, 0), al = a;
     if (FUSED) {
         // a fixed owner's a/alpha never feed the integrator (they are reduced on demand); a/alpha are not stored in
@@ -1331,8 +1335,8 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         // the per-contact contributions (launch_full_reduction)
         GatherLds& lds = *reinterpret_cast<GatherLds*>(smem);
         const bool hv = valid && g.heavy[o];
-        gather_block(g, p.nOwners, o, valid && !ghost && !fixed && !hv, lds, a, al);
-        if (valid && !ghost) {
+        gather_block(g, p.nOwners, o, valid && !ghost && !fixed && !hv && !later, lds, a, al);
+        if (valid && !ghost && !later) {
             if (g.world && !fixed && !hv)
                 acc_from_world(p, r, a, al);
             if (hv) {
@@ -1346,14 +1350,41 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         a = ap[0];
         al = ap[1];
     }
-    if (valid && !ghost)
+    if (valid && !ghost && !later)
         integrate_owner(p, r, a, al, o, fflags, fixed, g, pa);
 #if DEME_INT_COOP
     coop_store_owner(owners, p.nOwners, waveBase, stage, r);  // a record nobody integrated goes back as it came
 #else
-    if (valid && !ghost)
+    if (valid && !ghost && !later)
         store_owner(owners, o, r);
 #endif
+}
+
+// the owners k_integrate left for later (revPhase 1): the same update, one thread per listed owner, sums gathered per thread in the
+// same fixed order (gather_owner == gather_block bit for bit)
+__global__ __launch_bounds__(256) void k_integrate_list(const DevParams p, OwnerRec* __restrict__ owners, const AccRec* __restrict__ acc,
+                                                        const GatherArgs g, const PrescArgs pa, const uint32_t* __restrict__ ids,
+                                                        uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t o = ids[i];
+    OwnerRec r = load_owner(owners, o);
+    if (ghost_of(r.family))
+        return;
+    const uint32_t fflags = p.familyFlags[fam_of(r.family)];
+    const bool fixed = (fflags & 1u) != 0;
+    float4 a = make_float4(0, 0, 0, 0), al = a;
+    if (g.heavy[o]) {
+        const float4* ap = reinterpret_cast<const float4*>(acc + o);
+        a = ap[0], al = ap[1];
+    } else if (!fixed) {
+        gather_owner(g, o, a, al);
+        if (g.world)
+            acc_from_world(p, r, a, al);
+    }
+    integrate_owner(p, r, a, al, o, fflags, fixed, g, pa);
+    store_owner(owners, o, r);
 }
 
 // the explicit update of one owner (DEMIntegrationKernels.cu:100-236); r is updated in place
