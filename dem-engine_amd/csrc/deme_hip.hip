@@ -20,7 +20,7 @@
 #include <rocprim/rocprim.hpp>
 // Radix-sort configurations measured on MI355X for the detection's list sizes (a few million entries: the library's defaults are
 // tuned for lists that fill the chip many times over; at these sizes workgroups of 1024 with 8 keys each shorten the chained
-// look-back of every pass).  tools/rsbench.hip, profiles/r04/r04j_radix_configs.txt: incidences (4.4e6 pairs, 21 bits) 192 -> 149 us,
+// look-back of every pass).  tools/rsbench.hip, profiles/r04/r04j_radix_configs.txt: incidences (8.2e6 pairs, 21 bits) 227 -> 206 us (4.4e6: 192 -> 149),
 // crossing records by B owner (1.4e6 pairs, 20 bits, two 10-bit passes) 108 -> 68 us, contact keys (4.3e6 u64, 24 bits) 150 -> 141 us.
 template <unsigned RB>
 using DemeRadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
