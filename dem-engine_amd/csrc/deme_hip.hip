@@ -1092,6 +1092,16 @@ void launch_reduce_heavy(deme_ctx* c, bool skipFixed) {
                        skipFixed ? c->fixedFlag.as<uint8_t>() : (const uint8_t*)nullptr, c->acc.as<AccRec>());
 }
 
+// the stride of the staged owner records of a tile launch (TileArgs::rs16): padded by 16 bytes when that costs no workgroup per CU
+// (160 KB of LDS per CU, allocated in 512-byte blocks; the kernels' registers allow four workgroups)
+static uint32_t tile_record_stride(uint32_t hCap, uint32_t lCap, uint32_t tabBytes, int model) {
+    const uint32_t base = tile_rec16(model);
+    static const int padEnv = getenv("DEME_TILE_PAD_RECORDS") ? atoi(getenv("DEME_TILE_PAD_RECORDS")) : 1;
+    if (model == 2 || !padEnv)  // (80-byte records start on 16 banks already)
+        return base;
+    auto groups = [&](uint32_t rs) { return std::min<uint32_t>(4u, 163840u / ((tile_lds_bytes(hCap, lCap, tabBytes, rs) + 511u) & ~511u)); };
+    return groups(base + 1u) == groups(base) ? base + 1u : base;
+}
 // pass: -1 everything in one launch; 0 / 1 the two halves of a split step (contacts that read no ghost owner / the rest)
 // `fs`: the stream of a tile-form launch when it is not the context's (the ghost-dependent pass of a split step runs on the halo
 // stream, beside the tail of the interior pass)
@@ -1172,11 +1182,12 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
             nBlk = (nBlk + 8u * ta.xcdGroup - 1u) / (8u * ta.xcdGroup) * (8u * ta.xcdGroup);
         // LDS sized from this list's largest tile (rounded up so that a launch configuration serves many detections)
         ta.hCap = std::min<uint32_t>(DEME_TILE_HMAX, (c->tileMaxHalo + 15u) & ~15u);
-        ta.lCap = std::min<uint32_t>(DEME_TILE_LMAX, (c->tileMaxList + 63u) & ~63u);
+        ta.lCap = std::min<uint32_t>(DEME_TILE_LMAX, (c->tileMaxList + 15u) & ~15u);
         ta.nComp = c->nComp, ta.nAnal = c->nAnal, ta.nMass = c->nMassProps;
         static const uint32_t ldsPad = getenv("DEME_TILE_LDS_PAD") ? (uint32_t)atoi(getenv("DEME_TILE_LDS_PAD")) : 0u;  // occupancy experiments
-        const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial),
-                                                 tile_rec16(customTile ? 2 : 0)) + ldsPad;
+        const uint32_t tabBytes = tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial);
+        ta.rs16 = tile_record_stride(ta.hCap, ta.lCap, tabBytes, customTile ? 2 : 0);
+        const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tabBytes, ta.rs16) + ldsPad;
         hipStream_t st = fs ? fs : c->stream;
         ScopedTimer tm(c, "calc_forces", false, st);
         const bool mesh = c->nTri > 0 && c->nSM > 0;
@@ -1293,7 +1304,7 @@ int launch_fused_step(deme_ctx* c, bool dry) {
     ta.xcdGroup = c->xcdGroup;
     ta.tileBig = c->tileBig.as<uint32_t>(), ta.bigList = c->bigList.as<uint32_t>(), ta.info = c->info.as<uint4>();
     ta.hCap = std::min<uint32_t>(DEME_TILE_HMAX, (c->tileMaxHaloIn + 15u) & ~15u);
-    ta.lCap = std::min<uint32_t>(DEME_TILE_LMAX, (c->tileMaxList + 63u) & ~63u);
+    ta.lCap = std::min<uint32_t>(DEME_TILE_LMAX, (c->tileMaxList + 15u) & ~15u);
     ta.nComp = c->nComp, ta.nAnal = c->nAnal, ta.nMass = c->nMassProps;
     sa.ownersNext = dry ? c->owners.as<OwnerRec>() : c->ownersNext.as<OwnerRec>();
     sa.wcNext = c->wc[cur ^ 1].as<float>();
@@ -1304,7 +1315,9 @@ int launch_fused_step(deme_ctx* c, bool dry) {
     unsigned nBlk = ta.nTiles;
     if (ta.xcdGroup)
         nBlk = (nBlk + 8u * ta.xcdGroup - 1u) / (8u * ta.xcdGroup) * (8u * ta.xcdGroup);
-    const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial));
+    const uint32_t tabBytes = tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial);
+    ta.rs16 = tile_record_stride(ta.hCap, ta.lCap, tabBytes, 0);
+    const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tabBytes, ta.rs16);
     {
         ScopedTimer tm(c, dry ? "fused_replay" : "calc_forces");
         if (c->hp.forceModel == DEME_FORCE_HERTZIAN)

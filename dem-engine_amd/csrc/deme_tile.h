@@ -42,7 +42,9 @@ static_assert(DEME_TILE_T >= 2 * DEME_TILE_NB, "one pulling thread per owner and
 static_assert(DEME_TILE_NB + DEME_TILE_HMAX <= 2 * DEME_TILE_T, "a thread stages at most two owner records");
 static_assert(DEME_TILE_LMAX == DEME_TILE_LREG * DEME_TILE_T, "list entries per thread");
 #define DEME_TILE_HASH 1024u
+#ifndef DEME_TILE_REC
 #define DEME_TILE_REC 6    // uint4 per staged owner (96 bytes) for the built-in models
+#endif
 // A run-time compiled model (MODEL 2, deme_jit.h) is written against the reference's body-frame vocabulary (AOriQ, ARotVel, locCPA):
 // its staged record carries the quaternion and the body-frame angular velocity instead of the nine rotation coefficients and the
 // world-frame one -- 80 bytes; the coefficients are formed per contact.
@@ -114,6 +116,11 @@ struct TileArgs {
     float timeElapsed;
     float* rec[4];             // contact recording (REC variants): force, torque-only force, contact point in A's / B's body frame
     uint32_t nOwners, nTiles, pass, xcdGroup;
+    // Stride of the staged records in LDS, in 16-byte units: tile_rec16(model), or ONE MORE for the built-in models when the workgroups
+    // per CU stay the same -- 96-byte records start on 8 different banks (24 words: gcd(24, 64) = 8), so two lanes' ds_read_b128 of two
+    // random slots collide twice as often as with 112-byte records (28 words: 16 starting banks x 4 words = all 64); measured
+    // -3 us on the pass (profiles/r04/r04p_record_stride.txt)
+    uint32_t rs16;
     uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
     uint32_t nComp, nAnal, nMass;  // table sizes (tile_table_bytes)
 };
@@ -163,8 +170,8 @@ __device__ inline void tile_stage_owner_user(const DevParams& p, const float mas
     dst[3] = make_uint4(__float_as_uint(r.vx), __float_as_uint(r.vy), __float_as_uint(r.vz), __float_as_uint(r.wx));
     dst[4] = make_uint4(__float_as_uint(r.wy), __float_as_uint(r.wz), 0u, 0u);
 }
-__device__ inline TileOwner tile_read_owner_user(const uint4* sOwn, uint32_t slot) {
-    const uint4* q = sOwn + slot * DEME_TILE_REC_USER;
+__device__ inline TileOwner tile_read_owner_user(const uint4* sOwn, uint32_t at) {
+    const uint4* q = sOwn + at;
     const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
     TileOwner o;
     uint2 t;
@@ -186,9 +193,9 @@ __device__ inline void tile_stage(const DevParams& p, const float mass, const Ow
         tile_stage_owner_m(p, mass, r, u0x, u0y, u0z, dst);
 }
 template <int MODEL>
-__device__ inline TileOwner tile_read(const uint4* sOwn, uint32_t slot);
-__device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t slot) {
-    const uint4* q = sOwn + slot * DEME_TILE_REC;
+__device__ inline TileOwner tile_read(const uint4* sOwn, uint32_t at);  // `at`: slot x the launch's record stride (TileArgs::rs16)
+__device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t at) {
+    const uint4* q = sOwn + at;
     const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
     TileOwner o;
     uint2 t;
@@ -203,11 +210,11 @@ __device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t slot) {
     return o;
 }
 template <>
-__device__ inline TileOwner tile_read<0>(const uint4* sOwn, uint32_t slot) { return tile_read_owner(sOwn, slot); }
+__device__ inline TileOwner tile_read<0>(const uint4* sOwn, uint32_t at) { return tile_read_owner(sOwn, at); }
 template <>
-__device__ inline TileOwner tile_read<1>(const uint4* sOwn, uint32_t slot) { return tile_read_owner(sOwn, slot); }
+__device__ inline TileOwner tile_read<1>(const uint4* sOwn, uint32_t at) { return tile_read_owner(sOwn, at); }
 template <>
-__device__ inline TileOwner tile_read<2>(const uint4* sOwn, uint32_t slot) { return tile_read_owner_user(sOwn, slot); }
+__device__ inline TileOwner tile_read<2>(const uint4* sOwn, uint32_t at) { return tile_read_owner_user(sOwn, at); }
 
 // what only a run-time compiled model needs beside the staged records (MODEL 2; everything here that the user's statements do
 // not name is dead code after inlining)
@@ -491,6 +498,7 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
 //   lPos  [lCap x 2 B]
 //   tables: components [nComp x 16 B], material pairs [nMat^2 x 32 B], analytical objects [nAnal x 64 B], masses [nMass x 4 B],
 //           family margins [256 x 4 B, only when a family has one]
+#define DEME_TILE_BOUNDS_BYTES ((2u * (DEME_TILE_NB + 1u) * 2u + 15u) & ~15u)  // the owners' run bounds: two 16-bit arrays of NB + 1
 #define DEME_TILE_RSLOTS (DEME_TILE_T + 2)  // a round's contribution slots + the ZERO slot (index DEME_TILE_T) the pulls read for "no entry"
                                             // (+ 1: the arrays behind stay 16-byte aligned)
 #define DEME_TILE_TABLE_MAX 4096u  // bytes of tables a scene may have and still take the tile path
@@ -498,7 +506,7 @@ __host__ __device__ inline uint32_t tile_table_bytes(uint32_t nComp, uint32_t nM
     return nComp * 16u + nMat * nMat * 32u + nAnal * 64u + ((nMass * 4u + 15u) & ~15u) + (famTrivial ? 0u : 1024u);
 }
 __host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap, uint32_t tableBytes, uint32_t rec16 = DEME_TILE_REC) {
-    return (DEME_TILE_NB + hCap) * rec16 * 16u + DEME_TILE_RSLOTS * 40u + 2u * (DEME_TILE_NB + 1u) * 4u + 8u + ((lCap * 2u + 15u) & ~15u) +
+    return (DEME_TILE_NB + hCap) * rec16 * 16u + DEME_TILE_RSLOTS * 40u + DEME_TILE_BOUNDS_BYTES + ((lCap * 2u + 15u) & ~15u) +
            tableBytes + 16u;
 }
 
@@ -506,13 +514,13 @@ template <int MODEL, bool MESH, bool REC = false>
 __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(const DevParams p, const TileArgs a) {
     extern __shared__ uint4 tileLds[];
     uint4* const sOwn = tileLds;
-    constexpr uint32_t RSZ = tile_rec16(MODEL);
+    const uint32_t RSZ = a.rs16;  // uint4 per staged record: what the record holds, or one more (see TileArgs::rs16)
     float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * RSZ);
     float4* const recT = recA4 + DEME_TILE_RSLOTS;
     float2* const recA2 = reinterpret_cast<float2*>(recT + DEME_TILE_RSLOTS);
-    uint32_t* const sALo = reinterpret_cast<uint32_t*>(recA2 + DEME_TILE_RSLOTS);
-    uint32_t* const sLLo = sALo + (DEME_TILE_NB + 1);
-    uint16_t* const sLPos = reinterpret_cast<uint16_t*>(sLLo + (DEME_TILE_NB + 1) + 2);  // (16-byte aligned: 2 x 129 + 2 words)
+    uint16_t* const sALo = reinterpret_cast<uint16_t*>(recA2 + DEME_TILE_RSLOTS);  // (a tile's contact range is at most DEME_TILE_CMAX long)
+    uint16_t* const sLLo = sALo + (DEME_TILE_NB + 1);
+    uint16_t* const sLPos = sALo + DEME_TILE_BOUNDS_BYTES / 2u;  // (16-byte aligned)
     const uint32_t t = tile_block_id(a.xcdGroup);
     if (t >= a.nTiles)
         return;
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         if (h1 < nH)
             tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * RSZ);
         if (tid <= DEME_TILE_NB)
-            sALo[tid] = bA - c0, sLLo[tid] = bL;
+            sALo[tid] = (uint16_t)(bA - c0), sLLo[tid] = (uint16_t)bL;
         if (tid == DEME_TILE_T - 1u)  // the zero slot of the contribution arrays
             recA4[DEME_TILE_T] = make_float4(0, 0, 0, 0), recT[DEME_TILE_T] = make_float4(0, 0, 0, 0), recA2[DEME_TILE_T] = make_float2(0, 0);
 #pragma unroll
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 const uint2 ci = inf[d];
                 float4 h = hist[d];
                 const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
-                const TileOwner A = tile_read<MODEL>(sOwn, slotA), B = tile_read<MODEL>(sOwn, slotB);
+                const TileOwner A = tile_read<MODEL>(sOwn, slotA * RSZ), B = tile_read<MODEL>(sOwn, slotB * RSZ);
                 f3 force, tA, tB;
                 if (MESH && ((ci.x >> 20) & 3u) == DEME_KEY_CLASS_SM) {  // (rare, and only in tiles along the mesh: the loads sit behind a branch)
                     const float4 a4 = a.conA4[c], b4 = a.conB4[c];

@@ -45,13 +45,13 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_step(const 
     const TileArgs& a = sa.t;
     extern __shared__ uint4 tileLds[];
     uint4* const sOwn = tileLds;
-    constexpr uint32_t RSZ = tile_rec16(MODEL);
+    const uint32_t RSZ = a.rs16;
     float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * RSZ);
     float4* const recT = recA4 + DEME_TILE_RSLOTS;
     float2* const recA2 = reinterpret_cast<float2*>(recT + DEME_TILE_RSLOTS);
-    uint32_t* const sALo = reinterpret_cast<uint32_t*>(recA2 + DEME_TILE_RSLOTS);
-    uint32_t* const sLLo = sALo + (DEME_TILE_NB + 1);
-    uint16_t* const sLPos = reinterpret_cast<uint16_t*>(sLLo + (DEME_TILE_NB + 1) + 2);
+    uint16_t* const sALo = reinterpret_cast<uint16_t*>(recA2 + DEME_TILE_RSLOTS);  // (a tile's contact range is at most DEME_TILE_CMAX long)
+    uint16_t* const sLLo = sALo + (DEME_TILE_NB + 1);
+    uint16_t* const sLPos = sALo + DEME_TILE_BOUNDS_BYTES / 2u;  // (16-byte aligned)
     const uint32_t t = tile_block_id(a.xcdGroup);
     if (t >= a.nTiles)
         return;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_step(const 
         if (h1 < nH)
             tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, 0, 0, 0, sOwn + (DEME_TILE_NB + h1) * RSZ);
         if (tid <= DEME_TILE_NB)
-            sALo[tid] = bA - c0, sLLo[tid] = bL;
+            sALo[tid] = (uint16_t)(bA - c0), sLLo[tid] = (uint16_t)bL;
         if (tid == DEME_TILE_T - 1u)
             recA4[DEME_TILE_T] = make_float4(0, 0, 0, 0), recT[DEME_TILE_T] = make_float4(0, 0, 0, 0), recA2[DEME_TILE_T] = make_float2(0, 0);
 #pragma unroll
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_step(const 
             const uint2 ci = inf[0];
             float4 h = hist[0];
             const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
-            const TileOwner A = tile_read<MODEL>(sOwn, slotA), B = tile_read<MODEL>(sOwn, slotB);
+            const TileOwner A = tile_read<MODEL>(sOwn, slotA * RSZ), B = tile_read<MODEL>(sOwn, slotB * RSZ);
             f3 force, tA, tB;
             tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
             if (MODEL == 0 && q < nOwnC && !sa.dry)
