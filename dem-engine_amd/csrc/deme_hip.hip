@@ -1187,6 +1187,10 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         static const uint32_t ldsPad = getenv("DEME_TILE_LDS_PAD") ? (uint32_t)atoi(getenv("DEME_TILE_LDS_PAD")) : 0u;  // occupancy experiments
         const uint32_t tabBytes = tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial);
         ta.rs16 = tile_record_stride(ta.hCap, ta.lCap, tabBytes, customTile ? 2 : 0);
+        static const int swzEnv = getenv("DEME_TILE_SWIZZLE") ? atoi(getenv("DEME_TILE_SWIZZLE")) : 1;  // (2: rotate instead of padding everywhere)
+        if (swzEnv == 2 && !customTile)
+            ta.rs16 = tile_rec16(0);
+        ta.swz = (swzEnv && !customTile && ta.rs16 == tile_rec16(0)) ? 1u : 0u;
         const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tabBytes, ta.rs16) + ldsPad;
         hipStream_t st = fs ? fs : c->stream;
         ScopedTimer tm(c, "calc_forces", false, st);
@@ -1317,6 +1321,7 @@ int launch_fused_step(deme_ctx* c, bool dry) {
         nBlk = (nBlk + 8u * ta.xcdGroup - 1u) / (8u * ta.xcdGroup) * (8u * ta.xcdGroup);
     const uint32_t tabBytes = tile_table_bytes(c->nComp, c->nMat, c->nAnal, c->nMassProps, c->dp.familyTrivial);
     ta.rs16 = tile_record_stride(ta.hCap, ta.lCap, tabBytes, 0);
+    ta.swz = ta.rs16 == tile_rec16(0) ? 1u : 0u;
     const uint32_t ldsBytes = tile_lds_bytes(ta.hCap, ta.lCap, tabBytes, ta.rs16);
     {
         ScopedTimer tm(c, dry ? "fused_replay" : "calc_forces");

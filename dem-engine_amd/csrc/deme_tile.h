@@ -121,6 +121,10 @@ struct TileArgs {
     // random slots collide twice as often as with 112-byte records (28 words: 16 starting banks x 4 words = all 64); measured
     // -3 us on the pass (profiles/r04/r04p_record_stride.txt)
     uint32_t rs16;
+    // ... and where a padded record would cost a workgroup (a list whose largest tile stages more than 128 foreign owners): the six
+    // cells of every record whose slot has bit 3 set are rotated by one (swz = 1) -- 6 s + f + bit3(s) runs through all 16 starting
+    // bank groups over 16 consecutive slots, at no cost in LDS
+    uint32_t swz;
     uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
     uint32_t nComp, nAnal, nMass;  // table sizes (tile_table_bytes)
 };
@@ -136,8 +140,11 @@ struct TileOwner {
     float qw, qx, qy, qz;  // MODEL 2 only
 };
 
+// `rot` (0 / 1): the record's six 16-byte cells rotated by one (TileArgs::swz) -- cell f lies at dst[(f + rot) % 6]
 __device__ inline void tile_stage_owner_m(const DevParams& p, const float mass, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z,
-                                          uint4* dst) {
+                                          uint4* dst0, uint32_t rot = 0u) {
+    uint4* const dst = dst0 + rot;
+    uint4* const last = dst0 + (rot ? 0 : 5);
     int64_t ux, uy, uz;
     pos_units(r, p, ux, uy, uz);
     const double px = (double)(ux - u0x) * p.l, py = (double)(uy - u0y) * p.l, pz = (double)(uz - u0z) * p.l;
@@ -150,12 +157,9 @@ __device__ inline void tile_stage_owner_m(const DevParams& p, const float mass, 
     dst[2] = make_uint4(__float_as_uint(R.xx), __float_as_uint(R.xy), __float_as_uint(R.xz), __float_as_uint(R.yx));
     dst[3] = make_uint4(__float_as_uint(R.yy), __float_as_uint(R.yz), __float_as_uint(R.zx), __float_as_uint(R.zy));
     dst[4] = make_uint4(__float_as_uint(R.zz), __float_as_uint(r.vx), __float_as_uint(r.vy), __float_as_uint(r.vz));
-    dst[5] = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), 0u);
+    *last = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), 0u);
 }
-__device__ inline void tile_stage_owner(const DevParams& p, const float* massTable, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z,
-                                        uint4* dst) {
-    tile_stage_owner_m(p, massTable[r.inertiaOff], r, u0x, u0y, u0z, dst);
-}
+
 // MODEL 2: position, mass, family | inertia offset << 16, quaternion, velocity, body-frame angular velocity
 __device__ inline void tile_stage_owner_user(const DevParams& p, const float mass, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z,
                                              uint4* dst) {
@@ -186,17 +190,18 @@ __device__ inline TileOwner tile_read_owner_user(const uint4* sOwn, uint32_t at)
     return o;
 }
 template <int MODEL>
-__device__ inline void tile_stage(const DevParams& p, const float mass, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z, uint4* dst) {
+__device__ inline void tile_stage(const DevParams& p, const float mass, const OwnerRec& r, int64_t u0x, int64_t u0y, int64_t u0z, uint4* dst,
+                                  uint32_t rot = 0u) {
     if (MODEL == 2)
         tile_stage_owner_user(p, mass, r, u0x, u0y, u0z, dst);
     else
-        tile_stage_owner_m(p, mass, r, u0x, u0y, u0z, dst);
+        tile_stage_owner_m(p, mass, r, u0x, u0y, u0z, dst, rot);
 }
 template <int MODEL>
-__device__ inline TileOwner tile_read(const uint4* sOwn, uint32_t at);  // `at`: slot x the launch's record stride (TileArgs::rs16)
-__device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t at) {
-    const uint4* q = sOwn + at;
-    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
+__device__ inline TileOwner tile_read(const uint4* sOwn, uint32_t at, uint32_t rot);  // `at`: slot x the launch's record stride (TileArgs::rs16)
+__device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t at, uint32_t rot) {
+    const uint4* q = sOwn + at + rot;
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = sOwn[at + (rot ? 0u : 5u)];
     TileOwner o;
     uint2 t;
     t = make_uint2(a.x, a.y), __builtin_memcpy(&o.px, &t, 8);
@@ -210,11 +215,11 @@ __device__ inline TileOwner tile_read_owner(const uint4* sOwn, uint32_t at) {
     return o;
 }
 template <>
-__device__ inline TileOwner tile_read<0>(const uint4* sOwn, uint32_t at) { return tile_read_owner(sOwn, at); }
+__device__ inline TileOwner tile_read<0>(const uint4* sOwn, uint32_t at, uint32_t rot) { return tile_read_owner(sOwn, at, rot); }
 template <>
-__device__ inline TileOwner tile_read<1>(const uint4* sOwn, uint32_t at) { return tile_read_owner(sOwn, at); }
+__device__ inline TileOwner tile_read<1>(const uint4* sOwn, uint32_t at, uint32_t rot) { return tile_read_owner(sOwn, at, rot); }
 template <>
-__device__ inline TileOwner tile_read<2>(const uint4* sOwn, uint32_t at) { return tile_read_owner_user(sOwn, at); }
+__device__ inline TileOwner tile_read<2>(const uint4* sOwn, uint32_t at, uint32_t) { return tile_read_owner_user(sOwn, at); }
 
 // what only a run-time compiled model needs beside the staged records (MODEL 2; everything here that the user's statements do
 // not name is dead code after inlining)
@@ -626,18 +631,18 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         if (tid < nLoc + nH) {
             OwnerRec r2 = rec0;
             ki_opaque(r2.qw), ki_opaque(r2.wx), ki_opaque(r2.family);
-            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * RSZ);
+            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * RSZ, ((tid < nLoc ? tid : DEME_TILE_NB + h0) >> 3) & a.swz);
         }
         if (h1 < nH) {
             OwnerRec r2 = rec1;
             ki_opaque(r2.qw), ki_opaque(r2.wx), ki_opaque(r2.family);
-            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * RSZ);
+            tile_stage<MODEL>(p, T.mass[r2.inertiaOff], r2, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * RSZ, ((DEME_TILE_NB + h1) >> 3) & a.swz);
         }
 #endif
         if (tid < nLoc + nH)
-            tile_stage<MODEL>(p, T.mass[rec0.inertiaOff], rec0, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * RSZ);
+            tile_stage<MODEL>(p, T.mass[rec0.inertiaOff], rec0, u0x, u0y, u0z, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * RSZ, ((tid < nLoc ? tid : DEME_TILE_NB + h0) >> 3) & a.swz);
         if (h1 < nH)
-            tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * RSZ);
+            tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, u0x, u0y, u0z, sOwn + (DEME_TILE_NB + h1) * RSZ, ((DEME_TILE_NB + h1) >> 3) & a.swz);
         if (tid <= DEME_TILE_NB)
             sALo[tid] = (uint16_t)(bA - c0), sLLo[tid] = (uint16_t)bL;
         if (tid == DEME_TILE_T - 1u)  // the zero slot of the contribution arrays
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 const uint2 ci = inf[d];
                 float4 h = hist[d];
                 const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
-                const TileOwner A = tile_read<MODEL>(sOwn, slotA * RSZ), B = tile_read<MODEL>(sOwn, slotB * RSZ);
+                const TileOwner A = tile_read<MODEL>(sOwn, slotA * RSZ, (slotA >> 3) & a.swz), B = tile_read<MODEL>(sOwn, slotB * RSZ, (slotB >> 3) & a.swz);
                 f3 force, tA, tB;
                 if (MESH && ((ci.x >> 20) & 3u) == DEME_KEY_CLASS_SM) {  // (rare, and only in tiles along the mesh: the loads sit behind a branch)
                     const float4 a4 = a.conA4[c], b4 = a.conB4[c];
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(DEME_TILE_T) void k_tile_forces_big(const DevParams
                 const OwnerRec ra = load_owner(a.owners, oa), rb = load_owner(a.owners, ob);
                 tile_stage<MODEL>(p, p.massProps[ra.inertiaOff].x, ra, u0x, u0y, u0z, sa);
                 tile_stage<MODEL>(p, p.massProps[rb.inertiaOff].x, rb, u0x, u0y, u0z, sb);
-                const TileOwner A = tile_read<MODEL>(sa, 0u), B = tile_read<MODEL>(sb, 0u);
+                const TileOwner A = tile_read<MODEL>(sa, 0u, 0u), B = tile_read<MODEL>(sb, 0u, 0u);
                 if (MODEL == 2) {
                     constexpr int NWU = DEME_JIT_NW;
                     float uw[NWU];

@@ -141,9 +141,9 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_step(const 
         // ONE origin for every tile: the world's (fp64 positions: 1e-16 m at a metre).  Two tiles that evaluate the same contact
         // stage the same numbers, so their results are the same bits.
         if (tid < nLoc + nH)
-            tile_stage<MODEL>(p, T.mass[rec0.inertiaOff], rec0, 0, 0, 0, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * RSZ);
+            tile_stage<MODEL>(p, T.mass[rec0.inertiaOff], rec0, 0, 0, 0, sOwn + (tid < nLoc ? tid : DEME_TILE_NB + h0) * RSZ, ((tid < nLoc ? tid : DEME_TILE_NB + h0) >> 3) & a.swz);
         if (h1 < nH)
-            tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, 0, 0, 0, sOwn + (DEME_TILE_NB + h1) * RSZ);
+            tile_stage<MODEL>(p, T.mass[rec1.inertiaOff], rec1, 0, 0, 0, sOwn + (DEME_TILE_NB + h1) * RSZ, ((DEME_TILE_NB + h1) >> 3) & a.swz);
         if (tid <= DEME_TILE_NB)
             sALo[tid] = (uint16_t)(bA - c0), sLLo[tid] = (uint16_t)bL;
         if (tid == DEME_TILE_T - 1u)
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_step(const 
             const uint2 ci = inf[0];
             float4 h = hist[0];
             const uint32_t slotA = ci.x & 1023u, slotB = (ci.x >> 10) & 1023u;
-            const TileOwner A = tile_read<MODEL>(sOwn, slotA * RSZ), B = tile_read<MODEL>(sOwn, slotB * RSZ);
+            const TileOwner A = tile_read<MODEL>(sOwn, slotA * RSZ, (slotA >> 3) & a.swz), B = tile_read<MODEL>(sOwn, slotB * RSZ, (slotB >> 3) & a.swz);
             f3 force, tA, tB;
             tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
             if (MODEL == 0 && q < nOwnC && !sa.dry)
