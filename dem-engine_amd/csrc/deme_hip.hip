@@ -22,9 +22,9 @@
 // tuned for lists that fill the chip many times over; at these sizes workgroups of 1024 with 8 keys each shorten the chained
 // look-back of every pass).  tools/rsbench.hip, profiles/r04/r04j_radix_configs.txt: incidences (8.2e6 pairs, 21 bits) 227 -> 206 us (4.4e6: 192 -> 149),
 // crossing records by B owner (1.4e6 pairs, 20 bits, two 10-bit passes) 108 -> 68 us, contact keys (4.3e6 u64, 24 bits) 150 -> 141 us.
-template <unsigned RB>
+template <unsigned RB, unsigned IPT = 8>
 using DemeRadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, RB,
+                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, IPT>, rocprim::kernel_config<1024, IPT>, RB,
                                                                                     rocprim::block_radix_rank_algorithm::match>,
                                                 1024 * 1024>;
 #include <iterator>
@@ -597,15 +597,19 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
             while (bits < 32 && (1ull << bits) < nBins)
                 bits++;
             size_t need = 0;
-            HIPCK(rocprim::radix_sort_pairs<DemeRadixCfg<8>>(nullptr, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
-                                            c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
-                                            st));
+            // bin ids of up to 22 bits: two passes of 11 bits (16 keys per thread) take as long as three of 8 and save a pass's launches
+            const bool twoPass = bits > 16 && bits <= 22;
+            auto sortInc = [&](void* tmp, size_t& bytes) {
+                return twoPass ? rocprim::radix_sort_pairs<DemeRadixCfg<11, 16>>(tmp, bytes, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
+                                                                                 c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits, st)
+                               : rocprim::radix_sort_pairs<DemeRadixCfg<8>>(tmp, bytes, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
+                                                                            c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits, st);
+            };
+            HIPCK(sortInc(nullptr, need));
             if (int rc = ensure(c, c->sortTmp, need))
                 return rc;
             need = c->sortTmp.bytes;
-            HIPCK(rocprim::radix_sort_pairs<DemeRadixCfg<8>>(c->sortTmp.p, need, c->incKeys[0].as<uint32_t>(), c->incKeys[1].as<uint32_t>(),
-                                            c->incVals[0].as<uint32_t>(), c->incVals[1].as<uint32_t>(), (size_t)P, 0, bits,
-                                            st));
+            HIPCK(sortInc(c->sortTmp.p, need));
             sortedIdx = 1;
             const uint32_t nWin = (uint32_t)grid_for(P, SW_T);
             if (int rc = ensure(c, c->binStat, (size_t)nWin * sizeof(uint2)))
