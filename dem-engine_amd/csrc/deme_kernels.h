@@ -955,12 +955,29 @@ struct GatherLds {
     float4 c4[DEME_GATHER_TILE];
     float2 c2[DEME_GATHER_TILE];
 };
-__device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint32_t o, bool want, GatherLds& L, float4& a,
-                                    float4& al) {
-    const uint32_t t = threadIdx.x;
+// What gather_block needs that hangs on nothing but the owner's number: asked for at the very start of the integrator, before its
+// owner records are loaded and transposed -- the kernel is a chain of dependent loads per workgroup (bounds -> indices -> records),
+// and these were a fourth link behind the records' barrier (42.5 -> 41.7 us; fetching the first tile of records into registers as
+// well costs 17 VGPRs and a workgroup per CU: 43.2-44.6 us, not kept)
+struct GatherPre {
+    uint32_t loB, hiB, sA, eA, sB, eB;
+};
+__device__ inline GatherPre gather_prefetch(const GatherArgs& g, uint32_t nOwners, uint32_t o, bool valid) {
+    GatherPre q;
     const uint32_t oFirst = blockIdx.x * blockDim.x;
     const uint32_t oEnd = (oFirst + blockDim.x < nOwners) ? oFirst + blockDim.x : nOwners;
-    const uint32_t loB = g.bStart[oFirst], hiB = g.bStart[oEnd];
+    q.loB = g.bStart[oFirst], q.hiB = g.bStart[oEnd];
+    q.sA = q.eA = q.sB = q.eB = 0;
+    if (valid) {
+        q.sA = g.aStart[o], q.eA = g.aStart[o + 1];
+        q.sB = g.bStart[o], q.eB = g.bStart[o + 1];
+    }
+    return q;
+}
+__device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint32_t o, bool want, GatherLds& L, float4& a,
+                                    float4& al, const GatherPre& q) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t loB = q.loB, hiB = q.hiB;
     if (hiB - loB > 8u * DEME_GATHER_TILE) {  // workgroup-uniform: a giant run inside
         if (want)
             gather_owner(g, o, a, al);
@@ -969,8 +986,8 @@ __device__ inline void gather_block(const GatherArgs& g, uint32_t nOwners, uint3
     float ax = 0.f, ay = 0.f, az = 0.f, lx = 0.f, ly = 0.f, lz = 0.f;
     uint32_t sA = 0, eA = 0, sB = 0, eB = 0;
     if (want) {
-        sA = g.aStart[o], eA = g.aStart[o + 1];
-        sB = g.bStart[o], eB = g.bStart[o + 1];
+        sA = q.sA, eA = q.eA;
+        sB = q.sB, eB = q.eB;
     }
     if (want)
         a_side_sum(g, o, sA, eA, ax, ay, az, lx, ly, lz);
@@ -1313,6 +1330,9 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
     // one LDS area: the record transposes at both ends of the kernel, the gather tiles of the fused path in between
     constexpr uint32_t kStage16 = DEME_INT_COOP ? 4u * DEME_INT_STAGE : 1u, kGather16 = FUSED ? (uint32_t)(sizeof(GatherLds) / 16) : 1u;
     __shared__ uint4 smem[kStage16 > kGather16 ? kStage16 : kGather16];
+    GatherPre pre{};
+    if (FUSED)
+        pre = gather_prefetch(g, p.nOwners, o, valid);
 #if DEME_INT_COOP
     uint4* stage = smem + (threadIdx.x >> 6) * DEME_INT_STAGE;
     const uint32_t waveBase = o - (threadIdx.x & 63u);
@@ -1335,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_integrate(const DevParams p, OwnerRec* 
         // the per-contact contributions (launch_full_reduction)
         GatherLds& lds = *reinterpret_cast<GatherLds*>(smem);
         const bool hv = valid && g.heavy[o];
-        gather_block(g, p.nOwners, o, valid && !ghost && !fixed && !hv && !later, lds, a, al);
+        gather_block(g, p.nOwners, o, valid && !ghost && !fixed && !hv && !later, lds, a, al, pre);
         if (valid && !ghost && !later) {
             if (g.world && !fixed && !hv)
                 acc_from_world(p, r, a, al);
