@@ -368,6 +368,167 @@ class HaloGroup:
             pass
 
 
+class DecompPlan:
+    """deme_decomp_*: the slab decomposition of a global scene, computed by the library on the host (no device needed).  The plan
+    keeps pointers into the scene's arrays while it is built only; a slab's scene points into the plan (keep the plan alive while
+    a slab scene is in use)."""
+
+    def __init__(self, params, scene, n_slabs, axis=-1, halo=0.0, edges=None, shared_free=False, snap=True):
+        self.lib = load_library()
+        L = self.lib
+        L.deme_decomp_create.argtypes = [C.POINTER(DemeParams), C.POINTER(DemeScene), C.c_uint32, C.c_int, C.c_double, _P, C.c_uint32,
+                                         C.POINTER(_P), C.c_char_p, C.c_size_t]
+        L.deme_decomp_destroy.argtypes = [_P]
+        L.deme_decomp_destroy.restype = None
+        L.deme_decomp_info.argtypes = [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_double), _P, C.POINTER(C.c_uint32)]
+        L.deme_decomp_slab.argtypes = [_P, C.c_uint32, C.POINTER(DemeScene), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P),
+                                       C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        h = _P()
+        err = C.create_string_buffer(1024)
+        e = None if edges is None else np.ascontiguousarray(edges, np.float64)
+        flags = (1 if shared_free else 0) | (0 if snap else 2)
+        rc = L.deme_decomp_create(C.byref(params), C.byref(scene), int(n_slabs), int(axis), float(halo), None if e is None else _ptr(e),
+                                  flags, C.byref(h), err, len(err))
+        if rc != 0:
+            raise DemeError(f"deme_decomp_create failed (status {rc}): {err.value.decode()}")
+        self.h = h
+        self._scene = scene  # (the tables a slab scene shares with the scene it was cut from)
+        n, ax, hl, nf = C.c_uint32(0), C.c_int(0), C.c_double(0), C.c_uint32(0)
+        L.deme_decomp_info(self.h, C.byref(n), C.byref(ax), C.byref(hl), None, C.byref(nf))
+        self.n_slabs, self.axis, self.halo, self.n_free = int(n.value), int(ax.value), float(hl.value), int(nf.value)
+        ed = np.zeros(self.n_slabs + 1, np.float64)
+        L.deme_decomp_info(self.h, None, None, None, _ptr(ed), None)
+        self.edges = ed
+
+    def slab(self, s):
+        """dict: scene (DemeScene), n_own, n_ghost_lower, n_ghost_upper, owner_global, sphere_global, send_lower, send_upper, range"""
+        sc = DemeScene()
+        cnt = (C.c_uint32 * 3)()
+        og, sg, sl, su = _P(), _P(), _P(), _P()
+        nl, nu = C.c_uint32(0), C.c_uint32(0)
+        rg = (C.c_double * 2)()
+        rc = self.lib.deme_decomp_slab(self.h, int(s), C.byref(sc), cnt, C.byref(og), C.byref(sg), C.byref(sl), C.byref(nl), C.byref(su),
+                                       C.byref(nu), rg)
+        if rc != 0:
+            raise DemeError(f"deme_decomp_slab({s}) failed (status {rc})")
+
+        def arr(ptr, n):
+            if not n:
+                return np.zeros(0, np.uint32)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(int(n),)).copy()
+        sc._keep = self  # the plan owns the slab's arrays
+        return {"scene": sc, "n_own": int(cnt[0]), "n_ghost_lower": int(cnt[1]), "n_ghost_upper": int(cnt[2]),
+                "owner_global": arr(og, sc.nOwners), "sphere_global": arr(sg, sc.nSpheres), "send_lower": arr(sl, nl.value),
+                "send_upper": arr(su, nu.value), "range": (float(rg[0]), float(rg[1]))}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.deme_decomp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count():
+    lib = load_library()
+    n = C.c_int(0)
+    lib.deme_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.deme_device_count(C.byref(n))
+    return int(n.value)
+
+
+class Multi:
+    """deme_multi_*: one process, several devices -- what the C++ shell's DEMSolver(nGPUs / device ids) opens.  One device with
+    several slabs exercises every step of it on a single GPU (the slabs exchange by sends to self)."""
+
+    def __init__(self, devices=(0,)):
+        self.lib = load_library()
+        L = self.lib
+        L.deme_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(_P), C.c_char_p, C.c_size_t]
+        L.deme_multi_destroy.argtypes = [_P]
+        L.deme_multi_destroy.restype = None
+        L.deme_multi_last_error.argtypes = [_P]
+        L.deme_multi_last_error.restype = C.c_char_p
+        L.deme_multi_build.argtypes = [_P, C.POINTER(DemeParams), C.POINTER(DemeScene), C.c_uint32, C.c_int, C.c_double, C.c_uint32, C.c_int,
+                                       C.c_uint32]
+        L.deme_multi_num_slabs.argtypes = [_P, C.POINTER(C.c_uint32)]
+        L.deme_multi_slab_ctx.argtypes = [_P, C.c_uint32, C.POINTER(_P)]
+        L.deme_multi_set_migration.argtypes = [_P, C.c_uint32]
+        L.deme_multi_step.argtypes = [_P, C.c_uint32]
+        L.deme_multi_sync.argtypes = [_P]
+        L.deme_multi_download_state.argtypes = [_P, C.POINTER(DemeOwnerState), C.c_uint32]
+        L.deme_multi_upload_state.argtypes = [_P, C.POINTER(DemeOwnerState), C.c_uint32]
+        L.deme_multi_counts.argtypes = [_P, C.POINTER(DemeCounts), C.POINTER(C.c_uint64)]
+        dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = _P()
+        err = C.create_string_buffer(1024)
+        rc = L.deme_multi_create(dev, len(devices), C.byref(h), err, len(err))
+        if rc != 0:
+            raise DemeError(f"deme_multi_create failed (status {rc}): {err.value.decode()}")
+        self.h = h
+        self.n_owners = 0
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            msg = self.lib.deme_multi_last_error(self.h)
+            raise DemeError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+    def build(self, params, scene, slabs_per_device=1, axis=-1, halo=0.0, shared_free=False, arith=None, flip_mask=7):
+        a = -1 if arith is None else {"fast": 1, "exact": 0}.get(arith, arith)
+        self._ck(self.lib.deme_multi_build(self.h, C.byref(params), C.byref(scene), int(slabs_per_device), int(axis), float(halo),
+                                           1 if shared_free else 0, int(a), int(flip_mask)), "deme_multi_build")
+        self.n_owners = int(scene.nOwners)
+
+    def num_slabs(self):
+        n = C.c_uint32(0)
+        self._ck(self.lib.deme_multi_num_slabs(self.h, C.byref(n)), "deme_multi_num_slabs")
+        return int(n.value)
+
+    def slab_ctx(self, s):
+        """the slab's context as a borrowed Context (owned by the library: do not close it)"""
+        h = _P()
+        self._ck(self.lib.deme_multi_slab_ctx(self.h, int(s), C.byref(h)), "deme_multi_slab_ctx")
+        return Context.borrowed(h)
+
+    def set_migration(self, every):
+        self._ck(self.lib.deme_multi_set_migration(self.h, int(every)), "deme_multi_set_migration")
+
+    def step(self, n):
+        self._ck(self.lib.deme_multi_step(self.h, int(n)), "deme_multi_step")
+
+    def sync(self):
+        self._ck(self.lib.deme_multi_sync(self.h), "deme_multi_sync")
+
+    def download_state(self):
+        st, out = make_state_struct(self.n_owners)
+        self._ck(self.lib.deme_multi_download_state(self.h, C.byref(st), self.n_owners), "deme_multi_download_state")
+        return out
+
+    def upload_state(self, arrays):
+        st, keep = make_state_struct(self.n_owners, arrays)
+        self._ck(self.lib.deme_multi_upload_state(self.h, C.byref(st), self.n_owners), "deme_multi_upload_state")
+
+    def counts(self):
+        c, mig = DemeCounts(), C.c_uint64(0)
+        self._ck(self.lib.deme_multi_counts(self.h, C.byref(c), C.byref(mig)), "deme_multi_counts")
+        return c, int(mig.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.deme_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def exported_symbols():
     """Names include/deme_hip.h declares (parsed from the header)."""
     import re
@@ -406,9 +567,30 @@ class Context:
         self.n_spheres = 0
         self.n_wildcards = 0
 
+    @classmethod
+    def borrowed(cls, handle):
+        """a context the LIBRARY owns (a slab of deme_halo_group_build / deme_multi_build): every call works, close() leaves it alone"""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self.h = handle
+        self._borrowed = True
+        v = (C.c_uint32 * 4)()
+        self.lib.deme_scene_sizes.argtypes = [_P, C.POINTER(C.c_uint32)]
+        self._ck(self.lib.deme_scene_sizes(self.h, v), "deme_scene_sizes")
+        self.n_owners, self.n_spheres, self.n_wildcards = int(v[0]), int(v[2]), int(v[3])
+        return self
+
+    def refresh_sizes(self):
+        """owner / sphere counts change when clumps migrate between slabs"""
+        v = (C.c_uint32 * 4)()
+        self.lib.deme_scene_sizes.argtypes = [_P, C.POINTER(C.c_uint32)]
+        self._ck(self.lib.deme_scene_sizes(self.h, v), "deme_scene_sizes")
+        self.n_owners, self.n_spheres = int(v[0]), int(v[2])
+
     def close(self):
         if getattr(self, "h", None):
-            self.lib.deme_ctx_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.deme_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):

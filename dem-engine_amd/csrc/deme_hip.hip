@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -215,6 +216,8 @@ struct deme_ctx {
     // renewing the order at run time (order_renew): the engine watches the tiles of every detection -- mean foreign owners per
     // tile, tiles that no longer fit -- against what they were right after the last (re)ordering
     bool orderEligible = false;     // the scene may be reordered (fast mode, no ghosts: what order_decide checks)
+    bool orderStructOK = false;     // ... the part of that which does not depend on the arithmetic mode
+    bool geoStale = false;          // the per-sphere geometry of the last detection sits in slots an order renewal has left
     bool orderRenewDue = false;
     uint32_t orderBaseHalo = 0;     // mean halo (x 16) at the first detection after the last ordering; 0 = not taken yet
     uint64_t orderDetAt = 0, nOrderRenewals = 0;
@@ -527,6 +530,7 @@ int detect_part1(deme_ctx* c, hipStream_t st, OwnerRec* ow, bool async, uint64_t
         if (segmented)
             HIPCK(hipMemsetAsync(c->segCtr.p, 0, DEME_KEY_SEGS * DEME_KEY_SEG_STRIDE * 8, st));
         if (nS) {
+            c->geoStale = false;
             hipLaunchKernelGGL(k_sphere_prep, dim3(grid_for(nS)), dim3(256), 0, st, c->dp,
                                ow, c->spheres.as<SphereRec>(), c->geo.as<GeoRec>(),
                                c->binLo.as<uint4>(), c->binN.as<uint2>(), c->counts.as<uint32_t>(),
@@ -1217,7 +1221,7 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         if (customTile) {  // the same kernels compiled at run time around the user's statements (deme_jit.h)
             void* argsT[] = {&c->dp, &ta};
             HIPCK(hipModuleLaunchKernel(c->customTileFn[mesh ? 1 : 0], nBlk, 1, 1, DEME_TILE_T, 1, 1, ldsBytes, st, argsT, nullptr));
-            if (nBig && c->customTileFn[mesh ? 3 : 2])
+            if (nBig)
                 HIPCK(hipModuleLaunchKernel(c->customTileFn[mesh ? 3 : 2], nBig, 1, 1, DEME_TILE_T, 1, 1, 0, st, argsT, nullptr));
         } else {
             // (model, mesh records, recording) -> the instance of the two kernels
@@ -1583,9 +1587,20 @@ int deme_set_arith_mode(deme_ctx* c, int mode) {
     if (!c || (mode != DEME_ARITH_FAST && mode != DEME_ARITH_EXACT))
         return DEME_ERR_INVALID;
     if (mode != c->arith) {
-        HIPCK(hipStreamSynchronize(c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));  // (an asynchronous detection cycle ends inside deme_step: nothing is in flight beside the stream)
         c->arith = mode;
         c->conValid = false;  // stored contributions are in the other mode's units
+        if (mode == DEME_ARITH_EXACT) {
+            // The exact mode's contract is bit-identity with the oracle, which sums an owner's contributions in the CALLER's order:
+            // a context the engine had reordered goes back to that order (deme_order.inc: order_restore) and stays there.
+            c->orderEligible = false, c->orderRenewDue = false;
+            if (c->permuted && c->haveScene)
+                if (int rc = order_restore(c))
+                    return rc;
+        } else if (c->haveScene && c->orderStructOK) {  // back in the fast mode: the next lock-step detection may reorder again
+            c->orderEligible = true;
+            c->orderRenewDue = true;
+        }
     }
     return DEME_OK;
 }
@@ -1655,8 +1670,10 @@ int deme_order_renewals(const deme_ctx* c, uint64_t* n) {
 int deme_renew_order(deme_ctx* c) {
     if (int rc = check_ready(c))
         return rc;
-    if (!c->orderEligible)
+    if (!c->orderEligible || c->arith != DEME_ARITH_FAST)
         return fail(c, DEME_ERR_INVALID, "this scene keeps the caller's order (exact arithmetic mode, ghosts, or reordering switched off)");
+    // (the re-keyed list is left as the SEED of the next detection -- order_apply: deme_calc_forces refuses it, a step detects first,
+    // the history map and contact records are not offered from it, the sphere geometry is recomputed by that detection)
     return order_renew(c);
 }
 int deme_order_probe(const DemeParams* p, size_t nClumps, const uint64_t* voxelID, const uint16_t* locX, const uint16_t* locY,
@@ -1710,6 +1727,13 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
         return fail(c, DEME_ERR_INVALID, "sphere ids must fit 31 bits");
     if (s->nOwners >= (1u << 30))
         return fail(c, DEME_ERR_INVALID, "owner ids must fit 30 bits");
+    // Spheres are clump-major with ascending owners (kT.cpp:766-797): the A / B roles of a pair follow the owner
+    // numbers (= the reference's "smaller sphere id first" exactly under this contract), and seeded history and persistent marks
+    // are canonicalised by sphere id.
+    for (size_t i = 1; i < s->nSpheres; i++)
+        if (s->ownerClumpBody[i] < s->ownerClumpBody[i - 1])
+            return fail(c, DEME_ERR_INVALID, "deme_upload_scene: spheres must be clump-major with ascending owners (sphere %zu belongs to owner %u, "
+                        "sphere %zu to owner %u)", i - 1, s->ownerClumpBody[i - 1], i, s->ownerClumpBody[i]);
     hipSetDevice(c->device);
     c->nOwners = s->nOwners, c->nOwnerClumps = s->nOwnerClumps, c->nSpheres = s->nSpheres, c->nAnal = s->nAnal;
     c->nextAccPending = false;  // per-owner records of the previous scene do not carry over
@@ -2177,7 +2201,7 @@ static int ensure_adaptive_events(deme_ctx* c) {
 // margins + detection + history migration of a step whose list is due, with the controllers' timing around it
 static int order_renew(deme_ctx* c);
 static int detection_phase(deme_ctx* c) {
-    if (c->orderRenewDue && c->asyncLead == 0 && !c->inGroupStep)
+    if (c->orderRenewDue && !c->inGroupStep)  // (asynchronous cycles begin and end inside deme_step: none is in flight here)
         if (int rc = order_renew(c))
             return rc;
     const bool adaptive = c->ad.autoBinSize || c->ad.autoUpdateFreq;
@@ -2404,7 +2428,11 @@ int deme_step(deme_ctx* c, uint32_t nsteps) {
     if (!c->hShared.empty())
         return fail(c, DEME_ERR_INVALID, "this slab holds replicated free owners: step it through deme_halo_group_step, which adds their accelerations up across the slabs");
     for (uint32_t i = 0; i < nsteps; i++) {
-        if (async_detection_can_start(c, nsteps - i)) {
+        if (c->orderRenewDue && !c->inGroupStep && async_detection_can_start(c, nsteps - i)) {
+            // the order is to be renewed: this update is a lock-step one (the renewal is host-driven and needs the context idle)
+            if (int rc = detection_phase(c))
+                return rc;
+        } else if (async_detection_can_start(c, nsteps - i)) {
             if (int rc = async_detection_cycle(c))
                 return rc;
             i += c->asyncLead - 1;
@@ -2715,6 +2743,10 @@ struct deme_halo_group {
     bool pairsOnce = false;  // deme_halo_group_set_cross_contacts: one evaluation per cross-cut contact, reactions sent back
     uint64_t nRevExchanges = 0;
     std::vector<HaloSlab> slabs;
+    int axis = 0;                    // the axis the slabs were cut along (deme_halo_group_set_axis / _build): what "left" and "right" mean
+    uint32_t firstSlab = 0;          // number of this rank's first slab in the whole chain (deme_halo_group_build)
+    std::vector<deme_ctx*> ownedCtx; // contexts deme_halo_group_build created: destroyed with the group
+    uint32_t nOwnersGlobal = 0, nClumpsGlobal = 0;
     uint32_t nShared = 0;            // replicated free owners (the same on every slab): a / alpha summed across slabs every step
     void* sharedSum = nullptr;       // nShared x AccRec
     void* agreeBuf = nullptr;        // 16 bytes: the error flag the ranks add up before a collective phase (mig_agree)
@@ -2824,6 +2856,8 @@ void deme_halo_group_destroy(deme_halo_group* g) {
         hipEventDestroy(g->evExchanged);
     if (g->xstream)
         hipStreamDestroy(g->xstream);
+    for (deme_ctx* c : g->ownedCtx)
+        deme_ctx_destroy(c);
     delete g;
 }
 
@@ -3373,7 +3407,10 @@ int deme_download_contacts(deme_ctx* c, uint32_t* idA, uint32_t* idB, uint8_t* t
     if (int rc = order_current_view(c))
         return rc;
     const std::vector<uint64_t>& k = c->viewKeys;
-    if (mapping && n) {
+    if (mapping && n && c->seeded) {  // a seeded list (deme_seed_contacts, a renewed order) has no previous list to map to
+        for (size_t i = 0; i < n; i++)
+            mapping[i] = 0xFFFFFFFFu;
+    } else if (mapping && n) {
         std::vector<uint32_t> m(n);
         HIPCK(hipMemcpyAsync(m.data(), c->mapping.p, n * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
@@ -3548,6 +3585,8 @@ int deme_download_contact_records(deme_ctx* c, float* force, float* torqueOnly, 
         return rc;
     if (!c->record)
         return fail(c, DEME_ERR_INVALID, "contact recording is off (deme_set_record_contacts)");
+    if (c->seeded)
+        return fail(c, DEME_ERR_INVALID, "the list is a seed (deme_seed_contacts, or the engine's order was just renewed): its contacts have not been evaluated yet -- step or detect first");
     const size_t n = c->nContacts;
     if (cap < n)
         return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
@@ -3578,6 +3617,8 @@ int deme_download_sphere_geometry(deme_ctx* c, double* X, double* Y, double* Z, 
     const size_t n = c->nSpheres;
     if (cap < n)
         return fail(c, DEME_ERR_INVALID, "buffer too small: need %zu", n);
+    if (c->geoStale)
+        return fail(c, DEME_ERR_INVALID, "the engine's order was renewed after the last detection: the sphere geometry of the new slots is computed by the next one");
     std::vector<GeoRec> h(n);
     if (n)
         HIPCK(hipMemcpyAsync(h.data(), c->geo.p, n * sizeof(GeoRec), hipMemcpyDeviceToHost, c->stream));
@@ -3649,9 +3690,13 @@ int deme_compile_force_model_ex(deme_ctx* c, const char* src, size_t len, const 
     HIPCK(hipModuleLoadData(&c->customMod, it->second.data()));
     HIPCK(hipModuleGetFunction(&c->customFn[0], c->customMod, "deme_custom_forces_ss"));
     HIPCK(hipModuleGetFunction(&c->customFn[1], c->customMod, "deme_custom_forces_sm"));
+    bool tileAll = true;
     for (int k = 0; k < 4; k++)
         if (hipModuleGetFunction(&c->customTileFn[k], c->customMod, deme_jit::kTileEntry[k]) != hipSuccess)
-            c->customTileFn[k] = nullptr;  // (lists of this model are evaluated by the general kernel then)
+            tileAll = false;
+    if (!tileAll)  // all four (tile / big-tile fallback, with and without mesh records) or none: a list with a tile that does not fit
+                   // LDS, or a scene with a mesh, must never find its entry missing -- the general kernel evaluates the lists then
+        c->customTileFn[0] = c->customTileFn[1] = c->customTileFn[2] = c->customTileFn[3] = nullptr;
     c->listStale = true;  // the list structures depend on which kernel evaluates the list
     return DEME_OK;
 }
@@ -3773,6 +3818,7 @@ int deme_add_owner_acc(deme_ctx* c, uint32_t owner, uint32_t n, const float* acc
             return rc;
         HIPCK(hipMemsetAsync(c->nextAcc.p, 0, (size_t)c->nOwners * sizeof(AccRec), c->stream));
     }
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t slot = order_owner_in(c, owner + k);
         AccRec& r = c->hNextAcc[slot];
@@ -3780,11 +3826,11 @@ int deme_add_owner_acc(deme_ctx* c, uint32_t owner, uint32_t n, const float* acc
             r.ax = acc[3 * k], r.ay = acc[3 * k + 1], r.az = acc[3 * k + 2];
         if (angAcc)
             r.lx = angAcc[3 * k], r.ly = angAcc[3 * k + 1], r.lz = angAcc[3 * k + 2];
-        if (c->permuted)  // (the caller's range is not a range of slots)
-            HIPCK(hipMemcpyAsync(c->nextAcc.as<AccRec>() + slot, &r, sizeof(AccRec), hipMemcpyHostToDevice, c->stream));
+        lo = std::min(lo, slot), hi = std::max(hi, slot + 1u);
     }
-    if (n && !c->permuted)
-        HIPCK(hipMemcpyAsync(c->nextAcc.as<AccRec>() + owner, c->hNextAcc.data() + owner, (size_t)n * sizeof(AccRec),
+    if (n)  // one copy of the touched range of slots (the caller's range is not a range of slots on a reordered context: the host
+            // mirror holds every record, so what lies between the touched ones is written back unchanged)
+        HIPCK(hipMemcpyAsync(c->nextAcc.as<AccRec>() + lo, c->hNextAcc.data() + lo, (size_t)(hi - lo) * sizeof(AccRec),
                              hipMemcpyHostToDevice, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
     c->nextAccPending = true;
@@ -4166,3 +4212,6 @@ int deme_halo_unpack(deme_ctx* c, const uint32_t* d_ids, uint32_t n, const void*
 }
 
 }  // extern "C"
+
+// (templates inside: after the extern "C" block; its entry points take C linkage from their declarations in deme_hip.h)
+#include "deme_decomp.inc"

@@ -63,15 +63,19 @@ __global__ __launch_bounds__(256) void k_mig_first_sphere(uint32_t nS, const Sph
             start[o] = nS;
 }
 
-__device__ inline double mig_world_x(const OwnerRec& r, const DevParams& p) {
-    const uint64_t vx = r.voxelID & (((uint64_t)1 << p.nvXp2) - 1);
-    return (double)vx * p.voxelSize + (double)r.locX * p.l + (double)p.LBFX;
+// a clump centre's coordinate along the axis the slabs were cut along (0 / 1 / 2; deme_halo_group_set_axis)
+__device__ inline double mig_world_coord(const OwnerRec& r, const DevParams& p, int axis) {
+    if (axis == 0)
+        return (double)(r.voxelID & (((uint64_t)1 << p.nvXp2) - 1)) * p.voxelSize + (double)r.locX * p.l + (double)p.LBFX;
+    if (axis == 1)
+        return (double)((r.voxelID >> p.nvXp2) & (((uint64_t)1 << p.nvYp2) - 1)) * p.voxelSize + (double)r.locY * p.l + (double)p.LBFY;
+    return (double)(r.voxelID >> (p.nvXp2 + p.nvYp2)) * p.voxelSize + (double)r.locZ * p.l + (double)p.LBFZ;
 }
 
 // dest[o]: 0 stays, 1 leaves to the left, 2 to the right, 3 a ghost (dropped: the neighbours send their ghosts anew);
 // cnt[o] = the scan element (cnt[nClumps] = zero closes the scan)
 __global__ __launch_bounds__(256) void k_mig_classify(const DevParams p, const OwnerRec* __restrict__ owners, uint32_t nOwn,
-                                                      uint32_t nClumps, double xLo, double xHi, const uint32_t* __restrict__ firstSph,
+                                                      uint32_t nClumps, int axis, double xLo, double xHi, const uint32_t* __restrict__ firstSph,
                                                       uint8_t* __restrict__ dest, MigCount* __restrict__ cnt) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o > nClumps)
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void k_mig_classify(const DevParams p, const O
     if (o < nClumps) {
         uint8_t d = 3;
         if (o < nOwn) {
-            const double x = mig_world_x(owners[o], p);
+            const double x = mig_world_coord(owners[o], p, axis);
             d = x < xLo ? 1 : (x >= xHi ? 2 : 0);
             m.c[d] = 1, m.s[d] = firstSph[o + 1] - firstSph[o];
         }
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256) void k_mig_pack_rows(uint32_t nC, uint32_t nW,
 }
 
 // the own clumps of the re-assembled slab that lie within the halo of a face: flags for the two ghost packets
-__global__ __launch_bounds__(256) void k_mig_ghost_flags(const DevParams p, const OwnerRec* __restrict__ owners, uint32_t nOwn,
+__global__ __launch_bounds__(256) void k_mig_ghost_flags(const DevParams p, const OwnerRec* __restrict__ owners, uint32_t nOwn, int axis,
                                                          double xLo, double xHi, double halo, int hasLeft, int hasRight,
                                                          const uint32_t* __restrict__ firstSphNew, uint8_t* __restrict__ dest,
                                                          MigCount* __restrict__ cnt) {
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void k_mig_ghost_flags(const DevParams p, cons
         return;
     MigCount m{};
     if (o < nOwn) {
-        const double x = mig_world_x(owners[o], p);
+        const double x = mig_world_coord(owners[o], p, axis);
         const uint32_t ns = firstSphNew[o + 1] - firstSphNew[o];
         uint8_t d = 0;
         if (hasLeft && x < xLo + halo)

@@ -490,6 +490,14 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
 #ifndef DEME_TILE_PKPULL
 #define DEME_TILE_PKPULL 1  // the pulls add register pairs (v_pk_add_f32); a missing entry reads the zero slot
 #endif
+#ifndef DEME_TILE_SPLITLOOP
+#define DEME_TILE_SPLITLOOP 0  // 1: a tile of at most DEME_TILE_DEPTH rounds (its streams were all asked for in the prologue) runs a copy of the round
+                               // loop without refills: no load is in flight there, so the rotation of the stream registers waits for nothing --
+                               // in the refilling loop the compiler's s_waitcnt vmcnt(0) in front of the rotation also drains the round's STORES
+#endif
+#ifndef DEME_TILE_PRIO
+#define DEME_TILE_PRIO 0  // > 0: wavefront priority of the prologue (ids -> records -> staging); the rounds run at 0
+#endif
 #ifndef DEME_TILE_DEPTH
 #define DEME_TILE_DEPTH 3  // rounds whose streams are in flight (tInfo + history: 24 bytes per thread and round)
 #endif
@@ -515,9 +523,17 @@ __host__ __device__ inline uint32_t tile_lds_bytes(uint32_t hCap, uint32_t lCap,
            tableBytes + 16u;
 }
 
+template <bool B>
+struct TileFlag {
+    static constexpr bool value = B;
+};
+
 template <int MODEL, bool MESH, bool REC = false>
 __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(const DevParams p, const TileArgs a) {
     extern __shared__ uint4 tileLds[];
+#if DEME_TILE_PRIO
+    __builtin_amdgcn_s_setprio(DEME_TILE_PRIO);
+#endif
     uint4* const sOwn = tileLds;
     const uint32_t RSZ = a.rs16;  // uint4 per staged record: what the record holds, or one more (see TileArgs::rs16)
     float4* const recA4 = reinterpret_cast<float4*>(sOwn + (DEME_TILE_NB + a.hCap) * RSZ);
@@ -653,6 +669,9 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 sLPos[tid + k * DEME_TILE_T] = (uint16_t)lp[k];
     }
     __syncthreads();
+#if DEME_TILE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // the pulling side of this thread: threads 0 .. NB - 1 take the A runs, NB .. 2 NB - 1 the local-B lists
     const uint32_t po = tid % DEME_TILE_NB;
     const bool sideA = tid < DEME_TILE_NB, sideB = !sideA && tid < 2 * DEME_TILE_NB;
@@ -680,7 +699,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             rbase[d] = a.rankC[cd - (tid & 63u)];
         }
     };
-    auto round = [&](const int d, const uint32_t rlo) __attribute__((always_inline)) {
+    auto round = [&](auto RF, const int d, const uint32_t rlo) __attribute__((always_inline)) {
             const uint32_t c = c0 + rlo + tid;
             bool crossing = false;
             float4 x4 = make_float4(0, 0, 0, 0), x2 = x4;
@@ -772,7 +791,8 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 for (int k = 0; k < NWU; k++)
                     uwv[q][k] = uwv[q + 1][k];
             }
-            refill(DEME_TILE_DEPTH - 1, c);
+            if (decltype(RF)::value)
+                refill(DEME_TILE_DEPTH - 1, c);
 #endif
 
             __syncthreads();
@@ -874,12 +894,18 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             const uint32_t rlo = rb + d * DEME_TILE_T;
             if (rlo >= nCt)  // (uniform over the workgroup)
                 break;
-            round(d, rlo);
+            round(TileFlag<true>{}, d, rlo);
         }
     }
 #else
+#if DEME_TILE_SPLITLOOP
+    if (nCt <= DEME_TILE_DEPTH * DEME_TILE_T) {
+        for (uint32_t rlo = 0; rlo < nCt; rlo += DEME_TILE_T)
+            round(TileFlag<false>{}, 0, rlo);
+    } else
+#endif
     for (uint32_t rlo = 0; rlo < nCt; rlo += DEME_TILE_T)  // stage 0 is the current round; the stages are rotated after it
-        round(0, rlo);
+        round(TileFlag<true>{}, 0, rlo);
 #endif
     // A-side sum + B-side sum, through LDS (the contribution arrays are free now)
     if (sideB) {

@@ -137,6 +137,27 @@ def decompose(arrays, counts, clump_x, n_ranks, halo, shared_free=False, edges=N
     return out
 
 
+def decompose_lib(params, scene, n_ranks, halo, axis=0, edges=None, shared_free=False, snap=False):
+    """The same decomposition computed by the LIBRARY (deme_decomp_create: what a C++ host calls; DEMSolver(nGPUs) goes through it).
+    Returns (plan, parts) with parts[r] holding the keys of decompose() that the halo group and the migration books read: scene,
+    counts, n_own, global_ids, ghost_left_g / ghost_right_g, owner_global, sphere_global, send / recv lists, edges.  Keep `plan`
+    alive while a slab scene is in use (its arrays belong to the plan)."""
+    plan = abi.DecompPlan(params, scene, n_ranks, axis=axis, halo=halo, edges=edges, shared_free=shared_free, snap=snap)
+    parts = []
+    for r in range(n_ranks):
+        q = plan.slab(r)
+        n_own, nl, nu = q["n_own"], q["n_ghost_lower"], q["n_ghost_upper"]
+        og = q["owner_global"].astype(np.int64)
+        sc = q["scene"]
+        parts.append({
+            "scene": sc, "counts": {"nOwners": int(sc.nOwners), "nOwnerClumps": int(sc.nOwnerClumps), "nSpheres": int(sc.nSpheres)},
+            "n_own": n_own, "global_ids": og[:n_own], "ghost_left_g": og[n_own:n_own + nl], "ghost_right_g": og[n_own + nl:n_own + nl + nu],
+            "owner_global": og, "sphere_global": q["sphere_global"].astype(np.int64), "edges": q["range"], "all_edges": plan.edges,
+            "send_left": q["send_lower"], "send_right": q["send_upper"],
+            "recv_left": np.arange(n_own, n_own + nl, dtype=np.uint32), "recv_right": np.arange(n_own + nl, n_own + nl + nu, dtype=np.uint32)})
+    return plan, parts
+
+
 GHOST_STATE_KEYS = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ",
                     "omgBarX", "omgBarY", "omgBarZ", "familyID")
 

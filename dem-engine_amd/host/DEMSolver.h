@@ -434,18 +434,38 @@ class DEMForceModel {
 
 class DEMSolver {
   public:
+    /// DEM/API.h:52-56, DEM/APIPublic.cpp:22-110: the reference picks its devices here (kT on one, dT on another).  This engine
+    /// replaces that functional split by a spatial one: nGPUs devices = nGPUs x-/y-/z-slabs of the bed, one per device,
+    /// exchanging ghost clumps over RCCL every step (deme_multi_*, csrc/deme_decomp.inc).  One device = one plain context.
+    /// DEME_SLABS_PER_DEVICE=S (environment) cuts every device's part into S slabs -- the whole multi-device path on one GPU.
     explicit DEMSolver(unsigned int nGPUs = 1) {
-        (void)nGPUs;  // one context per process; multi-GPU runs use one process per GPU
-        if (deme_ctx_create(0, &m_ctx) != DEME_OK)
-            throw std::runtime_error("DEMSolver: no usable HIP device");  // GpuManager.cpp:64-68
-        m_force_model = std::make_shared<DEMForceModel>();
-        m_force_model->SetForceModelType(FORCE_MODEL::HERTZIAN);
-        m_family_flags[RESERVED_FAMILY_NUM] = DEME_FAMILY_FIXED;
+        if (nGPUs < 1)
+            throw std::runtime_error("DEMSolver: at least one GPU");
+        std::vector<int> ids(nGPUs);
+        for (unsigned i = 0; i < nGPUs; i++)
+            ids[i] = (int)i;
+        open_devices(ids);
     }
+    explicit DEMSolver(const std::vector<int>& device_ids) { open_devices(device_ids); }
     ~DEMSolver() {
-        if (m_ctx)
+        if (m_multi)
+            deme_multi_destroy(m_multi);
+        else if (m_ctx)
             deme_ctx_destroy(m_ctx);
     }
+    /// slabs per device of a decomposed run (not in the reference; the environment variable DEME_SLABS_PER_DEVICE does the same
+    /// for an unchanged script), the clumps' migration interval in steps (0: never) and the ghost layer thickness (0: four clump
+    /// reaches).  Before Initialize().
+    void SetSlabsPerDevice(unsigned int s) { m_slabs_per_device = s < 1 ? 1 : s; }
+    void SetSlabMigrationInterval(unsigned int steps) { m_migrate_every = steps; }
+    void SetSlabHalo(float halo) { m_slab_halo = halo; }
+    unsigned int GetNumSlabs() const {
+        uint32_t n = 1;
+        if (m_multi)
+            deme_multi_num_slabs(m_multi, &n);
+        return n;
+    }
+    const std::vector<int>& GetDeviceIDs() const { return m_devices; }
     DEMSolver(const DEMSolver&) = delete;
     DEMSolver& operator=(const DEMSolver&) = delete;
 
@@ -737,7 +757,7 @@ class DEMSolver {
         m_family_rules.push_back({ID_from, ID_to, condition});
     }
     void ChangeFamily(unsigned int ID_from, unsigned int ID_to) {
-        check(deme_change_family(m_ctx, ID_from, ID_to));
+        each_ctx([&](deme_ctx* c) { return deme_change_family(c, ID_from, ID_to); });
         m_state_fresh = false;
     }
     // ---- wildcard values (API.h:852-868, 936-1014).  Owner and geometry wildcards belong to a user force model
@@ -808,14 +828,14 @@ class DEMSolver {
     }
     // Persistent contacts (DEM/API.h:874-905): contacts of the current list that qualify stay in the list at every later
     // contact detection.  Like the reference these are post-Initialize calls.
-    void MarkFamilyPersistentContactEither(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 1, N, 0, 1)); }
-    void MarkFamilyPersistentContactBoth(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 2, N, 0, 1)); }
-    void MarkFamilyPersistentContact(unsigned int N1, unsigned int N2) { check(deme_mark_persistent_contacts(m_ctx, 3, N1, N2, 1)); }
-    void MarkPersistentContact() { check(deme_mark_persistent_contacts(m_ctx, 0, 0, 0, 1)); }
-    void RemoveFamilyPersistentContactEither(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 1, N, 0, 0)); }
-    void RemoveFamilyPersistentContactBoth(unsigned int N) { check(deme_mark_persistent_contacts(m_ctx, 2, N, 0, 0)); }
-    void RemoveFamilyPersistentContact(unsigned int N1, unsigned int N2) { check(deme_mark_persistent_contacts(m_ctx, 3, N1, N2, 0)); }
-    void RemovePersistentContact() { check(deme_mark_persistent_contacts(m_ctx, 0, 0, 0, 0)); }
+    void MarkFamilyPersistentContactEither(unsigned int N) { each_ctx([&](deme_ctx* c) { return deme_mark_persistent_contacts(c, 1, N, 0, 1); }); }
+    void MarkFamilyPersistentContactBoth(unsigned int N) { each_ctx([&](deme_ctx* c) { return deme_mark_persistent_contacts(c, 2, N, 0, 1); }); }
+    void MarkFamilyPersistentContact(unsigned int N1, unsigned int N2) { each_ctx([&](deme_ctx* c) { return deme_mark_persistent_contacts(c, 3, N1, N2, 1); }); }
+    void MarkPersistentContact() { each_ctx([&](deme_ctx* c) { return deme_mark_persistent_contacts(c, 0, 0, 0, 1); }); }
+    void RemoveFamilyPersistentContactEither(unsigned int N) { each_ctx([&](deme_ctx* c) { return deme_mark_persistent_contacts(c, 1, N, 0, 0); }); }
+    void RemoveFamilyPersistentContactBoth(unsigned int N) { each_ctx([&](deme_ctx* c) { return deme_mark_persistent_contacts(c, 2, N, 0, 0); }); }
+    void RemoveFamilyPersistentContact(unsigned int N1, unsigned int N2) { each_ctx([&](deme_ctx* c) { return deme_mark_persistent_contacts(c, 3, N1, N2, 0); }); }
+    void RemovePersistentContact() { each_ctx([&](deme_ctx* c) { return deme_mark_persistent_contacts(c, 0, 0, 0, 0); }); }
     void DisableContactBetweenFamilies(unsigned int a, unsigned int b) {
         if (a > b)
             std::swap(a, b);
@@ -874,7 +894,10 @@ class DEMSolver {
     void DoDynamics(double t) { step((uint32_t)std::llround(t / (double)m_h)); }
     void DoDynamicsThenSync(double t) {
         DoDynamics(t);
-        check(deme_sync(m_ctx));
+        if (m_multi)
+            mcheck(deme_multi_sync(m_multi));
+        else
+            check(deme_sync(m_ctx));
     }
     void DoStepDynamics(unsigned int n = 1) { step(n); }
     double GetSimTime() const { return m_time; }
@@ -882,8 +905,7 @@ class DEMSolver {
     // ---- queries (subset of DEMTracker / GetOwner* getters)
     size_t GetNumClumps() const { return m_n_clumps; }
     size_t GetNumContacts() {
-        DemeCounts c{};
-        check(deme_get_counts(m_ctx, &c));
+        const DemeCounts c = api_counts();
         return (size_t)c.nContacts;
     }
     float3 GetOwnerPosition(unsigned int owner) {
@@ -918,7 +940,7 @@ class DEMSolver {
             f[owner + k] = (uint8_t)fam;
         DemeOwnerState st{};
         st.familyID = f.data();
-        check(deme_upload_owner_state(m_ctx, &st));
+        ul_state(&st);
         m_state_fresh = false;
     }
     /// every clump whose CoM lies in the box becomes family `fam_num`; returns how many did (API.h:699-709)
@@ -936,7 +958,7 @@ class DEMSolver {
         }
         DemeOwnerState st{};
         st.familyID = f.data();
-        check(deme_upload_owner_state(m_ctx, &st));
+        ul_state(&st);
         return changed;
     }
     float GetMaxOwnerSpeed() {
@@ -1019,10 +1041,9 @@ class DEMSolver {
         st.vX = f[4].data(), st.vY = f[5].data(), st.vZ = f[6].data();
         st.omgBarX = f[7].data(), st.omgBarY = f[8].data(), st.omgBarZ = f[9].data();
         st.familyID = fam.data();
-        check(deme_download_owner_state(m_ctx, &st));
+        dl_state(&st);
         // contact list + wildcards
-        DemeCounts c{};
-        check(deme_get_counts(m_ctx, &c));
+        const DemeCounts c = api_counts();
         const size_t nc = (size_t)c.nContacts;
         const uint32_t nW = m_p.nContactWildcards;
         std::vector<uint32_t> a(nc), b(nc), map(nc);
@@ -1055,17 +1076,17 @@ class DEMSolver {
         s2.vX = g[4].data(), s2.vY = g[5].data(), s2.vZ = g[6].data();
         s2.omgBarX = g[7].data(), s2.omgBarY = g[8].data(), s2.omgBarZ = g[9].data();
         s2.familyID = fam2.data();
-        check(deme_download_owner_state(m_ctx, &s2));
+        dl_state(&s2);
         for (size_t o = 0; o < oldOwners; o++) {
             const size_t dst = o < oldClumps ? o : m_n_clumps + (o - oldClumps);
             vid2[dst] = vid[o], lx2[dst] = lx[o], ly2[dst] = ly[o], lz2[dst] = lz[o], fam2[dst] = fam[o];
             for (int k = 0; k < 10; k++)
                 g[k][dst] = f[k][o];
         }
-        check(deme_upload_owner_state(m_ctx, &s2));
+        ul_state(&s2);
         m_time = t;
         m_p.timeElapsed = t;
-        check(deme_set_params(m_ctx, &m_p));
+        each_ctx([&](deme_ctx* c) { return deme_set_params(c, &m_p); });
         if (nc)
             check(deme_seed_contacts(m_ctx, a.data(), b.data(), ty.data(), nW ? W.data() : nullptr, nc));
         m_state_fresh = false;
@@ -1091,9 +1112,8 @@ class DEMSolver {
         st.vX = f[4].data(), st.vY = f[5].data(), st.vZ = f[6].data();
         st.omgBarX = f[7].data(), st.omgBarY = f[8].data(), st.omgBarZ = f[9].data();
         st.familyID = fam.data();
-        check(deme_download_owner_state(m_ctx, &st));
-        DemeCounts c{};
-        check(deme_get_counts(m_ctx, &c));
+        dl_state(&st);
+        const DemeCounts c = api_counts();
         const size_t nc = (size_t)c.nContacts;
         const uint32_t nW = m_p.nContactWildcards;
         std::vector<uint32_t> a(nc), b(nc), map(nc);
@@ -1188,10 +1208,10 @@ class DEMSolver {
         s2.vX = g[4].data(), s2.vY = g[5].data(), s2.vZ = g[6].data();
         s2.omgBarX = g[7].data(), s2.omgBarY = g[8].data(), s2.omgBarZ = g[9].data();
         s2.familyID = fam2.data();
-        check(deme_upload_owner_state(m_ctx, &s2));
+        ul_state(&s2);
         m_time = t;
         m_p.timeElapsed = t;
-        check(deme_set_params(m_ctx, &m_p));
+        each_ctx([&](deme_ctx* c) { return deme_set_params(c, &m_p); });
         const bool hertz = m_force_model->type == FORCE_MODEL::HERTZIAN;
         auto remap = [&](std::vector<uint32_t>& A, std::vector<uint32_t>& B, const std::vector<uint8_t>& T, std::vector<float>* wc) {
             for (size_t i = 0; i < A.size(); i++) {
@@ -1223,17 +1243,16 @@ class DEMSolver {
         m_h = (float)ts;
         m_p.h = m_h;
         m_p.timeElapsed = m_time;
-        check(deme_set_params(m_ctx, &m_p));
+        each_ctx([&](deme_ctx* c) { return deme_set_params(c, &m_p); });
     }
     double GetTimeStepSize() const { return m_h; }
     void UpdateSimParams() {
         m_p.timeElapsed = m_time;
-        check(deme_set_params(m_ctx, &m_p));
+        each_ctx([&](deme_ctx* c) { return deme_set_params(c, &m_p); });
     }
     /// Sphere-geometry id pairs of the current contact list and their types (GetContacts / contact info getters)
     std::vector<std::pair<bodyID_t, bodyID_t>> GetContacts() {
-        DemeCounts c{};
-        check(deme_get_counts(m_ctx, &c));
+        const DemeCounts c = api_counts();
         const size_t n = (size_t)c.nContacts;
         std::vector<uint32_t> a(n), b(n), map(n);
         std::vector<uint8_t> ty(n);
@@ -1270,8 +1289,7 @@ class DEMSolver {
     size_t GetOwnerContactForces(const std::vector<bodyID_t>& owners, std::vector<float3>& points, std::vector<float3>& forces,
                                  std::vector<float3>* torques = nullptr, bool torque_in_local = false) {
         const Snapshot sn = snapshot(true);
-        DemeCounts c{};
-        check(deme_get_counts(m_ctx, &c));
+        const DemeCounts c = api_counts();
         const size_t nc = sn.idA.size();
         std::vector<float> cpB(3 * nc);
         {
@@ -1328,8 +1346,7 @@ class DEMSolver {
         }
     }
     void ShowThreadCollaborationStats() {
-        DemeCounts c{};
-        check(deme_get_counts(m_ctx, &c));
+        const DemeCounts c = api_counts();
         std::printf("steps %llu, contact detections %llu (every %u steps), contacts %llu\n", (unsigned long long)c.nSteps,
                     (unsigned long long)c.nDetections, m_cd_freq, (unsigned long long)c.nContacts);
     }
@@ -1365,19 +1382,18 @@ class DEMSolver {
     }
     /// average number of contacts per sphere (kT's avgCntsPerSphere, API.h:251): contacts of the current list / spheres
     float GetAvgSphContacts() {
-        DemeCounts c{};
-        check(deme_get_counts(m_ctx, &c));
+        const DemeCounts c = api_counts();
         return m_keep.sphOwner.empty() ? 0.f : (float)((double)c.nContacts / (double)m_keep.sphOwner.size());
     }
     /// SetFamilyClumpMaterial / SetFamilyMeshMaterial (API.h:970-974, dT::setFamilyClumpMaterial): every sphere (triangle) whose
     /// owner is of family N takes the material, from the next step on
     void SetFamilyClumpMaterial(unsigned int N, const std::shared_ptr<DEMMaterial>& mat) {
         require_init("SetFamilyClumpMaterial");
-        check(deme_set_family_material(m_ctx, N, mat->load_order, 0));
+        each_ctx([&](deme_ctx* c) { return deme_set_family_material(c, N, mat->load_order, 0); });
     }
     void SetFamilyMeshMaterial(unsigned int N, const std::shared_ptr<DEMMaterial>& mat) {
         require_init("SetFamilyMeshMaterial");
-        check(deme_set_family_material(m_ctx, N, mat->load_order, 1));
+        each_ctx([&](deme_ctx* c) { return deme_set_family_material(c, N, mat->load_order, 1); });
     }
     void require_init(const char* who) const {
         if (!m_initialized)
@@ -1659,7 +1675,82 @@ class DEMSolver {
     }
 
   private:
-    deme_ctx* m_ctx = nullptr;
+    deme_ctx* m_ctx = nullptr;       // the context of a one-device, one-slab run; of a decomposed run: the FIRST slab's (owned by m_multi)
+    deme_multi* m_multi = nullptr;   // a decomposed run: several devices and / or several slabs per device
+    std::vector<int> m_devices;
+    unsigned int m_slabs_per_device = 1, m_migrate_every = 1000;
+    float m_slab_halo = 0.f;
+
+    void open_devices(const std::vector<int>& ids) {
+        int visible = 0;
+        deme_device_count(&visible);
+        if (ids.empty())
+            throw std::runtime_error("DEMSolver: at least one device id");
+        for (int d : ids)
+            if (d < 0 || d >= visible)  // GpuManager.cpp:64-68: "more GPUs are requested than available"
+                throw std::runtime_error("DEMSolver: device id " + std::to_string(d) + " is not present (" + std::to_string(visible) +
+                                         " HIP device(s) visible)");
+        m_devices = ids;
+        if (const char* e = std::getenv("DEME_SLABS_PER_DEVICE"))
+            m_slabs_per_device = (unsigned)std::max(1, atoi(e));
+        if (ids.size() == 1) {  // (a decomposed run on one device opens its deme_multi at Initialize, when the slab count is final)
+            if (deme_ctx_create(ids[0], &m_ctx) != DEME_OK)
+                throw std::runtime_error("DEMSolver: no usable HIP device");
+        } else {
+            char err[512];
+            if (deme_multi_create(ids.data(), (int)ids.size(), &m_multi, err, sizeof err) != DEME_OK)
+                throw std::runtime_error(std::string("DEMSolver: ") + err);
+        }
+        m_force_model = std::make_shared<DEMForceModel>();
+        m_force_model->SetForceModelType(FORCE_MODEL::HERTZIAN);
+        m_family_flags[RESERVED_FAMILY_NUM] = DEME_FAMILY_FIXED;
+    }
+    bool decomposed() const { return m_multi != nullptr; }
+    /// what a decomposed run does not offer yet says so instead of touching one slab only
+    void single_only(const char* what) const {
+        if (m_multi)
+            throw std::runtime_error(std::string(what) + " is not available on a decomposed run (several GPUs / DEME_SLABS_PER_DEVICE) yet");
+    }
+    void mcheck(int rc) {
+        if (rc)
+            throw std::runtime_error(deme_multi_last_error(m_multi));
+    }
+    /// the same call on the context, or on every slab's context
+    template <class F>
+    void each_ctx(F f) {
+        if (!m_multi) {
+            check(f(m_ctx));
+            return;
+        }
+        uint32_t n = 0;
+        mcheck(deme_multi_num_slabs(m_multi, &n));
+        for (uint32_t i = 0; i < n; i++) {
+            deme_ctx* c = nullptr;
+            mcheck(deme_multi_slab_ctx(m_multi, i, &c));
+            if (int rc = f(c))
+                throw std::runtime_error(deme_last_error(c));
+        }
+    }
+    void dl_state(DemeOwnerState* st) {
+        if (m_multi)
+            mcheck(deme_multi_download_state(m_multi, st, (uint32_t)m_n_owners));
+        else
+            check(deme_download_owner_state(m_ctx, st));
+    }
+    void ul_state(const DemeOwnerState* st) {
+        if (m_multi)
+            mcheck(deme_multi_upload_state(m_multi, st, (uint32_t)m_n_owners));
+        else
+            check(deme_upload_owner_state(m_ctx, st));
+    }
+    DemeCounts api_counts() {
+        DemeCounts c{};
+        if (m_multi)
+            mcheck(deme_multi_counts(m_multi, &c, nullptr));
+        else
+            check(deme_get_counts(m_ctx, &c));
+        return c;
+    }
     std::vector<std::shared_ptr<DEMMaterial>> m_materials;
     std::map<std::string, std::map<std::pair<unsigned, unsigned>, float>> m_pair_overrides;
     std::vector<std::shared_ptr<DEMClumpTemplate>> m_templates;
@@ -1750,14 +1841,13 @@ class DEMSolver {
         std::vector<uint8_t> fam(m_n_owners);
         DemeOwnerState st{};
         st.familyID = fam.data();
-        check(deme_download_owner_state(m_ctx, &st));
+        dl_state(&st);
         return fam;
     }
     // mode 0 all, 1 either owner's family == N1, 2 both, 3 the pair (N1, N2): APIPrivate.cpp's setFamilyContactWildcardValue_impl
     void set_contact_wc(int mode, unsigned int N1, unsigned int N2, const std::string& name, float val) {
         const uint32_t w = wc_slot(m_force_model->contact_wildcards, name, "contact");
-        DemeCounts c{};
-        check(deme_get_counts(m_ctx, &c));
+        const DemeCounts c = api_counts();
         const size_t nc = (size_t)c.nContacts;
         if (!nc)
             return;
@@ -1790,7 +1880,7 @@ class DEMSolver {
     DemeAdaptive m_adaptive{0u, 25u, 0.05f, 0.1f, 0.25f, 0.3f, 0u, 2500u, 4u};
     void push_adaptive() {  // the knobs may be turned before or after Initialize
         if (m_initialized)
-            check(deme_set_adaptive(m_ctx, &m_adaptive));
+            each_ctx([&](deme_ctx* c) { return deme_set_adaptive(c, &m_adaptive); });
     }
     double m_time = 0;
     bool m_state_fresh = false;
@@ -1882,7 +1972,7 @@ class DEMSolver {
                 acc += head + block("accPre", {{"accX", "accX"}, {"accY", "accY"}, {"accZ", "accZ"}}) +
                        block("angAccPre", {{"angAccX", "angAccX"}, {"angAccY", "angAccY"}, {"angAccZ", "angAccZ"}}) + "break; }";
             }
-            check(deme_compile_prescriptions(m_ctx, vel.c_str(), pos.c_str(), acc.c_str()));
+            each_ctx([&](deme_ctx* c) { return deme_compile_prescriptions(c, vel.c_str(), pos.c_str(), acc.c_str()); });
         }
         if (!m_family_rules.empty()) {  // equipFamilyOnFlyChanges, APIPrivate.cpp:1576-1598
             std::string rules = " ";
@@ -1890,7 +1980,7 @@ class DEMSolver {
                 rules += "if (family_code == " + std::to_string(r.from) + ") { bool shouldMakeChange = false;" +
                          replace_all(r.cond, "return", "shouldMakeChange = ") +
                          "if (shouldMakeChange) {granData->familyID[myOwner] = " + std::to_string(r.to) + ";}}";
-            check(deme_compile_family_rules(m_ctx, rules.c_str()));
+            each_ctx([&](deme_ctx* c) { return deme_compile_family_rules(c, rules.c_str()); });
         }
     }
     unsigned int m_out_content = QUAT | ABSV;                                      // API.h:1418
@@ -1984,7 +2074,7 @@ class DEMSolver {
         st.aX = f[10].data(), st.aY = f[11].data(), st.aZ = f[12].data();
         st.alphaX = f[13].data(), st.alphaY = f[14].data(), st.alphaZ = f[15].data();
         st.familyID = sn.fam.data();
-        check(deme_download_owner_state(m_ctx, &st));
+        dl_state(&st);
         sn.com.resize(n), sn.q.resize(n), sn.v.resize(n), sn.w.resize(n), sn.a.resize(n), sn.al.resize(n);
         const float vs = (float)m_p.voxelSize, l = (float)m_p.l;
         for (size_t i = 0; i < n; i++) {  // voxelIDToPosition<float, ...> then + LBF, all fp32 (dT.cpp:1312-1320)
@@ -1999,8 +2089,7 @@ class DEMSolver {
             sn.al[i] = {f[13][i], f[14][i], f[15][i]};
         }
         if (contacts) {
-            DemeCounts c{};
-            check(deme_get_counts(m_ctx, &c));
+            const DemeCounts c = api_counts();
             const size_t nc = (size_t)c.nContacts;
             sn.idA.resize(nc), sn.idB.resize(nc), sn.type.resize(nc);
             std::vector<uint32_t> map(nc);
@@ -2061,8 +2150,9 @@ class DEMSolver {
     }
 
     void check(int rc) {
-        if (rc)
-            throw std::runtime_error(deme_last_error(m_ctx));
+        if (rc)  // (a decomposed run keeps no single context: a call that has no decomposed form yet arrives here with a null one)
+            throw std::runtime_error(m_multi ? "this call is not available on a decomposed run (several GPUs / DEME_SLABS_PER_DEVICE) yet"
+                                             : deme_last_error(m_ctx));
     }
     // owners are numbered: clumps (batch load order), analytical objects (+ the bounding box last), meshes
     size_t tracker_first_owner(int kind, size_t index) const {
@@ -2090,7 +2180,7 @@ class DEMSolver {
                 const float3 a = m->vertices.at(f[0]), b = m->vertices.at(f[1]), c = m->vertices.at(f[2]);
                 t1.insert(t1.end(), {a.x, a.y, a.z}), t2.insert(t2.end(), {b.x, b.y, b.z}), t3.insert(t3.end(), {c.x, c.y, c.z});
             }
-        check(deme_update_tri_nodes(m_ctx, t1.data(), t2.data(), t3.data()));
+        each_ctx([&](deme_ctx* c) { return deme_update_tri_nodes(c, t1.data(), t2.data(), t3.data()); });
     }
     // tracker setters: read-modify-write of the affected SoA columns (null columns keep their device values)
     void set_owner(size_t o, const float3* pos, const float3* vel, const float3* angvel, const float4* q) {
@@ -2105,7 +2195,7 @@ class DEMSolver {
         st.oriQw = f[0].data(), st.oriQx = f[1].data(), st.oriQy = f[2].data(), st.oriQz = f[3].data();
         st.vX = f[4].data(), st.vY = f[5].data(), st.vZ = f[6].data();
         st.omgBarX = f[7].data(), st.omgBarY = f[8].data(), st.omgBarZ = f[9].data();
-        check(deme_download_owner_state(m_ctx, &st));
+        dl_state(&st);
         if (pos) {  // positionToVoxelID of (pos - LBF), as at initialisation
             const double P[3] = {(double)(pos->x - m_p.LBFX), (double)(pos->y - m_p.LBFY), (double)(pos->z - m_p.LBFZ)};
             uint64_t nn[3];
@@ -2123,11 +2213,14 @@ class DEMSolver {
             f[4][o] = vel->x, f[5][o] = vel->y, f[6][o] = vel->z;
         if (angvel)
             f[7][o] = angvel->x, f[8][o] = angvel->y, f[9][o] = angvel->z;
-        check(deme_upload_owner_state(m_ctx, &st));
+        ul_state(&st);
         m_state_fresh = false;
     }
     void step(uint32_t n) {
-        check(deme_step(m_ctx, n));
+        if (m_multi)
+            mcheck(deme_multi_step(m_multi, n));
+        else
+            check(deme_step(m_ctx, n));
         m_time += (double)n * (double)m_h;
         m_state_fresh = false;
     }
@@ -2142,7 +2235,7 @@ class DEMSolver {
         DemeOwnerState st{};
         st.voxelID = vid.data(), st.locX = lx.data(), st.locY = ly.data(), st.locZ = lz.data();
         st.vX = m_st_v[0].data(), st.vY = m_st_v[1].data(), st.vZ = m_st_v[2].data();
-        check(deme_download_owner_state(m_ctx, &st));
+        dl_state(&st);
         m_pos.resize(m_n_owners);
         for (size_t i = 0; i < m_n_owners; i++) {  // voxelIDToPosition + LBF, DEMHelperKernels.cuh:116-134
             const uint64_t vx = vid[i] & ((1ull << m_p.nvXp2) - 1), vy = (vid[i] >> m_p.nvXp2) & ((1ull << m_p.nvYp2) - 1),
@@ -2452,11 +2545,27 @@ class DEMSolver {
         s.triMaterialOffset = triMat.data();
         if (const char* dump = std::getenv("DEME_DUMP_SCENE"))  // test hook: what this shell hands the engine (tests/test_host_shell.py
             dump_scene(dump, p, s);                              // compares it field by field with model.py's scene)
-        check(deme_set_params(m_ctx, &p));
-        check(deme_upload_scene(m_ctx, &s));
+        if (m_devices.size() == 1 && m_slabs_per_device > 1 && !m_multi) {  // one device cut into slabs: the context opened by the
+            deme_ctx_destroy(m_ctx);                                          // constructor gives way to a deme_multi of that device
+            m_ctx = nullptr;
+            char err[512];
+            if (deme_multi_create(m_devices.data(), 1, &m_multi, err, sizeof err) != DEME_OK)
+                throw std::runtime_error(std::string("DEMSolver: ") + err);
+        }
+        if (m_multi) {  // the bed cut along its longest side into devices x slabs-per-device slabs, bin-aligned (csrc/deme_decomp.inc)
+            bool freeOwner = false;  // a mesh / analytical body that moves under contact forces: its accelerations are summed across slabs
+            for (size_t o = nC; o < nO; o++)
+                freeOwner = freeOwner || !(m_family_flags[fam[o]] & (DEME_FAMILY_FIXED | DEME_FAMILY_PRESCRIBED));
+            mcheck(deme_multi_build(m_multi, &p, &s, m_slabs_per_device, -1, (double)m_slab_halo, freeOwner ? DEME_DECOMP_SHARED_FREE : 0u, -1,
+                                    p.forceModel == DEME_FORCE_HERTZIAN ? 7u : 0u));
+            mcheck(deme_multi_set_migration(m_multi, m_migrate_every));
+        } else {
+            check(deme_set_params(m_ctx, &p));
+            check(deme_upload_scene(m_ctx, &s));
+        }
         volumes.resize(mass.size(), 0.f);  // analytical / mesh owners: unused, like the reference (dT.cpp:607-618)
         if (std::any_of(volumes.begin(), volumes.end(), [](float v) { return v != 0.f; }))
-            check(deme_upload_volumes(m_ctx, volumes.data(), volumes.size()));
+            each_ctx([&](deme_ctx* c) { return deme_upload_volumes(c, volumes.data(), volumes.size()); });
         if (m_force_model->type == FORCE_MODEL::CUSTOM) {
             // _materialDefs_ for properties beyond the five built-in ones (APIPrivate.cpp:1877-2026)
             std::set<std::string> extra;
@@ -2496,9 +2605,11 @@ class DEMSolver {
                 onames.push_back(n.c_str());
             for (auto& n : m_force_model->geo_wildcards)
                 gnames.push_back(n.c_str());
-            check(deme_compile_force_model_ex(m_ctx, m_force_model->code.c_str(), m_force_model->code.size(), names.data(),
-                                              (uint32_t)names.size(), onames.data(), (uint32_t)onames.size(), gnames.data(),
-                                              (uint32_t)gnames.size(), prereq.c_str()));
+            each_ctx([&](deme_ctx* c) {
+                return deme_compile_force_model_ex(c, m_force_model->code.c_str(), m_force_model->code.size(), names.data(),
+                                                   (uint32_t)names.size(), onames.data(), (uint32_t)onames.size(), gnames.data(),
+                                                   (uint32_t)gnames.size(), prereq.c_str());
+            });
         }
         m_n_clumps = nC, m_n_owners = nO;
         m_state_fresh = false;
@@ -2543,7 +2654,7 @@ class DEMSolver {
             m_keep.templateName[m_templates[i]->mark] = m_templates[i]->m_name.empty() ? std::string(nm) : m_templates[i]->m_name;
         }
         if (m_cnt_out_content & (FORCE | CNT_POINT | NORMAL | TORQUE))
-            check(deme_set_record_contacts(m_ctx, 1));
+            each_ctx([&](deme_ctx* c) { return deme_set_record_contacts(c, 1); });
         // restart: existing sphere-sphere contacts of the batches (geometry ids are batch-relative, Structs.h:857)
         {
             std::vector<uint32_t> a, b;
@@ -2592,9 +2703,29 @@ class DEMInspector {
         m_code = it->second;
     }
     float GetValue() {
-        if (m_region < 0 && m_region_code.find_first_not_of(" \t\n") != std::string::npos)
+        if (!m_sys->decomposed() && m_region < 0 && m_region_code.find_first_not_of(" \t\n") != std::string::npos)
             m_sys->check(deme_compile_region(m_sys->m_ctx, m_region_code.c_str(), &m_region));
         float v = 0;
+        if (m_sys->decomposed()) {  // every slab reduces over its OWN clumps (ghost copies are left out of inspections): max / min / sum of those
+            const bool isMax = m_code == DEME_INSPECT_CLUMP_MAX_Z || m_code == DEME_INSPECT_CLUMP_MAX_ABSV || m_code == DEME_INSPECT_MAX_ABSV;
+            const bool isMin = m_code == DEME_INSPECT_CLUMP_MIN_Z;
+            if (m_code == DEME_INSPECT_ABSV)
+                m_sys->single_only("DEMInspector(\"absv\")");
+            bool first = true;
+            m_sys->each_ctx([&](deme_ctx* c) {
+                float w = 0;
+                int reg = -1;
+                if (m_region_code.find_first_not_of(" \t\n") != std::string::npos)
+                    if (int rc = deme_compile_region(c, m_region_code.c_str(), &reg))  // (cached by source inside the library)
+                        return rc;
+                if (int rc = deme_inspect_region(c, m_code, reg, &w))
+                    return rc;
+                v = first ? w : (isMax ? std::max(v, w) : isMin ? std::min(v, w) : v + w);
+                first = false;
+                return (int)DEME_OK;
+            });
+            return v;
+        }
         m_sys->check(deme_inspect_region(m_sys->m_ctx, m_code, m_region, &v));
         return v;
     }

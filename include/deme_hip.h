@@ -517,6 +517,74 @@ int deme_halo_group_comm_count(const deme_halo_group* g, int* ranks);
  * free owners (DemeScene.ownerGhost = 2). */
 int deme_halo_group_set_cross_contacts(deme_halo_group* g, int evaluateOnce);
 
+/* ---- the decomposition itself, behind the C-ABI (round 5; north_star: "the reference's two-GPU kT/dT split is replaced by a per-GPU
+ * spatial-domain decomposition ... host orchestration in C++").  The reference picks its devices in the constructor
+ * (DEM/API.h:52-56, DEM/APIPublic.cpp:22-110: DEMSolver(nGPUs) / DEMSolver(device ids)); here that constructor opens a deme_multi.
+ *
+ * deme_decomp_*: the PLAN -- pure host code, no device needed.  A global scene (no ghosts) is cut into nSlabs slabs along `axis`
+ * (0 / 1 / 2, or -1: the longest side of the clumps' bounding box) at equal-count boundaries snapped to bin faces (`edges`: nSlabs + 1
+ * boundaries of the caller's own instead; the outer two are taken as -inf / +inf); a slab's scene is [own clumps | ghosts from the
+ * lower neighbour | ghosts from the upper neighbour | replicated owners], a ghost being a neighbour's clump whose centre lies within
+ * `halo` of the shared face (halo <= 0: four clump reaches + twice the widest family margin).  Every rule is the one
+ * dem-engine_amd/decomp.py states in numpy (the CPU tests hold the two against each other). */
+#define DEME_DECOMP_SHARED_FREE 1u /* allow replicated owners that move under contact forces (DemeScene.ownerGhost = 2) */
+#define DEME_DECOMP_NO_SNAP 2u     /* keep the equal-count boundaries where the quantiles put them (not snapped to bin faces) */
+typedef struct deme_decomp deme_decomp;
+int deme_decomp_create(const DemeParams* p, const DemeScene* scene, uint32_t nSlabs, int axis, double halo, const double* edges, uint32_t flags,
+                       deme_decomp** out, char* err, size_t errCap);
+void deme_decomp_destroy(deme_decomp* d);
+int deme_decomp_info(const deme_decomp* d, uint32_t* nSlabs, int* axis, double* halo, double* edges /* nSlabs + 1 */, uint32_t* nFreeReplicated);
+/* one slab of the plan: its scene (pointers into the plan's storage: valid until deme_decomp_destroy), {own, ghosts from below, ghosts
+ * from above} clump counts, the global owner id of every slab owner and the global sphere id of every slab sphere, the LOCAL owner
+ * ids sent to the lower / upper neighbour (what arrives lands on the ghost ranges, in order), the slab's range along the axis */
+int deme_decomp_slab(const deme_decomp* d, uint32_t slab, DemeScene* scene, uint32_t counts[3], const uint32_t** ownerGlobal,
+                     const uint32_t** sphereGlobal, const uint32_t** sendLower, uint32_t* nSendLower, const uint32_t** sendUpper,
+                     uint32_t* nSendUpper, double range[2]);
+
+/* The slabs of a plan that THIS rank holds (slab s belongs to rank s * world / nSlabs; nSlabs must be a multiple of the group's world)
+ * become contexts on the group's device: deme_ctx_create, deme_set_arith_mode(arith: DEME_ARITH_*, or -1 for the process default),
+ * deme_set_params, deme_upload_scene, deme_halo_group_attach, deme_halo_group_set_slab (flipMask as there), then one exchange.
+ * The contexts belong to the group (deme_halo_group_destroy destroys them); deme_halo_group_slab_ctx hands them out in slab order
+ * for what a script sets per context (force models, prescriptions, recording ...).  deme_halo_group_set_axis: the axis the slabs of
+ * an attach-by-hand group were cut along (default 0; _build sets it from the plan). */
+int deme_halo_group_build(deme_halo_group* g, const DemeParams* p, const deme_decomp* plan, int arith, uint32_t flipMask);
+int deme_halo_group_set_axis(deme_halo_group* g, int axis);
+int deme_halo_group_slab_ctx(deme_halo_group* g, uint32_t i, deme_ctx** ctx, uint32_t* globalSlab);
+int deme_halo_group_num_slabs(const deme_halo_group* g, uint32_t* n);
+/* Owner state by GLOBAL owner id: every slab of this rank writes its OWN clumps' rows (replicated owners: the first slab's) into the
+ * caller's arrays of the global scene's length / reads them from there (ghost copies are refreshed by one exchange).  With several
+ * ranks each process fills / takes only its part. */
+int deme_halo_group_download_state(deme_halo_group* g, DemeOwnerState* global, uint32_t nOwnersGlobal);
+int deme_halo_group_upload_state(deme_halo_group* g, const DemeOwnerState* global, uint32_t nOwnersGlobal);
+
+/* One process, several devices: the reference's DEMSolver(nGPUs) / DEMSolver(std::vector<int>) (DEM/API.h:52-56).  deme_multi_create
+ * checks every id against the visible devices (an absent one: DEME_ERR_INVALID, the message names it -- GpuManager.cpp:64-68 throws
+ * there), opens one halo group per device -- one RCCL rank each, the communicators initialised together in one grouped
+ * ncclCommInitRank -- and deme_multi_build cuts the scene into nDevices * slabsPerDevice slabs (deme_decomp_create) and hands every
+ * device its block (deme_halo_group_build).  deme_multi_step steps all groups (one host thread per device when there are several:
+ * each group's loop is the per-process loop of deme_halo_group_step) and migrates clumps between slabs every `migrateEvery` steps
+ * (deme_multi_set_migration; 0 = never).  With one device and one slab per device this is a plain context behind the same calls. */
+typedef struct deme_multi deme_multi;
+int deme_multi_create(const int* devices, int nDevices, deme_multi** out, char* err, size_t errCap);
+void deme_multi_destroy(deme_multi* m);
+const char* deme_multi_last_error(const deme_multi* m);
+int deme_multi_build(deme_multi* m, const DemeParams* p, const DemeScene* scene, uint32_t slabsPerDevice, int axis, double halo, uint32_t flags,
+                     int arith, uint32_t flipMask);
+int deme_multi_num_slabs(const deme_multi* m, uint32_t* n);
+int deme_multi_slab_ctx(deme_multi* m, uint32_t slab, deme_ctx** ctx);
+int deme_multi_set_migration(deme_multi* m, uint32_t migrateEvery);
+int deme_multi_step(deme_multi* m, uint32_t nsteps);
+int deme_multi_sync(deme_multi* m);
+int deme_multi_download_state(deme_multi* m, DemeOwnerState* global, uint32_t nOwnersGlobal);
+int deme_multi_upload_state(deme_multi* m, const DemeOwnerState* global, uint32_t nOwnersGlobal);
+/* contacts of all slabs together (a contact that straddles a cut is on two lists unless deme_halo_group_set_cross_contacts(1):
+ * `nContacts` counts list entries), steps taken, detections of the first slab, clumps that changed slabs so far */
+int deme_multi_counts(deme_multi* m, DemeCounts* sum, uint64_t* clumpsMigrated);
+/* the visible HIP devices (0 and DEME_OK where there is none: what the constructors check ids against) */
+int deme_device_count(int* n);
+/* {owners, clump owners, spheres, contact wildcards} of the scene a context holds (a slab's change when clumps migrate) */
+int deme_scene_sizes(const deme_ctx* ctx, uint32_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -657,3 +657,93 @@ def test_migration_carries_the_current_state_of_moving_replicated_owners(pkg, or
     X, V = gather_positions(pkg, parts2, sims2, p, sc.nOwnerClumps)
     X0, V0 = gather_positions(pkg, parts, sims, p, sc.nOwnerClumps)
     assert np.abs(X - X0).max() < 1e-8 and np.abs(V - V0).max() < 1e-4
+
+
+# ---- the decomposition inside the library (deme_decomp_*: what a C++ host calls) against the numpy statement above ----------------
+def _scene_arrays(sc, name, dtype, n):
+    import ctypes as C
+    ptr = getattr(sc, name)
+    if not ptr or not n:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(int(n),)).copy()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3, 5])
+def test_library_decomposition_equals_the_numpy_statement(pkg, n_ranks):
+    """deme_decomp_create (csrc/deme_decomp.inc; pure host code, runs without a device) cuts the same scene at the same boundaries into
+    the same slabs as decomp.decompose: owners, ghosts, sphere lists, renumbered references, exchange lists, per-owner arrays."""
+    b, p, sc, _ = build_global(pkg)
+    halo = 0.03
+    # (the library reads the clumps' coordinates from the ENCODED positions of the scene -- what the kernels see)
+    x = pkg.model.decode_positions(b.arrays["voxelID"], b.arrays["locX"], b.arrays["locY"], b.arrays["locZ"], p.nvXp2, p.nvYp2, p.voxelSize,
+                                   p.l)[:, 0] + float(p.LBFX)
+    ref = pkg.decomp.decompose(b.arrays, b.counts, x, n_ranks, halo=halo)
+    plan, parts = pkg.decomp.decompose_lib(p, sc, n_ranks, halo, axis=0, edges=ref[0]["all_edges"])
+    assert plan.axis == 0 and plan.halo == halo and plan.n_slabs == n_ranks
+    for r in range(n_ranks):
+        a, q = ref[r], parts[r]
+        assert q["n_own"] == a["n_own"]
+        for k in ("global_ids", "ghost_left_g", "ghost_right_g", "owner_global", "sphere_global", "send_left", "send_right", "recv_left",
+                  "recv_right"):
+            assert np.array_equal(np.asarray(q[k], np.int64), np.asarray(a[k], np.int64)), (r, k)
+        s1, s0 = q["scene"], a["scene"]
+        for k in ("nOwners", "nOwnerClumps", "nSpheres", "nAnal", "nTri", "nMat", "nComp", "nMassProps"):
+            assert getattr(s1, k) == getattr(s0, k), (r, k)
+        for k, dt in pkg.abi.SCENE_DTYPES.items():
+            n = {"ownerClumpBody": s0.nSpheres, "clumpComponentOffset": s0.nSpheres, "sphereMaterialOffset": s0.nSpheres,
+                 "objOwner": s0.nAnal, "ownerMesh": s0.nTri, "ownerGhost": s0.nOwners}.get(k)
+            if n is None and k in pkg.decomp._OWNER_KEYS:
+                n = s0.nOwners
+            if n is None:
+                continue  # tables shared with the global scene
+            assert np.array_equal(_scene_arrays(s1, k, dt, n), _scene_arrays(s0, k, dt, n)), (r, k)
+
+
+def test_library_decomposition_picks_axis_halo_and_bin_aligned_cuts(pkg):
+    """defaults of a C++ caller: axis -1 = the longest side of the clumps' bounding box, halo 0 = four clump reaches, equal-count cuts
+    snapped to bin faces; every clump owned once, every ghost within the halo of a face, counts balanced to within one bin layer"""
+    b, p, sc, x = build_global(pkg)  # aspect (2, 1, 0.5): x is the long side
+    plan, parts = pkg.decomp.decompose_lib(p, sc, 4, halo=0.0, axis=-1, snap=True)
+    assert plan.axis == 0
+    reach = max(np.hypot(np.hypot(b.arrays["CDRelPosX"], b.arrays["CDRelPosY"]), b.arrays["CDRelPosZ"]) + b.arrays["Radii"])
+    assert abs(plan.halo - 4.0 * float(reach)) < 1e-6 * reach
+    inner = plan.edges[1:-1]
+    k = (inner - float(p.LBFX)) / float(p.binSize)
+    assert np.abs(k - np.rint(k)).max() < 1e-9, "cuts must lie on bin faces"
+    assert np.isinf(plan.edges[0]) and np.isinf(plan.edges[-1])
+    own = np.sort(np.concatenate([q["global_ids"] for q in parts]))
+    assert np.array_equal(own, np.arange(sc.nOwnerClumps))
+    xq = pkg.model.decode_positions(b.arrays["voxelID"], b.arrays["locX"], b.arrays["locY"], b.arrays["locZ"], p.nvXp2, p.nvYp2, p.voxelSize,
+                                    p.l)[:sc.nOwnerClumps, 0] + float(p.LBFX)
+    for r, q in enumerate(parts):
+        lo, hi = q["edges"]
+        assert ((xq[q["global_ids"]] >= lo) & (xq[q["global_ids"]] < hi)).all()
+        assert (xq[q["ghost_left_g"]] >= lo - plan.halo).all() and (xq[q["ghost_left_g"]] < lo).all()
+        assert (xq[q["ghost_right_g"]] < hi + plan.halo).all() and (xq[q["ghost_right_g"]] >= hi).all()
+    n = np.array([q["n_own"] for q in parts])
+    assert n.min() > 0.6 * n.mean(), n
+    # a rotated bed: z is the long side
+    b2 = pkg.model.packed_bed(1200, seed=4, cd_freq=0, spacing_mult=2.5, aspect=(0.5, 0.5, 3.0))
+    p2, sc2 = b2.Initialize()
+    plan2, _ = pkg.decomp.decompose_lib(p2, sc2, 2, halo=0.0, axis=-1)
+    assert plan2.axis == 2
+
+
+def test_library_decomposition_refusals(pkg):
+    b, p, sc, x = build_global(pkg)
+    with pytest.raises(pkg.abi.DemeError, match="thinner than the halo"):
+        pkg.decomp.decompose_lib(p, sc, 12, halo=0.2, axis=0)
+    own = sc._keep["ownerClumpBody"]
+    own[[0, len(own) - 1]] = own[[len(own) - 1, 0]]
+    with pytest.raises(pkg.abi.DemeError, match="clump-major"):
+        pkg.decomp.decompose_lib(p, sc, 2, halo=0.03, axis=0)
+
+
+def test_multi_refuses_absent_devices(pkg):
+    """DEMSolver(device ids) -> deme_multi_create: an id that is not among the visible devices is refused with a message that names it
+    (the reference throws in GpuManager.cpp:64-68); here, without a GPU, every id is absent"""
+    n = pkg.abi.device_count()
+    with pytest.raises(pkg.abi.DemeError, match=f"device id {n + 3} is not present"):
+        pkg.abi.Multi(devices=(n + 3,))
+    with pytest.raises(pkg.abi.DemeError, match="at least one device"):
+        pkg.abi.Multi(devices=())

@@ -382,3 +382,101 @@ def test_the_engine_renews_a_degraded_order_by_itself(pkg, orc):
     print(f"order renewed by the engine after the bed was swapped: largest halo back to {ctx.tile_stats()[2]} (was {halo_good}); |dx| {dx:.3e} m, |dv| {dv:.3e} m/s vs the oracle")
     assert dx <= 5e-8 and dv <= 2e-4
     ctx.close()
+
+
+def test_exact_mode_on_a_reordered_context_goes_back_to_the_callers_order(pkg, orc):
+    """deme_set_arith_mode(EXACT) on a context the engine had reordered: the exact mode's contract is bit-identity with the oracle,
+    which sums an owner's contributions in the caller's order -- so the records, the sphere references and the current list (re-keyed,
+    as the seed of the next detection) go back to the caller's slots, and the run that follows is the oracle's bit for bit.  The
+    renewal entry points leave an exact-mode context alone."""
+    b = _bed(pkg)
+    p, sc, st = _settled(pkg, b)
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st)
+    assert ctx.engine_order()[0]
+    ctx.compute_margins(0), ctx.detect(), ctx.migrate()  # a list in the engine's slots (no force evaluation: the history stays zero)
+    la = ctx.contacts()
+    ctx.set_arith_mode("exact")
+    assert not ctx.engine_order()[0]
+    lb = ctx.contacts()  # the list survives in the caller's ids and canonical order
+    assert all(np.array_equal(x, y) for x, y in zip(la[:3], lb[:3]))
+    assert (lb[3] == 0xFFFFFFFF).all()  # ... as a seed: no previous list
+    with pytest.raises(pkg.abi.DemeError):
+        ctx.calc_forces()  # a seed is not evaluated: detect first
+    with pytest.raises(pkg.abi.DemeError):
+        ctx.renew_order()  # the exact mode keeps the caller's order
+    back = ctx.download_state()
+    assert all(np.array_equal(back[k], st[k]) for k in KEYS)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st)
+    ctx.step(25), sim.step(25)
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert len(ga[0]) > 4000 and all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    g, o = ctx.download_state(), sim.download_state()
+    assert all(np.array_equal(g[k], o[k]) for k in KEYS), "exact mode after a restored order: states must be bit-identical to the oracle"
+    assert ctx.order_renewals() == 0 and not ctx.engine_order()[0]
+    # back in the fast mode the next lock-step detection reorders again
+    ctx.set_arith_mode("fast")
+    ctx.step(2)
+    assert ctx.engine_order()[0] and ctx.force_kernel()[0] == "k_tile_forces<0, false>", (ctx.engine_order(), ctx.force_kernel())
+    ctx.close()
+
+
+def test_a_renewed_order_leaves_a_seed_not_a_list(pkg, orc):
+    """deme_renew_order without a step behind it: the per-contact and per-sphere products of the last detection sit in the old slots,
+    so the re-keyed list is offered as a SEED only -- forces are refused, the history map reads 'no previous contact', contact records
+    and sphere geometry are refused -- until the next detection, after which everything agrees with the oracle again."""
+    b = _bed(pkg)
+    p, sc, st = _settled(pkg, b)
+    n = int(sc.nOwnerClumps)
+    perm = np.random.default_rng(29).permutation(n)
+    st2 = {k: v.copy() for k, v in st.items()}
+    for k in KEYS:
+        st2[k][:n] = st[k][:n][perm]
+    ctx = pkg.Context(0)
+    ctx.set_arith_mode("fast")
+    ctx.set_record_contacts(True)
+    ctx.set_params(p), ctx.upload_scene(sc), ctx.upload_state(st2)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state(st2)
+    ctx.step(3), sim.step(3)
+    la = ctx.contacts()
+    ctx.contact_records(), ctx.sphere_geometry()  # (fine before the renewal)
+    ctx.renew_order()
+    assert ctx.order_renewals() == 1
+    lb = ctx.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(la[:3], lb[:3])) and (lb[3] == 0xFFFFFFFF).all()
+    for refused in (ctx.calc_forces, ctx.contact_records, ctx.sphere_geometry):
+        with pytest.raises(pkg.abi.DemeError):
+            refused()
+    # accelerations added through the caller's ids land on the right slots after the renewal (one upload of the touched range)
+    acc = np.zeros((n, 3), np.float32)
+    acc[:, 2] = np.linspace(0.0, 1.0, n, dtype=np.float32)
+    ctx.add_owner_acc(0, acc)
+    sim.add_owner_acc(0, acc)
+    ctx.step(4), sim.step(4)
+    ga, oa = ctx.contacts(), sim.contacts()
+    assert all(np.array_equal(x, y) for x, y in zip(ga[:3], oa[:3]))
+    fr, gx = ctx.contact_records(), ctx.sphere_geometry()
+    ox = sim.sphere_geometry()
+    assert np.abs(gx[0] - ox[0]).max() <= 5e-8 and np.array_equal(gx[3], ox[3])  # (fast-mode positions; radii land on the caller's spheres)
+    g, o = ctx.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g) - _positions(pkg, p, o)).max()
+    dv = max(np.abs(g[k] - o[k]).max() for k in ("vX", "vY", "vZ"))
+    assert dx <= 5e-8 and dv <= 2e-4, (dx, dv)
+    ctx.close()
+
+
+def test_spheres_must_be_clump_major(pkg):
+    """the A / B roles of a pair follow the owner numbers, which is the reference's 'smaller sphere id first' only for clump-major
+    spheres with ascending owners: a scene that breaks the contract is refused at upload"""
+    b = pkg.model.packed_bed(400, seed=3, cd_freq=0)
+    p, sc = b.Initialize()
+    own = sc._keep["ownerClumpBody"]  # (the array the struct points at)
+    own[[0, len(own) - 1]] = own[[len(own) - 1, 0]]  # the first sphere now belongs to the last clump
+    ctx = pkg.Context(0)
+    ctx.set_params(p)
+    with pytest.raises(pkg.abi.DemeError, match="clump-major"):
+        ctx.upload_scene(sc)
+    ctx.close()

@@ -1,0 +1,113 @@
+"""The decomposition behind the C-ABI (csrc/deme_decomp.inc), on the GPU: deme_multi_* is what the C++ shell's DEMSolver(nGPUs /
+device ids) opens (reference: DEM/API.h:52-56, DEM/APIPublic.cpp:22-110 pick the devices in the constructor).  One GPU is available
+to the tests, so a deme_multi of ONE device is cut into several slabs: the same plan, contexts, exchange lists, migration books and
+step loop as one slab per device -- the records travel by RCCL sends to self."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_decomp import GKEYS, _sheared_bed, build_global
+
+pytestmark = pytest.mark.gpu
+
+
+def _bed(pkg, n=1600, seed=4, cd_freq=0):
+    b = pkg.model.packed_bed(n, seed=seed, cd_freq=cd_freq, spacing_mult=2.5, init_vz=-0.4, aspect=(2.0, 1.0, 0.5))
+    if cd_freq:
+        b.SetExpandSafetyAdder(0.5)
+    p, sc = b.Initialize()
+    return b, p, sc
+
+
+def _positions(pkg, p, st, n):
+    return pkg.model.decode_positions(st["voxelID"], st["locX"], st["locY"], st["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:n]
+
+
+@pytest.mark.parametrize("n_slabs,axis", [(2, -1), (4, 0), (3, 1)])
+def test_multi_slabs_equal_the_single_domain_oracle(pkg, orc, n_slabs, axis):
+    """exact arithmetic: the owner states gathered by GLOBAL id (deme_multi_download_state) after 60 steps with a detection every
+    7 are those of the oracle's single-domain run to fp32 summation order (a slab numbers its clumps its own way: 1e-9 m), the
+    union of the slabs' contact lists in global ids is the oracle's list, and the y-cut (axis 1) works like the x-cut"""
+    b, p, sc = _bed(pkg, cd_freq=7)
+    nc = int(sc.nOwnerClumps)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc, slabs_per_device=n_slabs, axis=axis, halo=0.03, arith="exact")
+    assert m.num_slabs() == n_slabs
+    sim = orc.make_sim(pkg, p, sc)
+    st0 = m.download_state()
+    so0 = sim.download_state()
+    assert all(np.array_equal(st0[k], so0[k]) for k in GKEYS)  # the gather by global id lands on the caller's rows
+    m.step(60), sim.step(60)
+    m.sync()
+    g, o = m.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g, nc) - _positions(pkg, p, o, nc)).max()
+    dv = max(np.abs(g[k][:nc] - o[k][:nc]).max() for k in ("vX", "vY", "vZ"))
+    assert dx < 1e-9 and dv < 1e-5, (dx, dv)
+    cnt, moved = m.counts()
+    assert int(cnt.nSteps) == 60 and int(cnt.nContacts) >= int(sim.counts().nContacts)  # (cross-cut contacts are on two lists)
+    # a state uploaded by global id reaches own clumps, ghost copies and replicated owners alike
+    m.upload_state({k: so0[k] for k in GKEYS})
+    back = m.download_state()
+    assert all(np.array_equal(back[k], so0[k]) for k in GKEYS)
+    for s in range(n_slabs):
+        c = m.slab_ctx(s)
+        assert c.n_owners > 0 and c.counts().nSteps == 60
+    m.close()
+
+
+def test_multi_migrates_a_drifting_bed(pkg, orc):
+    """a sheared bed in three library-made slabs with deme_multi_set_migration(50): clumps change slabs inside deme_multi_step, the
+    gather by global id follows them (the books come from the library), and the run stays on the oracle's single-domain trajectory
+    like the hand-attached slabs of tests/test_config2_slabs.py do"""
+    b, p, sc, x = _sheared_bed(pkg, 20_000, 6)
+    nc = int(sc.nOwnerClumps)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc, slabs_per_device=3, axis=0, halo=0.035, arith="exact")
+    m.set_migration(50)
+    sim = orc.make_sim(pkg, p, sc)
+    orc.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        m.step(151), sim.step(151)
+        m.sync()
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+    cnt, moved = m.counts()
+    assert moved > 20, moved
+    g, o = m.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g, nc) - _positions(pkg, p, o, nc)).max()
+    print(f"drifting bed in 3 library-made slabs, {moved} clumps migrated inside deme_multi_step: |dx| {dx:.3e} m vs the single-domain oracle")
+    assert dx < 1e-4
+    own = sum(m.slab_ctx(s).n_owners for s in range(3))
+    assert own > nc  # (own clumps + ghosts + replicated owners)
+    m.close()
+
+
+def test_multi_fast_mode_takes_the_tile_pass_per_slab(pkg, orc):
+    b, p, sc = _bed(pkg, n=6000, cd_freq=10)
+    nc = int(sc.nOwnerClumps)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc, slabs_per_device=2, axis=-1, halo=0.03, arith="fast")
+    sim = orc.make_sim(pkg, p, sc)
+    m.step(40), sim.step(40)
+    m.sync()
+    assert m.slab_ctx(0).force_kernel()[0] == "k_tile_forces<0, false>", m.slab_ctx(0).force_kernel()
+    g, o = m.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g, nc) - _positions(pkg, p, o, nc)).max()
+    dv = max(np.abs(g[k][:nc] - o[k][:nc]).max() for k in ("vX", "vY", "vZ"))
+    assert dx < 5e-8 and dv < 1e-3, (dx, dv)
+    m.close()
+
+
+def test_multi_of_one_slab_is_a_plain_context(pkg, orc):
+    b, p, sc = _bed(pkg)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc, slabs_per_device=1, arith="exact")
+    sim = orc.make_sim(pkg, p, sc)
+    m.step(20), sim.step(20)
+    m.sync()
+    g, o = m.download_state(), sim.download_state()
+    assert all(np.array_equal(g[k], o[k]) for k in GKEYS)
+    with pytest.raises(pkg.abi.DemeError, match="device id 99 is not present"):
+        pkg.abi.Multi(devices=(0, 99))
+    m.close()
