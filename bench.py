@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
+GUIDE_COPY_GBS = 6290.0  # ... its measured float4 copy
 README_CLUMP_STEPS_PER_S = 1e6 * 1e6 / 3600.0  # reference README.md:48, two RTX 3080 ("around 1 hour")
 HALO = 0.03  # ghost layer thickness [m]: two lattice spacings (clump reach 7.3 mm)
 
@@ -832,10 +833,13 @@ def main():
     if halo:
         par += (", overlapped with the interior force evaluation on a second stream" if halo.overlap else "")
         par += f", ghost exchange every step over {'gloo via host memory (PLUMBING TEST, not a measurement)' if via_host else 'RCCL'} ({halo.bytes_per_step} B sent per step by rank 0)"
+    # the attainable HBM rate of THIS box beside the nominal 8 TB/s -- the library's own 16 B / lane streaming copy kernel
+    # (deme_copy_rate_probe; 1 GiB each way, beyond the 256 MiB Infinity Cache); the guide's figure for such a copy is 6.29 TB/s.
+    # (Round 4 used torch's device-to-device copy here, which reaches 4.7-5.4 TB/s: a fraction of THAT flattered the kernel.)
     copy_gbs = None
     if rank == 0:
         try:
-            copy_gbs = attainable_copy_gbs(torch)
+            copy_gbs = pkg.abi.copy_rate_probe(local_rank)
         except Exception as e:  # (a box short of 2 GiB of free HBM)
             print(f"[bench] attainable-rate probe skipped: {e}", file=sys.stderr)
     halo_loop = "library" if group is not None else ("python" if halo is not None else None)
@@ -877,7 +881,9 @@ def main():
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
         "roofline": {"kernel": fk_name + (" (hipRTC)" if (args.config5 or args.custom_model) else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "attainable_copy_GBs": copy_gbs, "frac_of_attainable": (achieved / copy_gbs if copy_gbs else None),
+                     "attainable_copy_GBs": copy_gbs, "attainable_copy_kernel": "k_copy16 (libdeme_hip: 16 B / lane, 1 GiB read + 1 GiB written)",
+                     "guide_copy_GBs": GUIDE_COPY_GBS, "frac_of_attainable": (achieved / copy_gbs if copy_gbs else None),
+                     "frac_of_guide_copy": achieved / GUIDE_COPY_GBS,
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),
                      "fused_step": ({"what": "contact forces + accumulation + integration in one kernel (closed owner tiles)",
                                      "force_pass_bytes": force_only_bytes, "integration_write_back_bytes": 54 * int(sc.nOwners),

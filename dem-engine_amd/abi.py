@@ -433,6 +433,17 @@ class DecompPlan:
             pass
 
 
+def copy_rate_probe(device=0, nbytes=1 << 30, reps=5):
+    """GB/s (read + written) of the library's own 16 B / lane streaming copy kernel: the attainable HBM rate of the box"""
+    lib = load_library()
+    v = C.c_double(0)
+    lib.deme_copy_rate_probe.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    rc = lib.deme_copy_rate_probe(int(device), int(nbytes), int(reps), C.byref(v))
+    if rc != 0:
+        raise DemeError(f"deme_copy_rate_probe failed (status {rc})")
+    return float(v.value)
+
+
 def device_count():
     lib = load_library()
     n = C.c_int(0)
@@ -653,7 +664,7 @@ class Context:
     def set_fused_step(self, on):
         """the one-kernel step (k_tile_step<M>, deme_tile_step.h); off by default: deme_set_fused_step"""
         self.lib.deme_set_fused_step.argtypes = [_P, C.c_int]
-        self._ck(self.lib.deme_set_fused_step(self.h, 1 if on else 0), "deme_set_fused_step")
+        self._ck(self.lib.deme_set_fused_step(self.h, 2 if on == "auto" else (1 if on else 0)), "deme_set_fused_step")
 
     def engine_order(self):
         """(reordered, spread in the caller's order, spread along the curve): deme_get_order"""

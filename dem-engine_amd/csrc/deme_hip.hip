@@ -100,6 +100,7 @@ struct deme_ctx {
     int tileEnable = 1;       // DEME_TILE=0 keeps the round-2 kernels (A/B measurements)
     // the whole step in one kernel (deme_tile_step.h): closed tiles -- a contact that straddles two tiles is evaluated by both --
     // integrate their own owners; owners and history are double-buffered
+#define DEME_FUSED_AUTO_MAX_OWNERS 100000u  // deme_set_fused_step(ctx, 2): the one-kernel step where it was measured faster (header)
     int fusedEnable = 0;          // deme_set_fused_step / DEME_FUSED=1: the one-kernel step (measured slower on the packed bed: DESIGN 3.7)
     bool fusedList = false;       // the current list has the incoming structures (decided per detection)
     bool fusedChecked = false;    // ... and the device has been asked whether every closed tile fits
@@ -943,7 +944,8 @@ int detect_part2(deme_ctx* c, uint64_t nC) {
                 // closed tiles (deme_tile_step.h): the contacts that hold a tile's owners as B from other tiles, in the tile's frame
                 static const int fusedEnv = getenv("DEME_FUSED") ? atoi(getenv("DEME_FUSED")) : -1;  // (1 / 0 override the context's switch)
                 c->fusedList = false;
-                if ((fusedEnv < 0 ? c->fusedEnable : fusedEnv) && hr.nBig == 0 && c->hp.forceModel != DEME_FORCE_CUSTOM && !c->record && c->nTri == 0 &&
+                const int fusedMode = fusedEnv < 0 ? c->fusedEnable : fusedEnv;  // 0 off, 1 on, 2 by the size of the bed
+                if ((fusedMode == 2 ? c->nOwners <= DEME_FUSED_AUTO_MAX_OWNERS : fusedMode != 0) && hr.nBig == 0 && c->hp.forceModel != DEME_FORCE_CUSTOM && !c->record && c->nTri == 0 &&
                     !c->hasGhosts && !c->prescFn && !c->rulesFn && c->hShared.empty() && c->asyncLead == 0 && !c->listOwnersSnap &&
                     !c->ad.autoBinSize && !c->ad.autoUpdateFreq) {
                     hipLaunchKernelGGL(k_in_count, dim3(grid_for((size_t)c->nOwners + 1)), dim3(256), 0, c->stream, c->dp, list_owners(c),
@@ -1648,7 +1650,7 @@ int deme_set_tile_policy(deme_ctx* c, uint32_t minContactsPerTileCustom) {
 int deme_set_fused_step(deme_ctx* c, int on) {
     if (!c)
         return DEME_ERR_INVALID;
-    c->fusedEnable = on ? 1 : 0;
+    c->fusedEnable = on == 2 ? 2 : (on ? 1 : 0);
     c->listStale = true;
     return DEME_OK;
 }

@@ -75,6 +75,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // a register pair: += c
 __device__ inline void ki_opaque(float& v) { asm volatile("" : "+v"(v)); }
 __device__ inline void ki_opaque(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ inline void ki_sink(float v) { asm volatile("" ::"v"(v)); }
+__device__ inline void ki_sink(uint32_t v) { asm volatile("" ::"v"(v)); }
 
 // tInfo.x: slot of A (10) | slot of B (10) | class (2) | B lives in another tile: write a record (1) | 1 spare | material of A (4) |
 //          material of B (4);  tInfo.y: component of A (16) | component of B or analytical-object index (16)
@@ -495,6 +496,15 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
                                // loop without refills: no load is in flight there, so the rotation of the stream registers waits for nothing --
                                // in the refilling loop the compiler's s_waitcnt vmcnt(0) in front of the rotation also drains the round's STORES
 #endif
+#ifndef DEME_TILE_PRIO_ROUNDS
+#define DEME_TILE_PRIO_ROUNDS 0  // wavefront priority of the rounds (the prologue runs at DEME_TILE_PRIO)
+#endif
+#ifndef DEME_TILE_PRIO_PULL
+#define DEME_TILE_PRIO_PULL 0  // > 0: wavefront priority between a round's two barriers (the pulls: the whole workgroup waits for them)
+#endif
+#ifndef DEME_TILE_NOZERO
+#define DEME_TILE_NOZERO 1  // 1: no zero defaults for values that are only read where they were set (refilled stream stages, crossing records)
+#endif
 #ifndef DEME_TILE_PRIO
 #define DEME_TILE_PRIO 0  // > 0: wavefront priority of the prologue (ids -> records -> staging); the rounds run at 0
 #endif
@@ -635,6 +645,8 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         rec0 = load_owner(a.owners, id0);
     if (h1 < nH)
         rec1 = load_owner(a.owners, id1);
+    // (the touches go out with the foreign records -- the second level of this tile's own chain: they come back with them, and
+    // nothing in front of the rounds waits for a load of its own)
     if (tid < nTab16)
         tabBase[tid] = tab16;
     if (tid < a.nMass)
@@ -669,9 +681,10 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 sLPos[tid + k * DEME_TILE_T] = (uint16_t)lp[k];
     }
     __syncthreads();
-#if DEME_TILE_PRIO
-    __builtin_amdgcn_s_setprio(0);
+#if DEME_TILE_PRIO || DEME_TILE_PRIO_ROUNDS
+    __builtin_amdgcn_s_setprio(DEME_TILE_PRIO_ROUNDS);
 #endif
+
     // the pulling side of this thread: threads 0 .. NB - 1 take the A runs, NB .. 2 NB - 1 the local-B lists
     const uint32_t po = tid % DEME_TILE_NB;
     const bool sideA = tid < DEME_TILE_NB, sideB = !sideA && tid < 2 * DEME_TILE_NB;
@@ -683,10 +696,12 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const uint32_t nCt = c1 - c0;
     auto refill = [&](const int d, const uint32_t c) __attribute__((always_inline)) {  // stage d takes the round DEME_TILE_DEPTH rounds ahead of contact c
         const uint32_t cd = c + DEME_TILE_DEPTH * DEME_TILE_T;
+#if !DEME_TILE_NOZERO
         inf[d] = make_uint2(0, 0), hist[d] = make_float4(0, 0, 0, 0), rbase[d] = 0u;
 #pragma unroll
         for (int k = 0; k < NWU; k++)
             uwv[d][k] = 0.f;
+#endif
         if (cd < c1) {
             inf[d] = stream_load(a.tInfo + cd);
             if (MODEL == 0)
@@ -702,7 +717,11 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     auto round = [&](auto RF, const int d, const uint32_t rlo) __attribute__((always_inline)) {
             const uint32_t c = c0 + rlo + tid;
             bool crossing = false;
+#if DEME_TILE_NOZERO
+            float4 x4, x2;  // (read only where `crossing` was set)
+#else
             float4 x4 = make_float4(0, 0, 0, 0), x2 = x4;
+#endif
             if (c < c1) {
                 const uint2 ci = inf[d];
                 float4 h = hist[d];
@@ -796,6 +815,9 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
 #endif
 
             __syncthreads();
+#if DEME_TILE_PRIO_PULL
+            __builtin_amdgcn_s_setprio(DEME_TILE_PRIO_PULL);
+#endif
             const uint32_t rhi = rlo + DEME_TILE_T;
             auto pulls = [&]() {
                 if (sideA) {  // my A run's part of this round: positions [plo, min(phi, rhi)); a missing entry reads the zero slot
@@ -883,6 +905,9 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             }
 #endif
             pulls();
+#if DEME_TILE_PRIO_PULL
+            __builtin_amdgcn_s_setprio(DEME_TILE_PRIO_ROUNDS);
+#endif
             __syncthreads();
     };
 #if DEME_TILE_UNROLL

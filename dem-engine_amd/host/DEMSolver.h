@@ -1693,9 +1693,14 @@ class DEMSolver {
         m_devices = ids;
         if (const char* e = std::getenv("DEME_SLABS_PER_DEVICE"))
             m_slabs_per_device = (unsigned)std::max(1, atoi(e));
+        if (const char* e = std::getenv("DEME_SLAB_MIGRATE_EVERY"))  // (SetSlabMigrationInterval)
+            m_migrate_every = (unsigned)std::max(0, atoi(e));
+        if (const char* e = std::getenv("DEME_SLAB_HALO"))  // ghost layer thickness [m] of an unchanged script (SetSlabHalo)
+            m_slab_halo = (float)atof(e);
         if (ids.size() == 1) {  // (a decomposed run on one device opens its deme_multi at Initialize, when the slab count is final)
             if (deme_ctx_create(ids[0], &m_ctx) != DEME_OK)
                 throw std::runtime_error("DEMSolver: no usable HIP device");
+            deme_set_fused_step(m_ctx, 2);  // small beds (<= 1e5 owners) step in one launch where the scene allows it (include/deme_hip.h)
         } else {
             char err[512];
             if (deme_multi_create(ids.data(), (int)ids.size(), &m_multi, err, sizeof err) != DEME_OK)

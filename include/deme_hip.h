@@ -212,7 +212,10 @@ int deme_force_kernel_name(const deme_ctx* ctx, char* name, size_t cap, uint32_t
  * configs[1] the closed tiles stage ~220 foreign owners instead of ~95 and evaluate 1.2x the contacts, and the one launch
  * (143 us) is slower than force pass + integrator (92 + 43 us) -- DESIGN.md 3.7.  Built-in models, FAST arithmetic, no mesh,
  * no ghosts, no prescription / family-rule kernels, no recording; anything else keeps the two-kernel form silently.
- * Environment DEME_FUSED=1 / 0 overrides the switch for every context of the process. */
+ * Where it pays (round 5, profiles/r05/fused_small_beds.txt): beds whose step is two short launches -- 10^4 clumps 0.0258 -> 0.0192
+ * ms/step (-26 %), 5x10^4 0.0373 -> 0.0306 (-18 %); at 2x10^5 the closed tiles no longer fit and the two-kernel form runs anyway.
+ * on = 2: by size -- the one-kernel step for scenes of at most 10^5 owners (what the C++ shell asks for), the two kernels beyond.
+ * Environment DEME_FUSED=2 / 1 / 0 overrides the switch for every context of the process. */
 int deme_set_fused_step(deme_ctx* ctx, int on);
 
 /* The engine's own numbering (csrc/deme_order.inc).  Owner and sphere ids at this boundary are ALWAYS the caller's -- load order,
@@ -582,6 +585,9 @@ int deme_multi_upload_state(deme_multi* m, const DemeOwnerState* global, uint32_
 int deme_multi_counts(deme_multi* m, DemeCounts* sum, uint64_t* clumpsMigrated);
 /* the visible HIP devices (0 and DEME_OK where there is none: what the constructors check ids against) */
 int deme_device_count(int* n);
+/* Measurement aid (quote the attainable rate beside the nominal 8 TB/s): a hand-written 16 B / lane streaming copy of
+ * `bytes` (choose well beyond the 256 MiB Infinity Cache), best of `reps` timings, read + written bytes per second in GB/s. */
+int deme_copy_rate_probe(int device, size_t bytes, int reps, double* GBs);
 /* {owners, clump owners, spheres, contact wildcards} of the scene a context holds (a slab's change when clumps migrate) */
 int deme_scene_sizes(const deme_ctx* ctx, uint32_t out[4]);
 
