@@ -373,7 +373,7 @@ class DecompPlan:
     keeps pointers into the scene's arrays while it is built only; a slab's scene points into the plan (keep the plan alive while
     a slab scene is in use)."""
 
-    def __init__(self, params, scene, n_slabs, axis=-1, halo=0.0, edges=None, shared_free=False, snap=True):
+    def __init__(self, params, scene, n_slabs, axis=-1, halo=0.0, edges=None, shared_free=False, snap=True, spatial_order=False):
         self.lib = load_library()
         L = self.lib
         L.deme_decomp_create.argtypes = [C.POINTER(DemeParams), C.POINTER(DemeScene), C.c_uint32, C.c_int, C.c_double, _P, C.c_uint32,
@@ -386,7 +386,7 @@ class DecompPlan:
         h = _P()
         err = C.create_string_buffer(1024)
         e = None if edges is None else np.ascontiguousarray(edges, np.float64)
-        flags = (1 if shared_free else 0) | (0 if snap else 2)
+        flags = (1 if shared_free else 0) | (0 if snap else 2) | (4 if spatial_order else 0)
         rc = L.deme_decomp_create(C.byref(params), C.byref(scene), int(n_slabs), int(axis), float(halo), None if e is None else _ptr(e),
                                   flags, C.byref(h), err, len(err))
         if rc != 0:
@@ -488,10 +488,10 @@ class Multi:
             msg = self.lib.deme_multi_last_error(self.h)
             raise DemeError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
 
-    def build(self, params, scene, slabs_per_device=1, axis=-1, halo=0.0, shared_free=False, arith=None, flip_mask=7):
+    def build(self, params, scene, slabs_per_device=1, axis=-1, halo=0.0, shared_free=False, arith=None, flip_mask=7, caller_order=False):
         a = -1 if arith is None else {"fast": 1, "exact": 0}.get(arith, arith)
         self._ck(self.lib.deme_multi_build(self.h, C.byref(params), C.byref(scene), int(slabs_per_device), int(axis), float(halo),
-                                           1 if shared_free else 0, int(a), int(flip_mask)), "deme_multi_build")
+                                           (1 if shared_free else 0) | (8 if caller_order else 0), int(a), int(flip_mask)), "deme_multi_build")
         self.n_owners = int(scene.nOwners)
 
     def num_slabs(self):

@@ -137,12 +137,13 @@ def decompose(arrays, counts, clump_x, n_ranks, halo, shared_free=False, edges=N
     return out
 
 
-def decompose_lib(params, scene, n_ranks, halo, axis=0, edges=None, shared_free=False, snap=False):
+def decompose_lib(params, scene, n_ranks, halo, axis=0, edges=None, shared_free=False, snap=False, spatial_order=False):
     """The same decomposition computed by the LIBRARY (deme_decomp_create: what a C++ host calls; DEMSolver(nGPUs) goes through it).
     Returns (plan, parts) with parts[r] holding the keys of decompose() that the halo group and the migration books read: scene,
     counts, n_own, global_ids, ghost_left_g / ghost_right_g, owner_global, sphere_global, send / recv lists, edges.  Keep `plan`
     alive while a slab scene is in use (its arrays belong to the plan)."""
-    plan = abi.DecompPlan(params, scene, n_ranks, axis=axis, halo=halo, edges=edges, shared_free=shared_free, snap=snap)
+    plan = abi.DecompPlan(params, scene, n_ranks, axis=axis, halo=halo, edges=edges, shared_free=shared_free, snap=snap,
+                          spatial_order=spatial_order)
     parts = []
     for r in range(n_ranks):
         q = plan.slab(r)

@@ -532,6 +532,11 @@ int deme_halo_group_set_cross_contacts(deme_halo_group* g, int evaluateOnce);
  * dem-engine_amd/decomp.py states in numpy (the CPU tests hold the two against each other). */
 #define DEME_DECOMP_SHARED_FREE 1u /* allow replicated owners that move under contact forces (DemeScene.ownerGhost = 2) */
 #define DEME_DECOMP_NO_SNAP 2u     /* keep the equal-count boundaries where the quantiles put them (not snapped to bin faces) */
+#define DEME_DECOMP_SPATIAL_ORDER 4u /* number every slab's own clumps in the engine's own order (compact owner tiles, csrc/deme_order.inc;
+                                      * ghosts follow their owner slab's order) instead of by ascending global id: a scene with ghosts keeps
+                                      * the order it is uploaded in, so this is what gives a slab of a sampler-ordered bed its tiles.
+                                      * deme_multi_build sets it unless DEME_DECOMP_CALLER_ORDER is given */
+#define DEME_DECOMP_CALLER_ORDER 8u
 typedef struct deme_decomp deme_decomp;
 int deme_decomp_create(const DemeParams* p, const DemeScene* scene, uint32_t nSlabs, int axis, double halo, const double* edges, uint32_t flags,
                        deme_decomp** out, char* err, size_t errCap);

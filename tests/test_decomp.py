@@ -747,3 +747,38 @@ def test_multi_refuses_absent_devices(pkg):
         pkg.abi.Multi(devices=(n + 3,))
     with pytest.raises(pkg.abi.DemeError, match="at least one device"):
         pkg.abi.Multi(devices=())
+
+
+def test_library_decomposition_in_the_engines_order(pkg):
+    """DEME_DECOMP_SPATIAL_ORDER (what deme_multi_build asks for): the same slabs -- owners, ghosts, boundaries -- with every slab's own
+    clumps numbered along the engine's own order instead of by global id; ghosts follow their owner slab's order, so the exchange lists
+    still name the same clumps in the same order on both sides and the sender's list ascends.  On a bed handed over in random order
+    the owner tiles of a slab (128 consecutive clumps) become compact."""
+    b = pkg.model.packed_bed(6000, seed=5, cd_freq=0, spacing_mult=3.0, init_vz=-1.0, aspect=(2.0, 1.0, 0.25), order="random")
+    p, sc = b.Initialize()
+    plan0, ref = pkg.decomp.decompose_lib(p, sc, 3, 0.03, axis=0)
+    plan1, got = pkg.decomp.decompose_lib(p, sc, 3, 0.03, axis=0, spatial_order=True)
+    assert np.array_equal(plan0.edges, plan1.edges)
+    X = pkg.model.decode_positions(b.arrays["voxelID"], b.arrays["locX"], b.arrays["locY"], b.arrays["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+
+    def tile_extent(gids):  # mean bounding-box diagonal of the 128-clump tiles
+        ext = []
+        for k in range(0, len(gids) - 127, 128):
+            q = X[gids[k:k + 128]]
+            ext.append(np.linalg.norm(q.max(0) - q.min(0)))
+        return float(np.mean(ext))
+    for r, (a, q) in enumerate(zip(ref, got)):
+        for k in ("global_ids", "ghost_left_g", "ghost_right_g"):
+            assert np.array_equal(np.sort(a[k]), np.sort(q[k])), (r, k)  # the same clumps ...
+        assert not np.array_equal(a["global_ids"], q["global_ids"])      # ... in another order
+        assert tile_extent(q["global_ids"]) < 0.5 * tile_extent(a["global_ids"]), (tile_extent(q["global_ids"]), tile_extent(a["global_ids"]))
+        assert (np.diff(q["send_left"].astype(np.int64)) > 0).all() and (np.diff(q["send_right"].astype(np.int64)) > 0).all()
+        if r + 1 < len(got):
+            nb = got[r + 1]
+            assert np.array_equal(q["global_ids"][q["send_right"]], nb["ghost_left_g"])
+            assert np.array_equal(nb["global_ids"][nb["send_left"]], q["ghost_right_g"])
+        sc1 = q["scene"]
+        own = _scene_arrays(sc1, "ownerClumpBody", np.uint32, sc1.nSpheres)
+        assert (np.diff(own.astype(np.int64)) >= 0).all()  # spheres stay clump-major in the slab's numbering
+        vid = _scene_arrays(sc1, "voxelID", np.uint64, sc1.nOwners)
+        assert np.array_equal(vid, b.arrays["voxelID"][q["owner_global"]])

@@ -27,7 +27,7 @@ def _positions(pkg, p, st, n):
 @pytest.mark.parametrize("n_slabs,axis", [(2, -1), (4, 0), (3, 1)])
 def test_multi_slabs_equal_the_single_domain_oracle(pkg, orc, n_slabs, axis):
     """exact arithmetic: the owner states gathered by GLOBAL id (deme_multi_download_state) after 60 steps with a detection every
-    7 are those of the oracle's single-domain run to fp32 summation order (a slab numbers its clumps its own way: 1e-9 m), the
+    7 are those of the oracle's single-domain run to fp32 summation order (a slab numbers its clumps its own way: 5e-9 m), the
     union of the slabs' contact lists in global ids is the oracle's list, and the y-cut (axis 1) works like the x-cut"""
     b, p, sc = _bed(pkg, cd_freq=7)
     nc = int(sc.nOwnerClumps)
@@ -43,7 +43,7 @@ def test_multi_slabs_equal_the_single_domain_oracle(pkg, orc, n_slabs, axis):
     g, o = m.download_state(), sim.download_state()
     dx = np.abs(_positions(pkg, p, g, nc) - _positions(pkg, p, o, nc)).max()
     dv = max(np.abs(g[k][:nc] - o[k][:nc]).max() for k in ("vX", "vY", "vZ"))
-    assert dx < 1e-9 and dv < 1e-5, (dx, dv)
+    assert dx < 5e-9 and dv < 1e-4, (dx, dv)  # (measured 1.3e-9 m / 1.6e-5 m/s: a slab numbers its clumps in the engine's order)
     cnt, moved = m.counts()
     assert int(cnt.nSteps) == 60 and int(cnt.nContacts) >= int(sim.counts().nContacts)  # (cross-cut contacts are on two lists)
     # a state uploaded by global id reaches own clumps, ghost copies and replicated owners alike
@@ -111,3 +111,35 @@ def test_multi_of_one_slab_is_a_plain_context(pkg, orc):
     with pytest.raises(pkg.abi.DemeError, match="device id 99 is not present"):
         pkg.abi.Multi(devices=(0, 99))
     m.close()
+
+
+def test_multi_gives_the_slabs_of_a_random_order_bed_the_engines_order(pkg, orc):
+    """a bed handed over in random order (the reference's ids are load order, DEM/dT.cpp:700-800) cut into three slabs: a scene with
+    ghosts keeps the order it is uploaded in, so deme_multi_build numbers every slab's clumps along the engine's own order
+    (DEME_DECOMP_SPATIAL_ORDER) -- the owner-tile pass then evaluates every tile of every slab itself, where the caller's order sends
+    most of them through the per-tile fallback; both runs sit on the oracle's single-domain trajectory within the fast mode's bounds"""
+    b = pkg.model.packed_bed(9000, seed=5, cd_freq=10, spacing_mult=3.0, init_vz=-1.0, aspect=(2.0, 1.0, 0.25), order="random")
+    b.SetExpandSafetyAdder(0.5)
+    p, sc = b.Initialize()
+    nc = int(sc.nOwnerClumps)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.step(40)
+    o = sim.download_state()
+    big = {}
+    for caller_order in (False, True):
+        m = pkg.abi.Multi(devices=(0,))
+        m.build(p, sc, slabs_per_device=3, axis=0, halo=0.03, arith="fast", caller_order=caller_order)
+        m.step(40)
+        m.sync()
+        stats = [m.slab_ctx(s).tile_stats() for s in range(3)]
+        assert all(m.slab_ctx(s).force_kernel()[0] == "k_tile_forces<0, false>" for s in range(3))
+        big[caller_order] = (sum(t[1] for t in stats), sum(t[0] for t in stats), max(t[2] for t in stats))
+        g = m.download_state()
+        dx = np.abs(_positions(pkg, p, g, nc) - _positions(pkg, p, o, nc)).max()
+        dv = max(np.abs(g[k][:nc] - o[k][:nc]).max() for k in ("vX", "vY", "vZ"))
+        assert dx < 5e-8 and dv < 1e-3, (caller_order, dx, dv)
+        m.close()
+    print(f"(tiles through the per-tile fallback, tiles, largest halo): engine order {big[False]}, caller's random order {big[True]}")
+    # (the bed is still loose after 40 steps -- few contacts per tile, so even the random numbering's tiles fit; the foreign owners a
+    # tile stages tell the two numberings apart)
+    assert big[False][0] == 0 and big[False][2] < 0.6 * big[True][2]
