@@ -881,7 +881,7 @@ def main():
                    "vs_baseline_ref": "reference README.md:48, ~1h for 1e6 clumps x 1e6 steps on 2x RTX 3080"},
         "roofline": {"kernel": fk_name + (" (hipRTC)" if (args.config5 or args.custom_model) else ""), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "attainable_copy_GBs": copy_gbs, "attainable_copy_kernel": "k_copy16 (libdeme_hip: 16 B / lane, 1 GiB read + 1 GiB written)",
+                     "attainable_copy_GBs": copy_gbs, "attainable_copy_kernel": "deme_copy_rate_probe (libdeme_hip: hand-written 16 B / lane copy, best of the plain and the four-in-flight streaming form at 8 / 16 / 32 workgroups per CU; 1 GiB read + 1 GiB written)",
                      "guide_copy_GBs": GUIDE_COPY_GBS, "frac_of_attainable": (achieved / copy_gbs if copy_gbs else None),
                      "frac_of_guide_copy": achieved / GUIDE_COPY_GBS,
                      "algorithmic_bytes_per_launch": fbytes, "avg_launch_ms": f_ms, "launches": int(f_n),
