@@ -40,3 +40,14 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "elementwise.npz"))
 
 
+
+
+def record_measured(test, **values):
+    """the achieved figures of a tolerance-bounded comparison, kept where the judge can read them: appended to
+    gpurun_out/measured_errors.txt on the box the GPU suite runs on (copied to profiles/<round>/ with the round's other records)"""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "measured_errors.txt"), "a") as f:
+            f.write(test + ": " + ", ".join(f"{k} {v:.4g}" if isinstance(v, float) else f"{k} {v}" for k, v in values.items()) + "\n")
+    except OSError:
+        pass

@@ -4,6 +4,8 @@ every listed pair really within reach, every sampled sphere's neighbourhood comp
 import numpy as np
 import pytest
 
+from tests.conftest import record_measured
+
 N = 1_000_000
 
 
@@ -187,14 +189,18 @@ def test_full_size_fast_mode_matches_oracle(pkg, orc, big):
         Y = pkg.model.decode_positions(o["voxelID"], o["locX"], o["locY"], o["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
         dx = float(np.abs(X - Y).max())
         dv = max(float(np.abs(g[k] - o[k]).max()) for k in ("vX", "vY", "vZ"))
-        assert dx <= 5e-8, f"fast mode at 1e6 clumps: positions differ by {dx} m from the oracle after 100 steps"
-        assert dv <= 2e-4, f"fast mode at 1e6 clumps: velocities differ by {dv} m/s"
+        print(f"fast mode at 1e6 clumps, 100 steps (3 detections) vs the oracle: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
+        record_measured("test_full_size fast mode 1e6 clumps 100 steps", dx_m=dx, dv_m_per_s=dv)
+        # (measured 1.2e-9 m, 1.1e-5 m/s, no pair in one list only: profiles/r05/measured_errors.txt; round 4 allowed 5e-8 / 2e-4 / 3)
+        assert dx <= 5e-9, f"fast mode at 1e6 clumps: positions differ by {dx} m from the oracle after 100 steps"
+        assert dv <= 5e-5, f"fast mode at 1e6 clumps: velocities differ by {dv} m/s"
         ga, gb, gt, _ = fast.contacts()
         oa, ob, ot, _ = sim.contacts()
         kg = (ga.astype(np.uint64) << np.uint64(34)) | (gt.astype(np.uint64) << np.uint64(31)) | gb.astype(np.uint64)
         ko = (oa.astype(np.uint64) << np.uint64(34)) | (ot.astype(np.uint64) << np.uint64(31)) | ob.astype(np.uint64)
         diff = np.setxor1d(kg, ko)
-        assert len(ga) > 3_000_000 and len(diff) <= 3, f"{len(diff)} pairs are in one list only"
+        record_measured("test_full_size fast mode 1e6 clumps list", pairs=len(ga), pairs_in_one_list_only=len(diff))
+        assert len(ga) > 3_000_000 and len(diff) <= 1, f"{len(diff)} pairs are in one list only"
     finally:
         orc.set_num_threads(min(8, os.cpu_count() or 1))
         fast.close()
@@ -236,7 +242,8 @@ def test_full_size_tile_pass_one_launch_matches_oracle(pkg, orc, big):
             scale = np.abs(O).max()
             err = np.abs(G - O).max()
             print(f"1e6 clumps, one tile-pass launch, {ks[0][:-1]}: max |fast - oracle| / max |oracle| = {err / scale:.3e}")
-            assert scale > 0 and err <= 2e-4 * scale, (ks, err / scale)
+            record_measured("test_full_size 1e6 clumps one tile-pass launch " + ks[0][:-1], rel_err=float(err / scale))
+            assert scale > 0 and err <= 3e-6 * scale, (ks, err / scale)  # (measured 1.0e-7 / 5.7e-7; round 4 allowed 2e-4)
         for w in range(4):
             gw, ow = fast.wildcard(w), sim.wildcard(w)
             assert np.abs(gw - ow).max() <= 1e-5 * max(np.abs(ow).max(), 1e-12) + 1e-12, w
@@ -291,7 +298,8 @@ def test_full_size_row_major_bed_is_tiled_either_way(pkg):
     dx = float(np.abs(X - Y).max())
     dv = max(float(np.abs(sa[k] - s2[k]).max()) for k in ("vX", "vY", "vZ"))
     print(f"row-major 1e6 bed: engine order ({tiles} tiles, none through the fallback) vs caller's order ({nbig_t} of {tiles_t} through it): |dx| {dx:.3e} m, |dv| {dv:.3e} m/s")
-    assert dx <= 5e-8 and dv <= 2e-4
+    record_measured("test_full_size row-major 1e6 bed engine order vs caller's order", dx_m=dx, dv_m_per_s=dv)
+    assert dx <= 2e-9 and dv <= 5e-5  # (measured 2.6e-10 m, 4.9e-6 m/s: profiles/r05/measured_errors.txt)
     a.close(), t.close()
 
 
@@ -385,7 +393,8 @@ def test_mesh_flavour_at_scale_fast_mode_matches_oracle(pkg, orc):
         dx = float(np.abs(X - Y).max())
         dv = max(float(np.abs(g[k] - o[k]).max()) for k in ("vX", "vY", "vZ"))
         print(f"fast mode, 3e5 clumps on a 30k-triangle plate, 100 steps: |dx| {dx:.3e} m, |dv| {dv:.3e} m/s vs the oracle")
-        assert dx <= 5e-8 and dv <= 2e-4, (dx, dv)
+        record_measured("test_full_size fast mode 3e5 clumps on a 30k-triangle plate 100 steps", dx_m=dx, dv_m_per_s=dv)
+        assert dx <= 1e-8 and dv <= 1e-4, (dx, dv)  # (measured 1.3e-9 m, 1.0e-5 m/s)
         ga, gb, gt, _ = fast.contacts()
         oa, ob, ot, _ = sim.contacts()
         kg = (ga.astype(np.uint64) << np.uint64(34)) | (gt.astype(np.uint64) << np.uint64(31)) | gb.astype(np.uint64)
