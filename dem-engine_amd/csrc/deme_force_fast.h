@@ -61,6 +61,11 @@ __device__ inline f3 faxpy(float s, f3 a, f3 b) { return mk3(s * a.x + b.x, s * 
 #ifndef DEME_FAST_NT
 #define DEME_FAST_NT 1
 #endif
+#ifndef DEME_REC24
+#define DEME_REC24 1  // 1: the tile sums and the crossing contacts' records are 24 bytes (six floats as three 8-byte pieces) instead of
+                      // two 16-byte pieces with two unused floats: -22 MB written by the force pass and -22 MB read by the integrator at
+                      // 1e6 clumps (the integrator moves its bytes at the copy rate; the force pass answers to bytes with ~0.3)
+#endif
 typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int nt_u2 __attribute__((ext_vector_type(2)));
 template <typename T>

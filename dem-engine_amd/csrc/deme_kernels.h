@@ -865,8 +865,14 @@ struct GatherArgs {
 // one B-side record for the per-owner gather: by contact index from the two per-contact arrays, or (tile form) by record number
 __device__ inline void gather_b_load(const GatherArgs& g, uint32_t idx, float4& c4, float2& c2) {
     if (g.tile) {
+#if DEME_REC24
+        const float2* r24 = reinterpret_cast<const float2*>(g.rec32) + 3 * (size_t)idx;  // deme_tile.h: 24-byte records
+        const float2 r0 = r24[0], r1 = r24[1];
+        c4 = make_float4(r0.x, r0.y, r1.x, r1.y), c2 = r24[2];
+#else
         const float4 r0 = g.rec32[2 * (size_t)idx], r1 = g.rec32[2 * (size_t)idx + 1];
         c4 = r0, c2 = make_float2(r1.x, r1.y);
+#endif
     } else {
         conb_load(g.conB4, g.conB2, idx, c4, c2);
     }
@@ -886,6 +892,14 @@ __device__ inline void acc_from_world(const DevParams& p, const OwnerRec& r, flo
 // same in-order sum over the per-contact records (loads issued four at a time).
 __device__ inline void a_side_sum(const GatherArgs& g, uint32_t o, uint32_t s, uint32_t e, float& ax, float& ay, float& az,
                                   float& lx, float& ly, float& lz) {
+#if DEME_REC24
+    if (g.tile) {  // the tile pass leaves six floats per owner (deme_tile.h)
+        const float2* t24 = reinterpret_cast<const float2*>(g.aSum) + 3 * (size_t)o;
+        const float2 u = t24[0], v = t24[1], w = t24[2];
+        ax = u.x, ay = u.y, az = v.x, lx = v.y, ly = w.x, lz = w.y;
+        return;
+    }
+#endif
     if (g.tile || a_run_in_one_block(s, e)) {
         const float4 v = g.aSum[2 * (size_t)o], w = g.aSum[2 * (size_t)o + 1];
         ax = v.x, ay = v.y, az = v.z, lx = w.x, ly = w.y, lz = w.z;
@@ -1064,8 +1078,16 @@ __global__ __launch_bounds__(256) void k_reduce_heavy(const DevParams p, const G
         const uint32_t a0 = g.aStart[o], a1 = g.aStart[o + 1];
         if (g.tile || a_run_in_one_block(a0, a1)) {
             if (threadIdx.x == 0) {
-                const float4 v = g.aSum[2 * (size_t)o], w = g.aSum[2 * (size_t)o + 1];
-                s[0] = v.x, s[1] = v.y, s[2] = v.z, s[3] = w.x, s[4] = w.y, s[5] = w.z;
+#if DEME_REC24
+                if (g.tile) {
+                    const float2* t24 = reinterpret_cast<const float2*>(g.aSum) + 3 * (size_t)o;
+                    s[0] = t24[0].x, s[1] = t24[0].y, s[2] = t24[1].x, s[3] = t24[1].y, s[4] = t24[2].x, s[5] = t24[2].y;
+                } else
+#endif
+                {
+                    const float4 v = g.aSum[2 * (size_t)o], w = g.aSum[2 * (size_t)o + 1];
+                    s[0] = v.x, s[1] = v.y, s[2] = v.z, s[3] = w.x, s[4] = w.y, s[5] = w.z;
+                }
             }
         } else {
             for (uint32_t c = a0 + threadIdx.x; c < a1; c += 256) {

@@ -792,8 +792,15 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 if (crossing) {
                     const uint32_t k = rbase[d] + (uint32_t)__popcll(m & ((1ull << (tid & 63u)) - 1ull));
 #if !(DEME_TILE_KI & 32)
+#if DEME_REC24
+                    float2* const r24 = reinterpret_cast<float2*>(a.rec32) + 3 * (size_t)k;  // (-F.x -F.y) (-F.z tB.x) (tB.y tB.z)
+                    stream_store(r24, make_float2(x4.x, x4.y));
+                    stream_store(r24 + 1, make_float2(x4.z, x4.w));
+                    stream_store(r24 + 2, make_float2(x2.x, x2.y));
+#else
                     stream_store(a.rec32 + 2 * (size_t)k, x4);
                     stream_store(a.rec32 + 2 * (size_t)k + 1, x2);
+#endif
 #else
                     ki_sink(x4.x + x2.x + (float)k);
 #endif
@@ -942,8 +949,15 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         const float4 b4 = recA4[po];
         const float2 b2 = recA2[po];
 #if !(DEME_TILE_KI & 64)
+#if DEME_REC24
+        float2* const t24 = reinterpret_cast<float2*>(a.tSum) + 3 * (size_t)(o0 + po);  // (F.x F.y) (F.z t.x) (t.y t.z)
+        t24[0] = make_float2(s01.x + b4.x, s01.y + b4.y);
+        t24[1] = make_float2(s23.x + b4.z, s23.y + b4.w);
+        t24[2] = make_float2(s45.x + b2.x, s45.y + b2.y);
+#else
         a.tSum[2 * (size_t)(o0 + po)] = make_float4(s01.x + b4.x, s01.y + b4.y, s23.x + b4.z, 0.f);
         a.tSum[2 * (size_t)(o0 + po) + 1] = make_float4(s23.y + b4.w, s45.x + b2.x, s45.y + b2.y, 0.f);
+#endif
 #else
         ki_sink(s01.x + b4.x + s01.y + b4.y + s23.x + b4.z + s23.y + b4.w + s45.x + b2.x + s45.y + b2.y);
 #endif
@@ -1040,8 +1054,15 @@ __global__ __launch_bounds__(DEME_TILE_T) void k_tile_forces_big(const DevParams
             recA4[tid] = make_float4(force.x, force.y, force.z, tA.x);
             recA2[tid] = make_float2(tA.y, tA.z);
             const uint32_t k = a.rankC[c];  // (this contact's own record)
+#if DEME_REC24
+            float2* const r24 = reinterpret_cast<float2*>(a.rec32) + 3 * (size_t)k;
+            stream_store(r24, make_float2(-force.x, -force.y));
+            stream_store(r24 + 1, make_float2(-force.z, tB.x));
+            stream_store(r24 + 2, make_float2(tB.y, tB.z));
+#else
             stream_store(a.rec32 + 2 * (size_t)k, make_float4(-force.x, -force.y, -force.z, tB.x));
             stream_store(a.rec32 + 2 * (size_t)k + 1, make_float4(tB.y, tB.z, 0.f, 0.f));
+#endif
         }
         __syncthreads();
         if (sideA) {
@@ -1066,8 +1087,13 @@ __global__ __launch_bounds__(DEME_TILE_T) void k_tile_forces_big(const DevParams
         __syncthreads();
     }
     if (sideA) {
+#if DEME_REC24
+        float2* const t24 = reinterpret_cast<float2*>(a.tSum) + 3 * (size_t)(o0 + tid);
+        t24[0] = make_float2(s01.x, s01.y), t24[1] = make_float2(s23.x, s23.y), t24[2] = make_float2(s45.x, s45.y);
+#else
         a.tSum[2 * (size_t)(o0 + tid)] = make_float4(s01.x, s01.y, s23.x, 0.f);
         a.tSum[2 * (size_t)(o0 + tid) + 1] = make_float4(s23.y, s45.x, s45.y, 0.f);
+#endif
     }
 }
 
