@@ -502,6 +502,9 @@ __device__ inline uint32_t tile_block_id(uint32_t G) {
 #ifndef DEME_TILE_PRIO_PULL
 #define DEME_TILE_PRIO_PULL 0  // > 0: wavefront priority between a round's two barriers (the pulls: the whole workgroup waits for them)
 #endif
+#ifndef DEME_TILE_PULLW
+#define DEME_TILE_PULLW 4  // entries an owner thread pulls per trip (a missing entry reads the zero slot)
+#endif
 #ifndef DEME_TILE_NOZERO
 #define DEME_TILE_NOZERO 1  // 1: no zero defaults for values that are only read where they were set (refilled stream stages, crossing records)
 #endif
@@ -830,53 +833,53 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 if (sideA) {  // my A run's part of this round: positions [plo, min(phi, rhi)); a missing entry reads the zero slot
                     const uint32_t e = min(phi, rhi);
                     while (plo < e) {
-                        float4 v4[4];
-                        float2 v2[4];
+                        float4 v4[DEME_TILE_PULLW];
+                        float2 v2[DEME_TILE_PULLW];
 #if DEME_TILE_PKPULL
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < DEME_TILE_PULLW; k++) {
                             const uint32_t i = (plo + k < e) ? plo + k - rlo : (uint32_t)DEME_TILE_T;
                             v4[k] = recA4[i], v2[k] = recA2[i];
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < DEME_TILE_PULLW; k++) {
                             s01 += v2f{v4[k].x, v4[k].y};
                             s23 += v2f{v4[k].z, v4[k].w};
                             s45 += v2f{v2[k].x, v2[k].y};
                         }
 #else
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < DEME_TILE_PULLW; k++) {
                             const uint32_t i = min(plo + k, e - 1u) - rlo;
                             v4[k] = recA4[i], v2[k] = recA2[i];
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
+                        for (int k = 0; k < DEME_TILE_PULLW; k++)
                             if (plo + k < e)
                                 s01.x += v4[k].x, s01.y += v4[k].y, s23.x += v4[k].z, s23.y += v4[k].w, s45.x += v2[k].x, s45.y += v2[k].y;
 #endif
-                        plo = min(plo + 4u, e);
+                        plo = min(plo + (uint32_t)DEME_TILE_PULLW, e);
                     }
                 } else if (sideB) {  // my local-B list's entries that fall into this round: -F and tB of those contacts
                     while (plo < phi) {
-                        uint32_t pos[4];
+                        uint32_t pos[DEME_TILE_PULLW];
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
+                        for (int k = 0; k < DEME_TILE_PULLW; k++)
                             pos[k] = (plo + k < phi) ? (uint32_t)sLPos[plo + k] : 0xFFFFFFFFu;
                         if (pos[0] >= rhi)
                             break;
-                        float4 v4[4], vt[4];
+                        float4 v4[DEME_TILE_PULLW], vt[DEME_TILE_PULLW];
                         uint32_t used = 0;
 #if DEME_TILE_PKPULL
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < DEME_TILE_PULLW; k++) {
                             const bool in = pos[k] < rhi;  // (ascending: the entries of this round come first)
                             const uint32_t i = in ? pos[k] - rlo : (uint32_t)DEME_TILE_T;
                             v4[k] = recA4[i], vt[k] = recT[i];
                             used += in ? 1u : 0u;
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < DEME_TILE_PULLW; k++) {
                             s01 -= v2f{v4[k].x, v4[k].y};
                             s23.x -= v4[k].z;
                             s23.y += vt[k].z;
@@ -884,19 +887,19 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                         }
 #else
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < DEME_TILE_PULLW; k++) {
                             const uint32_t i = (pos[k] < rhi ? pos[k] : pos[0]) - rlo;
                             v4[k] = recA4[i], vt[k] = recT[i];
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
+                        for (int k = 0; k < DEME_TILE_PULLW; k++)
                             if (pos[k] < rhi) {
                                 s01.x -= v4[k].x, s01.y -= v4[k].y, s23.x -= v4[k].z, s23.y += vt[k].z, s45.x += vt[k].x, s45.y += vt[k].y;
                                 used++;
                             }
 #endif
                         plo += used;
-                        if (used < 4u)
+                        if (used < (uint32_t)DEME_TILE_PULLW)
                             break;
                     }
                 }
