@@ -528,6 +528,34 @@ class Multi:
         self._ck(self.lib.deme_multi_counts(self.h, C.byref(c), C.byref(mig)), "deme_multi_counts")
         return c, int(mig.value)
 
+    def num_contacts(self):
+        n = C.c_size_t(0)
+        self.lib.deme_multi_num_contacts.argtypes = [_P, C.POINTER(C.c_size_t)]
+        self._ck(self.lib.deme_multi_num_contacts(self.h, C.byref(n)), "deme_multi_num_contacts")
+        return int(n.value)
+
+    def contacts(self):
+        """(idA, idB, type) of the merged list in GLOBAL sphere ids: a pair that straddles a cut once, canonical order"""
+        n = self.num_contacts()
+        a, b, t = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        self.lib.deme_multi_download_contacts.argtypes = [_P, _P, _P, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_download_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), n), "deme_multi_download_contacts")
+        return a, b, t
+
+    def wildcard(self, w):
+        n = self.num_contacts()
+        out = np.zeros(n, np.float32)
+        self.lib.deme_multi_download_contact_wildcard.argtypes = [_P, C.c_uint32, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_download_contact_wildcard(self.h, int(w), _ptr(out), n), "deme_multi_download_contact_wildcard")
+        return out
+
+    def contact_records(self):
+        n = self.num_contacts()
+        arrs = [np.zeros((n, 3), np.float32) for _ in range(4)]
+        self.lib.deme_multi_download_contact_records.argtypes = [_P, _P, _P, _P, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_download_contact_records(self.h, *[_ptr(a) for a in arrs], n), "deme_multi_download_contact_records")
+        return arrs
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.deme_multi_destroy(self.h)

@@ -904,10 +904,7 @@ class DEMSolver {
 
     // ---- queries (subset of DEMTracker / GetOwner* getters)
     size_t GetNumClumps() const { return m_n_clumps; }
-    size_t GetNumContacts() {
-        const DemeCounts c = api_counts();
-        return (size_t)c.nContacts;
-    }
+    size_t GetNumContacts() { return n_contacts(); }
     float3 GetOwnerPosition(unsigned int owner) {
         refresh_state();
         return m_pos.at(owner);
@@ -1044,14 +1041,14 @@ class DEMSolver {
         dl_state(&st);
         // contact list + wildcards
         const DemeCounts c = api_counts();
-        const size_t nc = (size_t)c.nContacts;
+        const size_t nc = n_contacts();
         const uint32_t nW = m_p.nContactWildcards;
         std::vector<uint32_t> a(nc), b(nc), map(nc);
         std::vector<uint8_t> ty(nc);
-        check(deme_download_contacts(m_ctx, a.data(), b.data(), ty.data(), map.data(), nc));
+        dl_contacts(a.data(), b.data(), ty.data(), map.data(), nc);
         std::vector<float> W(nc * nW), col(nc);
         for (uint32_t w = 0; w < nW; w++) {
-            check(deme_download_contact_wildcard(m_ctx, w, col.data(), nc));
+            dl_contact_wc(w, col.data(), nc);
             for (size_t i = 0; i < nc; i++)
                 W[i * nW + w] = col[i];
         }
@@ -1114,14 +1111,14 @@ class DEMSolver {
         st.familyID = fam.data();
         dl_state(&st);
         const DemeCounts c = api_counts();
-        const size_t nc = (size_t)c.nContacts;
+        const size_t nc = n_contacts();
         const uint32_t nW = m_p.nContactWildcards;
         std::vector<uint32_t> a(nc), b(nc), map(nc);
         std::vector<uint8_t> ty(nc);
-        check(deme_download_contacts(m_ctx, a.data(), b.data(), ty.data(), map.data(), nc));
+        dl_contacts(a.data(), b.data(), ty.data(), map.data(), nc);
         std::vector<float> W(nc * nW), col(nc);
         for (uint32_t w = 0; w < nW; w++) {
-            check(deme_download_contact_wildcard(m_ctx, w, col.data(), nc));
+            dl_contact_wc(w, col.data(), nc);
             for (size_t i = 0; i < nc; i++)
                 W[i * nW + w] = col[i];
         }
@@ -1253,10 +1250,10 @@ class DEMSolver {
     /// Sphere-geometry id pairs of the current contact list and their types (GetContacts / contact info getters)
     std::vector<std::pair<bodyID_t, bodyID_t>> GetContacts() {
         const DemeCounts c = api_counts();
-        const size_t n = (size_t)c.nContacts;
+        const size_t n = n_contacts();
         std::vector<uint32_t> a(n), b(n), map(n);
         std::vector<uint8_t> ty(n);
-        check(deme_download_contacts(m_ctx, a.data(), b.data(), ty.data(), map.data(), n));
+        dl_contacts(a.data(), b.data(), ty.data(), map.data(), n);
         std::vector<std::pair<bodyID_t, bodyID_t>> out;
         for (size_t i = 0; i < n; i++)
             if (ty[i] == 1)
@@ -1294,7 +1291,7 @@ class DEMSolver {
         std::vector<float> cpB(3 * nc);
         {
             std::vector<float> f(3 * nc), t(3 * nc), a(3 * nc);
-            check(deme_download_contact_records(m_ctx, f.data(), t.data(), a.data(), cpB.data(), nc));
+            dl_contact_records(f.data(), t.data(), a.data(), cpB.data(), nc);
         }
         std::vector<bodyID_t> sorted = owners;
         std::sort(sorted.begin(), sorted.end());
@@ -1748,6 +1745,39 @@ class DEMSolver {
         else
             check(deme_upload_owner_state(m_ctx, st));
     }
+    /// the contact list / per-contact arrays of the run: the context's, or the merged list of a decomposed run in global sphere ids
+    /// (deme_multi_download_contacts: a pair that straddles a cut once; there is no history map across slabs: NULL entries)
+    size_t n_contacts() {
+        if (m_multi) {
+            size_t n = 0;
+            mcheck(deme_multi_num_contacts(m_multi, &n));
+            return n;
+        }
+        DemeCounts c{};
+        check(deme_get_counts(m_ctx, &c));
+        return (size_t)c.nContacts;
+    }
+    void dl_contacts(uint32_t* a, uint32_t* b, uint8_t* ty, uint32_t* map, size_t nc) {
+        if (m_multi) {
+            mcheck(deme_multi_download_contacts(m_multi, a, b, ty, nc));
+            if (map)
+                std::fill(map, map + nc, 0xFFFFFFFFu);
+        } else {
+            check(deme_download_contacts(m_ctx, a, b, ty, map, nc));
+        }
+    }
+    void dl_contact_wc(uint32_t w, float* col, size_t nc) {
+        if (m_multi)
+            mcheck(deme_multi_download_contact_wildcard(m_multi, w, col, nc));
+        else
+            check(deme_download_contact_wildcard(m_ctx, w, col, nc));
+    }
+    void dl_contact_records(float* f, float* t, float* a, float* b, size_t nc) {
+        if (m_multi)
+            mcheck(deme_multi_download_contact_records(m_multi, f, t, a, b, nc));
+        else
+            check(deme_download_contact_records(m_ctx, f, t, a, b, nc));
+    }
     DemeCounts api_counts() {
         DemeCounts c{};
         if (m_multi)
@@ -1853,14 +1883,14 @@ class DEMSolver {
     void set_contact_wc(int mode, unsigned int N1, unsigned int N2, const std::string& name, float val) {
         const uint32_t w = wc_slot(m_force_model->contact_wildcards, name, "contact");
         const DemeCounts c = api_counts();
-        const size_t nc = (size_t)c.nContacts;
+        const size_t nc = n_contacts();
         if (!nc)
             return;
         std::vector<uint32_t> a(nc), b(nc), map(nc);
         std::vector<uint8_t> ty(nc);
-        check(deme_download_contacts(m_ctx, a.data(), b.data(), ty.data(), map.data(), nc));
+        dl_contacts(a.data(), b.data(), ty.data(), map.data(), nc);
         std::vector<float> col(nc);
-        check(deme_download_contact_wildcard(m_ctx, w, col.data(), nc));
+        dl_contact_wc(w, col.data(), nc);
         const std::vector<uint8_t> fam = owner_families();
         for (size_t i = 0; i < nc; i++) {
             const unsigned fA = fam[m_keep.sphOwner[a[i]]];
@@ -2095,16 +2125,16 @@ class DEMSolver {
         }
         if (contacts) {
             const DemeCounts c = api_counts();
-            const size_t nc = (size_t)c.nContacts;
+            const size_t nc = n_contacts();
             sn.idA.resize(nc), sn.idB.resize(nc), sn.type.resize(nc);
             std::vector<uint32_t> map(nc);
-            check(deme_download_contacts(m_ctx, sn.idA.data(), sn.idB.data(), sn.type.data(), map.data(), nc));
+            dl_contacts(sn.idA.data(), sn.idB.data(), sn.type.data(), map.data(), nc);
             sn.F.assign(3 * nc, 0.f), sn.T.assign(3 * nc, 0.f), sn.cpA.assign(3 * nc, 0.f);
             std::vector<float> cpB(3 * nc);
-            check(deme_download_contact_records(m_ctx, sn.F.data(), sn.T.data(), sn.cpA.data(), cpB.data(), nc));
+            dl_contact_records(sn.F.data(), sn.T.data(), sn.cpA.data(), cpB.data(), nc);
             sn.wc.assign(m_p.nContactWildcards, std::vector<float>(nc));
             for (uint32_t w = 0; w < m_p.nContactWildcards; w++)
-                check(deme_download_contact_wildcard(m_ctx, w, sn.wc[w].data(), nc));
+                dl_contact_wc(w, sn.wc[w].data(), nc);
         }
         return sn;
     }

@@ -588,6 +588,15 @@ int deme_multi_upload_state(deme_multi* m, const DemeOwnerState* global, uint32_
 /* contacts of all slabs together (a contact that straddles a cut is on two lists unless deme_halo_group_set_cross_contacts(1):
  * `nContacts` counts list entries), steps taken, detections of the first slab, clumps that changed slabs so far */
 int deme_multi_counts(deme_multi* m, DemeCounts* sum, uint64_t* clumpsMigrated);
+/* The contact list of a decomposed run in GLOBAL sphere ids (analytical-component / triangle ids are global already): a pair that
+ * straddles a cut is reported once, sphere-sphere pairs as (smaller, larger) id, rows in the canonical order of an undivided
+ * context (A, then class, then B).  Per-contact wildcards and recorded forces / contact points follow in the same order; where a slab
+ * held a pair the other way round, its B -> A vector wildcards (the flipMask given at build) and its recorded force change sign and
+ * its two contact points swap.  The list is rebuilt after every step / state upload. */
+int deme_multi_num_contacts(deme_multi* m, size_t* n);
+int deme_multi_download_contacts(deme_multi* m, uint32_t* idA, uint32_t* idB, uint8_t* type, size_t cap);
+int deme_multi_download_contact_wildcard(deme_multi* m, uint32_t w, float* out, size_t cap);
+int deme_multi_download_contact_records(deme_multi* m, float* force, float* torqueOnly, float* cpA, float* cpB, size_t cap);
 /* the visible HIP devices (0 and DEME_OK where there is none: what the constructors check ids against) */
 int deme_device_count(int* n);
 /* Measurement aid (quote the attainable rate beside the nominal 8 TB/s): a hand-written 16 B / lane streaming copy of

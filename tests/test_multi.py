@@ -46,6 +46,18 @@ def test_multi_slabs_equal_the_single_domain_oracle(pkg, orc, n_slabs, axis):
     assert dx < 5e-9 and dv < 1e-4, (dx, dv)  # (measured 1.3e-9 m / 1.6e-5 m/s: a slab numbers its clumps in the engine's order)
     cnt, moved = m.counts()
     assert int(cnt.nSteps) == 60 and int(cnt.nContacts) >= int(sim.counts().nContacts)  # (cross-cut contacts are on two lists)
+    # the merged list in global sphere ids: every pair once, the oracle's list row for row; history in the same rows, B -> A vector
+    # wildcards with the sign of the GLOBAL pair order wherever a slab held the pair the other way round
+    ga, gb, gt = m.contacts()
+    oa, ob, ot, _ = sim.contacts()
+    assert len(ga) == len(oa) > 500 and np.array_equal(ga, oa) and np.array_equal(gb, ob) and np.array_equal(gt, ot)
+    for w in range(4):
+        gw, ow = m.wildcard(w), sim.wildcard(w)
+        scale = max(float(np.abs(ow).max()), 1e-12)
+        off = np.abs(gw - ow) > 1e-5 * scale + 1e-12
+        # (a pair that begins to touch within rounding of a step boundary starts its history one step apart in the two runs --
+        # tools/slab_diag4.py: one row of 2 255, 2.4 % = one step of forty -- everything else to fp32 rounding, signs included)
+        assert off.sum() <= 3 and np.abs(gw - ow).max() <= 0.05 * scale, (w, int(off.sum()), float(np.abs(gw - ow).max()), scale)
     # a state uploaded by global id reaches own clumps, ghost copies and replicated owners alike
     m.upload_state({k: so0[k] for k in GKEYS})
     back = m.download_state()
