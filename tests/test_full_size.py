@@ -403,3 +403,64 @@ def test_mesh_flavour_at_scale_fast_mode_matches_oracle(pkg, orc):
     finally:
         orc.set_num_threads(min(8, os.cpu_count() or 1))
         fast.close()
+
+
+@pytest.mark.gpu
+def test_mesh_flavour_at_its_full_size_properties(pkg):
+    """BASELINE configs[3] AT ITS SIZE: 2e6 three-sphere clumps settled on a 49 928-triangle wavy plate (what bench.py
+    --clumps 2000000 --mesh-triangles 50000 runs).  No oracle at this size inside a test; properties instead, between the fast mode
+    (owner tiles taking the sphere-triangle records of the mesh variant of the general kernel) and the exact mode of the SAME library on
+    the SAME state -- two independent force paths over one detection code:
+      * the kernel the bench's roofline names evaluates the list: k_tile_forces<0, true>, no tile through the fallback;
+      * the two contexts hold the same contact list (> 4e6 pairs after 12 000 settling steps, > 3e5 of them sphere-triangle);
+      * Newton's third law over the whole scene: the mass-weighted contact accelerations of ALL owners -- clumps, the box, the plate --
+        add up to zero to fp32 rounding of their magnitude sum;
+      * per-owner a / alpha of ONE launch agree between the two paths to 3e-6 of the largest (the bound of the 1e6 leg)."""
+    import copy
+    import bench
+    b = bench.build_bed(pkg, 2_000_000, 2024, 40, order="morton")
+    lo, hi = b.user_box_min, b.user_box_max
+    v, f = pkg.model.plate_mesh(158, 158, float(hi[0] - lo[0]) * 0.98, float(hi[1] - lo[1]) * 0.98, z=0.0, wavy=0.002)
+    assert len(f) == 49_928
+    m = b.AddMeshObject(v, f, 0)
+    m.SetInitPos(((lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, 0.021))
+    p, sc = b.Initialize()
+    keys = ("voxelID", "locX", "locY", "locZ", "oriQw", "oriQx", "oriQy", "oriQz", "vX", "vY", "vZ", "omgBarX", "omgBarY", "omgBarZ")
+    settle = pkg.Context(0)
+    settle.set_arith_mode("fast")
+    settle.set_params(p), settle.upload_scene(sc)
+    settle.step(12000)  # the lattice settles onto the plate
+    st = settle.download_state()
+    settle.close()
+    fast, exact = pkg.Context(0), pkg.Context(0)  # two fresh contexts: the same state, no contact history in either
+    fast.set_arith_mode("fast"), exact.set_arith_mode("exact")
+    for c in (fast, exact):
+        c.set_params(p), c.upload_scene(sc)
+        c.upload_state({k: st[k] for k in keys})
+    for c in (fast, exact):
+        c.compute_margins(0), c.detect(), c.migrate(), c.calc_forces()
+    assert fast.force_kernel()[0] == "k_tile_forces<0, true>", fast.force_kernel()
+    tiles, nbig, halo, _ = fast.tile_stats()
+    assert tiles == (int(sc.nOwners) + 127) // 128 and nbig == 0, (tiles, nbig, halo)
+    fa, ea = fast.contacts(), exact.contacts()
+    n_sm = int((fa[2] == 2).sum())
+    assert len(fa[0]) > 4_000_000 and n_sm > 300_000, (len(fa[0]), n_sm)
+    assert all(np.array_equal(x, y) for x, y in zip(fa[:3], ea[:3]))
+    g, o = fast.download_state(), exact.download_state()
+    mass = np.asarray(b.arrays["MassProperties"], np.float64)[np.asarray(b.arrays["inertiaPropOffsets"], np.int64)]
+    for name, s in (("fast", g), ("exact", o)):
+        A = np.stack([s["aX"], s["aY"], s["aZ"]], 1).astype(np.float64)
+        F = A * mass[:, None]
+        net, mag = np.abs(F.sum(0)).max(), np.abs(F).sum()
+        print(f"2e6 clumps + 49 928 triangles, {name}: |sum m a| / sum |m a| = {net / mag:.3e} over {len(mass)} owners")
+        record_measured(f"test_full_size configs[3] full size Newton III ({name})", net_over_sum=float(net / mag))
+        assert net <= 2e-6 * mag, (name, net, mag)
+    n = int(sc.nOwnerClumps)
+    for ks in (("aX", "aY", "aZ"), ("alphaX", "alphaY", "alphaZ")):
+        G = np.stack([g[k][:n] for k in ks], 1).astype(np.float64)
+        O = np.stack([o[k][:n] for k in ks], 1).astype(np.float64)
+        rel = float(np.abs(G - O).max() / np.abs(O).max())
+        print(f"2e6 clumps + 49 928 triangles, one launch, {ks[0][:-1]}: max |fast - exact| / max |exact| = {rel:.3e} ({len(fa[0])} contacts, {n_sm} sphere-triangle)")
+        record_measured("test_full_size configs[3] full size one launch " + ks[0][:-1], rel_err=rel)
+        assert rel <= 3e-6, (ks, rel)
+    fast.close(), exact.close()
