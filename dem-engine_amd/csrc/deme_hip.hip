@@ -395,6 +395,9 @@ int check_ready(deme_ctx* c) {
         return DEME_ERR_INVALID;
     if (!c->haveParams || !c->haveScene)
         return fail(c, DEME_ERR_INVALID, "deme_set_params and deme_upload_scene must be called first");
+    // (a process may hold contexts on several devices -- deme_multi: every entry point works on the context's own device)
+    if (hipSetDevice(c->device) != hipSuccess)
+        return fail(c, DEME_ERR_HIP, "device %d cannot be selected", c->device);
     return DEME_OK;
 }
 
@@ -1572,6 +1575,7 @@ const char* deme_last_error(const deme_ctx* c) { return c ? c->err.c_str() : "nu
 int deme_ctx_set_stream(deme_ctx* c, void* s) {
     if (!c)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     HIPCK(hipStreamSynchronize(c->stream));
     if (s) {
         if (c->ownStream)
@@ -1588,6 +1592,7 @@ int deme_ctx_set_stream(deme_ctx* c, void* s) {
 int deme_set_arith_mode(deme_ctx* c, int mode) {
     if (!c || (mode != DEME_ARITH_FAST && mode != DEME_ARITH_EXACT))
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     if (mode != c->arith) {
         HIPCK(hipStreamSynchronize(c->stream));  // (an asynchronous detection cycle ends inside deme_step: nothing is in flight beside the stream)
         c->arith = mode;
@@ -1698,6 +1703,7 @@ int deme_set_reorder(deme_ctx* c, int enable) {
 int deme_sync(deme_ctx* c) {
     if (!c)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     HIPCK(hipStreamSynchronize(c->stream));
     return DEME_OK;
 }
@@ -2569,6 +2575,7 @@ int deme_halo_unpack_async(deme_ctx* c, const uint32_t* d_ids, uint32_t n, const
 int deme_halo_sync(deme_ctx* c) {
     if (!c)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     if (c->haloStream)
         HIPCK(hipStreamSynchronize(c->haloStream));
     return DEME_OK;
@@ -3574,6 +3581,7 @@ int deme_seed_contacts(deme_ctx* c, const uint32_t* idA, const uint32_t* idB, co
 int deme_set_record_contacts(deme_ctx* c, int enable) {
     if (!c)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     c->record = enable != 0;
     if (c->record && c->cntCap)
         for (int k = 0; k < 4; k++)
@@ -3742,6 +3750,7 @@ int deme_download_wildcard_array(deme_ctx* c, uint32_t kind, uint32_t index, flo
 int deme_compile_prescriptions(deme_ctx* c, const char* velCases, const char* posCases, const char* accCases) {
     if (!c)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     HIPCK(hipStreamSynchronize(c->stream));
     if (c->prescMod) {
         (void)hipModuleUnload(c->prescMod);
@@ -3771,6 +3780,7 @@ int deme_compile_prescriptions(deme_ctx* c, const char* velCases, const char* po
 int deme_compile_family_rules(deme_ctx* c, const char* rules) {
     if (!c)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     HIPCK(hipStreamSynchronize(c->stream));
     if (c->rulesMod) {
         (void)hipModuleUnload(c->rulesMod);
@@ -4022,6 +4032,7 @@ int deme_set_timing(deme_ctx* c, int enable) {
 int deme_kernel_time_reset(deme_ctx* c) {
     if (!c)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     hipStreamSynchronize(c->stream);
     drain_timers(c);
     for (auto& kv : c->timers) {
@@ -4113,6 +4124,7 @@ int deme_inspect(deme_ctx* c, uint32_t q, float* out) { return deme_inspect_regi
 int deme_compile_region(deme_ctx* c, const char* code, int* regionId) {
     if (!c || !regionId)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     const std::string r = code ? code : "";
     auto word = [&](const std::string& w) {
         for (size_t pos = r.find(w); pos != std::string::npos; pos = r.find(w, pos + 1)) {
@@ -4184,6 +4196,7 @@ int deme_inspect_values(deme_ctx* c, uint32_t q, float* out, size_t cap) {
 int deme_kernel_time_ms(deme_ctx* c, const char* name, double* avg_ms, uint64_t* launches) {
     if (!c || !name)
         return DEME_ERR_INVALID;
+    hipSetDevice(c->device);  // (a process may hold contexts on several devices: deme_multi)
     hipStreamSynchronize(c->stream);
     drain_timers(c);
     auto it = c->timers.find(name);
