@@ -155,3 +155,24 @@ def test_multi_gives_the_slabs_of_a_random_order_bed_the_engines_order(pkg, orc)
     # (the bed is still loose after 40 steps -- few contacts per tile, so even the random numbering's tiles fit; the foreign owners a
     # tile stages tell the two numberings apart)
     assert big[False][0] == 0 and big[False][2] < 0.6 * big[True][2]
+
+
+def test_multi_of_one_slab_in_the_fast_mode_gets_the_engines_order(pkg, orc):
+    """a plan of one slab holds no ghost copy: its context is a plain one, and in the fast mode the engine reorders a bed handed
+    over in random order as it does for deme_upload_scene -- every id at the boundary (the state by global id) stays the caller's"""
+    b = pkg.model.packed_bed(6000, seed=5, cd_freq=0, spacing_mult=3.0, init_vz=-1.0, aspect=(1.0, 1.0, 0.25), order="random")
+    p, sc = b.Initialize()
+    nc = int(sc.nOwnerClumps)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc, slabs_per_device=1, arith="fast")
+    c = m.slab_ctx(0)
+    assert c.engine_order()[0], c.engine_order()
+    sim = orc.make_sim(pkg, p, sc)
+    st0, so0 = m.download_state(), sim.download_state()
+    assert all(np.array_equal(st0[k], so0[k]) for k in GKEYS)
+    m.step(30), sim.step(30)
+    m.sync()
+    g, o = m.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g, nc) - _positions(pkg, p, o, nc)).max()
+    assert dx < 5e-8, dx
+    m.close()
