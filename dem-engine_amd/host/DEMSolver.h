@@ -865,12 +865,12 @@ class DEMSolver {
     void SetCDMaxUpdateFreq(unsigned int max_freq) { m_adaptive.maxUpdateFreq = max_freq, push_adaptive(); }
     double GetBinSize() const {
         double b = 0;
-        deme_get_adaptive_state(m_ctx, &b, nullptr, nullptr, nullptr);
+        deme_get_adaptive_state(diag_ctx(), &b, nullptr, nullptr, nullptr);
         return b;
     }
     unsigned int GetUpdateFreq() const {
         uint32_t k = 0;
-        deme_get_adaptive_state(m_ctx, nullptr, &k, nullptr, nullptr);
+        deme_get_adaptive_state(diag_ctx(), nullptr, &k, nullptr, nullptr);
         return k;
     }
     void SetNoForceRecord(bool flag = true) {  // per-contact force records are only kept when the contact output needs them
@@ -1338,7 +1338,7 @@ class DEMSolver {
         for (const char* name : {"calc_forces", "integrate", "detect"}) {
             double ms = 0;
             uint64_t n = 0;
-            if (deme_kernel_time_ms(m_ctx, name, &ms, &n) == DEME_OK)
+            if (deme_kernel_time_ms(diag_ctx(), name, &ms, &n) == DEME_OK)
                 std::printf("%-12s %10.4f ms per launch over %llu launches\n", name, ms, (unsigned long long)n);
         }
     }
@@ -1358,23 +1358,23 @@ class DEMSolver {
     /// its own (ids seen here are always load order), and how many owner tiles go through the per-tile fallback
     std::string GetForceKernelName() const {
         char name[64] = {0};
-        deme_force_kernel_name(m_ctx, name, sizeof(name), nullptr, nullptr);
+        deme_force_kernel_name(diag_ctx(), name, sizeof(name), nullptr, nullptr);
         return name;
     }
     bool IsEngineReordered() const {
         int r = 0;
-        deme_get_order(m_ctx, &r, nullptr);
+        deme_get_order(diag_ctx(), &r, nullptr);
         return r != 0;
     }
     unsigned GetNumFallbackTiles() const {
         uint32_t t[4] = {0, 0, 0, 0};
-        deme_tile_stats(m_ctx, t);
+        deme_tile_stats(diag_ctx(), t);
         return t[1];
     }
     /// ShowMemStats (API.h:584): device memory in use by this process, as the HIP runtime reports it through the library
     void ShowMemStats() const {
         size_t used = 0, total = 0;
-        if (deme_device_memory(m_ctx, &used, &total) == DEME_OK)
+        if (deme_device_memory(diag_ctx(), &used, &total) == DEME_OK)
             std::printf("Device memory in use: %.1f MiB of %.1f MiB\n", used / 1048576.0, total / 1048576.0);
     }
     /// average number of contacts per sphere (kT's avgCntsPerSphere, API.h:251): contacts of the current list / spheres
@@ -1396,7 +1396,7 @@ class DEMSolver {
         if (!m_initialized)
             throw std::runtime_error(std::string(who) + " can only be called after the simulation system is initialized");
     }
-    void ClearTimingStats() { deme_kernel_time_reset(m_ctx); }
+    void ClearTimingStats() { deme_kernel_time_reset(diag_ctx()); }
     void ClearThreadCollaborationStats() {}
     void UseCubForceCollection(bool = true) {}  // accumulation is atomics-free here: nothing to choose
     void SetExpandSafetyType(const std::string& insp_type) {  // DEM/APIPublic.cpp:836-843: only "auto" exists
@@ -1708,6 +1708,14 @@ class DEMSolver {
         m_family_flags[RESERVED_FAMILY_NUM] = DEME_FAMILY_FIXED;
     }
     bool decomposed() const { return m_multi != nullptr; }
+    /// diagnostics (kernel names, timers, tile statistics, device memory) of a decomposed run are its first slab's
+    deme_ctx* diag_ctx() const {
+        if (!m_multi)
+            return m_ctx;
+        deme_ctx* c = nullptr;
+        deme_multi_slab_ctx(m_multi, 0, &c);
+        return c;
+    }
     /// what a decomposed run does not offer yet says so instead of touching one slab only
     void single_only(const char* what) const {
         if (m_multi)
