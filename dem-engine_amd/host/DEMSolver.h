@@ -1040,7 +1040,6 @@ class DEMSolver {
         st.familyID = fam.data();
         dl_state(&st);
         // contact list + wildcards
-        const DemeCounts c = api_counts();
         const size_t nc = n_contacts();
         const uint32_t nW = m_p.nContactWildcards;
         std::vector<uint32_t> a(nc), b(nc), map(nc);
@@ -1110,7 +1109,6 @@ class DEMSolver {
         st.omgBarX = f[7].data(), st.omgBarY = f[8].data(), st.omgBarZ = f[9].data();
         st.familyID = fam.data();
         dl_state(&st);
-        const DemeCounts c = api_counts();
         const size_t nc = n_contacts();
         const uint32_t nW = m_p.nContactWildcards;
         std::vector<uint32_t> a(nc), b(nc), map(nc);
@@ -1249,7 +1247,6 @@ class DEMSolver {
     }
     /// Sphere-geometry id pairs of the current contact list and their types (GetContacts / contact info getters)
     std::vector<std::pair<bodyID_t, bodyID_t>> GetContacts() {
-        const DemeCounts c = api_counts();
         const size_t n = n_contacts();
         std::vector<uint32_t> a(n), b(n), map(n);
         std::vector<uint8_t> ty(n);
@@ -1286,7 +1283,6 @@ class DEMSolver {
     size_t GetOwnerContactForces(const std::vector<bodyID_t>& owners, std::vector<float3>& points, std::vector<float3>& forces,
                                  std::vector<float3>* torques = nullptr, bool torque_in_local = false) {
         const Snapshot sn = snapshot(true);
-        const DemeCounts c = api_counts();
         const size_t nc = sn.idA.size();
         std::vector<float> cpB(3 * nc);
         {
@@ -1890,7 +1886,6 @@ class DEMSolver {
     // mode 0 all, 1 either owner's family == N1, 2 both, 3 the pair (N1, N2): APIPrivate.cpp's setFamilyContactWildcardValue_impl
     void set_contact_wc(int mode, unsigned int N1, unsigned int N2, const std::string& name, float val) {
         const uint32_t w = wc_slot(m_force_model->contact_wildcards, name, "contact");
-        const DemeCounts c = api_counts();
         const size_t nc = n_contacts();
         if (!nc)
             return;
@@ -2132,7 +2127,6 @@ class DEMSolver {
             sn.al[i] = {f[13][i], f[14][i], f[15][i]};
         }
         if (contacts) {
-            const DemeCounts c = api_counts();
             const size_t nc = n_contacts();
             sn.idA.resize(nc), sn.idB.resize(nc), sn.type.resize(nc);
             std::vector<uint32_t> map(nc);
