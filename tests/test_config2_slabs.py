@@ -659,3 +659,49 @@ def test_ten_million_clumps_in_eight_slabs_properties(pkg):
         c.close()
     union = np.unique(np.concatenate(keys))
     assert union.shape == ref.shape and np.array_equal(union, ref), (union.shape, ref.shape)
+
+
+@pytest.mark.parametrize("n_slabs,mode", [(8, "fast"), (2, "exact")])
+def test_million_clumps_through_deme_multi_against_single_domain_oracle(pkg, orc, packed_million, n_slabs, mode):
+    """configs[2] through the C++ decomposition (csrc/deme_decomp.inc: what DEMSolver(nGPUs) runs): the settled 1e6-clump bed handed
+    to deme_multi_build, which cuts it into bin-aligned slabs along its longest side, numbers every slab in the engine's order and
+    steps them with the ghost exchange overlapped -- against the ORACLE's single-domain run from the same state (no history on
+    either side).  The merged contact list in global ids IS the oracle's list, row for row; after 100 steps (detection every 40, the
+    bench's margins) the state gathered by global id is within the bounds of the hand-attached slabs above; in the fast mode every
+    slab's list goes through the owner-tile pass with no tile through the fallback."""
+    b, p, sc, st, cnt, W = packed_million
+    nc = int(sc.nOwnerClumps)
+    g_arrays = dict(b.arrays)
+    for k in GKEYS:
+        g_arrays[k] = np.asarray(st[k]).copy()
+    sc2 = pkg.abi.make_scene_struct(g_arrays, b.counts)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc2, slabs_per_device=n_slabs, axis=-1, halo=0.03, arith=mode)
+    sim = orc.make_sim(pkg, p, sc2)
+    orc.set_num_threads(min(64, os.cpu_count() or 1))
+    try:
+        m.step(1), sim.step(1)
+        ga, gb, gt = m.contacts()
+        oa, ob, ot, _ = sim.contacts()
+        assert len(oa) > 3_000_000 and np.array_equal(ga, oa) and np.array_equal(gb, ob) and np.array_equal(gt, ot)
+        m.step(99), sim.step(99)
+        m.sync()
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+    if mode == "fast":
+        for s in range(n_slabs):
+            c = m.slab_ctx(s)
+            assert c.force_kernel()[0] == "k_tile_forces<0, false>" and c.tile_stats()[1] == 0, (s, c.force_kernel(), c.tile_stats())
+    g, o = m.download_state(), sim.download_state()
+    X = pkg.model.decode_positions(g["voxelID"], g["locX"], g["locY"], g["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:nc]
+    Xo = pkg.model.decode_positions(o["voxelID"], o["locX"], o["locY"], o["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:nc]
+    dx = float(np.abs(X - Xo).max())
+    dv = max(float(np.abs(g[k][:nc] - o[k][:nc]).max()) for k in ("vX", "vY", "vZ"))
+    print(f"configs[2] through deme_multi, {n_slabs} slabs ({mode}): {len(oa)} contacts, |dx| {dx:.3e} m, |dv| {dv:.3e} m/s after 100 steps vs the single-domain oracle")
+    from tests.conftest import record_measured
+    record_measured(f"test_config2_slabs deme_multi {n_slabs} slabs {mode} 1e6 clumps 100 steps", dx_m=dx, dv_m_per_s=dv)
+    # (exact mode: a slab numbers its clumps in the engine's order, so an owner's contributions add up in another order than in the
+    # single domain -- fp32 rounding, measured 1.5e-9 m / 1.2e-5 m/s on this bed restarted without its friction history; fast mode:
+    # the bounds of tests/test_fast_mode.py, measured 9.8e-10 m / 2.6e-5 m/s)
+    assert (dx <= 5e-9 and dv <= 5e-5) if mode == "exact" else (dx <= 5e-8 and dv <= 2e-4)
+    m.close()
