@@ -528,6 +528,15 @@ class Multi:
         self._ck(self.lib.deme_multi_counts(self.h, C.byref(c), C.byref(mig)), "deme_multi_counts")
         return c, int(mig.value)
 
+    def add_owner_acc(self, owner, acc=None, ang_acc=None):
+        """deme_multi_add_owner_acc: accelerations for the next step, by GLOBAL owner id"""
+        a = None if acc is None else np.ascontiguousarray(acc, np.float32).reshape(-1, 3)
+        l = None if ang_acc is None else np.ascontiguousarray(ang_acc, np.float32).reshape(-1, 3)
+        n = len(a) if a is not None else len(l)
+        self.lib.deme_multi_add_owner_acc.argtypes = [_P, C.c_uint32, C.c_uint32, _P, _P]
+        self._ck(self.lib.deme_multi_add_owner_acc(self.h, int(owner), n, None if a is None else _ptr(a), None if l is None else _ptr(l)),
+                 "deme_multi_add_owner_acc")
+
     def num_contacts(self):
         n = C.c_size_t(0)
         self.lib.deme_multi_num_contacts.argtypes = [_P, C.POINTER(C.c_size_t)]

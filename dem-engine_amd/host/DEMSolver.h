@@ -1782,6 +1782,12 @@ class DEMSolver {
         else
             check(deme_download_contact_records(m_ctx, f, t, a, b, nc));
     }
+    void add_owner_acc(uint32_t owner, uint32_t n, const float* acc, const float* angAcc) {
+        if (m_multi)
+            mcheck(deme_multi_add_owner_acc(m_multi, owner, n, acc, angAcc));
+        else
+            check(deme_add_owner_acc(m_ctx, owner, n, acc, angAcc));
+    }
     DemeCounts api_counts() {
         DemeCounts c{};
         if (m_multi)
@@ -2905,12 +2911,12 @@ class DEMTracker {
     /// AddAcc / AddAngAcc (AuxClasses.h:264-274): extra acceleration for the coming step only (co-simulation hand-over)
     void AddAcc(float3 acc, size_t offset = 0) {
         const float v[3] = {acc.x, acc.y, acc.z};
-        m_sys->check(deme_add_owner_acc(m_sys->m_ctx, GetOwnerID(offset), 1, v, nullptr));
+        m_sys->add_owner_acc(GetOwnerID(offset), 1, v, nullptr);
     }
     void AddAcc(const std::vector<float3>& acc) { add_many(acc, true); }
     void AddAngAcc(float3 angAcc, size_t offset = 0) {
         const float v[3] = {angAcc.x, angAcc.y, angAcc.z};
-        m_sys->check(deme_add_owner_acc(m_sys->m_ctx, GetOwnerID(offset), 1, nullptr, v));
+        m_sys->add_owner_acc(GetOwnerID(offset), 1, nullptr, v);
     }
     void AddAngAcc(const std::vector<float3>& angAcc) { add_many(angAcc, false); }
     /// every contact force on one tracked owner / on all of them (AuxClasses.h:335-410)
@@ -2981,8 +2987,8 @@ class DEMTracker {
         std::vector<float> flat(3 * m_n);
         for (size_t k = 0; k < m_n; k++)
             flat[3 * k] = v[k].x, flat[3 * k + 1] = v[k].y, flat[3 * k + 2] = v[k].z;
-        m_sys->check(deme_add_owner_acc(m_sys->m_ctx, GetOwnerID(0), (uint32_t)m_n, linear ? flat.data() : nullptr,
-                                        linear ? nullptr : flat.data()));
+        m_sys->add_owner_acc(GetOwnerID(0), (uint32_t)m_n, linear ? flat.data() : nullptr,
+                                        linear ? nullptr : flat.data());
     }
     std::vector<bodyID_t> all_owner_ids() const {
         std::vector<bodyID_t> ids(m_n);

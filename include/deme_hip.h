@@ -597,6 +597,8 @@ int deme_multi_num_contacts(deme_multi* m, size_t* n);
 int deme_multi_download_contacts(deme_multi* m, uint32_t* idA, uint32_t* idB, uint8_t* type, size_t cap);
 int deme_multi_download_contact_wildcard(deme_multi* m, uint32_t w, float* out, size_t cap);
 int deme_multi_download_contact_records(deme_multi* m, float* force, float* torqueOnly, float* cpA, float* cpB, size_t cap);
+/* deme_add_owner_acc by GLOBAL owner id: a clump's entry goes to the slab that owns it, a replicated owner's to every slab */
+int deme_multi_add_owner_acc(deme_multi* m, uint32_t owner, uint32_t n, const float* acc, const float* angAcc);
 /* the visible HIP devices (0 and DEME_OK where there is none: what the constructors check ids against) */
 int deme_device_count(int* n);
 /* Measurement aid (quote the attainable rate beside the nominal 8 TB/s): a hand-written 16 B / lane streaming copy of

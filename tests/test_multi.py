@@ -68,6 +68,25 @@ def test_multi_slabs_equal_the_single_domain_oracle(pkg, orc, n_slabs, axis):
     m.close()
 
 
+def test_multi_adds_accelerations_by_global_owner_id(pkg, orc):
+    """deme_multi_add_owner_acc (a tracker's AddAcc on a decomposed run): a clump's entry reaches the slab that owns it, the next
+    step takes it once -- two steps later the velocities are the oracle's"""
+    b, p, sc = _bed(pkg, cd_freq=7)
+    nc = int(sc.nOwnerClumps)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc, slabs_per_device=3, axis=0, halo=0.03, arith="exact")
+    sim = orc.make_sim(pkg, p, sc)
+    v0 = sim.download_state()["vX"][:nc].copy()
+    acc = np.zeros((nc, 3), np.float32)
+    acc[:, 0] = np.linspace(-2.0e3, 2.0e3, nc, dtype=np.float32)
+    m.add_owner_acc(0, acc), sim.add_owner_acc(0, acc)
+    m.step(2), sim.step(2)
+    m.sync()
+    g, o = m.download_state(), sim.download_state()
+    assert np.abs(g["vX"][:nc] - o["vX"][:nc]).max() < 1e-5 and np.abs(o["vX"][:nc] - v0).max() > 5e-3
+    m.close()
+
+
 def test_multi_migrates_a_drifting_bed(pkg, orc):
     """a sheared bed in three library-made slabs with deme_multi_set_migration(50): clumps change slabs inside deme_multi_step, the
     gather by global id follows them (the books come from the library), and the run stays on the oracle's single-domain trajectory
