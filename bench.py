@@ -837,7 +837,7 @@ def main():
     # (deme_copy_rate_probe; 1 GiB each way, beyond the 256 MiB Infinity Cache); the guide's figure for such a copy is 6.29 TB/s.
     # (Round 4 used torch's device-to-device copy here, which reaches 4.7-5.4 TB/s: a fraction of THAT flattered the kernel.)
     copy_gbs = None
-    if rank == 0:
+    if rank == 0 and not args.no_cpu_baseline:  # (profiling and A/B runs pass --no-cpu-baseline: their traces hold the bench's kernels only)
         try:
             copy_gbs = pkg.abi.copy_rate_probe(local_rank)
         except Exception as e:  # (a box short of 2 GiB of free HBM)
