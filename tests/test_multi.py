@@ -195,3 +195,32 @@ def test_multi_of_one_slab_in_the_fast_mode_gets_the_engines_order(pkg, orc):
     dx = np.abs(_positions(pkg, p, g, nc) - _positions(pkg, p, o, nc)).max()
     assert dx < 5e-8, dx
     m.close()
+
+
+def test_multi_migrates_along_another_axis(pkg, orc):
+    """the cut axis is the plan's (the longest side of the bed: y here), and the migration kernels classify clumps by THAT coordinate
+    (deme_migrate.h: mig_world_coord): a bed sheared in y, three slabs cut along y, clumps change slabs inside deme_multi_step and the
+    run stays on the oracle's single-domain trajectory"""
+    b = pkg.model.packed_bed(20_000, seed=6, cd_freq=0, spacing_mult=2.5, init_vz=-0.4, aspect=(1.0, 2.0, 0.5))
+    p, sc = b.Initialize()
+    nc = int(sc.nOwnerClumps)
+    b.arrays["vY"][:nc] = np.where(np.arange(nc) % 2 == 0, 0.6, 0.3).astype(np.float32)
+    sc = pkg.abi.make_scene_struct(b.arrays, b.counts)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc, slabs_per_device=3, axis=-1, halo=0.035, arith="exact")
+    plan_axis = 1
+    sim = orc.make_sim(pkg, p, sc)
+    m.set_migration(50)
+    orc.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        m.step(151), sim.step(151)
+        m.sync()
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+    cnt, moved = m.counts()
+    assert moved > 20, moved
+    g, o = m.download_state(), sim.download_state()
+    dx = np.abs(_positions(pkg, p, g, nc) - _positions(pkg, p, o, nc)).max()
+    print(f"bed sheared in y, 3 slabs along axis {plan_axis}, {moved} clumps migrated: |dx| {dx:.3e} m vs the single-domain oracle")
+    assert dx < 1e-4
+    m.close()
