@@ -528,6 +528,25 @@ class Multi:
         self._ck(self.lib.deme_multi_counts(self.h, C.byref(c), C.byref(mig)), "deme_multi_counts")
         return c, int(mig.value)
 
+    def rebalance(self):
+        """deme_multi_rebalance: (clumps moved, boundaries in force afterwards)"""
+        n = C.c_uint32(0)
+        e = np.zeros(self.num_slabs() + 1, np.float64)
+        self.lib.deme_multi_rebalance.argtypes = [_P, C.POINTER(C.c_uint32), _P]
+        self._ck(self.lib.deme_multi_rebalance(self.h, C.byref(n), _ptr(e)), "deme_multi_rebalance")
+        return int(n.value), e
+
+    def set_rebalance(self, every_nth_migration):
+        self.lib.deme_multi_set_rebalance.argtypes = [_P, C.c_uint32]
+        self._ck(self.lib.deme_multi_set_rebalance(self.h, int(every_nth_migration)), "deme_multi_set_rebalance")
+
+    def slab_counts(self, s):
+        """((own, ghosts below, ghosts above, owners, spheres, seeded contacts), (lo, hi)) of a slab"""
+        v, r = (C.c_uint32 * 6)(), (C.c_double * 2)()
+        self.lib.deme_multi_slab_counts.argtypes = [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        self._ck(self.lib.deme_multi_slab_counts(self.h, int(s), v, r), "deme_multi_slab_counts")
+        return tuple(int(x) for x in v), (float(r[0]), float(r[1]))
+
     def add_owner_acc(self, owner, acc=None, ang_acc=None):
         """deme_multi_add_owner_acc: accelerations for the next step, by GLOBAL owner id"""
         a = None if acc is None else np.ascontiguousarray(acc, np.float32).reshape(-1, 3)

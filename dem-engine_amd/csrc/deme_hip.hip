@@ -1726,6 +1726,44 @@ int deme_set_params(deme_ctx* c, const DemeParams* p) {
     return DEME_OK;
 }
 
+// ---- the scratch a scene of nO owners / nS spheres needs: ONE statement of it, used by deme_upload_scene and by the slab migration
+// (deme_migrate_host.inc), whose slabs change their counts.  (A second, shorter list in the migration once missed sphFam: a slab that
+// had grown wrote its ghosts' family words past the end of the buffer.)
+static int owner_scratch_for_counts(deme_ctx* c, size_t nO) {
+    if (int rc = ensure(c, c->acc, std::max<size_t>(nO, 1) * sizeof(AccRec)))
+        return rc;
+    if (ensure(c, c->ownersNext, std::max<size_t>(nO, 1) * sizeof(OwnerRec)) || ensure(c, c->inCnt, (nO + 2) * 4) || ensure(c, c->inStart, (nO + 2) * 4))
+        return c->lastStatus;
+    c->fusedList = c->fusedPrevValid = false;
+    HIPCK(hipMemsetAsync(c->acc.p, 0, c->acc.bytes, c->stream));
+    if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->aSum, (nO + 1) * 32) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
+        ensure(c, c->fixedFlag, nO + 1) || ensure(c, c->heavyList, 4096 * 4) || ensure(c, c->rangeCtr, sizeof(RangeCounters)))
+        return c->lastStatus;
+    const size_t nTiles = (nO + DEME_TILE_NB - 1) / DEME_TILE_NB + 1;
+    if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->hCountIn, nTiles * 4) ||
+        ensure(c, c->tileMode, nTiles * 4) || ensure(c, c->tileOrg, nTiles * 24) || ensure(c, c->rStart, (nO + 1) * 4) ||
+        ensure(c, c->lOff, nTiles * (DEME_TILE_NB + 1) * 2) || ensure(c, c->lCount, nTiles * 4) || ensure(c, c->tileRem, (nTiles + 1) * 4) ||
+        ensure(c, c->tileBase, (nTiles + 1) * 4) || ensure(c, c->tileBig, nTiles * 4) || ensure(c, c->bigList, nTiles * 4))
+        return c->lastStatus;
+    HIPCK(hipMemsetAsync(c->hCount.p, 0, c->hCount.bytes, c->stream));
+    c->tileActive = c->conTile = false;
+    HIPCK(hipMemsetAsync(c->aStart.p, 0, c->aStart.bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->bStart.p, 0, c->bStart.bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->heavy.p, 0, c->heavy.bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->fixedFlag.p, 0, c->fixedFlag.bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->rangeCtr.p, 0, sizeof(RangeCounters), c->stream));
+    return DEME_OK;
+}
+static int sphere_scratch_for_counts(deme_ctx* c, size_t nS) {
+    if (ensure(c, c->sphFam, std::max<size_t>(nS, 1) * 2) || ensure(c, c->geo, std::max<size_t>(nS, 1) * sizeof(GeoRec)) ||
+        ensure(c, c->binLo, std::max<size_t>(nS, 1) * 16) || ensure(c, c->binN, std::max<size_t>(nS, 1) * 8) || ensure(c, c->counts, (nS + 1) * 4) ||
+        ensure(c, c->offsets, (nS + 1) * 4))
+        return c->lastStatus;
+    size_t need = 0;
+    HIPCK(rocprim::exclusive_scan(nullptr, need, c->counts.as<uint32_t>(), c->offsets.as<uint32_t>(), 0u, nS + 1, rocprim::plus<uint32_t>(), c->stream));
+    return ensure(c, c->scanTmp, need);
+}
+
 int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     if (!c || !s)
         return DEME_ERR_INVALID;
@@ -1774,30 +1812,8 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     }
     if (int rc = upload(c, c->owners, ho.data(), nO))
         return rc;
-    if (int rc = ensure(c, c->acc, std::max<size_t>(nO, 1) * sizeof(AccRec)))
+    if (int rc = owner_scratch_for_counts(c, nO))
         return rc;
-    if (ensure(c, c->ownersNext, std::max<size_t>(nO, 1) * sizeof(OwnerRec)) || ensure(c, c->inCnt, (nO + 2) * 4) || ensure(c, c->inStart, (nO + 2) * 4))
-        return c->lastStatus;
-    c->fusedList = c->fusedPrevValid = false;
-    HIPCK(hipMemsetAsync(c->acc.p, 0, c->acc.bytes, c->stream));
-    if (ensure(c, c->aStart, (nO + 1) * 4) || ensure(c, c->aSum, (nO + 1) * 32) || ensure(c, c->bStart, (nO + 1) * 4) || ensure(c, c->heavy, nO + 1) ||
-        ensure(c, c->fixedFlag, nO + 1) || ensure(c, c->heavyList, 4096 * 4) || ensure(c, c->rangeCtr, sizeof(RangeCounters)))
-        return c->lastStatus;
-    {
-        const size_t nTiles = (nO + DEME_TILE_NB - 1) / DEME_TILE_NB + 1;
-        if (ensure(c, c->hList, nTiles * DEME_TILE_HMAX * 4) || ensure(c, c->hCount, nTiles * 4) || ensure(c, c->hCountIn, nTiles * 4) || ensure(c, c->tileMode, nTiles * 4) || ensure(c, c->tileOrg, nTiles * 24) ||
-            ensure(c, c->rStart, (nO + 1) * 4) || ensure(c, c->lOff, nTiles * (DEME_TILE_NB + 1) * 2) || ensure(c, c->lCount, nTiles * 4) ||
-            ensure(c, c->tileRem, (nTiles + 1) * 4) || ensure(c, c->tileBase, (nTiles + 1) * 4) || ensure(c, c->tileBig, nTiles * 4) ||
-            ensure(c, c->bigList, nTiles * 4))
-            return c->lastStatus;
-        HIPCK(hipMemsetAsync(c->hCount.p, 0, c->hCount.bytes, c->stream));
-        c->tileActive = c->conTile = false;
-    }
-    HIPCK(hipMemsetAsync(c->aStart.p, 0, c->aStart.bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->bStart.p, 0, c->bStart.bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->heavy.p, 0, c->heavy.bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->fixedFlag.p, 0, c->fixedFlag.bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->rangeCtr.p, 0, sizeof(RangeCounters), c->stream));
     c->nHeavy = c->nHeavyFree = 0;
     c->hrPending = false;
     c->conValid = false;
@@ -1898,17 +1914,8 @@ int deme_upload_scene(deme_ctx* c, const DemeScene* s) {
     }
     c->dp.hasGhosts = (c->hasGhosts ? 1u : 0u) | (c->pairsOnce ? 2u : 0u);
     // detection scratch
-    if (ensure(c, c->sphFam, std::max<size_t>(nS, 1) * 2) || ensure(c, c->geo, std::max<size_t>(nS, 1) * sizeof(GeoRec)) || ensure(c, c->binLo, std::max<size_t>(nS, 1) * 16) ||
-        ensure(c, c->binN, std::max<size_t>(nS, 1) * 8) || ensure(c, c->counts, (nS + 1) * 4) ||
-        ensure(c, c->offsets, (nS + 1) * 4))
-        return c->lastStatus;
-    {
-        size_t need = 0;
-        HIPCK(rocprim::exclusive_scan(nullptr, need, c->counts.as<uint32_t>(), c->offsets.as<uint32_t>(), 0u, nS + 1,
-                                      rocprim::plus<uint32_t>(), c->stream));
-        if (int rc = ensure(c, c->scanTmp, need))
-            return rc;
-    }
+    if (int rc = sphere_scratch_for_counts(c, nS))
+        return rc;
     if (int rc = grow_incidence_arena(c, std::max<size_t>(8 * nS, 4096)))
         return rc;
     c->nTri = s->nTri;  // before the contact arena: its mesh work-list buffers exist only when triangles do

@@ -455,7 +455,9 @@ class DEMSolver {
     }
     /// slabs per device of a decomposed run (not in the reference; the environment variable DEME_SLABS_PER_DEVICE does the same
     /// for an unchanged script), the clumps' migration interval in steps (0: never) and the ghost layer thickness (0: four clump
-    /// reaches).  Before Initialize().
+    /// reaches); every n-th migration may recompute the slab boundaries from where the clumps are by then (0: the boundaries stay
+    /// where Initialize() put them).  Before Initialize().
+    void SetSlabRebalanceInterval(unsigned int nthMigration) { m_rebalance_every = nthMigration; }
     void SetSlabsPerDevice(unsigned int s) { m_slabs_per_device = s < 1 ? 1 : s; }
     void SetSlabMigrationInterval(unsigned int steps) { m_migrate_every = steps; }
     void SetSlabHalo(float halo) { m_slab_halo = halo; }
@@ -1671,7 +1673,7 @@ class DEMSolver {
     deme_ctx* m_ctx = nullptr;       // the context of a one-device, one-slab run; of a decomposed run: the FIRST slab's (owned by m_multi)
     deme_multi* m_multi = nullptr;   // a decomposed run: several devices and / or several slabs per device
     std::vector<int> m_devices;
-    unsigned int m_slabs_per_device = 1, m_migrate_every = 1000;
+    unsigned int m_slabs_per_device = 1, m_migrate_every = 1000, m_rebalance_every = 0;
     float m_slab_halo = 0.f;
 
     void open_devices(const std::vector<int>& ids) {
@@ -1688,6 +1690,8 @@ class DEMSolver {
             m_slabs_per_device = (unsigned)std::max(1, atoi(e));
         if (const char* e = std::getenv("DEME_SLAB_MIGRATE_EVERY"))  // (SetSlabMigrationInterval)
             m_migrate_every = (unsigned)std::max(0, atoi(e));
+        if (const char* e = std::getenv("DEME_SLAB_REBALANCE_EVERY"))  // (SetSlabRebalanceInterval)
+            m_rebalance_every = (unsigned)std::max(0, atoi(e));
         if (const char* e = std::getenv("DEME_SLAB_HALO"))  // ghost layer thickness [m] of an unchanged script (SetSlabHalo)
             m_slab_halo = (float)atof(e);
         if (ids.size() == 1) {  // (a decomposed run on one device opens its deme_multi at Initialize, when the slab count is final)
@@ -2602,6 +2606,7 @@ class DEMSolver {
             mcheck(deme_multi_build(m_multi, &p, &s, m_slabs_per_device, -1, (double)m_slab_halo, freeOwner ? DEME_DECOMP_SHARED_FREE : 0u, -1,
                                     p.forceModel == DEME_FORCE_HERTZIAN ? 7u : 0u));
             mcheck(deme_multi_set_migration(m_multi, m_migrate_every));
+            mcheck(deme_multi_set_rebalance(m_multi, m_rebalance_every));
         } else {
             check(deme_set_params(m_ctx, &p));
             check(deme_upload_scene(m_ctx, &s));

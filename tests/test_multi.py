@@ -224,3 +224,89 @@ def test_multi_migrates_along_another_axis(pkg, orc):
     print(f"bed sheared in y, 3 slabs along axis {plan_axis}, {moved} clumps migrated: |dx| {dx:.3e} m vs the single-domain oracle")
     assert dx < 1e-4
     m.close()
+
+
+def test_multi_rebalance_moves_the_slab_boundaries(pkg, orc):
+    """deme_multi_rebalance: a bed whose clumps all drift in +x empties its first slab and crowds its last one; the boundaries are
+    recomputed from the current positions (equal counts, bin-aligned), the library's migration moves the clumps that now lie beyond
+    them -- the counts are evener, every clump is owned once.  The run that rebalanced and a twin that did not start from the same
+    state and are compared 101 steps later (the bed is landing and hitting a wall at 2 m/s by then: against the oracle's
+    single-domain trajectory both carry the same amplified summation-order difference, which is recorded, and which the rebalance
+    must not add to)."""
+    b = pkg.model.packed_bed(20_000, seed=6, cd_freq=0, spacing_mult=2.5, init_vz=-0.2, aspect=(2.0, 1.0, 0.5))
+    p, sc = b.Initialize()
+    nc = int(sc.nOwnerClumps)
+    b.arrays["vX"][:nc] = 2.0  # the whole bed drifts
+    sc = pkg.abi.make_scene_struct(b.arrays, b.counts)
+    runs = []
+    for _ in range(2):
+        m = pkg.abi.Multi(devices=(0,))
+        m.build(p, sc, slabs_per_device=4, axis=0, halo=0.035, arith="exact")
+        m.set_migration(100)
+        runs.append(m)
+    m, twin = runs
+    sim = orc.make_sim(pkg, p, sc)
+    orc.set_num_threads(min(16, os.cpu_count() or 1))
+    try:
+        m.step(1500), twin.step(1500), sim.step(1500)  # 3 cm of drift: the lower slabs thin out, the top one fills
+        m.sync(), twin.sync()
+        x0, xt0, xo0 = (_positions(pkg, p, r.download_state(), nc) for r in (m, twin, sim))
+        assert np.array_equal(x0, xt0)  # (exact mode: the twins are bit-identical so far)
+        dx_o0 = np.abs(x0 - xo0).max()
+        own0 = [m.slab_counts(s)[0][0] for s in range(4)]
+        e0 = [m.slab_counts(s)[1] for s in range(4)]
+        moved, edges = m.rebalance()
+        own1 = [m.slab_counts(s)[0][0] for s in range(4)]
+        assert sum(own0) == sum(own1) == nc and moved > 0
+        assert max(own1) - min(own1) < max(own0) - min(own0), (own0, own1)
+        inner = (edges[1:-1] - float(p.LBFX)) / float(p.binSize)
+        assert np.abs(inner - np.rint(inner)).max() < 1e-9 and all(edges[i + 1] - edges[i] >= 0.035 for i in range(1, 3))
+        assert np.array_equal(_positions(pkg, p, m.download_state(), nc), x0)  # moving clumps between slabs moves none of them in space
+        m.step(101), twin.step(101), sim.step(101)
+        m.sync(), twin.sync()
+    finally:
+        orc.set_num_threads(min(8, os.cpu_count() or 1))
+    x1, xt1, xo1 = (_positions(pkg, p, r.download_state(), nc) for r in (m, twin, sim))
+    dx_t, dx_o1, dx_to1 = np.abs(x1 - xt1).max(), np.abs(x1 - xo1).max(), np.abs(xt1 - xo1).max()
+    print(f"drifting bed, 4 slabs: own clumps {own0} -> {own1} after deme_multi_rebalance ({moved} moved; boundaries "
+          f"{np.round(edges[1:-1], 4).tolist()}, were {[round(e[1], 4) for e in e0[:-1]]}); 101 steps later |dx| {dx_t:.3e} m vs the twin that "
+          f"kept its boundaries; vs the oracle {dx_o0:.3e} m before, {dx_o1:.3e} m after (the twin: {dx_to1:.3e} m)")
+    assert dx_t < max(1e-6, 3 * dx_o0)
+    assert dx_o1 < 3 * max(dx_o0, dx_to1) + 1e-7
+    m.close(), twin.close()
+
+
+def test_slabs_that_grow_keep_their_scratch_in_step(pkg, monkeypatch):
+    """A slab that a migration left with MORE spheres than it was uploaded with needs every per-sphere / per-owner buffer of the
+    context at the new size (one list of them serves deme_upload_scene and the migration).  The drifting bed fills its upper slabs:
+    twelve migrations with the library's own check of the books after each (DEME_MIG_CHECK: every id of every re-assembled slab
+    names a row of the global scene), and the state read back by global id every time.  (Before the lists were one, the ghosts'
+    family words of a grown slab were written past their buffer -- into the neighbour allocation, which here was the id table.)"""
+    monkeypatch.setenv("DEME_MIG_CHECK", "1")
+    b = pkg.model.packed_bed(20_000, seed=6, cd_freq=0, spacing_mult=2.5, init_vz=-0.2, aspect=(2.0, 1.0, 0.5))
+    p, sc = b.Initialize()
+    nc = int(sc.nOwnerClumps)
+    b.arrays["vX"][:nc] = 2.0
+    sc = pkg.abi.make_scene_struct(b.arrays, b.counts)
+    spread = {}
+    for caller_order in (True, False):
+        m = pkg.abi.Multi(devices=(0,))
+        m.build(p, sc, slabs_per_device=4, axis=0, halo=0.035, arith="exact", caller_order=caller_order)
+        m.set_migration(100)
+        if not caller_order:
+            m.set_rebalance(3)  # (the second run also moves its boundaries, at every third migration)
+        grew = 0
+        n0 = [m.slab_counts(s)[0][4] for s in range(4)]
+        for _ in range(12):
+            m.step(100), m.sync()
+            st = m.download_state()
+            assert np.isfinite(st["vX"][:nc]).all()
+            grew = max(grew, max(m.slab_counts(s)[0][4] - n0[s] for s in range(4)))
+        own = [m.slab_counts(s)[0][0] for s in range(4)]
+        assert sum(own) == nc
+        spread[caller_order] = max(own) - min(own)
+        if caller_order:
+            assert grew > 500, grew  # (a slab did outgrow its upload by hundreds of spheres)
+        m.close()
+    print(f"own-clump spread over 4 slabs after 1200 steps of drift: {spread[True]} with fixed boundaries, {spread[False]} rebalanced at every third migration")
+    assert spread[False] < spread[True]  # (a boundary sits on a bin face: one 1.6 cm column of this bed holds ~500 clumps)
