@@ -536,6 +536,26 @@ class Multi:
         self._ck(self.lib.deme_multi_rebalance(self.h, C.byref(n), _ptr(e)), "deme_multi_rebalance")
         return int(n.value), e
 
+    def wildcard_array(self, kind, index, n):
+        """a user model's wildcard array by GLOBAL id (kind: owner, sphere; n = the global scene's count)"""
+        out = np.zeros(int(n), np.float32)
+        self.lib.deme_multi_download_wildcard_array.argtypes = [_P, C.c_uint32, C.c_uint32, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_download_wildcard_array(self.h, Context.WC_KINDS[kind], int(index), _ptr(out), out.size),
+                 "deme_multi_download_wildcard_array")
+        return out
+
+    def set_wildcard_array(self, kind, index, values):
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        self.lib.deme_multi_upload_wildcard_array.argtypes = [_P, C.c_uint32, C.c_uint32, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_upload_wildcard_array(self.h, Context.WC_KINDS[kind], int(index), _ptr(v), v.size),
+                 "deme_multi_upload_wildcard_array")
+
+    def set_contact_wildcard(self, w, values):
+        """a per-contact wildcard column of the merged list (every slab's copy of a pair takes the value)"""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        self.lib.deme_multi_upload_contact_wildcard.argtypes = [_P, C.c_uint32, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_upload_contact_wildcard(self.h, int(w), _ptr(v), v.size), "deme_multi_upload_contact_wildcard")
+
     def set_rebalance(self, every_nth_migration):
         self.lib.deme_multi_set_rebalance.argtypes = [_P, C.c_uint32]
         self._ck(self.lib.deme_multi_set_rebalance(self.h, int(every_nth_migration)), "deme_multi_set_rebalance")

@@ -2722,6 +2722,7 @@ struct HaloSide {
 };
 struct MigBuf {  // one direction of a migration exchange: clumps, their spheres, history rows (device buffers, counts on the host)
     void *clumps = nullptr, *spheres = nullptr, *rowH = nullptr, *rowW = nullptr, *counts = nullptr;
+    void *owc = nullptr, *swc = nullptr;  // user wildcard arrays of the clumps / spheres: [clump][k], [sphere][k] floats
     uint32_t nC = 0, nS = 0, nR = 0;
     bool borrowed = false;  // the buffers belong to a neighbour slab of this process
 };

@@ -255,6 +255,55 @@ __global__ __launch_bounds__(256) void k_mig_pack_ghosts(uint32_t nOwn, const Ow
     }
 }
 
+// user wildcard arrays (deme_compile_force_model_ex: up to 8 per-owner and 8 per-sphere float arrays) travel beside the clump packets
+// in two more streams: [clump][k] and [sphere][k], in the packets' own order
+struct MigWcPtrs {
+    float* p[8];
+};
+__global__ __launch_bounds__(256) void k_mig_pack_wc(uint32_t nClumps, const uint8_t* __restrict__ dest, const MigCount* __restrict__ pos,
+                                                     uint32_t d, int bitCoded, const uint32_t* __restrict__ firstSph, uint32_t nOW,
+                                                     uint32_t nGW, MigWcPtrs ow, MigWcPtrs gw, float* __restrict__ outO,
+                                                     float* __restrict__ outS) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nClumps)
+        return;
+    if (bitCoded ? !(dest[o] & d) : dest[o] != d)
+        return;
+    const uint32_t j = pos[o].c[d];
+    for (uint32_t k = 0; k < nOW; k++)
+        outO[(size_t)j * nOW + k] = ow.p[k][o];
+    if (nGW) {
+        const uint32_t fs = firstSph[o], ns = firstSph[o + 1] - fs, sj = pos[o].s[d];
+        for (uint32_t s = 0; s < ns; s++)
+            for (uint32_t k = 0; k < nGW; k++)
+                outS[(size_t)(sj + s) * nGW + k] = gw.p[k][fs + s];
+    }
+}
+// sphOff: the exclusive scan of the packet's sphere counts over n + 1 entries (sphOff[n] = the packet's spheres)
+__global__ __launch_bounds__(256) void k_mig_unpack_wc(uint32_t n, const float* __restrict__ inO, const float* __restrict__ inS,
+                                                       const uint32_t* __restrict__ sphOff, uint32_t ownerBase, uint32_t sphBase, uint32_t nOW,
+                                                       uint32_t nGW, MigWcPtrs ow, MigWcPtrs gw) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    for (uint32_t k = 0; k < nOW; k++)
+        ow.p[k][ownerBase + i] = inO[(size_t)i * nOW + k];
+    if (nGW) {
+        const uint32_t s0 = sphOff[i], ns = sphOff[i + 1] - s0;
+        for (uint32_t s = 0; s < ns; s++)
+            for (uint32_t k = 0; k < nGW; k++)
+                gw.p[k][sphBase + s0 + s] = inS[(size_t)(s0 + s) * nGW + k];
+    }
+}
+__global__ __launch_bounds__(256) void k_mig_copy_extras_wc(uint32_t n, uint32_t oldBase, uint32_t newBase, uint32_t nOW, MigWcPtrs oldW,
+                                                            MigWcPtrs newW) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    for (uint32_t k = 0; k < nOW; k++)
+        newW.p[k][newBase + i] = oldW.p[k][oldBase + i];
+}
+
 __global__ __launch_bounds__(256) void k_mig_copy_extras(uint32_t n, const OwnerRec* __restrict__ oldOwners, const uint32_t* __restrict__ oldGid,
                                                          uint32_t oldBase, uint32_t newBase, OwnerRec* __restrict__ owners,
                                                          uint32_t* __restrict__ ownerGid) {

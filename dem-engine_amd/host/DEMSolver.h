@@ -1717,6 +1717,19 @@ class DEMSolver {
         return c;
     }
     /// what a decomposed run does not offer yet says so instead of touching one slab only
+    // a user model's wildcard arrays: one context's, or by global id across the slabs of a decomposed run
+    void ul_wc_array(uint32_t kind, uint32_t j, const float* v, size_t n) {
+        if (m_multi)
+            mcheck(deme_multi_upload_wildcard_array(m_multi, kind, j, v, n));
+        else
+            check(deme_upload_wildcard_array(m_ctx, kind, j, v, n));
+    }
+    void dl_wc_array(uint32_t kind, uint32_t j, float* v, size_t n) {
+        if (m_multi)
+            mcheck(deme_multi_download_wildcard_array(m_multi, kind, j, v, n));
+        else
+            check(deme_download_wildcard_array(m_ctx, kind, j, v, n));
+    }
     void single_only(const char* what) const {
         if (m_multi)
             throw std::runtime_error(std::string(what) + " is not available on a decomposed run (several GPUs / DEME_SLABS_PER_DEVICE) yet");
@@ -1845,18 +1858,18 @@ class DEMSolver {
             std::vector<float> a(m_n_owners, 0.f);
             for (size_t o = 0; o < w.owner[j].size(); o++)
                 a[new_owner(o)] = w.owner[j][o];
-            check(deme_upload_wildcard_array(m_ctx, 0, j, a.data(), a.size()));
+            ul_wc_array(0, j, a.data(), a.size());
         }
         for (uint32_t j = 0; j < w.sphere.size(); j++) {
             std::vector<float> a(m_keep.sphOwner.size(), 0.f);
             for (size_t i = 0; i < w.sphere[j].size(); i++)
                 a[new_sphere(i)] = w.sphere[j][i];
-            check(deme_upload_wildcard_array(m_ctx, 1, j, a.data(), a.size()));
+            ul_wc_array(1, j, a.data(), a.size());
         }
         for (uint32_t j = 0; j < w.tri.size(); j++)
-            check(deme_upload_wildcard_array(m_ctx, 2, j, w.tri[j].data(), w.tri[j].size()));
+            ul_wc_array(2, j, w.tri[j].data(), w.tri[j].size());
         for (uint32_t j = 0; j < w.anal.size(); j++)
-            check(deme_upload_wildcard_array(m_ctx, 3, j, w.anal[j].data(), w.anal[j].size()));
+            ul_wc_array(3, j, w.anal[j].data(), w.anal[j].size());
     }
     static uint32_t wc_slot(const std::set<std::string>& names, const std::string& name, const char* what) {
         uint32_t j = 0;
@@ -1867,14 +1880,14 @@ class DEMSolver {
     }
     std::vector<float> get_wildcard(uint32_t kind, size_t n, const std::set<std::string>& names, const std::string& name) {
         std::vector<float> a(n, 0.f);
-        check(deme_download_wildcard_array(m_ctx, kind, wc_slot(names, name, kind ? "geometry" : "owner"), a.data(), n));
+        dl_wc_array(kind, wc_slot(names, name, kind ? "geometry" : "owner"), a.data(), n);
         return a;
     }
     template <typename F>
     void edit_wildcard(uint32_t kind, size_t n, const std::set<std::string>& names, const std::string& name, F&& edit) {
         std::vector<float> a = get_wildcard(kind, n, names, name);
         edit(a);
-        check(deme_upload_wildcard_array(m_ctx, kind, wc_slot(names, name, kind ? "geometry" : "owner"), a.data(), n));
+        ul_wc_array(kind, wc_slot(names, name, kind ? "geometry" : "owner"), a.data(), n);
     }
     void set_geo(uint32_t kind, size_t n, bodyID_t geoID, const std::string& name, const std::vector<float>& vals) {
         edit_wildcard(kind, n, m_force_model->geo_wildcards, name, [&](std::vector<float>& a) {
@@ -1914,7 +1927,10 @@ class DEMSolver {
             if (q)
                 col[i] = val;
         }
-        check(deme_upload_contact_wildcard(m_ctx, w, col.data(), nc));
+        if (m_multi)
+            mcheck(deme_multi_upload_contact_wildcard(m_multi, w, col.data(), nc));
+        else
+            check(deme_upload_contact_wildcard(m_ctx, w, col.data(), nc));
     }
     bool m_initialized = false;
     unsigned int m_max_sph_in_bin = 32768;  // API.h:1483 default
@@ -2081,7 +2097,7 @@ class DEMSolver {
         for (auto it = names.begin(); it != names.end(); ++it, ++j) {
             out.emplace_back(n_elem, 0.f);
             if (m_force_model->type == FORCE_MODEL::CUSTOM)
-                const_cast<DEMSolver*>(this)->check(deme_download_wildcard_array(m_ctx, kind, j, out.back().data(), n_elem));
+                const_cast<DEMSolver*>(this)->dl_wc_array(kind, j, out.back().data(), n_elem);
         }
         return out;
     }

@@ -597,6 +597,8 @@ int deme_multi_num_contacts(deme_multi* m, size_t* n);
 int deme_multi_download_contacts(deme_multi* m, uint32_t* idA, uint32_t* idB, uint8_t* type, size_t cap);
 int deme_multi_download_contact_wildcard(deme_multi* m, uint32_t w, float* out, size_t cap);
 int deme_multi_download_contact_records(deme_multi* m, float* force, float* torqueOnly, float* cpA, float* cpB, size_t cap);
+/* deme_upload_contact_wildcard for the merged list (n = deme_multi_num_contacts): every slab's copy of a pair takes the value */
+int deme_multi_upload_contact_wildcard(deme_multi* m, uint32_t w, const float* in, size_t n);
 /* Moving the slab boundaries: equal counts again from the clumps' CURRENT coordinates (snapped to bin faces), then the migration of
  * deme_halo_group_migrate moves the clumps that now lie beyond a boundary.  One call moves a boundary by less than the narrower of its
  * two slabs minus the halo (a clump travels to a face neighbour only); newEdges (nSlabs + 1, may be NULL) receives the boundaries in
@@ -605,6 +607,12 @@ int deme_multi_rebalance(deme_multi* m, uint32_t* clumpsMoved, double* newEdges)
 /* every n-th migration that deme_multi_step finds due (deme_multi_set_migration) recomputes the boundaries first; 0: never (default) */
 int deme_multi_set_rebalance(deme_multi* m, uint32_t everyNthMigration);
 int deme_multi_slab_counts(deme_multi* m, uint32_t slab, uint32_t counts[6], double range[2]);
+/* deme_download / _upload_wildcard_array by GLOBAL id (kind 0: per owner, 1: per sphere; n = the global scene's count): a row is read
+ * from the slab that owns the clump (a replicated owner's from the first slab) and written to every copy.  Kinds 2, 3 (triangles,
+ * analytical components: replicated geometry) are written to every slab and read back only on a one-slab run.  The library's
+ * migration carries owner and sphere wildcard arrays with the clumps (deme_halo_group_migrate). */
+int deme_multi_download_wildcard_array(deme_multi* m, uint32_t kind, uint32_t index, float* out, size_t cap);
+int deme_multi_upload_wildcard_array(deme_multi* m, uint32_t kind, uint32_t index, const float* in, size_t n);
 /* deme_add_owner_acc by GLOBAL owner id: a clump's entry goes to the slab that owns it, a replicated owner's to every slab */
 int deme_multi_add_owner_acc(deme_multi* m, uint32_t owner, uint32_t n, const float* acc, const float* angAcc);
 /* the visible HIP devices (0 and DEME_OK where there is none: what the constructors check ids against) */

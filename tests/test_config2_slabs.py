@@ -705,3 +705,49 @@ def test_million_clumps_through_deme_multi_against_single_domain_oracle(pkg, orc
     # the bounds of tests/test_fast_mode.py, measured 9.8e-10 m / 2.6e-5 m/s)
     assert (dx <= 5e-9 and dv <= 5e-5) if mode == "exact" else (dx <= 5e-8 and dv <= 2e-4)
     m.close()
+
+
+@pytest.mark.gpu
+def test_library_migration_carries_user_wildcard_arrays(pkg):
+    """Owner and sphere wildcard arrays of a run-time compiled model across deme_halo_group_migrate: values tagged with the GLOBAL
+    ids before the clumps cross the cuts sit under the re-assembled slabs' numbering afterwards -- own clumps, ghost copies (their
+    values come from the slab that owns them) -- and a replicated owner keeps the slab's own value.  (The numpy statement of the same
+    rule: tests/test_decomp.py::test_redecomposition_carries_wildcard_arrays_and_persistent_marks.)"""
+    from tests.test_force_hook import PLAIN
+    b, p, sc, x = _sheared_bed(pkg, 3000, 6)
+    halo = 0.035
+    parts = pkg.decomp.decompose(b.arrays, b.counts, x, 3, halo=halo)
+    names = [f"unused_{k}" for k in range(int(p.nContactWildcards))]
+    ctxs = []
+    for pt in parts:
+        c = _make(pkg, p, pt["scene"])
+        c.compile_force_model(PLAIN, names, "", owner_wildcards=("tag", "twice"), geo_wildcards=("stag",))
+        n_c, n_o = int(pt["counts"]["nOwnerClumps"]), int(pt["counts"]["nOwners"])
+        og, sg = np.asarray(pt["owner_global"], np.float64), np.asarray(pt["sphere_global"], np.float64)
+        c.set_wildcard_array("owner", 0, np.r_[og[:n_c] + 0.5, np.full(n_o - n_c, -7.0)])
+        c.set_wildcard_array("owner", 1, np.r_[2 * og[:n_c], np.full(n_o - n_c, -9.0)])
+        c.set_wildcard_array("sphere", 0, sg + 0.25)
+        ctxs.append(c)
+    g = _group(pkg, ctxs, parts)
+    g.step(150)
+    g.sync()
+    for c, pt in zip(ctxs, parts):
+        g.set_slab(c, pt, halo)
+    g._ctxs = ctxs
+    moved = g.migrate()
+    assert moved >= 3
+    changed = 0
+    for c, pt in zip(ctxs, parts):
+        n_own, n_gl, n_gr, n_o, n_s, _ = g.slab_counts(c)
+        og, sg, _, _ = g.slab_ids(c)
+        n_c = n_own + n_gl + n_gr
+        changed += int(n_o != int(pt["counts"]["nOwners"]) or not np.array_equal(og[:n_c], np.asarray(pt["owner_global"][:n_c], np.uint32)))
+        tag, twice, stag = c.wildcard_array("owner", 0, n_o), c.wildcard_array("owner", 1, n_o), c.wildcard_array("sphere", 0, n_s)
+        assert np.array_equal(tag[:n_c], (og[:n_c] + 0.5).astype(np.float32)) and (tag[n_c:] == -7.0).all()
+        assert np.array_equal(twice[:n_c], (2.0 * og[:n_c]).astype(np.float32)) and (twice[n_c:] == -9.0).all()
+        assert np.array_equal(stag, (sg + 0.25).astype(np.float32))
+    assert changed >= 2  # (the slabs really were re-assembled)
+    g.step(20), g.sync()  # the model runs on with the arrays of the new sizes
+    for c in ctxs:
+        assert np.isfinite(c.download_state()["vX"]).all()
+    g.close()

@@ -177,6 +177,29 @@ def test_custom_model_demo_wildcards_from_the_script(tmp_path):
     assert abs(float(ci[2]) - fsum) <= 1e-5 * fsum  # the file prints 6-7 significant digits
 
 
+@pytest.mark.gpu
+def test_custom_model_demo_in_two_slabs_answers_like_one_domain(tmp_path):
+    """The UNCHANGED demo_custom program with DEME_SLABS_PER_DEVICE=2: a run-time compiled model with contact, owner and geometry
+    wildcards on a decomposed run.  Owner / sphere wildcard arrays are read and written by GLOBAL id (deme_multi_download_ /
+    _upload_wildcard_array: a row from the slab that owns the clump, to every copy), SetFamilyContactWildcardValueBoth writes every
+    slab's copy of a pair (deme_multi_upload_contact_wildcard), the files come from the merged list -- every CHECK line before the
+    renumbering section and the three output files are the single-domain run's, character for character."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    runs = {}
+    for tag, extra in (("one", {}), ("two", {"DEME_SLABS_PER_DEVICE": "2"})):
+        d = tmp_path / tag
+        d.mkdir()
+        (d / "demo_helpers.h").write_text("__device__ inline float demo_charge_force(float qq) { return (float)(2.5e-3 * qq); }\n")
+        out = subprocess.run([os.path.join(HOST, "demo_custom"), str(d)], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, DEME_KERNEL_INCLUDE_PATH=str(d), **extra))
+        assert out.returncode == 0 and "DEMO_OK" in out.stdout, out.stdout + out.stderr
+        runs[tag] = ([l for l in out.stdout.splitlines() if l.startswith("CHECK") and "resort" not in l and "slabs" not in l], d)
+    assert any(l.startswith("CHECK n_touch_total") for l in runs["one"][0])
+    assert runs["one"][0] == runs["two"][0]
+    for f in ("spheres.csv", "clumps.csv", "contacts.csv", "spheres_no3.csv"):
+        assert (runs["one"][1] / f).read_text() == (runs["two"][1] / f).read_text(), f
+
+
 REF_DEMOS = "/root/reference/src/demo"
 # the five scripts the round-1 review named (SURVEY section 2 row 17) first; the rest of the reference's demo directory after them
 NAMED = ["BallDrop", "Mixer", "SingleSphereCollide", "FlexibleMesh", "TestPack"]
