@@ -556,6 +556,34 @@ class Multi:
         self.lib.deme_multi_upload_contact_wildcard.argtypes = [_P, C.c_uint32, _P, C.c_size_t]
         self._ck(self.lib.deme_multi_upload_contact_wildcard(self.h, int(w), _ptr(v), v.size), "deme_multi_upload_contact_wildcard")
 
+    def seed_contacts(self, idA, idB, types, wildcards):
+        """deme_multi_seed_contacts: a saved list in GLOBAL ids (restart); wildcards (n, nW) float32 or None"""
+        a, b = np.ascontiguousarray(idA, np.uint32), np.ascontiguousarray(idB, np.uint32)
+        t = np.ascontiguousarray(types, np.uint8)
+        w = None if wildcards is None else np.ascontiguousarray(wildcards, np.float32)
+        self.lib.deme_multi_seed_contacts.argtypes = [_P, _P, _P, _P, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_seed_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), None if w is None else _ptr(w), a.size),
+                 "deme_multi_seed_contacts")
+
+    def mark_persistent_contacts(self, mode=0, n1=0, n2=0, mark=1):
+        self.lib.deme_multi_mark_persistent_contacts.argtypes = [_P, C.c_int, C.c_uint32, C.c_uint32, C.c_int]
+        self._ck(self.lib.deme_multi_mark_persistent_contacts(self.h, int(mode), int(n1), int(n2), int(mark)), "deme_multi_mark_persistent_contacts")
+
+    def persistent_contacts(self):
+        n = C.c_size_t(0)
+        self.lib.deme_multi_num_persistent_contacts.argtypes = [_P, C.POINTER(C.c_size_t)]
+        self._ck(self.lib.deme_multi_num_persistent_contacts(self.h, C.byref(n)), "deme_multi_num_persistent_contacts")
+        a, b, t = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint8)
+        self.lib.deme_multi_download_persistent_contacts.argtypes = [_P, _P, _P, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_download_persistent_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), n.value), "deme_multi_download_persistent_contacts")
+        return a, b, t
+
+    def set_persistent_contacts(self, idA, idB, types):
+        a, b = np.ascontiguousarray(idA, np.uint32), np.ascontiguousarray(idB, np.uint32)
+        t = np.ascontiguousarray(types, np.uint8)
+        self.lib.deme_multi_upload_persistent_contacts.argtypes = [_P, _P, _P, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_upload_persistent_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), a.size), "deme_multi_upload_persistent_contacts")
+
     def set_rebalance(self, every_nth_migration):
         self.lib.deme_multi_set_rebalance.argtypes = [_P, C.c_uint32]
         self._ck(self.lib.deme_multi_set_rebalance(self.h, int(every_nth_migration)), "deme_multi_set_rebalance")

@@ -28,6 +28,7 @@ using DemeRadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim
                                                 rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, IPT>, rocprim::kernel_config<1024, IPT>, RB,
                                                                                     rocprim::block_radix_rank_algorithm::match>,
                                                 1024 * 1024>;
+#include <array>
 #include <iterator>
 #include <limits>
 

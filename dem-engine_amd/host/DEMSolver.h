@@ -1086,7 +1086,7 @@ class DEMSolver {
         m_p.timeElapsed = t;
         each_ctx([&](deme_ctx* c) { return deme_set_params(c, &m_p); });
         if (nc)
-            check(deme_seed_contacts(m_ctx, a.data(), b.data(), ty.data(), nW ? W.data() : nullptr, nc));
+            mc_seed_contacts(a.data(), b.data(), ty.data(), nW ? W.data() : nullptr, nc);
         m_state_fresh = false;
     }
     /// Restore spatial order in a running simulation (no reference equivalent: its owner ids never change).  The clumps of every
@@ -1123,11 +1123,11 @@ class DEMSolver {
                 W[i * nW + w] = col[i];
         }
         size_t nP = 0;
-        check(deme_num_persistent_contacts(m_ctx, &nP));
+        mc_num_persistent_contacts(&nP);
         std::vector<uint32_t> pa(nP), pb(nP);
         std::vector<uint8_t> pt(nP);
         if (nP)
-            check(deme_download_persistent_contacts(m_ctx, pa.data(), pb.data(), pt.data(), nP));
+            mc_download_persistent_contacts(pa.data(), pb.data(), pt.data(), nP);
         // Z-order of the current positions, batch by batch (a batch keeps its id range)
         float rmax = 0.f;
         for (auto& t : m_templates)
@@ -1226,11 +1226,11 @@ class DEMSolver {
         };
         if (nc) {
             remap(a, b, ty, &W);
-            check(deme_seed_contacts(m_ctx, a.data(), b.data(), ty.data(), nW ? W.data() : nullptr, nc));
+            mc_seed_contacts(a.data(), b.data(), ty.data(), nW ? W.data() : nullptr, nc);
         }
         if (nP) {
             remap(pa, pb, pt, nullptr);
-            check(deme_upload_persistent_contacts(m_ctx, pa.data(), pb.data(), pt.data(), nP));
+            mc_upload_persistent_contacts(pa.data(), pb.data(), pt.data(), nP);
         }
         m_state_fresh = false;
         return new_of_old;
@@ -1729,6 +1729,31 @@ class DEMSolver {
             mcheck(deme_multi_download_wildcard_array(m_multi, kind, j, v, n));
         else
             check(deme_download_wildcard_array(m_ctx, kind, j, v, n));
+    }
+    // seeded / marked contacts: one context's, or in global ids across the slabs of a decomposed run
+    void mc_seed_contacts(const uint32_t* a, const uint32_t* b, const uint8_t* ty, const float* w, size_t n) {
+        if (m_multi)
+            mcheck(deme_multi_seed_contacts(m_multi, a, b, ty, w, n));
+        else
+            check(deme_seed_contacts(m_ctx, a, b, ty, w, n));
+    }
+    void mc_num_persistent_contacts(size_t* n) {
+        if (m_multi)
+            mcheck(deme_multi_num_persistent_contacts(m_multi, n));
+        else
+            check(deme_num_persistent_contacts(m_ctx, n));
+    }
+    void mc_download_persistent_contacts(uint32_t* a, uint32_t* b, uint8_t* ty, size_t cap) {
+        if (m_multi)
+            mcheck(deme_multi_download_persistent_contacts(m_multi, a, b, ty, cap));
+        else
+            check(deme_download_persistent_contacts(m_ctx, a, b, ty, cap));
+    }
+    void mc_upload_persistent_contacts(const uint32_t* a, const uint32_t* b, const uint8_t* ty, size_t n) {
+        if (m_multi)
+            mcheck(deme_multi_upload_persistent_contacts(m_multi, a, b, ty, n));
+        else
+            check(deme_upload_persistent_contacts(m_ctx, a, b, ty, n));
     }
     void single_only(const char* what) const {
         if (m_multi)
@@ -2739,7 +2764,7 @@ class DEMSolver {
             }
             if (!a.empty()) {
                 const std::vector<uint8_t> ty(a.size(), 1);
-                check(deme_seed_contacts(m_ctx, a.data(), b.data(), ty.data(), nW ? w.data() : nullptr, a.size()));
+                mc_seed_contacts(a.data(), b.data(), ty.data(), nW ? w.data() : nullptr, a.size());
             }
         }
     }

@@ -597,6 +597,14 @@ int deme_multi_num_contacts(deme_multi* m, size_t* n);
 int deme_multi_download_contacts(deme_multi* m, uint32_t* idA, uint32_t* idB, uint8_t* type, size_t cap);
 int deme_multi_download_contact_wildcard(deme_multi* m, uint32_t w, float* out, size_t cap);
 int deme_multi_download_contact_records(deme_multi* m, float* force, float* torqueOnly, float* cpA, float* cpB, size_t cap);
+/* Restart and marked pairs of a decomposed run, in GLOBAL ids: deme_seed_contacts / deme_*_persistent_contacts for every slab that holds
+ * a pair (both geometries present, one of them the slab's own), in the slab's ids and with the slab's sign of the B -> A vector
+ * wildcards; the downloads report a pair once (sphere-sphere pairs smaller id first, ascending). */
+int deme_multi_seed_contacts(deme_multi* m, const uint32_t* idA, const uint32_t* idB, const uint8_t* type, const float* wildcards, size_t n);
+int deme_multi_mark_persistent_contacts(deme_multi* m, int mode, uint32_t N1, uint32_t N2, int mark);
+int deme_multi_num_persistent_contacts(deme_multi* m, size_t* n);
+int deme_multi_download_persistent_contacts(deme_multi* m, uint32_t* idA, uint32_t* idB, uint8_t* type, size_t cap);
+int deme_multi_upload_persistent_contacts(deme_multi* m, const uint32_t* idA, const uint32_t* idB, const uint8_t* type, size_t n);
 /* deme_upload_contact_wildcard for the merged list (n = deme_multi_num_contacts): every slab's copy of a pair takes the value */
 int deme_multi_upload_contact_wildcard(deme_multi* m, uint32_t w, const float* in, size_t n);
 /* Moving the slab boundaries: equal counts again from the clumps' CURRENT coordinates (snapped to bin faces), then the migration of

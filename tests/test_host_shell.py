@@ -178,6 +178,34 @@ def test_custom_model_demo_wildcards_from_the_script(tmp_path):
 
 
 @pytest.mark.gpu
+def test_settle_demo_in_two_slabs_answers_like_one_domain(tmp_path):
+    """The UNCHANGED demo_settle program with DEME_SLABS_PER_DEVICE=2 (exact arithmetic): trackers, AddAcc, per-contact forces,
+    inspectors with regions, the three writers, a RESTART from the written files into a second decomposed solver
+    (deme_multi_seed_contacts), persistent marks, the prescribed lid -- every number the program prints is the single-domain run's to
+    the digits it prints (the bin-size controller's walk is timing-driven and left out)."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    import re
+    runs = {}
+    for tag, extra in (("one", {}), ("two", {"DEME_SLABS_PER_DEVICE": "2"})):
+        d = tmp_path / tag
+        d.mkdir()
+        out = subprocess.run([os.path.join(HOST, "demo_settle"), "10", "3000", str(d)], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, DEME_ARITH="exact", **extra))
+        assert out.returncode == 0 and "DEMO_OK clumps=1000" in out.stdout, out.stdout + out.stderr
+        runs[tag] = {l.split()[0]: l for l in out.stdout.splitlines() if l.split() and l.split()[0] in
+                     ("LID", "ADDACC", "TRACK", "FORCES", "INSPECT", "RESTART", "REGION", "PERSIST")}
+    assert set(runs["one"]) == set(runs["two"]) and len(runs["one"]) == 8
+    num = re.compile(r"-?\d+\.?\d*(?:[eE][-+]?\d+)?")
+    for k in runs["one"]:
+        a, b = num.findall(runs["one"][k]), num.findall(runs["two"][k])
+        assert len(a) == len(b) > 0, (runs["one"][k], runs["two"][k])
+        for x, y in zip(a, b):
+            assert abs(float(x) - float(y)) <= 1e-4 * max(abs(float(x)), abs(float(y))) + 1e-7, (k, runs["one"][k], runs["two"][k])
+    rs = runs["two"]["RESTART"]
+    assert float(rs.split("max_pos_diff=")[1]) < 5e-5, rs
+
+
+@pytest.mark.gpu
 def test_custom_model_demo_in_two_slabs_answers_like_one_domain(tmp_path):
     """The UNCHANGED demo_custom program with DEME_SLABS_PER_DEVICE=2: a run-time compiled model with contact, owner and geometry
     wildcards on a decomposed run.  Owner / sphere wildcard arrays are read and written by GLOBAL id (deme_multi_download_ /

@@ -310,3 +310,52 @@ def test_slabs_that_grow_keep_their_scratch_in_step(pkg, monkeypatch):
         m.close()
     print(f"own-clump spread over 4 slabs after 1200 steps of drift: {spread[True]} with fixed boundaries, {spread[False]} rebalanced at every third migration")
     assert spread[False] < spread[True]  # (a boundary sits on a bin face: one 1.6 cm column of this bed holds ~500 clumps)
+
+
+def test_multi_restart_from_a_merged_list_and_marks(pkg, orc):
+    """Restart of a decomposed run: the merged contact list with its history (global ids) and the state by global id go into a FRESH
+    decomposition of another slab count (deme_multi_seed_contacts: every slab that holds a pair gets it in its own ids, vector
+    wildcards with its own sign) and the run continues like the one that was never interrupted -- and like the oracle's single-domain
+    run restarted the same way.  Marked (persistent) pairs: marked on every slab, reported once in global ids, carried into the new
+    decomposition."""
+    b, p, sc = _bed(pkg, n=2400, seed=8, cd_freq=0)
+    nc = int(sc.nOwnerClumps)
+    a = pkg.abi.Multi(devices=(0,))
+    a.build(p, sc, slabs_per_device=3, axis=0, halo=0.03, arith="exact")
+    a.step(300), a.sync()
+    st = a.download_state()
+    ga, gb, gt = a.contacts()
+    W = np.stack([a.wildcard(w) for w in range(4)], 1)
+    assert len(ga) > 800 and np.abs(W[:, :3]).max() > 0  # (a list with tangential history)
+    a.mark_persistent_contacts(0)
+    pa, pb, pt = a.persistent_contacts()
+    assert len(pa) == len(ga) and np.array_equal(pa, ga) and np.array_equal(pb, gb) and np.array_equal(pt, gt)  # once each, canonical
+    # the restarted run: two slabs this time
+    r = pkg.abi.Multi(devices=(0,))
+    r.build(p, sc, slabs_per_device=2, axis=0, halo=0.03, arith="exact")
+    r.upload_state({k: st[k] for k in GKEYS})
+    r.seed_contacts(ga, gb, gt, W)
+    r.set_persistent_contacts(pa, pb, pt)
+    qa, qb, qt = r.persistent_contacts()
+    assert np.array_equal(qa, pa) and np.array_equal(qb, pb) and np.array_equal(qt, pt)
+    sim = orc.make_sim(pkg, p, sc)
+    sim.upload_state({k: st[k] for k in GKEYS})
+    sim.seed_contacts(ga, gb, gt, W)
+    a.step(40), r.step(40), sim.step(40)
+    a.sync(), r.sync()
+    xa, xr, xo = (_positions(pkg, p, m.download_state(), nc) for m in (a, r, sim))
+    d_ar, d_ro = np.abs(xa - xr).max(), np.abs(xr - xo).max()
+    print(f"restart of a decomposed run: 40 steps later |dx| {d_ar:.3e} m vs the uninterrupted 3-slab run, {d_ro:.3e} m vs the oracle restarted alike")
+    assert d_ar < 5e-9 and d_ro < 5e-9
+    # without the history the restarted run is somewhere else (the seeded rows matter)
+    n = pkg.abi.Multi(devices=(0,))
+    n.build(p, sc, slabs_per_device=2, axis=0, halo=0.03, arith="exact")
+    n.upload_state({k: st[k] for k in GKEYS})
+    n.step(40), n.sync()
+    assert np.abs(_positions(pkg, p, n.download_state(), nc) - xa).max() > 20 * max(d_ar, 1e-10)
+    # the marks are live in the restarted run: every marked pair stays listed
+    la, lb, lt = r.contacts()
+    listed = set(zip(la.tolist(), lb.tolist(), lt.tolist()))
+    assert set(zip(pa.tolist(), pb.tolist(), pt.tolist())) <= listed
+    for m in (a, r, n):
+        m.close()
