@@ -584,6 +584,13 @@ class Multi:
         self.lib.deme_multi_upload_persistent_contacts.argtypes = [_P, _P, _P, _P, C.c_size_t]
         self._ck(self.lib.deme_multi_upload_persistent_contacts(self.h, _ptr(a), _ptr(b), _ptr(t), a.size), "deme_multi_upload_persistent_contacts")
 
+    def inspect_values(self, quantity, n):
+        """deme_multi_inspect_values: per sphere / per owner, by GLOBAL id (n = the global scene's count)"""
+        out = np.zeros(int(n), np.float32)
+        self.lib.deme_multi_inspect_values.argtypes = [_P, C.c_uint32, _P, C.c_size_t]
+        self._ck(self.lib.deme_multi_inspect_values(self.h, Context.INSPECT_CODES[quantity], _ptr(out), out.size), "deme_multi_inspect_values")
+        return out
+
     def set_rebalance(self, every_nth_migration):
         self.lib.deme_multi_set_rebalance.argtypes = [_P, C.c_uint32]
         self._ck(self.lib.deme_multi_set_rebalance(self.h, int(every_nth_migration)), "deme_multi_set_rebalance")

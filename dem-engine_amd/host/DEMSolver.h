@@ -2798,8 +2798,8 @@ class DEMInspector {
         if (m_sys->decomposed()) {  // every slab reduces over its OWN clumps (ghost copies are left out of inspections): max / min / sum of those
             const bool isMax = m_code == DEME_INSPECT_CLUMP_MAX_Z || m_code == DEME_INSPECT_CLUMP_MAX_ABSV || m_code == DEME_INSPECT_MAX_ABSV;
             const bool isMin = m_code == DEME_INSPECT_CLUMP_MIN_Z;
-            if (m_code == DEME_INSPECT_ABSV)
-                m_sys->single_only("DEMInspector(\"absv\")");
+            if (m_code == DEME_INSPECT_ABSV)  // (one value per owner, not a reduction: GetValues)
+                throw std::runtime_error("DEMInspector(\"absv\") has one value per owner: use GetValues()");
             bool first = true;
             m_sys->each_ctx([&](deme_ctx* c) {
                 float w = 0;
@@ -2820,7 +2820,10 @@ class DEMInspector {
     }
     std::vector<float> GetValues() {
         std::vector<float> v(m_code <= DEME_INSPECT_CLUMP_MAX_ABSV ? m_sys->m_keep.sphOwner.size() : m_sys->m_n_owners);
-        m_sys->check(deme_inspect_values(m_sys->m_ctx, m_code, v.data(), v.size()));
+        if (m_sys->decomposed())
+            m_sys->mcheck(deme_multi_inspect_values(m_sys->m_multi, m_code, v.data(), v.size()));
+        else
+            m_sys->check(deme_inspect_values(m_sys->m_ctx, m_code, v.data(), v.size()));
         return v;
     }
 

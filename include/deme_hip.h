@@ -621,6 +621,8 @@ int deme_multi_slab_counts(deme_multi* m, uint32_t slab, uint32_t counts[6], dou
  * migration carries owner and sphere wildcard arrays with the clumps (deme_halo_group_migrate). */
 int deme_multi_download_wildcard_array(deme_multi* m, uint32_t kind, uint32_t index, float* out, size_t cap);
 int deme_multi_upload_wildcard_array(deme_multi* m, uint32_t kind, uint32_t index, const float* in, size_t n);
+/* deme_inspect_values by GLOBAL id (per sphere for the sphere-wise quantities, per owner otherwise) */
+int deme_multi_inspect_values(deme_multi* m, uint32_t quantity, float* out, size_t cap);
 /* deme_add_owner_acc by GLOBAL owner id: a clump's entry goes to the slab that owns it, a replicated owner's to every slab */
 int deme_multi_add_owner_acc(deme_multi* m, uint32_t owner, uint32_t n, const float* acc, const float* angAcc);
 /* the visible HIP devices (0 and DEME_OK where there is none: what the constructors check ids against) */

@@ -58,6 +58,13 @@ def test_multi_slabs_equal_the_single_domain_oracle(pkg, orc, n_slabs, axis):
         # (a pair that begins to touch within rounding of a step boundary starts its history one step apart in the two runs --
         # tools/slab_diag4.py: one row of 2 255, 2.4 % = one step of forty -- everything else to fp32 rounding, signs included)
         assert off.sum() <= 3 and np.abs(gw - ow).max() <= 0.05 * scale, (w, int(off.sum()), float(np.abs(gw - ow).max()), scale)
+    # unreduced inspector values by global id: what a single context answers for the same state
+    one = pkg.Context(0)
+    one.set_arith_mode("exact"), one.set_params(p), one.upload_scene(sc)
+    one.upload_state({k: g[k] for k in GKEYS})
+    n_o, n_s = int(sc.nOwners), int(sc.nSpheres)
+    assert np.array_equal(m.inspect_values("absv", n_o)[:nc], one.inspect_values("absv", n_o)[:nc])
+    assert np.array_equal(m.inspect_values("clump_max_z", n_s), one.inspect_values("clump_max_z", n_s))
     # a state uploaded by global id reaches own clumps, ghost copies and replicated owners alike
     m.upload_state({k: so0[k] for k in GKEYS})
     back = m.download_state()
