@@ -2644,6 +2644,10 @@ class DEMSolver {
             bool freeOwner = false;  // a mesh / analytical body that moves under contact forces: its accelerations are summed across slabs
             for (size_t o = nC; o < nO; o++)
                 freeOwner = freeOwner || !(m_family_flags[fam[o]] & (DEME_FAMILY_FIXED | DEME_FAMILY_PRESCRIBED));
+            uint32_t built = 0;
+            deme_multi_num_slabs(m_multi, &built);
+            if (built)  // a scene re-upload (UpdateClumps, ResortClumps): the old slabs go, the new scene is cut anew
+                mcheck(deme_multi_reset(m_multi));
             mcheck(deme_multi_build(m_multi, &p, &s, m_slabs_per_device, -1, (double)m_slab_halo, freeOwner ? DEME_DECOMP_SHARED_FREE : 0u, -1,
                                     p.forceModel == DEME_FORCE_HERTZIAN ? 7u : 0u));
             mcheck(deme_multi_set_migration(m_multi, m_migrate_every));

@@ -132,10 +132,7 @@ int main(int argc, char** argv) {
     DEMSim.DisableFamilyOutput(3);
     DEMSim.SetOutputContent(FAMILY);
     DEMSim.WriteSphereFile(dir + "/spheres_no3.csv");
-    if (DEMSim.GetNumSlabs() > 1) {  // (a decomposed run keeps the engine's numbering per slab: no renumbering in place there)
-        DEMSim.DoDynamicsThenSync(20 * 5e-6);
-        std::printf("CHECK slabs %u contacts %zu\n", DEMSim.GetNumSlabs(), DEMSim.GetNumContacts());
-    } else {  // renumbering in place: owner 3's state, counter and charge travel to its new id; the run carries on
+    {   // renumbering in place: owner 3's state, counter and charge travel to its new id; the run carries on
         const float t3 = DEMSim.GetOwnerWildcardValue(3, "n_touch")[0], q3 = DEMSim.GetSphereWildcardValue(3, "charge", 1)[0];
         const float3 p3 = DEMSim.GetOwnerPosition(3);
         const size_t nc = DEMSim.GetNumContacts();

@@ -588,6 +588,8 @@ int deme_multi_upload_state(deme_multi* m, const DemeOwnerState* global, uint32_
 /* contacts of all slabs together (a contact that straddles a cut is on two lists unless deme_halo_group_set_cross_contacts(1):
  * `nContacts` counts list entries), steps taken, detections of the first slab, clumps that changed slabs so far */
 int deme_multi_counts(deme_multi* m, DemeCounts* sum, uint64_t* clumpsMigrated);
+/* back to the state after deme_multi_create (slabs, contexts and plan dropped; the groups opened anew): a scene re-upload */
+int deme_multi_reset(deme_multi* m);
 /* The contact list of a decomposed run in GLOBAL sphere ids (analytical-component / triangle ids are global already): a pair that
  * straddles a cut is reported once, sphere-sphere pairs as (smaller, larger) id, rows in the canonical order of an undivided
  * context (A, then class, then B).  Per-contact wildcards and recorded forces / contact points follow in the same order; where a slab
@@ -617,7 +619,7 @@ int deme_multi_set_rebalance(deme_multi* m, uint32_t everyNthMigration);
 int deme_multi_slab_counts(deme_multi* m, uint32_t slab, uint32_t counts[6], double range[2]);
 /* deme_download / _upload_wildcard_array by GLOBAL id (kind 0: per owner, 1: per sphere; n = the global scene's count): a row is read
  * from the slab that owns the clump (a replicated owner's from the first slab) and written to every copy.  Kinds 2, 3 (triangles,
- * analytical components: replicated geometry) are written to every slab and read back only on a one-slab run.  The library's
+ * analytical components: replicated geometry) are written to every slab and read back from the first one.  The library's
  * migration carries owner and sphere wildcard arrays with the clumps (deme_halo_group_migrate). */
 int deme_multi_download_wildcard_array(deme_multi* m, uint32_t kind, uint32_t index, float* out, size_t cap);
 int deme_multi_upload_wildcard_array(deme_multi* m, uint32_t kind, uint32_t index, const float* in, size_t n);

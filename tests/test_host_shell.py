@@ -90,8 +90,11 @@ def test_demo_runs_and_settles(tmp_path, arith):
 
 
 @pytest.mark.gpu
-def test_mesh_demo_obj_prescription_deformation_vtk(tmp_path):
-    """AddWavefrontMeshObject (OBJ with v//vn faces and a quad), prescribed mesh motion, UpdateMesh, WriteMeshFile"""
+@pytest.mark.parametrize("slabs", [1, 2])
+def test_mesh_demo_obj_prescription_deformation_vtk(tmp_path, slabs):
+    """AddWavefrontMeshObject (OBJ with v//vn faces and a quad), prescribed mesh motion, UpdateMesh, WriteMeshFile, UpdateClumps -- as
+    one domain and cut into two slabs (the mesh is replicated; UpdateClumps re-uploads the grown scene into a fresh decomposition:
+    deme_multi_reset + build, state and history carried by global id)"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     n = 12  # a 0.12 m square plate of (n x n) quads written as mixed triangles / quads with normal indices
     xs = np.linspace(-0.06, 0.06, n + 1)
@@ -110,7 +113,7 @@ def test_mesh_demo_obj_prescription_deformation_vtk(tmp_path):
                     f.write(f"f {vid(i, j)}//1 {vid(i + 1, j)}//1 {vid(i + 1, j + 1)}//1\n")
                     f.write(f"f {vid(i, j)}//1 {vid(i + 1, j + 1)}//1 {vid(i, j + 1)}//1\n")
     out = subprocess.run([os.path.join(HOST, "demo_mesh"), str(tmp_path / "plate.obj"), str(tmp_path), "3000"], capture_output=True,
-                         text=True, timeout=600)
+                         text=True, timeout=600, env=dict(os.environ, DEME_SLABS_PER_DEVICE=str(slabs)))
     assert out.returncode == 0 and "DEMO_MESH_OK" in out.stdout, out.stdout + out.stderr
     line = [l for l in out.stdout.splitlines() if l.startswith("MESH")][0]
     vals = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in line.split()[1:]}
@@ -210,8 +213,9 @@ def test_custom_model_demo_in_two_slabs_answers_like_one_domain(tmp_path):
     """The UNCHANGED demo_custom program with DEME_SLABS_PER_DEVICE=2: a run-time compiled model with contact, owner and geometry
     wildcards on a decomposed run.  Owner / sphere wildcard arrays are read and written by GLOBAL id (deme_multi_download_ /
     _upload_wildcard_array: a row from the slab that owns the clump, to every copy), SetFamilyContactWildcardValueBoth writes every
-    slab's copy of a pair (deme_multi_upload_contact_wildcard), the files come from the merged list -- every CHECK line before the
-    renumbering section and the three output files are the single-domain run's, character for character."""
+    slab's copy of a pair (deme_multi_upload_contact_wildcard), the files come from the merged list, and ResortClumps re-uploads the
+    renumbered scene into a fresh decomposition (deme_multi_reset + build, state / history / wildcards by global id) -- every CHECK
+    line and the output files are the single-domain run's, character for character."""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     runs = {}
     for tag, extra in (("one", {}), ("two", {"DEME_SLABS_PER_DEVICE": "2"})):
@@ -221,8 +225,8 @@ def test_custom_model_demo_in_two_slabs_answers_like_one_domain(tmp_path):
         out = subprocess.run([os.path.join(HOST, "demo_custom"), str(d)], capture_output=True, text=True, timeout=600,
                              env=dict(os.environ, DEME_KERNEL_INCLUDE_PATH=str(d), **extra))
         assert out.returncode == 0 and "DEMO_OK" in out.stdout, out.stdout + out.stderr
-        runs[tag] = ([l for l in out.stdout.splitlines() if l.startswith("CHECK") and "resort" not in l and "slabs" not in l], d)
-    assert any(l.startswith("CHECK n_touch_total") for l in runs["one"][0])
+        runs[tag] = ([l for l in out.stdout.splitlines() if l.startswith("CHECK")], d)
+    assert any(l.startswith("CHECK n_touch_total") for l in runs["one"][0]) and any(l.startswith("CHECK resort_contacts") for l in runs["two"][0])
     assert runs["one"][0] == runs["two"][0]
     for f in ("spheres.csv", "clumps.csv", "contacts.csv", "spheres_no3.csv"):
         assert (runs["one"][1] / f).read_text() == (runs["two"][1] / f).read_text(), f
