@@ -25,6 +25,7 @@
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <functional>
 #include <map>
 #include <memory>
 #include <set>
@@ -1055,6 +1056,8 @@ class DEMSolver {
         }
         const double t = m_time;
         const SavedWildcards saved = save_user_wildcards();
+        m_reupload_state = &st, m_reupload_n = oldOwners;
+        m_reupload_dst = [=](size_t o, size_t newClumps) { return o < oldClumps ? o : newClumps + (o - oldClumps); };
         initialize_impl();  // rebuilds and uploads the scene with all batches
         if (m_n_clumps < oldClumps || m_n_owners - m_n_clumps != oldOwners - oldClumps)
             throw std::runtime_error("UpdateClumps can only append clumps");
@@ -1185,6 +1188,8 @@ class DEMSolver {
         };
         const double t = m_time;
         const SavedWildcards saved = save_user_wildcards();
+        m_reupload_state = &st, m_reupload_n = nO;
+        m_reupload_dst = [&](size_t o, size_t) { return (size_t)new_of_old[o]; };
         initialize_impl();
         restore_user_wildcards(saved, [&](size_t o) { return (size_t)new_of_old[o]; }, [&](size_t i) { return (size_t)new_sphere((uint32_t)i); });
         std::vector<uint64_t> vid2(nO);
@@ -1674,6 +1679,11 @@ class DEMSolver {
     deme_multi* m_multi = nullptr;   // a decomposed run: several devices and / or several slabs per device
     std::vector<int> m_devices;
     unsigned int m_slabs_per_device = 1, m_migrate_every = 1000, m_rebalance_every = 0;
+    // a scene re-upload (UpdateClumps, ResortClumps) hands the owners' CURRENT state to initialize_impl: a decomposed run is cut by
+    // where the clumps are now, not by where their batches were loaded (row o of the state goes to owner dst(o, new clump count))
+    const DemeOwnerState* m_reupload_state = nullptr;
+    size_t m_reupload_n = 0;
+    std::function<size_t(size_t, size_t)> m_reupload_dst;
     float m_slab_halo = 0.f;
 
     void open_devices(const std::vector<int>& ids) {
@@ -1760,8 +1770,10 @@ class DEMSolver {
             throw std::runtime_error(std::string(what) + " is not available on a decomposed run (several GPUs / DEME_SLABS_PER_DEVICE) yet");
     }
     void mcheck(int rc) {
-        if (rc)
-            throw std::runtime_error(deme_multi_last_error(m_multi));
+        if (rc) {
+            const std::string msg = deme_multi_last_error(m_multi);
+            throw std::runtime_error(msg.empty() ? "a call on the decomposed run failed with status " + std::to_string(rc) : msg);
+        }
     }
     /// the same call on the context, or on every slab's context
     template <class F>
@@ -2612,6 +2624,20 @@ class DEMSolver {
         p.errOutBinSphNum = m_max_sph_in_bin;
         p.errOutVel = m_err_vel;
 
+        if (m_reupload_state) {
+            const DemeOwnerState& st = *m_reupload_state;
+            for (size_t o = 0; o < m_reupload_n; o++) {
+                const size_t d = m_reupload_dst(o, nC);
+                if (d >= nO)
+                    continue;
+                vid[d] = st.voxelID[o], lx[d] = st.locX[o], ly[d] = st.locY[o], lz[d] = st.locZ[o];
+                qw[d] = st.oriQw[o], qx[d] = st.oriQx[o], qy[d] = st.oriQy[o], qz[d] = st.oriQz[o];
+                vx[d] = st.vX[o], vy[d] = st.vY[o], vz[d] = st.vZ[o];
+                wx[d] = st.omgBarX[o], wy[d] = st.omgBarY[o], wz[d] = st.omgBarZ[o];
+                fam[d] = st.familyID[o];
+            }
+            m_reupload_state = nullptr;
+        }
         DemeScene s{};
         s.nOwners = (uint32_t)nO, s.nOwnerClumps = (uint32_t)nC, s.nSpheres = (uint32_t)sphOwner.size();
         s.nAnal = (uint32_t)objType.size(), s.nTri = (uint32_t)triOwner.size(), s.nMat = (uint32_t)nM;

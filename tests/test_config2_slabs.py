@@ -751,3 +751,60 @@ def test_library_migration_carries_user_wildcard_arrays(pkg):
     for c in ctxs:
         assert np.isfinite(c.download_state()["vX"]).all()
     g.close()
+
+
+@pytest.mark.gpu
+def test_million_clumps_migrate_and_rebalance_inside_deme_multi(pkg, packed_million, monkeypatch):
+    """The settled 1e6-clump bed drifting at 1 m/s along x and y through deme_multi in 4 slabs, fast mode: migrations every 50 steps inside
+    deme_multi_step, every second one recomputing the slab boundaries (deme_multi_rebalance), the library checking the re-assembled
+    books after each (DEME_MIG_CHECK) -- against the SAME bed stepped by one context (the comparison at this size against the oracle
+    is the test above; here the subject is what migration and moving boundaries add): every clump owned once, thousands changed
+    slabs, every slab still through the owner-tile pass, the state by global id on the single context's."""
+    monkeypatch.setenv("DEME_MIG_CHECK", "1")
+    b, p, sc, st, cnt, W = packed_million
+    nc = int(sc.nOwnerClumps)
+    g_arrays = dict(b.arrays)
+    for k in GKEYS:
+        g_arrays[k] = np.asarray(st[k]).copy()
+    for k in ("vX", "vY"):  # (the cut runs along the longer side of the bed: x or y)
+        g_arrays[k] = g_arrays[k].copy()
+        g_arrays[k][:nc] += 1.0
+    sc2 = pkg.abi.make_scene_struct(g_arrays, b.counts)
+    m = pkg.abi.Multi(devices=(0,))
+    m.build(p, sc2, slabs_per_device=4, axis=-1, halo=0.03, arith="fast")
+    m.set_migration(50), m.set_rebalance(2)
+    twin = pkg.abi.Multi(devices=(0,))  # the same slabs without migration: the 3 cm halo covers 1.5 mm of drift
+    twin.build(p, sc2, slabs_per_device=4, axis=-1, halo=0.03, arith="fast")
+    one = _make(pkg, p, sc2, "fast")
+    own0 = [m.slab_counts(s)[0][0] for s in range(4)]
+    e0 = [m.slab_counts(s)[1] for s in range(4)]
+    m.step(301), twin.step(301), one.step(301)  # (six migrations; one more step: every slab has detected and evaluated its re-assembled list)
+    m.sync(), twin.sync()
+    own1 = [m.slab_counts(s)[0][0] for s in range(4)]
+    e1 = [m.slab_counts(s)[1] for s in range(4)]
+    _, moved = m.counts()
+    assert sum(own0) == sum(own1) == nc and moved > 1000, (own0, own1, moved)
+    # (every second migration recomputed the boundaries: on this bed 1.5 mm of drift leaves them on the same bin faces; the 3 m/s
+    # variant of this run moved the first one by a bin -- tests/test_multi.py moves them on a smaller bed)
+    for s in range(4):
+        c = m.slab_ctx(s)
+        assert c.force_kernel()[0] == "k_tile_forces<0, false>", (s, c.force_kernel())
+    big = [m.slab_ctx(s).tile_stats() for s in range(4)]
+    g, o = m.download_state(), one.download_state()
+    X = pkg.model.decode_positions(g["voxelID"], g["locX"], g["locY"], g["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:nc]
+    Xo = pkg.model.decode_positions(o["voxelID"], o["locX"], o["locY"], o["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:nc]
+    dx = float(np.abs(X - Xo).max())
+    dv = max(float(np.abs(g[k][:nc] - o[k][:nc]).max()) for k in ("vX", "vY", "vZ"))
+    tw = twin.download_state()
+    Xt = pkg.model.decode_positions(tw["voxelID"], tw["locX"], tw["locY"], tw["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)[:nc]
+    dx_t, dx_to = float(np.abs(X - Xt).max()), float(np.abs(Xt - Xo).max())
+    print(f"against the twin slabs that never migrated: |dx| {dx_t:.3e} m (the twin against one context: {dx_to:.3e} m)")
+    print(f"tile statistics per slab after the migrations (tiles, tiles through the fallback, ...): {big}")
+    print(f"1e6 clumps drifting through 4 slabs: own {own0} -> {own1}, {moved} clumps changed slabs, boundaries {[round(e[1], 4) for e in e0[:-1]]} -> "
+          f"{[round(e[1], 4) for e in e1[:-1]]}; |dx| {dx:.3e} m, |dv| {dv:.3e} m/s vs one context after 301 steps")
+    from tests.conftest import record_measured
+    record_measured("test_config2_slabs deme_multi 4 slabs fast 1e6 clumps drifting 300 steps migrate + rebalance", dx_m=dx, dv_m_per_s=dv, clumps_moved=moved, dx_vs_twin_without_migration_m=dx_t, twin_vs_one_context_m=dx_to)
+    # (the drifting bed presses into two walls: the slabs' own summation order grows to dx_to against one context with or without
+    # migration; what migration and moving boundaries may add is held to the same size)
+    assert dx_t <= max(3 * dx_to, 1e-8) and dx <= max(3 * dx_to, 1e-8)
+    m.close(), twin.close()

@@ -209,6 +209,28 @@ def test_settle_demo_in_two_slabs_answers_like_one_domain(tmp_path):
 
 
 @pytest.mark.gpu
+def test_scene_reuploads_on_a_drifting_decomposed_run():
+    """tests/clients/demo_drift.cpp: three layers of spheres drifting along x at 2 m/s (4.5 cm over the run: clumps change slabs),
+    AddClumps + UpdateClumps after the first third (once with an EMPTY contact list behind it: the bed is still falling), ResortClumps
+    after the second -- both re-upload the scene; a decomposed run drops its slabs and is cut anew by where the clumps are
+    (deme_multi_reset + build from the owners' current state, history and marks by global id).  In three slabs the program prints
+    what it prints as one domain (exact arithmetic), digit for digit."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    exe = os.path.join(os.path.dirname(__file__), "clients", "demo_drift")
+    outs = {}
+    for slabs in (1, 3):
+        out = subprocess.run([exe, "1500"], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, DEME_ARITH="exact", DEME_SLABS_PER_DEVICE=str(slabs)))
+        assert out.returncode == 0 and "DRIFT_OK" in out.stdout, out.stdout + out.stderr
+        assert f"SLABS {slabs}" in out.stdout
+        outs[slabs] = [l for l in out.stdout.splitlines() if l.startswith(("POS", "SUM"))]
+    assert len(outs[1]) > 100 and outs[1][-1].startswith("SUM clumps 5440")
+    num = lambda l: [float(x) for x in l.split()[1:] if x.replace(".", "").replace("-", "").replace("e", "").isdigit()]
+    for a, b in zip(outs[1], outs[3]):
+        assert a.split()[0] == b.split()[0] and np.allclose(num(a), num(b), rtol=0, atol=2e-6), (a, b)
+
+
+@pytest.mark.gpu
 def test_custom_model_demo_in_two_slabs_answers_like_one_domain(tmp_path):
     """The UNCHANGED demo_custom program with DEME_SLABS_PER_DEVICE=2: a run-time compiled model with contact, owner and geometry
     wildcards on a decomposed run.  Owner / sphere wildcard arrays are read and written by GLOBAL id (deme_multi_download_ /
