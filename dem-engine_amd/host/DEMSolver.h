@@ -1056,6 +1056,16 @@ class DEMSolver {
         }
         const double t = m_time;
         const SavedWildcards saved = save_user_wildcards();
+        // (a context keeps its persistent marks across a re-upload; a decomposed run gets new contexts: the marks go with the list)
+        size_t nP = 0;
+        std::vector<uint32_t> pa, pb;
+        std::vector<uint8_t> pt;
+        if (m_multi) {
+            mc_num_persistent_contacts(&nP);
+            pa.resize(nP), pb.resize(nP), pt.resize(nP);
+            if (nP)
+                mc_download_persistent_contacts(pa.data(), pb.data(), pt.data(), nP);
+        }
         m_reupload_state = &st, m_reupload_n = oldOwners;
         m_reupload_dst = [=](size_t o, size_t newClumps) { return o < oldClumps ? o : newClumps + (o - oldClumps); };
         initialize_impl();  // rebuilds and uploads the scene with all batches
@@ -1090,8 +1100,20 @@ class DEMSolver {
         each_ctx([&](deme_ctx* c) { return deme_set_params(c, &m_p); });
         if (nc)
             mc_seed_contacts(a.data(), b.data(), ty.data(), nW ? W.data() : nullptr, nc);
+        if (nP)
+            mc_upload_persistent_contacts(pa.data(), pb.data(), pt.data(), nP);
         m_state_fresh = false;
+        m_steps_since_replan = 0;
     }
+    /// A decomposed run cut anew by where the clumps are now: fresh slabs in the engine's own order (the migration appends arrivals
+    /// to a slab, so its tiles loosen over a long run of mixing), state, contact history, marks and wildcard arrays carried by global
+    /// id.  No reference equivalent.  SetSlabReplanInterval(n): every n steps inside DoDynamics (0, the default: never); a replan
+    /// opens the slabs' contexts and communicators again -- seconds at 10^6 clumps: an interval of 10^5 steps or more.
+    void ReplanSlabs() {
+        if (m_multi)
+            UpdateClumps();  // (nothing appended: the re-upload of the same batches with the owners' current state)
+    }
+    void SetSlabReplanInterval(unsigned int steps) { m_replan_every = steps; }
     /// Restore spatial order in a running simulation (no reference equivalent: its owner ids never change).  The clumps of every
     /// batch are renumbered along a Z-order curve of their current positions; state, contact list, contact history and
     /// persistent marks follow.  Mixing destroys the locality the load order had and the engine's gathers slow down with it
@@ -1678,7 +1700,8 @@ class DEMSolver {
     deme_ctx* m_ctx = nullptr;       // the context of a one-device, one-slab run; of a decomposed run: the FIRST slab's (owned by m_multi)
     deme_multi* m_multi = nullptr;   // a decomposed run: several devices and / or several slabs per device
     std::vector<int> m_devices;
-    unsigned int m_slabs_per_device = 1, m_migrate_every = 1000, m_rebalance_every = 0;
+    unsigned int m_slabs_per_device = 1, m_migrate_every = 1000, m_rebalance_every = 0, m_replan_every = 0;
+    uint64_t m_steps_since_replan = 0;
     // a scene re-upload (UpdateClumps, ResortClumps) hands the owners' CURRENT state to initialize_impl: a decomposed run is cut by
     // where the clumps are now, not by where their batches were loaded (row o of the state goes to owner dst(o, new clump count))
     const DemeOwnerState* m_reupload_state = nullptr;
@@ -1702,6 +1725,8 @@ class DEMSolver {
             m_migrate_every = (unsigned)std::max(0, atoi(e));
         if (const char* e = std::getenv("DEME_SLAB_REBALANCE_EVERY"))  // (SetSlabRebalanceInterval)
             m_rebalance_every = (unsigned)std::max(0, atoi(e));
+        if (const char* e = std::getenv("DEME_SLAB_REPLAN_EVERY"))  // (SetSlabReplanInterval)
+            m_replan_every = (unsigned)std::max(0, atoi(e));
         if (const char* e = std::getenv("DEME_SLAB_HALO"))  // ghost layer thickness [m] of an unchanged script (SetSlabHalo)
             m_slab_halo = (float)atof(e);
         if (ids.size() == 1) {  // (a decomposed run on one device opens its deme_multi at Initialize, when the slab count is final)
@@ -2317,12 +2342,21 @@ class DEMSolver {
         m_state_fresh = false;
     }
     void step(uint32_t n) {
-        if (m_multi)
-            mcheck(deme_multi_step(m_multi, n));
-        else
-            check(deme_step(m_ctx, n));
-        m_time += (double)n * (double)m_h;
-        m_state_fresh = false;
+        while (n) {
+            uint32_t k = n;
+            if (m_multi && m_replan_every)
+                k = (uint32_t)std::min<uint64_t>(n, m_replan_every - std::min<uint64_t>(m_steps_since_replan, m_replan_every - 1u));
+            if (m_multi)
+                mcheck(deme_multi_step(m_multi, k));
+            else
+                check(deme_step(m_ctx, k));
+            m_time += (double)k * (double)m_h;
+            m_steps_since_replan += k;
+            m_state_fresh = false;
+            n -= k;
+            if (m_multi && m_replan_every && m_steps_since_replan >= m_replan_every)
+                ReplanSlabs();  // (after the steps: what a script queued for its next step -- AddAcc -- has been consumed by then)
+        }
     }
 
     void refresh_state() {

@@ -189,7 +189,8 @@ def test_settle_demo_in_two_slabs_answers_like_one_domain(tmp_path):
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     import re
     runs = {}
-    for tag, extra in (("one", {}), ("two", {"DEME_SLABS_PER_DEVICE": "2"})):
+    for tag, extra in (("one", {}), ("two", {"DEME_SLABS_PER_DEVICE": "2"}),
+                       ("replanned", {"DEME_SLABS_PER_DEVICE": "2", "DEME_SLAB_REPLAN_EVERY": "1000"})):  # (SetSlabReplanInterval: cut anew every 1000 steps)
         d = tmp_path / tag
         d.mkdir()
         out = subprocess.run([os.path.join(HOST, "demo_settle"), "10", "3000", str(d)], capture_output=True, text=True, timeout=600,
@@ -197,13 +198,14 @@ def test_settle_demo_in_two_slabs_answers_like_one_domain(tmp_path):
         assert out.returncode == 0 and "DEMO_OK clumps=1000" in out.stdout, out.stdout + out.stderr
         runs[tag] = {l.split()[0]: l for l in out.stdout.splitlines() if l.split() and l.split()[0] in
                      ("LID", "ADDACC", "TRACK", "FORCES", "INSPECT", "RESTART", "REGION", "PERSIST")}
-    assert set(runs["one"]) == set(runs["two"]) and len(runs["one"]) == 8
+    assert set(runs["one"]) == set(runs["two"]) == set(runs["replanned"]) and len(runs["one"]) == 8
     num = re.compile(r"-?\d+\.?\d*(?:[eE][-+]?\d+)?")
-    for k in runs["one"]:
-        a, b = num.findall(runs["one"][k]), num.findall(runs["two"][k])
-        assert len(a) == len(b) > 0, (runs["one"][k], runs["two"][k])
-        for x, y in zip(a, b):
-            assert abs(float(x) - float(y)) <= 1e-4 * max(abs(float(x)), abs(float(y))) + 1e-7, (k, runs["one"][k], runs["two"][k])
+    for tag in ("two", "replanned"):
+        for k in runs["one"]:
+            a, b = num.findall(runs["one"][k]), num.findall(runs[tag][k])
+            assert len(a) == len(b) > 0, (runs["one"][k], runs[tag][k])
+            for x, y in zip(a, b):
+                assert abs(float(x) - float(y)) <= 1e-4 * max(abs(float(x)), abs(float(y))) + 1e-7, (tag, k, runs["one"][k], runs[tag][k])
     rs = runs["two"]["RESTART"]
     assert float(rs.split("max_pos_diff=")[1]) < 5e-5, rs
 
@@ -218,16 +220,17 @@ def test_scene_reuploads_on_a_drifting_decomposed_run():
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     exe = os.path.join(os.path.dirname(__file__), "clients", "demo_drift")
     outs = {}
-    for slabs in (1, 3):
+    for tag, slabs, extra in (("one", 1, {}), ("three", 3, {}), ("replanned", 3, {"DEME_SLAB_REPLAN_EVERY": "700"})):
         out = subprocess.run([exe, "1500"], capture_output=True, text=True, timeout=600,
-                             env=dict(os.environ, DEME_ARITH="exact", DEME_SLABS_PER_DEVICE=str(slabs)))
+                             env=dict(os.environ, DEME_ARITH="exact", DEME_SLABS_PER_DEVICE=str(slabs), **extra))
         assert out.returncode == 0 and "DRIFT_OK" in out.stdout, out.stdout + out.stderr
         assert f"SLABS {slabs}" in out.stdout
-        outs[slabs] = [l for l in out.stdout.splitlines() if l.startswith(("POS", "SUM"))]
-    assert len(outs[1]) > 100 and outs[1][-1].startswith("SUM clumps 5440")
+        outs[tag] = [l for l in out.stdout.splitlines() if l.startswith(("POS", "SUM"))]
+    assert len(outs["one"]) > 100 and outs["one"][-1].startswith("SUM clumps 5440")
     num = lambda l: [float(x) for x in l.split()[1:] if x.replace(".", "").replace("-", "").replace("e", "").isdigit()]
-    for a, b in zip(outs[1], outs[3]):
-        assert a.split()[0] == b.split()[0] and np.allclose(num(a), num(b), rtol=0, atol=2e-6), (a, b)
+    for tag in ("three", "replanned"):  # (replanned: the slabs cut anew every 700 steps inside DoDynamics, SetSlabReplanInterval)
+        for a, b in zip(outs["one"], outs[tag]):
+            assert a.split()[0] == b.split()[0] and np.allclose(num(a), num(b), rtol=0, atol=2e-6), (tag, a, b)
 
 
 @pytest.mark.gpu
