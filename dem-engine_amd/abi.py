@@ -591,6 +591,11 @@ class Multi:
         self._ck(self.lib.deme_multi_inspect_values(self.h, Context.INSPECT_CODES[quantity], _ptr(out), out.size), "deme_multi_inspect_values")
         return out
 
+    def reset(self):
+        """deme_multi_reset: slabs, contexts and plan dropped, the groups opened anew; build() follows"""
+        self.lib.deme_multi_reset.argtypes = [_P]
+        self._ck(self.lib.deme_multi_reset(self.h), "deme_multi_reset")
+
     def set_rebalance(self, every_nth_migration):
         self.lib.deme_multi_set_rebalance.argtypes = [_P, C.c_uint32]
         self._ck(self.lib.deme_multi_set_rebalance(self.h, int(every_nth_migration)), "deme_multi_set_rebalance")
