@@ -782,3 +782,59 @@ def test_library_decomposition_in_the_engines_order(pkg):
         assert (np.diff(own.astype(np.int64)) >= 0).all()  # spheres stay clump-major in the slab's numbering
         vid = _scene_arrays(sc1, "voxelID", np.uint64, sc1.nOwners)
         assert np.array_equal(vid, b.arrays["voxelID"][q["owner_global"]])
+
+
+@pytest.mark.parametrize("seed,n_slabs,axis,order,spatial", [(11, 2, 0, "random", True), (12, 4, 1, "lattice", False), (13, 7, -1, "morton", True),
+                                                              (14, 3, 2, "random", False), (15, 5, -1, "random", True)])
+def test_library_plans_keep_their_invariants_on_random_beds(pkg, seed, n_slabs, axis, order, spatial):
+    """Properties every plan of deme_decomp_create has to have, whatever the bed, the axis, the slab count and the numbering: every
+    clump owned by exactly one slab, inside that slab's range; the ghosts of a slab are exactly the neighbours' own clumps within the
+    halo of the shared face; what a slab sends is what its neighbour receives, in the same order, and the sender's list ascends;
+    replicated owners are on every slab; spheres stay clump-major; boundaries ascend and sit on bin faces."""
+    rng = np.random.default_rng(seed)
+    aspect = tuple(float(v) for v in rng.permutation([2.0, 1.0, 0.5]))
+    b = pkg.model.packed_bed(int(rng.integers(1500, 4000)), seed=seed, cd_freq=0, spacing_mult=float(rng.uniform(2.2, 3.2)), init_vz=-0.5,
+                             aspect=aspect, order=order)
+    p, sc = b.Initialize()
+    nc, no = int(sc.nOwnerClumps), int(sc.nOwners)
+    halo = float(rng.uniform(0.02, 0.04))
+    try:
+        plan, parts = pkg.decomp.decompose_lib(p, sc, n_slabs, halo, axis=axis, snap=True, spatial_order=spatial)
+    except pkg.abi.DemeError as e:  # (a bed too short along the chosen axis for that many slabs of at least a halo: a refusal, with the reason)
+        assert "halo" in str(e) or "thinner" in str(e) or "slab" in str(e), str(e)
+        return
+    ax = plan.axis
+    assert 0 <= ax <= 2 and (axis < 0 or ax == axis)
+    X = pkg.model.decode_positions(b.arrays["voxelID"], b.arrays["locX"], b.arrays["locY"], b.arrays["locZ"], p.nvXp2, p.nvYp2, p.voxelSize, p.l)
+    lbf = (float(p.LBFX), float(p.LBFY), float(p.LBFZ))[ax]
+    x = X[:nc, ax] + lbf
+    e = np.asarray(plan.edges)
+    assert len(e) == n_slabs + 1 and np.isneginf(e[0]) and np.isposinf(e[-1]) and (np.diff(e[1:-1]) > 0).all()
+    inner = (e[1:-1] - lbf) / float(p.binSize)
+    assert np.abs(inner - np.rint(inner)).max() < 1e-9
+    owned = np.concatenate([q["global_ids"] for q in parts])
+    assert len(owned) == nc and np.array_equal(np.sort(owned), np.arange(nc))
+    for r, q in enumerate(parts):
+        own = np.asarray(q["global_ids"], np.int64)
+        assert ((x[own] >= e[r]) & (x[own] < e[r + 1])).all()
+        og = np.asarray(q["owner_global"], np.int64)
+        n_c = q["n_own"] + len(q["ghost_left_g"]) + len(q["ghost_right_g"])
+        assert np.array_equal(np.sort(og[n_c:]), np.arange(nc, no))  # the replicated owners, all of them
+        if r > 0:
+            want = np.asarray(parts[r - 1]["global_ids"], np.int64)
+            want = want[x[want] >= e[r] - halo]
+            assert np.array_equal(np.sort(q["ghost_left_g"]), np.sort(want))
+            assert np.array_equal(np.asarray(parts[r - 1]["global_ids"])[parts[r - 1]["send_right"]], q["ghost_left_g"])
+        if r + 1 < n_slabs:
+            want = np.asarray(parts[r + 1]["global_ids"], np.int64)
+            want = want[x[want] < e[r + 1] + halo]
+            assert np.array_equal(np.sort(q["ghost_right_g"]), np.sort(want))
+            assert np.array_equal(np.asarray(parts[r + 1]["global_ids"])[parts[r + 1]["send_left"]], q["ghost_right_g"])
+        for k in ("send_left", "send_right"):
+            assert (np.diff(np.asarray(q[k], np.int64)) > 0).all()
+        s1 = q["scene"]
+        sph_owner = _scene_arrays(s1, "ownerClumpBody", np.uint32, s1.nSpheres).astype(np.int64)
+        assert (np.diff(sph_owner) >= 0).all() and (sph_owner < s1.nOwners).all()
+        # a sphere of the slab is the global sphere it names: same owner (through the owners' global ids), same component
+        g_owner = np.asarray(b.arrays["ownerClumpBody"], np.int64)[np.asarray(q["sphere_global"], np.int64)]
+        assert np.array_equal(og[sph_owner], g_owner)
