@@ -39,6 +39,9 @@ using DemeRadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim
 #include "deme_jit.h"
 #include "deme_kernels.h"
 #include "deme_tile.h"
+namespace deme_dev {
+int launch_tile_forces_p(int which, unsigned nCU, unsigned ldsBytes, hipStream_t st, const DevParams& dp, const TileArgs& ta);  // deme_tile_p.hip
+}
 #include "deme_tile_step.h"
 #include "deme_migrate.h"
 #include "deme_mesh_kernels.h"
@@ -67,6 +70,7 @@ struct TimerSlot {
 
 struct deme_ctx {
     int device = 0;
+    int nCU = 256;  // compute units of the device (how many persistent workgroups a launch holds)
     hipStream_t stream = nullptr;
     bool ownStream = true;
     std::string err;
@@ -86,6 +90,7 @@ struct deme_ctx {
     uint32_t nHeavy = 0, nHeavyFree = 0, nSA = 0, nSM = 0;
     DevBuf info;
     // owner-tile form of the force pass (deme_tile.h), rebuilt per detection
+    DevBuf tileCtr;  // k_tile_forces_p: (tiles handed out, workgroups through) per pass; zero between launches
     DevBuf tileBig, bigList, tInfo, hList, hCount, tileMode, tileOrg, rIdx, rStart, remKey[2], remVal, lPos, lOff, lCount, tileRem, tileBase, rankC, rec32;
     // the heavy-owner counts of a tiled list are fetched without stopping the stream: the copy lands in pinned memory, the first
     // reader (launch_reduce_heavy, one force launch later) waits for its event
@@ -1224,6 +1229,33 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
             }
         }
         const unsigned nBig = c->nBigTiles;  // tiles that do not fit LDS: one workgroup each, the same outputs (deme_tile.h)
+#if DEME_TILE_STAMPS
+        // measurement builds: DEME_TILE_STAMPS_FILE=path[:launch] -- the phase stamps of every tile of that launch (default the 100th), 16 words per tile
+        static const char* stampEnv = getenv("DEME_TILE_STAMPS_FILE");
+        static unsigned long long* stampBuf = nullptr;
+        static int stampLaunch = 0, stampAt = 100;
+        static std::string stampPath;
+        if (stampEnv && !stampBuf && !customTile) {
+            stampPath = stampEnv;
+            const size_t colon = stampPath.rfind(':');
+            if (colon != std::string::npos)
+                stampAt = atoi(stampPath.c_str() + colon + 1), stampPath.resize(colon);
+            HIPCK(hipMalloc(&stampBuf, (size_t)ta.nTiles * 16 * 8));
+            HIPCK(hipMemset(stampBuf, 0, (size_t)ta.nTiles * 16 * 8));
+        }
+        const bool stampNow = stampBuf && ++stampLaunch == stampAt;
+        ta.stamps = stampNow ? stampBuf : nullptr;
+        struct StampDump {
+            bool on; hipStream_t st; unsigned long long* buf; size_t n; const std::string& path;
+            ~StampDump() {
+                if (!on) return;
+                hipStreamSynchronize(st);
+                std::vector<unsigned long long> h(n);
+                hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(h.data(), 8, n, f); fclose(f); }
+            }
+        } stampDump{stampNow, st, stampBuf, (size_t)ta.nTiles * 16, stampPath};
+#endif
         if (customTile) {  // the same kernels compiled at run time around the user's statements (deme_jit.h)
             void* argsT[] = {&c->dp, &ta};
             HIPCK(hipModuleLaunchKernel(c->customTileFn[mesh ? 1 : 0], nBlk, 1, 1, DEME_TILE_T, 1, 1, ldsBytes, st, argsT, nullptr));
@@ -1232,12 +1264,26 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
         } else {
             // (model, mesh records, recording) -> the instance of the two kernels
             const int model = c->hp.forceModel == DEME_FORCE_HERTZIAN ? 0 : 1;
+            const int which = model * 4 + (mesh ? 2 : 0) + (c->record ? 1 : 0);
+            // persistent workgroups (deme_tile_p.h): as many as the chip holds at once, each taking tile after tile from a counter
+            static const int persistEnv = getenv("DEME_TILE_PERSIST") ? atoi(getenv("DEME_TILE_PERSIST")) : 1;
+            if (persistEnv) {
+                if (!c->tileCtr.p) {
+                    if (int rc = ensure(c, c->tileCtr, 64))
+                        return rc;
+                    HIPCK(hipMemset(c->tileCtr.p, 0, 64));
+                }
+                ta.tileCtr = c->tileCtr.as<uint32_t>() + 2 * (pass + 1);
+            }
+            hipError_t perr = hipSuccess;
             auto go = [&](auto tileK, auto bigK) {
-                hipLaunchKernelGGL(tileK, dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
+                if (persistEnv)
+                    perr = (hipError_t)launch_tile_forces_p(which, (unsigned)c->nCU, ldsBytes, st, c->dp, ta);
+                else
+                    hipLaunchKernelGGL(tileK, dim3(nBlk), dim3(DEME_TILE_T), ldsBytes, st, c->dp, ta);
                 if (nBig)
                     hipLaunchKernelGGL(bigK, dim3(nBig), dim3(DEME_TILE_T), 0, st, c->dp, ta);
             };
-            const int which = model * 4 + (mesh ? 2 : 0) + (c->record ? 1 : 0);
             switch (which) {
                 case 0: go(k_tile_forces<0, false, false>, k_tile_forces_big<0, false, false>); break;
                 case 1: go(k_tile_forces<0, false, true>, k_tile_forces_big<0, false, true>); break;
@@ -1248,6 +1294,8 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
                 case 6: go(k_tile_forces<1, true, false>, k_tile_forces_big<1, true, false>); break;
                 default: go(k_tile_forces<1, true, true>, k_tile_forces_big<1, true, true>); break;
             }
+            if (perr != hipSuccess)
+                return fail(c, DEME_ERR_HIP, "k_tile_forces_p: %s", hipGetErrorString(perr));
         }
         c->conValid = true;
         c->conTile = true;
@@ -1484,6 +1532,8 @@ int deme_ctx_create(int device, deme_ctx** out) {
         return DEME_ERR_HIP;
     deme_ctx* c = new deme_ctx();
     c->device = device;
+    if (hipDeviceGetAttribute(&c->nCU, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->nCU <= 0)
+        c->nCU = 256;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return DEME_ERR_HIP;
@@ -1553,7 +1603,7 @@ void deme_ctx_destroy(deme_ctx* c) {
         hipEventDestroy(c->evP1);
         hipStreamDestroy(c->detStream);
     }
-    DevBuf* all[] = {&c->hCountIn, &c->ownersNext, &c->recContact, &c->inCnt, &c->inStart, &c->tInfoIn, &c->inContact, &c->sphFam, &c->tileBig, &c->bigList, &c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
+    DevBuf* all[] = {&c->tileCtr, &c->hCountIn, &c->ownersNext, &c->recContact, &c->inCnt, &c->inStart, &c->tInfoIn, &c->inContact, &c->sphFam, &c->tileBig, &c->bigList, &c->dO2E, &c->dS2E, &c->segCtr, &c->tInfo, &c->hList, &c->hCount, &c->tileMode, &c->tileOrg, &c->rIdx, &c->rStart, &c->remKey[0], &c->remKey[1], &c->lPos, &c->lOff, &c->lCount, &c->tileRem, &c->tileBase, &c->remVal, &c->rankC, &c->rec32, &c->revSlot, &c->nextAcc, &c->binStat, &c->volumes, &c->persistKeys, &c->owners, &c->spheres, &c->acc, &c->conA4, &c->conA2, &c->conB4, &c->conB2, &c->aSum, &c->prescList, &c->prescSlot, &c->prescRec, &c->smFlag, &c->smList, &c->cDefer, &c->blockMode, &c->ownerA, &c->ownerB[0], &c->ownerB[1], &c->bIdx[0], &c->bIdx[1], &c->aStart, &c->bStart, &c->heavy, &c->fixedFlag, &c->heavyList, &c->rangeCtr, &c->info, &c->tris, &c->triWorld, &c->triLo, &c->triHi, &c->triCounts, &c->triOffsets, &c->triKeys[0], &c->triKeys[1], &c->triVals[0], &c->triVals[1], &c->comp, &c->massProps, &c->anal, &c->matPair,
                      &c->E, &c->nu, &c->CoR, &c->mu, &c->Crr, &c->famMasks, &c->famExtra, &c->famFlags, &c->geo,
                      &c->binLo, &c->binN, &c->counts, &c->offsets, &c->incKeys[0], &c->incKeys[1], &c->incVals[0],
                      &c->incVals[1], &c->keysRaw, &c->keysSorted[0], &c->keysSorted[1], &c->mapping, &c->wc[0],

@@ -67,9 +67,26 @@ namespace deme_dev {
 // Measurement builds (make variant EXTRA=-DDEME_TILE_KI=bits): "knock-in" duplicates of one section of k_tile_forces behind opaque
 // values -- the physics is untouched, the extra time of a variant is what that section costs (bit 0: the two sphere-offset
 // rotations + their fp64 conversions; 1: the pulls; 2: the staging conversion; 3: the whole per-contact evaluation) -- and
-// "knock-outs" of stores (bit 4: history; 5: crossing records; 6: tile sums: wrong results, timing only).
+// "knock-outs" of stores (bit 4: history; 5: crossing records; 6: tile sums: wrong results, timing only); bit 7: one more level of
+// dependent loads in front of the ids of the foreign owners; bit 8: one more barrier per round.
 #ifndef DEME_TILE_KI
 #define DEME_TILE_KI 0
+#endif
+// -DDEME_TILE_STAMPS=1: thread 0 of every tile leaves the 100 MHz wall clock at its phase boundaries (words 0 start, 1 tables in LDS,
+// 2 staged, 3.. the end of each round, 11 the end) and where it ran (word 12: HW_ID | XCC_ID << 32; 13: contacts; 14: foreign owners)
+#ifndef DEME_TILE_STAMPS
+#define DEME_TILE_STAMPS 0
+#endif
+#if DEME_TILE_STAMPS
+#define TILE_STAMP(k)                                                                  \
+    do {                                                                               \
+        if (a.stamps && threadIdx.x == 0)                                              \
+            a.stamps[(size_t)t * 16u + (k)] = (unsigned long long)wall_clock64();      \
+    } while (0)
+#else
+#define TILE_STAMP(k) \
+    do {              \
+    } while (0)
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));  // a register pair: += compiles to v_pk_add_f32
 __device__ inline void ki_opaque(float& v) { asm volatile("" : "+v"(v)); }
@@ -128,6 +145,8 @@ struct TileArgs {
     uint32_t swz;
     uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
     uint32_t nComp, nAnal, nMass;  // table sizes (tile_table_bytes)
+    uint32_t* tileCtr;             // k_tile_forces_p (deme_tile_p.h): tiles handed out, workgroups through; zero between launches
+    unsigned long long* stamps;    // measurement builds (-DDEME_TILE_STAMPS=1): 16 words per tile, see k_tile_forces
 };
 
 // one staged owner, as the contact loop reads it back from LDS
@@ -158,7 +177,9 @@ __device__ inline void tile_stage_owner_m(const DevParams& p, const float mass, 
     dst[2] = make_uint4(__float_as_uint(R.xx), __float_as_uint(R.xy), __float_as_uint(R.xz), __float_as_uint(R.yx));
     dst[3] = make_uint4(__float_as_uint(R.yy), __float_as_uint(R.yz), __float_as_uint(R.zx), __float_as_uint(R.zy));
     dst[4] = make_uint4(__float_as_uint(R.zz), __float_as_uint(r.vx), __float_as_uint(r.vy), __float_as_uint(r.vz));
-    *last = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), 0u);
+    // (the spare word takes the record's last one, the detection margin: nobody reads it back, but a word of a load that is dead on
+    // arrival is a register the allocator hands out again at once -- and whoever writes it has to wait for the load to land first)
+    *last = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(r.margin));
 }
 
 // MODEL 2: position, mass, family | inertia offset << 16, quaternion, velocity, body-frame angular velocity
@@ -565,11 +586,19 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const uint32_t tid = threadIdx.x;
     const uint32_t o0 = t * DEME_TILE_NB;
     const uint32_t nLoc = min((uint32_t)DEME_TILE_NB, a.nOwners - o0);
+    TILE_STAMP(0);
     // ---- every load that needs nothing but the tile number goes out first: the ids of the foreign owners behind my staging slots
     // (the list is padded to DEME_TILE_HMAX per tile: reading past the tile's own count is harmless), my local owner's record,
     // my entries of the small tables.  A tile's lifetime is a chain of memory latencies; this makes it two deep
     // (ids -> foreign records), with the scalars -> streams chain beside it.
     const uint32_t* hl = a.hList + (size_t)t * DEME_TILE_HMAX;
+#if DEME_TILE_KI & 128  // knock-in: one more level in the chain of dependent loads (a vector load in front of the ids)
+    {
+        uint32_t zz = a.rankC[t];
+        asm volatile("v_and_b32 %0, 0, %0" : "+v"(zz));
+        hl += zz;
+    }
+#endif
     const uint32_t h0 = tid - nLoc, h1 = tid + DEME_TILE_T - nLoc;  // my foreign slots (meaningful when < nH)
     uint32_t id0 = (tid >= nLoc && h0 < DEME_TILE_HMAX) ? hl[h0] : 0u;
     uint32_t id1 = (h1 < DEME_TILE_HMAX) ? hl[h1] : 0u;
@@ -657,6 +686,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     if (!p.familyTrivial)
         const_cast<float*>(T.fam)[tid & 255u] = tabFam;
     __syncthreads();  // (the staging below reads the masses)
+    TILE_STAMP(1);
     {   // stage the tile's owners, its halo, the owners' run bounds and local-B lists
 #if DEME_TILE_KI & 4
         if (tid < nLoc + nH) {
@@ -684,6 +714,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
                 sLPos[tid + k * DEME_TILE_T] = (uint16_t)lp[k];
     }
     __syncthreads();
+    TILE_STAMP(2);
 #if DEME_TILE_PRIO || DEME_TILE_PRIO_ROUNDS
     __builtin_amdgcn_s_setprio(DEME_TILE_PRIO_ROUNDS);
 #endif
@@ -825,6 +856,10 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
 #endif
 
             __syncthreads();
+#if DEME_TILE_KI & 256  // knock-in: one more barrier per round
+            asm volatile("s_nop 0" ::: "memory");
+            __syncthreads();
+#endif
 #if DEME_TILE_PRIO_PULL
             __builtin_amdgcn_s_setprio(DEME_TILE_PRIO_PULL);
 #endif
@@ -919,6 +954,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
             __builtin_amdgcn_s_setprio(DEME_TILE_PRIO_ROUNDS);
 #endif
             __syncthreads();
+            TILE_STAMP(min(3u + rlo / DEME_TILE_T, 10u));
     };
 #if DEME_TILE_UNROLL
     // The rounds, DEME_TILE_DEPTH at a time with the stage of the stream registers a round uses fixed at compile time: nothing is
@@ -965,6 +1001,17 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         ki_sink(s01.x + b4.x + s01.y + b4.y + s23.x + b4.z + s23.y + b4.w + s45.x + b2.x + s45.y + b2.y);
 #endif
     }
+#if DEME_TILE_STAMPS
+    TILE_STAMP(11);
+    if (a.stamps && tid == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.stamps[(size_t)t * 16u + 12u] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        a.stamps[(size_t)t * 16u + 13u] = nCt;
+        a.stamps[(size_t)t * 16u + 14u] = nH;
+    }
+#endif
 }
 
 // ---- the tiles that do not fit ---------------------------------------------------------------------------------------------------
@@ -1100,7 +1147,7 @@ __global__ __launch_bounds__(DEME_TILE_T) void k_tile_forces_big(const DevParams
     }
 }
 
-#ifndef DEME_JIT  // (the run-time compiled copy of this header holds the force pass only)
+#if !defined(DEME_JIT) && !defined(DEME_TILE_FORCE_ONLY)  // (the run-time compiled copy of this header and deme_tile_p.hip hold the force pass only)
 // ---- per-detection builders ----------------------------------------------------------------------------------------------------
 // (1) k_contact_owners counts, per tile, the contacts whose B owner lives in another tile (tileRem; deme_kernels.h); an exclusive
 //     scan gives every tile the number of its first record (tileBase).

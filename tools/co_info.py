@@ -10,23 +10,27 @@ import tempfile
 path, pats = sys.argv[1], sys.argv[2:]
 blob = open(path, "rb").read()
 magic = b"__CLANG_OFFLOAD_BUNDLE__"
+elfs = []  # one code object per translation unit linked into the library
 at = blob.find(magic)
 if at < 0:
     sys.exit("no offload bundle in " + path)
-n = struct.unpack_from("<Q", blob, at + 24)[0]
-pos = at + 32
-elf = None
-for _ in range(n):
-    off, size, tl = struct.unpack_from("<QQQ", blob, pos)
-    triple = blob[pos + 24:pos + 24 + tl].decode()
-    pos += 24 + tl
-    if "gfx950" in triple:
-        elf = blob[at + off:at + off + size]
-if elf is None:
+while at >= 0:
+    n = struct.unpack_from("<Q", blob, at + 24)[0]
+    pos = at + 32
+    for _ in range(n):
+        off, size, tl = struct.unpack_from("<QQQ", blob, pos)
+        triple = blob[pos + 24:pos + 24 + tl].decode()
+        pos += 24 + tl
+        if "gfx950" in triple:
+            elfs.append(blob[at + off:at + off + size])
+    at = blob.find(magic, at + 1)
+if not elfs:
     sys.exit("no gfx950 code object")
-with tempfile.NamedTemporaryFile(suffix=".co") as f:
-    f.write(elf), f.flush()
-    txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
+txt = ""
+for elf in elfs:
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(elf), f.flush()
+        txt += subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True, text=True).stdout
 for blk in re.split(r"\n\s*- \.agpr_count:", txt)[1:]:
     name = re.search(r"\.name:\s+(\S+)", blk)
     if not name or (pats and not any(p in name.group(1) for p in pats)):
