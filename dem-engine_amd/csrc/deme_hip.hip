@@ -11,6 +11,10 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <dlfcn.h>
 #include <map>
 #include <string>
@@ -39,6 +43,9 @@ using DemeRadixCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim
 #include "deme_jit.h"
 #include "deme_kernels.h"
 #include "deme_tile.h"
+#ifndef DEME_TILE_P_PARTS
+#define DEME_TILE_P_PARTS 32u  // (deme_tile_p.h)
+#endif
 namespace deme_dev {
 int launch_tile_forces_p(int which, unsigned nCU, unsigned ldsBytes, hipStream_t st, const DevParams& dp, const TileArgs& ta);  // deme_tile_p.hip
 }
@@ -1266,14 +1273,15 @@ int launch_forces(deme_ctx* c, int pass = -1, hipStream_t fs = nullptr) {
             const int model = c->hp.forceModel == DEME_FORCE_HERTZIAN ? 0 : 1;
             const int which = model * 4 + (mesh ? 2 : 0) + (c->record ? 1 : 0);
             // persistent workgroups (deme_tile_p.h): as many as the chip holds at once, each taking tile after tile from a counter
-            static const int persistEnv = getenv("DEME_TILE_PERSIST") ? atoi(getenv("DEME_TILE_PERSIST")) : 1;
+            static const int persistEnv = getenv("DEME_TILE_PERSIST") ? atoi(getenv("DEME_TILE_PERSIST")) : 0;
             if (persistEnv) {
+                const size_t ctrWords = ((size_t)DEME_TILE_P_PARTS + 1u) * 32u;  // (deme_tile_p.h: one set per pass)
                 if (!c->tileCtr.p) {
-                    if (int rc = ensure(c, c->tileCtr, 64))
+                    if (int rc = ensure(c, c->tileCtr, 3 * ctrWords * 4))
                         return rc;
-                    HIPCK(hipMemset(c->tileCtr.p, 0, 64));
+                    HIPCK(hipMemset(c->tileCtr.p, 0, 3 * ctrWords * 4));
                 }
-                ta.tileCtr = c->tileCtr.as<uint32_t>() + 2 * (pass + 1);
+                ta.tileCtr = c->tileCtr.as<uint32_t>() + ctrWords * (size_t)(pass + 1);
             }
             hipError_t perr = hipSuccess;
             auto go = [&](auto tileK, auto bigK) {
@@ -2909,6 +2917,13 @@ void deme_halo_group_destroy(deme_halo_group* g) {
         for (auto& sd : s.side)
             if (sd.revBuf)
                 hipFree(sd.revBuf);
+        // the slab's books of global ids (deme_halo_group_set_slab / every migration allocates them anew; a decomposed run that is
+        // re-planned -- UpdateClumps, ResortClumps, ReplanSlabs -- destroys and rebuilds its groups each time)
+        if (s.geo.ownerGid)
+            hipFree(s.geo.ownerGid);
+        if (s.geo.sphereGid)
+            hipFree(s.geo.sphereGid);
+        s.geo.ownerGid = s.geo.sphereGid = nullptr;
     }
     if (g->evRevDone)
         hipEventDestroy(g->evRevDone);

@@ -145,7 +145,8 @@ struct TileArgs {
     uint32_t swz;
     uint32_t hCap, lCap;       // LDS capacities of this launch: foreign owners / local-B list entries of the largest tile (rounded up)
     uint32_t nComp, nAnal, nMass;  // table sizes (tile_table_bytes)
-    uint32_t* tileCtr;             // k_tile_forces_p (deme_tile_p.h): tiles handed out, workgroups through; zero between launches
+    uint32_t* tileCtr;             // k_tile_forces_p (deme_tile_p.h): tiles handed out per partition, workgroups through; zero between launches
+    uint32_t ctrParts;             // ... partitions of the tiles (and of the workgroups), one counter each
     unsigned long long* stamps;    // measurement builds (-DDEME_TILE_STAMPS=1): 16 words per tile, see k_tile_forces
 };
 
@@ -579,10 +580,21 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const uint32_t t = tile_block_id(a.xcdGroup);
     if (t >= a.nTiles)
         return;
+    // (whether this tile is evaluated here at all -- the pass of a split step, a tile left to k_tile_forces_big -- is decided BEHIND
+    // the first loads, not in front of them: the two flags are words in memory, and a branch on them at the kernel's entry put two
+    // scalar round trips in front of every load of the tile; what goes out for a tile that then leaves is harmless)
+#ifndef DEME_TILE_LATE_SKIP
+#define DEME_TILE_LATE_SKIP 1
+#endif
+#if DEME_TILE_LATE_SKIP
+    const uint32_t skipBig = a.tileBig[t];
+    const uint32_t skipMode = a.tileMode ? a.tileMode[t] : 0xFFFFFFFFu;
+#else
     if (a.tileMode && !(a.tileMode[t] & (1u << a.pass)))
         return;
     if (a.tileBig[t])
         return;
+#endif
     const uint32_t tid = threadIdx.x;
     const uint32_t o0 = t * DEME_TILE_NB;
     const uint32_t nLoc = min((uint32_t)DEME_TILE_NB, a.nOwners - o0);
@@ -635,6 +647,10 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const uint16_t* const lOffT = a.lOff + (size_t)t * (DEME_TILE_NB + 1);
     const uint32_t nL = a.lCount[t];  // (a 32-bit word: a scalar load -- a 16-bit one would be a vector load, whose wait drains the loads issued before it)
     const int64_t u0x = a.org[3 * (size_t)t], u0y = a.org[3 * (size_t)t + 1], u0z = a.org[3 * (size_t)t + 2];
+#if DEME_TILE_LATE_SKIP
+    if (skipBig || !(skipMode & (1u << a.pass)))
+        return;
+#endif
     const float4* wc4 = reinterpret_cast<const float4*>(a.wc);
     uint2 inf[DEME_TILE_DEPTH];
     float4 hist[DEME_TILE_DEPTH];

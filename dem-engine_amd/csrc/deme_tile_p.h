@@ -59,12 +59,16 @@ __device__ inline TileScal tile_scalars(const TileArgs& a, const uint32_t t) {
     return S;
 }
 
+#ifndef DEME_TILE_P_PARTS
+#define DEME_TILE_P_PARTS 32u  // partitions of a full launch (one tile counter each)
+#endif
+#define DEME_TILE_P_CTR_WORDS ((DEME_TILE_P_PARTS + 1u) * 32u)  // counters of one launch: 128 bytes apart, then the workgroups-through word
 #ifndef DEME_TILE_P_OCC
 #define DEME_TILE_P_OCC 1
 #endif
 
-// a.tileCtr[0]: tiles handed out beyond the first gridDim.x (workgroup b starts with tile b); a.tileCtr[1]: workgroups that are
-// through.  Both are zero at launch; the last workgroup to leave sets them back.
+// a.tileCtr[32 k]: tiles of partition k handed out beyond every workgroup's first two; a.tileCtr[32 parts]: workgroups that are
+// through.  All zero at launch; the last workgroup to leave sets them back.
 template <int MODEL, bool MESH, bool REC = false>
 __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_P_OCC) void k_tile_forces_p(const DevParams p, const TileArgs a) {
     extern __shared__ uint4 tileLds[];
@@ -116,15 +120,25 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_P_OCC) void k_tile_forces_p(
     const float4* const wc4 = reinterpret_cast<const float4*>(a.wc);
     constexpr int NWU = MODEL == 2 ? DEME_JIT_NW : 1;
 
-    // ---- the first tile (its number is the workgroup's) and the second (from the counter): fetched here, one latency each
-    uint32_t t = blockIdx.x;  // (the host launches at most nTiles workgroups)
-    uint32_t tN;
-    {
-        if (tid == 0)
-            sNext[1] = gridDim.x + atomicAdd(a.tileCtr, 1u);
-        __syncthreads();  // (also: the tables are in LDS)
-        tN = __builtin_amdgcn_readfirstlane(sNext[1]);
-    }
+    // ---- which tiles this workgroup takes.  The tiles are dealt to a.ctrParts partitions (tile t belongs to partition t % parts),
+    // the workgroups likewise (workgroup b to partition b % parts; the host launches a multiple of `parts` workgroups, or parts = 1):
+    // one counter per partition, 128 bytes apart -- a single counter for the whole chip answers one atomic per ~15 ns, 7 800 tiles
+    // were 117 us of counter alone (measured: profiles/r06/persistent_first_attempt.txt).  A workgroup's first two tiles are
+    // fixed (its own rank in the partition, then that plus the partition's workgroups); from the third on the number comes from
+    // the partition's counter, asked for behind the staging barrier of one tile and handed to the workgroup at the staging
+    // barrier of the next -- a whole tile later, at a point where the wavefront has just waited for its records anyway.
+    const uint32_t parts = a.ctrParts, part = blockIdx.x % parts, wgPerPart = gridDim.x / parts;
+    uint32_t* const ctr = a.tileCtr + part * 32u;
+#ifndef DEME_TILE_P_CONTIG
+#define DEME_TILE_P_CONTIG 0  // 1: a partition is a contiguous range of tiles (neighbouring tiles on one XCD: their shared owner records in one L2)
+#endif
+#if DEME_TILE_P_CONTIG
+    const uint32_t chunk = (nTiles + parts - 1u) / parts;
+    auto tile_of = [&](uint32_t idx) { return idx < chunk ? part * chunk + idx : 0xFFFFFFFFu; };
+#else
+    auto tile_of = [&](uint32_t idx) { return part + parts * idx; };
+#endif
+    uint32_t t = tile_of(blockIdx.x / parts);  // (the host launches at most nTiles workgroups)
     TileScal S = tile_scalars(a, t);
     uint32_t id0 = 0u, id1 = 0u;
     {
@@ -136,26 +150,35 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_P_OCC) void k_tile_forces_p(
         if (h1 < DEME_TILE_HMAX)
             id1 = hl[h1];
     }
-    asm volatile("" : "+v"(id0), "+v"(id1));  // (waited for here, once: see the note behind the staging barrier)
+    asm volatile("" : "+v"(id0), "+v"(id1));  // (waited for here, once: see the note in the epilogue)
+    __syncthreads();  // (the tables are in LDS)
+    uint32_t pend = tile_of(blockIdx.x / parts + wgPerPart);  // thread 0: the tile after the current one, to be told at the staging barrier
     for (uint32_t it = 0;; it++) {
-        // ---- what tile tN will need first goes out now, a whole tile ahead: its scalars, the ids of its foreign owners; and the
-        // number of the tile after it
-        const bool haveN = tN < nTiles;
+        bool haveN = false;
         TileScal SN = S;
-        uint32_t idn0 = 0u, idn1 = 0u;
+        uint32_t idn0 = 0u, idn1 = 0u, tN = 0xFFFFFFFFu;
         uint32_t fetched = 0u;  // (thread 0 only)
-        if (haveN) {
-            SN = tile_scalars(a, tN);
-            const uint32_t nLocN = min((uint32_t)DEME_TILE_NB, a.nOwners - tN * DEME_TILE_NB);
-            const uint32_t* hlN = a.hList + (size_t)tN * DEME_TILE_HMAX;
-            const uint32_t h0N = tid - nLocN, h1N = tid + DEME_TILE_T - nLocN;
-            if (tid >= nLocN && h0N < DEME_TILE_HMAX)
-                idn0 = hlN[h0N];
-            if (h1N < DEME_TILE_HMAX)
-                idn1 = hlN[h1N];
+        // What tile tN will need first goes out behind the staging barrier of tile t: its scalars (SGPRs), the ids of its foreign
+        // owners (two VGPRs) -- and the question for the number of the tile after it.
+        auto hand_over_and_prefetch = [&]() __attribute__((always_inline)) {
             if (tid == 0)
-                fetched = atomicAdd(a.tileCtr, 1u);
-        }
+                sNext[it & 1u] = pend;
+            __syncthreads();
+            tN = __builtin_amdgcn_readfirstlane(sNext[it & 1u]);
+            haveN = tN < nTiles;
+            if (haveN) {
+                SN = tile_scalars(a, tN);
+                const uint32_t nLocN = min((uint32_t)DEME_TILE_NB, a.nOwners - tN * DEME_TILE_NB);
+                const uint32_t* hlN = a.hList + (size_t)tN * DEME_TILE_HMAX;
+                const uint32_t h0N = tid - nLocN, h1N = tid + DEME_TILE_T - nLocN;
+                if (tid >= nLocN && h0N < DEME_TILE_HMAX)
+                    idn0 = hlN[h0N];
+                if (h1N < DEME_TILE_HMAX)
+                    idn1 = hlN[h1N];
+                if (tid == 0)
+                    fetched = atomicAdd(ctr, 1u);
+            }
+        };
         if (!S.skip) {
             uint32_t tl = tid;  // (the thread's number, opaque per tile: what is derived from it -- a dozen stream and list addresses -- is
             asm volatile("" : "+v"(tl));  // formed per tile, not once per workgroup and kept in registers through every round)
@@ -230,11 +253,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_P_OCC) void k_tile_forces_p(
                     if (tl + k * DEME_TILE_T < nL)
                         sLPos[tl + k * DEME_TILE_T] = (uint16_t)lp[k];
             }
-            __syncthreads();
-            // (the next tile's ids and the counter's answer went out before this tile's records, which have arrived: telling the compiler
-            // so HERE spares the wait at the next tile's start -- for a value carried around the loop that is a wait for everything,
-            // the stores of this tile's last round included)
-            asm volatile("" : "+v"(idn0), "+v"(idn1), "+v"(fetched));
+            hand_over_and_prefetch();  // (with the staging barrier)
             TILE_STAMP(2);
             uint32_t plo = sideB ? sLLo[po] : sALo[po];
             const uint32_t phi = (sideA || sideB) ? (sideB ? sLLo[po + 1] : sALo[po + 1]) : plo;
@@ -287,8 +306,12 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_P_OCC) void k_tile_forces_p(
                         } else {
                             tile_contact<MODEL>(p, T, ci, A, B, h, force, tA, tB);
                         }
+#if !(DEME_TILE_KI & 16)
                         if (MODEL == 0)
                             stream_store(reinterpret_cast<float4*>(a.wc) + c, h);
+#else
+                        ki_sink(h.x + h.y + h.z + h.w);
+#endif
                     }
                     recA4[tl] = make_float4(force.x, force.y, force.z, tA.x);
                     recA2[tl] = make_float2(tA.y, tA.z);
@@ -303,7 +326,9 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_P_OCC) void k_tile_forces_p(
                     const uint64_t m = __ballot(crossing);
                     if (crossing) {
                         const uint32_t k = rbase[0] + (uint32_t)__popcll(m & ((1ull << (tl & 63u)) - 1ull));
-#if DEME_REC24
+#if DEME_TILE_KI & 32
+                        ki_sink(x4.x + x4.y + x4.z + x4.w + x2.x + x2.y + (float)k);
+#elif DEME_REC24
                         float2* const r24 = reinterpret_cast<float2*>(a.rec32) + 3 * (size_t)k;  // (-F.x -F.y) (-F.z tB.x) (tB.y tB.z)
                         stream_store(r24, make_float2(x4.x, x4.y));
                         stream_store(r24 + 1, make_float2(x4.z, x4.w));
@@ -393,13 +418,17 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_P_OCC) void k_tile_forces_p(
                 recA4[po] = make_float4(s01.x, s01.y, s23.x, s23.y);
                 recA2[po] = make_float2(s45.x, s45.y);
             }
-            if (tl == 0)
-                sNext[it & 1u] = haveN ? gridDim.x + fetched : 0xFFFFFFFFu;
+            // (the next tile's ids went out behind the staging barrier, rounds ago: telling the compiler HERE that they have arrived --
+            // it waits for whatever is outstanding, the last round's stores, which are about through -- spares the wait at the next
+            // tile's start, where the tile sums stored below would have to drain first)
+            asm volatile("" : "+v"(idn0), "+v"(idn1));
             __syncthreads();
             if (sideA && po < nLoc) {
                 const float4 b4 = recA4[po];
                 const float2 b2 = recA2[po];
-#if DEME_REC24
+#if DEME_TILE_KI & 64
+                ki_sink(s01.x + b4.x + s01.y + b4.y + s23.x + b4.z + s23.y + b4.w + s45.x + b2.x + s45.y + b2.y);
+#elif DEME_REC24
                 float2* const t24 = reinterpret_cast<float2*>(a.tSum) + 3 * (size_t)(o0 + po);  // (F.x F.y) (F.z t.x) (t.y t.z)
                 t24[0] = make_float2(s01.x + b4.x, s01.y + b4.y);
                 t24[1] = make_float2(s23.x + b4.z, s23.y + b4.w);
@@ -421,22 +450,23 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_P_OCC) void k_tile_forces_p(
             }
 #endif
         } else {  // (a tile of the other pass, or one that k_tile_forces_big takes: nothing but the hand-over)
-            if (tid == 0)
-                sNext[it & 1u] = haveN ? gridDim.x + fetched : 0xFFFFFFFFu;
-            __syncthreads();
+            hand_over_and_prefetch();
+            asm volatile("" : "+v"(idn0), "+v"(idn1));
         }
         if (!haveN)
             break;
         t = tN;
-        tN = __builtin_amdgcn_readfirstlane(sNext[it & 1u]);
         S = SN, id0 = idn0, id1 = idn1;
+        pend = tile_of(2u * wgPerPart + fetched);  // (thread 0; read at the next staging barrier)
     }
     // ---- the last workgroup to leave sets the counters back for the next launch
     if (tid == 0) {
-        const uint32_t done = atomicAdd(a.tileCtr + 1, 1u);
+        uint32_t* const doneCtr = a.tileCtr + parts * 32u;
+        const uint32_t done = atomicAdd(doneCtr, 1u);
         if (done == gridDim.x - 1u) {
-            atomicExch(a.tileCtr, 0u);
-            atomicExch(a.tileCtr + 1, 0u);
+            for (uint32_t k = 0; k < parts; k++)
+                atomicExch(a.tileCtr + k * 32u, 0u);
+            atomicExch(doneCtr, 0u);
         }
     }
 }

@@ -31,8 +31,12 @@ int launch_tile_forces_p(int which, unsigned nCU, unsigned ldsBytes, hipStream_t
                 return (int)e;
             perCU = std::max(n, 1), perCUlds = ldsBytes;
         }
-        const unsigned grid = std::min<unsigned>(ta.nTiles, (unsigned)perCU * nCU);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(DEME_TILE_T), ldsBytes, st, dp, ta);
+        unsigned grid = std::min<unsigned>(ta.nTiles, (unsigned)perCU * nCU);
+        TileArgs tb = ta;
+        tb.ctrParts = 1u;  // one counter per DEME_TILE_P_PARTS-th of the workgroups when the chip is full (see the kernel)
+        if (grid >= 8u * DEME_TILE_P_PARTS)
+            grid -= grid % DEME_TILE_P_PARTS, tb.ctrParts = DEME_TILE_P_PARTS;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(DEME_TILE_T), ldsBytes, st, dp, tb);
         return (int)hipGetLastError();
     };
     switch (which) {

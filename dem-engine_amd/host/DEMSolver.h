@@ -1066,6 +1066,7 @@ class DEMSolver {
             if (nP)
                 mc_download_persistent_contacts(pa.data(), pb.data(), pt.data(), nP);
         }
+        ReuploadGuard reuploadGuard{this};  // (st and the mapping live on this frame: whatever leaves it, an exception included, clears the members)
         m_reupload_state = &st, m_reupload_n = oldOwners;
         m_reupload_dst = [=](size_t o, size_t newClumps) { return o < oldClumps ? o : newClumps + (o - oldClumps); };
         initialize_impl();  // rebuilds and uploads the scene with all batches
@@ -1210,6 +1211,7 @@ class DEMSolver {
         };
         const double t = m_time;
         const SavedWildcards saved = save_user_wildcards();
+        ReuploadGuard reuploadGuard{this};  // (st, new_of_old live on this frame: whatever leaves it, an exception included, clears the members)
         m_reupload_state = &st, m_reupload_n = nO;
         m_reupload_dst = [&](size_t o, size_t) { return (size_t)new_of_old[o]; };
         initialize_impl();
@@ -1411,12 +1413,19 @@ class DEMSolver {
     /// owner is of family N takes the material, from the next step on
     void SetFamilyClumpMaterial(unsigned int N, const std::shared_ptr<DEMMaterial>& mat) {
         require_init("SetFamilyClumpMaterial");
+        m_family_material_log.push_back({N, (unsigned)mat->load_order, 0});
         each_ctx([&](deme_ctx* c) { return deme_set_family_material(c, N, mat->load_order, 0); });
     }
     void SetFamilyMeshMaterial(unsigned int N, const std::shared_ptr<DEMMaterial>& mat) {
         require_init("SetFamilyMeshMaterial");
+        m_family_material_log.push_back({N, (unsigned)mat->load_order, 1});
         each_ctx([&](deme_ctx* c) { return deme_set_family_material(c, N, mat->load_order, 1); });
     }
+    struct FamilyMaterial {
+        unsigned family, material;
+        int mesh;
+    };
+    std::vector<FamilyMaterial> m_family_material_log;  // replayed on the new slab contexts of a re-planned decomposed run
     void require_init(const char* who) const {
         if (!m_initialized)
             throw std::runtime_error(std::string(who) + " can only be called after the simulation system is initialized");
@@ -1705,6 +1714,10 @@ class DEMSolver {
     // a scene re-upload (UpdateClumps, ResortClumps) hands the owners' CURRENT state to initialize_impl: a decomposed run is cut by
     // where the clumps are now, not by where their batches were loaded (row o of the state goes to owner dst(o, new clump count))
     const DemeOwnerState* m_reupload_state = nullptr;
+    struct ReuploadGuard {  // the re-upload hand-over points at its caller's frame: never past that frame's end
+        DEMSolver* s;
+        ~ReuploadGuard() { s->m_reupload_state = nullptr, s->m_reupload_dst = nullptr; }
+    };
     size_t m_reupload_n = 0;
     std::function<size_t(size_t, size_t)> m_reupload_dst;
     float m_slab_halo = 0.f;
@@ -1747,9 +1760,9 @@ class DEMSolver {
     deme_ctx* diag_ctx() const {
         if (!m_multi)
             return m_ctx;
-        deme_ctx* c = nullptr;
-        deme_multi_slab_ctx(m_multi, 0, &c);
-        return c;
+        const deme_ctx* c = nullptr;
+        deme_multi_slab_ctx_peek(m_multi, 0, &c);  // (asking does not invalidate the run's merged contact list)
+        return const_cast<deme_ctx*>(c);
     }
     /// what a decomposed run does not offer yet says so instead of touching one slab only
     // a user model's wildcard arrays: one context's, or by global id across the slabs of a decomposed run
@@ -2712,6 +2725,13 @@ class DEMSolver {
                                     p.forceModel == DEME_FORCE_HERTZIAN ? 7u : 0u));
             mcheck(deme_multi_set_migration(m_multi, m_migrate_every));
             mcheck(deme_multi_set_rebalance(m_multi, m_rebalance_every));
+            if (built && m_initialized) {
+                // the slab contexts are new: what the script set on the old ones after Initialize goes onto them again (a single
+                // context survives a re-upload and keeps these by itself) -- the controllers' knobs, families' materials
+                push_adaptive();
+                for (const FamilyMaterial& fm : m_family_material_log)
+                    each_ctx([&](deme_ctx* c) { return deme_set_family_material(c, fm.family, fm.material, fm.mesh); });
+            }
         } else {
             check(deme_set_params(m_ctx, &p));
             check(deme_upload_scene(m_ctx, &s));

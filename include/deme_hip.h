@@ -580,6 +580,8 @@ int deme_multi_build(deme_multi* m, const DemeParams* p, const DemeScene* scene,
                      int arith, uint32_t flipMask);
 int deme_multi_num_slabs(const deme_multi* m, uint32_t* n);
 int deme_multi_slab_ctx(deme_multi* m, uint32_t slab, deme_ctx** ctx);
+/* the same handle for questions that change nothing (kernel names, bin size, timers): the merged contact list of the run stays valid */
+int deme_multi_slab_ctx_peek(const deme_multi* m, uint32_t slab, const deme_ctx** ctx);
 int deme_multi_set_migration(deme_multi* m, uint32_t migrateEvery);
 int deme_multi_step(deme_multi* m, uint32_t nsteps);
 int deme_multi_sync(deme_multi* m);

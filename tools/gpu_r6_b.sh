@@ -16,4 +16,4 @@ for f in sorted(glob.glob('gpurun_out/r6b/persist*.json')):
     except Exception as e: print(f,'ERR',e)
 PY
 DEME_HIP_LIB=$PWD/dem-engine_amd/csrc/libdeme_s_stamps.so DEME_TILE_STAMPS_FILE=$PWD/$out/stamps_p.bin:150 timeout 600 python bench.py --no-cpu-baseline --state-cache /tmp/bed.npz > $out/stamps_bench.json 2>$out/stamps.err
-timeout 1200 python -m pytest tests/test_full_size.py -x -q -m gpu -k "tile_pass_one_launch or fast_mode_matches or contact_list" > $out/pytest_fullsize.log 2>&1; tail -5 $out/pytest_fullsize.log
+timeout 900 python tools/persist_compare.py 200000 60 > $out/persist_compare.log 2>&1; tail -8 $out/persist_compare.log
