@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 5: the flavours of the bench on the final tree (as tools/gpu_r4_final.sh did for round 4) -> gpurun_out/r05/flavours.txt
-TAG=${1:-r05b}
-out=gpurun_out/r05; mkdir -p $out
+# the flavours of the bench on the current tree -> gpurun_out/<round dir>/flavours.txt     usage: gpu_flavours.sh [tag] [round dir]
+TAG=${1:-r06b}; RD=${2:-r06}
+out=gpurun_out/$RD; mkdir -p $out
 line() { python - "$@" <<'PY'
 import json,sys
 for f in sys.argv[1:]:
