@@ -580,11 +580,12 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const uint32_t t = tile_block_id(a.xcdGroup);
     if (t >= a.nTiles)
         return;
-    // (whether this tile is evaluated here at all -- the pass of a split step, a tile left to k_tile_forces_big -- is decided BEHIND
-    // the first loads, not in front of them: the two flags are words in memory, and a branch on them at the kernel's entry put two
-    // scalar round trips in front of every load of the tile; what goes out for a tile that then leaves is harmless)
+    // Whether this tile is evaluated here at all -- the pass of a split step, a tile left to k_tile_forces_big -- is decided in FRONT of
+    // the tile's loads.  (DEME_TILE_LATE_SKIP=1 decides it behind the first loads: two scalar round trips off every tile's start --
+    // measured: 88.9 against 89.0 us, nothing, and the ghost-dependent pass of a slab step, which leaves 95 % of its tiles at once,
+    // would fetch every tile's records first.)
 #ifndef DEME_TILE_LATE_SKIP
-#define DEME_TILE_LATE_SKIP 1
+#define DEME_TILE_LATE_SKIP 0
 #endif
 #if DEME_TILE_LATE_SKIP
     const uint32_t skipBig = a.tileBig[t];
