@@ -1,15 +1,19 @@
-// deme_tile_p.h -- the owner-tile force pass as PERSISTENT workgroups (round 6).
+// deme_tile_p.h -- the owner-tile force pass as PERSISTENT workgroups (round 6; opt-in: DEME_TILE_PERSIST=1).
 //
 // Same tiles, same staging, same rounds, same pulls, same outputs and the same arithmetic as k_tile_forces (deme_tile.h; physics:
-// kernel/DEMCalcForceKernels.cu:44-267 with FullHertzianForceModel.cu / FrictionlessHertzianForceModel.cu).  What changed is who
-// runs a tile and when its loads go out.  The phase stamps of round 6 (profiles/r06/tile_phase_stamps.txt) showed a tile living
-// 10.3 us of which 4.1 us pass before its first round starts -- two memory latencies in a row (the ids of the foreign owners, then
-// their records) -- and only ~925 of the 1024 workgroup slots of the chip occupied at any time: a slot stays empty for ~1 us
-// between the end of one workgroup and the start of the next.  Here a workgroup stays on its slot and takes tile after tile from
-// a counter in memory, always knowing the NEXT tile's number one tile ahead: while tile k is evaluated, the scalars of tile k + 1
-// (contact range, counts, origin: SGPRs) and the ids of its foreign owners (two VGPRs) are already on their way, so that at the
-// start of tile k + 1 every load it needs -- local records, foreign records, streams, lists -- goes out at once: the chain is ONE
-// latency deep.  The small tables are copied to LDS once per workgroup instead of once per tile.
+// kernel/DEMCalcForceKernels.cu:44-267 with FullHertzianForceModel.cu / FrictionlessHertzianForceModel.cu) -- bit for bit
+// (tools/persist_compare.py, tests/test_tile_persistent.py).  What changed is who runs a tile and when its loads go out.  The phase
+// stamps of round 6 (profiles/r06/tile_phase_stamps_plain.txt) showed a tile living 10.3 us of which 4.1 us pass before its first
+// round starts -- two memory latencies in a row (the ids of the foreign owners, then their records) -- and only ~925 of the 1024
+// workgroup slots of the chip occupied at any time: a slot stays empty for ~1 us between the end of one workgroup and the start of
+// the next.  Here a workgroup stays on its slot and takes tile after tile, always knowing the NEXT tile's number a tile ahead:
+// behind the staging barrier of tile k the scalars of tile k + 1 (contact range, counts, origin: SGPRs) and the ids of its foreign
+// owners (two VGPRs) go out, so that at the start of tile k + 1 every load it needs -- local records, foreign records, streams,
+// lists -- goes out at once: the chain is ONE latency deep.  The small tables are copied to LDS once per workgroup.
+//
+// What it measured (profiles/r06/force_pass_ceiling.md, tile_phase_stamps_persistent.txt): start -> staged 4.1 -> 2.5 us, every slot
+// full -- and the rounds 2.7 -> 3.1 us, because the pass is bound by VALU issue (65 us of it in an 88 us kernel), not by the waiting
+// this form removes: 99 us against 89 us.  Kept as an option and as the measurement; k_tile_forces is the default.
 #pragma once
 #include "deme_tile.h"
 
