@@ -73,7 +73,8 @@ namespace deme_dev {
 #define DEME_TILE_KI 0
 #endif
 // -DDEME_TILE_STAMPS=1: thread 0 of every tile leaves the 100 MHz wall clock at its phase boundaries (words 0 start, 1 tables in LDS,
-// 2 staged, 3.. the end of each round, 11 the end) and where it ran (word 12: HW_ID | XCC_ID << 32; 13: contacts; 14: foreign owners)
+// 2 staged, 3.. the end of each round, 11 the end) and where it ran (word 12: HW_ID | XCC_ID << 32; 13: contacts; 14: foreign owners;
+// 15: shader cycles (s_memtime) over the tile's life -- with words 0 and 11 the clock the kernel runs at)
 #ifndef DEME_TILE_STAMPS
 #define DEME_TILE_STAMPS 0
 #endif
@@ -600,6 +601,9 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
     const uint32_t o0 = t * DEME_TILE_NB;
     const uint32_t nLoc = min((uint32_t)DEME_TILE_NB, a.nOwners - o0);
     TILE_STAMP(0);
+#if DEME_TILE_STAMPS
+    const unsigned long long stampClk0 = (unsigned long long)clock64();  // (s_memtime: shader cycles; word 15 = cycles over the tile's life)
+#endif
     // ---- every load that needs nothing but the tile number goes out first: the ids of the foreign owners behind my staging slots
     // (the list is padded to DEME_TILE_HMAX per tile: reading past the tile's own count is harmless), my local owner's record,
     // my entries of the small tables.  A tile's lifetime is a chain of memory latencies; this makes it two deep
@@ -1027,6 +1031,7 @@ __global__ __launch_bounds__(DEME_TILE_T, DEME_TILE_OCC) void k_tile_forces(cons
         a.stamps[(size_t)t * 16u + 12u] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
         a.stamps[(size_t)t * 16u + 13u] = nCt;
         a.stamps[(size_t)t * 16u + 14u] = nH;
+        a.stamps[(size_t)t * 16u + 15u] = (unsigned long long)clock64() - stampClk0;
     }
 #endif
 }

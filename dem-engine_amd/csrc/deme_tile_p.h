@@ -12,7 +12,7 @@
 // lists -- goes out at once: the chain is ONE latency deep.  The small tables are copied to LDS once per workgroup.
 //
 // What it measured (profiles/r06/force_pass_ceiling.md, tile_phase_stamps_persistent.txt): start -> staged 4.1 -> 2.5 us, every slot
-// full -- and the rounds 2.7 -> 3.1 us, because the pass is bound by VALU issue (65 us of it in an 88 us kernel), not by the waiting
+// full -- and the rounds 2.7 -> 3.1 us, because the pass is bound by VALU issue (60 us of it in an 88 us kernel), not by the waiting
 // this form removes: 99 us against 89 us.  Kept as an option and as the measurement; k_tile_forces is the default.
 #pragma once
 #include "deme_tile.h"

@@ -30,6 +30,10 @@ for T in list(range(0, int(np.nanmax(end)) + 5, 5)):
     if 0 < i < len(conc):
         row.append(f"{T}:{int(conc[i-1])}")
 print("tiles in process at t [us]:", " ".join(row))
+clk = d[ok, 15].astype(np.float64)
+if (clk > 0).any():
+    m = (clk > 0) & (life > 1.0)
+    print(f"shader clock over the tiles' lives (s_memtime cycles / wall time): median {np.median(clk[m] / life[m]) / 1e3:.3f} GHz, p10 {np.percentile(clk[m] / life[m], 10) / 1e3:.3f}, p90 {np.percentile(clk[m] / life[m], 90) / 1e3:.3f}")
 hw = d[ok, 12]
 xcc = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(int)
 cu = ((hw >> np.uint64(8)) & np.uint64(0xF)).astype(int); se = ((hw >> np.uint64(13)) & np.uint64(7)).astype(int); sh = ((hw >> np.uint64(12)) & np.uint64(1)).astype(int)
